@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- frame-pairs/sec of the MultiSPA geometry pipe on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path (kernel K3, mspa_pair_reproject: back-projection ->
+reprojection -> depth-buffer visibility) over one batch of synthetic 640x480 RGB-D frame pairs that
+are already resident in HBM.  Workload = BASELINE.json configs[1]: visual_correspondence on 1k
+640x480 pairs, one MI355X.  With --gpus N (launched by torch.distributed.run, one rank per GPU)
+every rank processes its own batch of the same size (weak scaling, pairs shard embarrassingly) and
+the per-pair records are collated with one RCCL all_gather per step.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) with two extra objects:
+  roofline      algorithmic HBM bytes of the K3 launch / its HIP-event-measured duration vs 8 TB/s
+  cpu_baseline  the NumPy restatement of the reference path (oracle/np_oracle.py) timed on this box
+
+    python bench.py                      # N=1, 1000 pairs/step, corr variant
+    python bench.py --variant dense      # + rgb in, byte mask, xyz f32, rgba out
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, "multi-spatialmllm_amd"), ROOT]
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+H, W = 480, 640
+P = H * W
+
+# bytes per pixel that one pair MUST move (DESIGN.md "Algorithmic bytes"; SURVEY.md 8d formula):
+#   depth1 u16 + depth2 u16 (+ rgb u8x3) in; visibility + pixel index (+ xyz f32x3 + rgba) out
+VARIANTS = {
+    "corr": {"outputs": ("vis_bits", "pix_i16", "counts"), "rgb": False,
+             "bytes_per_px": 2 + 2 + 1 / 8 + 4},
+    "dense": {"outputs": ("vis_u8", "pix_i16", "xyz_f32", "rgba", "counts"), "rgb": True,
+              "bytes_per_px": 2 + 2 + 3 + 1 + 4 + 12 + 4},
+    "minimal": {"outputs": ("vis_bits", "counts"), "rgb": False, "bytes_per_px": 2 + 2 + 1 / 8},
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=1000, help="frame pairs per step per GPU")
+    ap.add_argument("--frames", type=int, default=2048, help="distinct device-resident frames per GPU")
+    ap.add_argument("--base-frames", type=int, default=24, help="frames rendered on the host per GPU")
+    ap.add_argument("--variant", choices=sorted(VARIANTS), default="corr")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--also", default="dense", help="comma list of extra variants timed briefly (rank 0 report)")
+    return ap.parse_args()
+
+
+def build_inputs(args, rank, device):
+    """Render a few frames on the host, expand them on the device into `frames` distinct frames."""
+    import torch
+    from mspa import engine, synth
+
+    sc = synth.make_scene(1000 + rank, n_points=64, n_frames=args.base_frames, color_hw=(H, W),
+                          depth_hw=(H, W), invalid_pose_frac=0.0, with_color=False)
+    ids = sc.valid_image_ids
+    nb = len(ids)
+    base_depth = np.stack([sc.depth[i] for i in ids])
+    base_mats = engine.frame_matrices(sc.K, sc.A, [sc.E[i] for i in ids])
+    reps = max(1, args.frames // nb)
+    n_frames = reps * nb
+    g = torch.Generator(device=device)
+    g.manual_seed(1234 + rank)
+    d0 = torch.from_numpy(base_depth.astype(np.int32)).to(device)                     # [nb,H,W]
+    depth = torch.empty((n_frames, H, W), dtype=torch.int16, device=device)
+    for r in range(reps):   # every replica gets its own +-3 mm noise so no two frames share bytes
+        noise = torch.randint(-3, 4, d0.shape, generator=g, device=device, dtype=torch.int32)
+        d = torch.where(d0 > 0, (d0 + noise).clamp_(1, 65535), d0)
+        depth[r * nb:(r + 1) * nb] = d.to(torch.int16)      # same 16 bits; the kernels read them as uint16
+    mats = torch.from_numpy(np.tile(base_mats, (reps, 1, 1))).to(device)
+    rgb = None
+    if VARIANTS[args.variant]["rgb"] or any(VARIANTS[v]["rgb"] for v in args.also.split(",") if v):
+        rgb = torch.randint(0, 256, (n_frames, H, W, 3), generator=g, device=device, dtype=torch.uint8)
+    # pairs: two different views of the same replica, walking through all replicas
+    rng = np.random.default_rng(77 + rank)
+    rep = np.arange(args.pairs) % reps
+    b1 = rng.integers(0, nb, args.pairs)
+    b2 = (b1 + rng.integers(1, min(4, nb), args.pairs)) % nb
+    pairs_np = np.stack([rep * nb + b1, rep * nb + b2], axis=1).astype(np.int32)
+    pairs = torch.from_numpy(pairs_np).to(device)
+    return sc, ids, depth, mats, rgb, pairs, pairs_np, nb
+
+
+def time_variant(variant, depth, mats, rgb, pairs, steps, warmup, dist_ctx):
+    """Returns (wall seconds for `steps` steps, mean kernel ms from HIP events, outputs)."""
+    import torch
+    from mspa import engine, shard
+
+    spec = VARIANTS[variant]
+    out = engine.alloc_pair_outputs(pairs.shape[0], (H, W), spec["outputs"], depth.device)
+    rgb_in = rgb if spec["rgb"] else None
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+
+    def step(k=None):
+        if k is not None:
+            ev[k][0].record()
+        engine.pair_reproject(depth, mats, pairs, (H, W), out, rgb=rgb_in)
+        if k is not None:
+            ev[k][1].record()
+        if dist_ctx is not None:
+            shard.collate_records(out["counts"], dist_ctx)    # RCCL all_gather of the per-pair records
+
+    for _ in range(warmup):
+        step()
+    if dist_ctx is not None:
+        dist_ctx.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+    torch.cuda.synchronize()
+    if dist_ctx is not None:
+        dist_ctx.barrier()
+    wall = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    return wall, kern_ms, out
+
+
+def cpu_baseline(sc, ids, pairs_np, nb, budget_s):
+    """Time the NumPy restatement of the reference path on a bounded sample of the same pairs."""
+    from oracle import np_oracle as O
+
+    color = np.zeros((H, W, 3), dtype=np.uint8)
+    n, t0 = 0, time.perf_counter()
+    checks = []
+    while True:
+        f1, f2 = ids[pairs_np[n, 0] % nb], ids[pairs_np[n, 1] % nb]
+        r = O.frame_pair(sc.depth[f1], sc.depth[f2], sc.K, sc.E[f1], sc.E[f2], sc.A, (H, W), color)
+        checks.append((int(pairs_np[n, 0] % nb), int(pairs_np[n, 1] % nb), r["n_valid"], r["n_vis"]))
+        n += 1
+        el = time.perf_counter() - t0
+        if (el > budget_s and n >= 8) or n >= len(pairs_np):
+            break
+    return {"value": round(n / el, 3), "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{n} of the step's 640x480 pairs through oracle/np_oracle.frame_pair "
+                      f"(NumPy {np.__version__}, 1 process, in-memory images) in {el:.1f} s",
+            "host_cores_available": os.cpu_count()}, checks
+
+
+def main():
+    args = parse_args()
+    import torch
+    from mspa import _lib, engine, shard
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    _lib.load()
+    dist_ctx = shard.init_distributed(device) if world > 1 else None
+
+    sc, ids, depth, mats, rgb, pairs, pairs_np, nb = build_inputs(args, rank, device)
+    wall, kern_ms, out = time_variant(args.variant, depth, mats, rgb, pairs, args.steps, args.warmup, dist_ctx)
+    if dist_ctx is not None:
+        wall = dist_ctx.max_over_ranks(wall)
+    pairs_per_step = args.pairs * world
+    value = pairs_per_step * args.steps / wall
+    spec = VARIANTS[args.variant]
+    bytes_per_launch = spec["bytes_per_px"] * P * args.pairs
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+
+    extra = {}
+    if rank == 0:
+        for v in [v for v in args.also.split(",") if v and v != args.variant]:
+            w2, k2, _ = time_variant(v, depth, mats, rgb, pairs, max(3, args.steps // 4), 1, None)
+            b2 = VARIANTS[v]["bytes_per_px"] * P * args.pairs
+            extra[v] = {"pairs_per_s_1gpu": round(args.pairs / (k2 * 1e-3), 1), "kernel_ms": round(k2, 4),
+                        "achieved_GBs": round(b2 / (k2 * 1e-3) / 1e9, 1),
+                        "frac": round(b2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "bytes_per_pair": int(VARIANTS[v]["bytes_per_px"] * P)}
+    elif dist_ctx is not None:
+        pass
+
+    if rank == 0:
+        cpu, traffic = None, None
+        counts = out["counts"].cpu().numpy()
+        if world == 1 and not args.no_cpu_baseline:
+            cpu, checks = cpu_baseline(sc, ids, pairs_np, nb, args.cpu_seconds)
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            t = json.load(open(tfile))
+            if t.get("variant") == args.variant and t.get("pairs") == args.pairs:
+                traffic = t.get("hbm_bytes_per_launch")
+        info = _lib.device_info(local_rank)
+        line = {
+            "metric": "frame-pairs/sec MultiSPA geometry pipe (640x480 RGB-D)",
+            "value": round(value, 1), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "visual_correspondence unproject+reproject+occlusion kernel (K3) on "
+                                   f"{args.pairs} 640x480 frame pairs per GPU per step (BASELINE.json configs[1])",
+                       "variant": args.variant, "outputs": list(spec["outputs"]),
+                       "pairs_per_step_per_gpu": args.pairs, "distinct_frames_per_gpu": int(depth.shape[0]),
+                       "image": "640x480 depth u16 (+rgb u8x3 for dense)", "parallelism": f"dp{world}",
+                       "collation": "RCCL all_gather of per-pair records" if world > 1 else "none (1 GPU)"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "mspa::pair_reproject_kernel", "kernel_ms": round(kern_ms, 4),
+                         "bytes_per_pair": int(spec["bytes_per_px"] * P),
+                         "note": "exact float64 chain: ~100 FP64 VALU ops/pixel, FP64-VALU co-limited (DESIGN.md)"},
+            "cpu_baseline": cpu,
+            "variants": extra,
+            "device": info,
+            "visible_fraction": round(float(counts[:, 1].sum() / max(1, counts[:, 0].sum())), 4),
+        }
+        print(json.dumps(line), flush=True)
+    if dist_ctx is not None:
+        dist_ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+/*
+ * mspa.h -- C ABI of libmspa.so, the MI355X (gfx950) geometry engine behind the MultiSPA
+ * data pipeline of facebookresearch/Multi-SpatialMLLM.
+ *
+ * The reference is pure Python and has no FFI of its own: its hot path sits behind plain Python
+ * callables.  Each entry point below names the reference callable(s) it
+ * replaces (paths relative to the reference tree; IH = spatial_engine/utils/scannet_utils/
+ * handler/info_handler.py, OPS = .../handler/ops.py, CFR = spatial_engine/camera_movement/
+ * calculate_frames_relations.py, MVI = spatial_engine/utils/scannet_utils/make_visibility_info.py,
+ * CME = spatial_engine/camera_movement/camera_movement_engine_train_val.py, OM_C =
+ * spatial_engine/object_movement/single_object_movement_engine_coord.py).  The ctypes binding a
+ * maintainer would add on the reference side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer (HBM) unless the name ends in _host.  The library never
+ *    allocates, frees or copies user buffers: the caller (PyTorch-ROCm tensors in the shipped host
+ *    layer) owns all memory and passes data_ptr() values plus element counts.
+ *  - `stream` is a hipStream_t (NULL = the default stream).  Calls enqueue work and return; they
+ *    never synchronise.  Entry points are re-entrant; there is no global mutable state besides the
+ *    thread-local error string.
+ *  - Matrices are 4x4, row-major, float64, affine (last row exactly 0 0 0 1; the host layer
+ *    verifies this and the finiteness of every entry, as the reference's pose-validity filter
+ *    IH:409-418 does, before calling).  Inverses are computed by the caller with the same LAPACK
+ *    routine the reference uses (numpy.linalg.inv) and passed in ready-made.
+ *  - All arithmetic is IEEE float64 in the reference's operation order (each matrix row is the
+ *    chain m0*x, fma(m1,y,.), fma(m2,z,.), +m3 -- what NumPy/OpenBLAS computes for K = 4), so
+ *    integer outputs and masks are bit-exact and float64 outputs are bit-identical to the C oracle.
+ *  - Return value: MSPA_OK or a negative MSPA_E* code; mspa_last_error_string() describes the
+ *    last failure on the calling thread.  Nothing throws or aborts.
+ */
+#ifndef MSPA_H
+#define MSPA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSPA_VERSION 100            /* 0.1.0 */
+
+#define MSPA_OK 0
+#define MSPA_EINVAL (-1)            /* bad argument (null pointer, size out of range, ...) */
+#define MSPA_EHIP (-2)              /* a HIP runtime call failed; see mspa_last_error_string() */
+#define MSPA_EUNSUPPORTED (-3)      /* valid request this build has no kernel for */
+
+typedef void *mspa_stream_t;        /* hipStream_t */
+
+/* Matrix slots of one frame record in `frame_mats` ([n_frames][MSPA_FRAME_MATS][16] float64). */
+#define MSPA_MAT_KINV 0             /* inv(K)            OPS:313 */
+#define MSPA_MAT_E 1                /* E, camera->world  OPS:316 */
+#define MSPA_MAT_A 2                /* A, world->aligned OPS:319-320 (identity when absent) */
+#define MSPA_MAT_EINV_ALIGNED 3     /* inv(A @ E)        IH:113-124, IH:57 */
+#define MSPA_MAT_K 4                /* K                 IH:66 */
+#define MSPA_FRAME_MATS 5
+
+/* flags of mspa_pair_reproject */
+#define MSPA_PAIR_FAST 1u           /* reserved: composed-matrix fast path with exact fallback */
+
+int mspa_version(void);
+const char *mspa_last_error_string(void);
+
+/* Device facts the host layer reports next to measurements.  Any out pointer may be NULL. */
+int mspa_device_info(int device, int *n_cu, int *wave_size, int64_t *hbm_bytes, int *clock_khz,
+                     char *name_host, int name_len);
+
+/*
+ * K3 -- the frame-pair pipe (BASELINE.json north_star).  For every pair (f1, f2) and every colour
+ * pixel (mx, my) of frame f1:
+ *   project_mask_to_3d          OPS:235-329   depth -> camera -> world -> aligned point
+ *   project_3d_point_to_image   IH:313-335, project_points IH:46-72   into frame f2
+ *   check_point_visibility      IH:337-386    bounds + strict depth-buffer test in frame f2
+ *
+ *   depth       [n_frames, dh, dw] uint16 millimetres
+ *   rgb         [n_frames, H, W, 3] uint8 or NULL (needed only for out_rgba)
+ *   frame_mats  [n_frames, MSPA_FRAME_MATS, 16] float64
+ *   pairs       [n_pairs, 2] int32 frame indices (f1, f2)
+ * Outputs, each optional (NULL = not produced), P = H*W pixels in row-major order:
+ *   out_vis_bits  [n_pairs, ceil(P/64)] uint64   bit (i & 63) of word (i >> 6) = pixel i visible
+ *   out_vis_u8    [n_pairs, P] uint8             1 = visible in f2, 0 otherwise
+ *   out_valid_u8  [n_pairs, P] uint8             1 = depth sample of f1 > 0 (OPS:297)
+ *   out_pix_i16   [n_pairs, P, 2] int16          clipped depth-pixel index (xi, yi) in f2
+ *                                                (IH:362-366); (-1,-1) where the f1 sample is 0
+ *   out_xyz_f32   [n_pairs, P, 3] float32        aligned world point, NaN where invalid
+ *   out_rgba      [n_pairs, P] uint32            r | g<<8 | b<<16 | (valid ? 255 : 0)<<24
+ *   out_xyz_f64   [n_pairs, P, 3], out_uv_f64 [n_pairs, P, 2], out_depth_f64 [n_pairs, P]
+ *                                                full-precision point, un-rounded (u, v) in f2
+ *                                                and camera-2 depth; NaN where invalid
+ *   out_counts    [n_pairs, 2] int32             (#valid, #visible); zeroed by the call
+ * Requires 2 <= dw,dh,W,H <= 32767 and H*W*W < 2^32.
+ */
+int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, const double *frame_mats,
+                        int32_t n_frames, const int32_t *pairs, int64_t n_pairs,
+                        int32_t dh, int32_t dw, int32_t H, int32_t W,
+                        uint64_t *out_vis_bits, uint8_t *out_vis_u8, uint8_t *out_valid_u8,
+                        int16_t *out_pix_i16, float *out_xyz_f32, uint32_t *out_rgba,
+                        double *out_xyz_f64, double *out_uv_f64, double *out_depth_f64,
+                        int32_t *out_counts, uint32_t flags, mspa_stream_t stream);
+
+/*
+ * K1 -- vertex visibility, HOT LOOP 1 of CFR.process_scene (CFR:152-164) and
+ * MVI.process_scene (MVI:93-100): project_3d_point_to_image (IH:313-335) + check_point_visibility
+ * (IH:375-386) of all scene vertices into a batch of images.
+ *
+ *   xyz         vertex coordinates, element (i, c) at xyz[i*point_stride + c*comp_stride]
+ *               ([N,3] rows: 3,1;  aligned_points.npy [N,6] rows: 6,1;  SoA [3,N]: 1,N)
+ *   cam_mats    [n_images, 2, 16] float64: inv(A @ E) then K, per image
+ *   depth       [n_images, dh, dw] uint16
+ * Outputs, each optional:
+ *   out_bits    [n_images, ceil(n_points/64)] uint64  visibility bitset (tail bits zero)
+ *   out_mask    [n_images, n_points] uint8
+ *   out_uv      [n_images, n_points, 2] float64        un-rounded projection (IH:72)
+ *   out_depth   [n_images, n_points] float64           signed camera depth (IH:63)
+ *   out_count   [n_images] int32                       visible vertices per image; zeroed by the call
+ */
+int mspa_vertex_visibility(const double *xyz, int64_t n_points, int64_t point_stride,
+                           int64_t comp_stride, const double *cam_mats, int32_t n_images,
+                           const uint16_t *depth, int32_t dh, int32_t dw, int32_t H, int32_t W,
+                           uint64_t *out_bits, uint8_t *out_mask, double *out_uv, double *out_depth,
+                           int32_t *out_count, mspa_stream_t stream);
+
+/*
+ * K2 -- pair overlap, HOT LOOP 2 of CFR.process_scene: calculate_camera_overlap (CFR:102-137)
+ * on K1's bitsets.  overlap = |a & b| / |a | b| * 100 in float64 (NaN for an empty union).
+ *
+ *   bits        [n_images, n_words] uint64
+ *   pairs       [n_pairs, 2] int32 image indices
+ *   out_overlap [n_pairs] float64;  out_inter / out_union [n_pairs] int32, optional
+ */
+int mspa_pair_overlap(const uint64_t *bits, int32_t n_images, int64_t n_words, const int32_t *pairs,
+                      int64_t n_pairs, double *out_overlap, int32_t *out_inter, int32_t *out_union,
+                      mspa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSPA_H */

@@ -1,0 +1,46 @@
+// Library-level entry points of libmspa.so: version, error string, device facts.
+#include "mspa_common.h"
+
+#include <cstring>
+
+namespace mspa {
+
+std::string &last_error() {
+    static thread_local std::string e;
+    return e;
+}
+
+int fail(int code, const std::string &what) {
+    last_error() = what;
+    return code;
+}
+
+int check_hip(hipError_t e, const char *what) {
+    if (e == hipSuccess) return MSPA_OK;
+    last_error() = std::string(what) + ": " + hipGetErrorString(e);
+    return MSPA_EHIP;
+}
+
+}  // namespace mspa
+
+using namespace mspa;
+
+extern "C" int mspa_version(void) { return MSPA_VERSION; }
+
+extern "C" const char *mspa_last_error_string(void) { return last_error().c_str(); }
+
+extern "C" int mspa_device_info(int device, int *n_cu, int *wave_size, int64_t *hbm_bytes, int *clock_khz,
+                                char *name_host, int name_len) {
+    hipDeviceProp_t prop;
+    int rc = check_hip(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+    if (rc) return rc;
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (wave_size) *wave_size = prop.warpSize;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if (clock_khz) *clock_khz = prop.clockRate;
+    if (name_host && name_len > 0) {
+        std::strncpy(name_host, prop.gcnArchName, (size_t)name_len - 1);
+        name_host[name_len - 1] = 0;
+    }
+    return MSPA_OK;
+}

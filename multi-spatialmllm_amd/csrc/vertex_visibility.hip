@@ -1,0 +1,113 @@
+// K1: scene vertices -> a batch of images: projection + bounds + depth-buffer test
+// (HOT LOOP 1 of CFR.process_scene / MVI.process_scene; see include/mspa.h).
+//
+// Mapping.  One lane per vertex; a workgroup (256 threads) keeps its 256 vertices in registers and
+// walks kImgPerBlock images, so vertex coordinates are fetched from HBM once per image chunk
+// instead of once per image.  Per image the two 3x4 matrices come in through wave-uniform scalar
+// loads.  The visibility word of a wave is its 64-lane ballot: bitsets are written coalesced, one
+// uint64 per wave per image, in exactly the layout K2 consumes.
+#include "mspa_common.h"
+
+namespace mspa {
+
+// Inputs are separate `const T *__restrict__` kernel parameters so the wave-uniform matrix reads
+// become scalar loads (see pair_reproject.hip).
+struct VertexArgs {
+    int64_t n_points, point_stride, comp_stride;
+    int n_images;
+    int dh, dw, H, W;
+    double sx, sy;
+    int64_t n_words;
+    uint64_t *bits;
+    uint8_t *mask;
+    double *uv;
+    double *depth_out;
+    int32_t *count;
+};
+
+constexpr int kVThreads = 256;
+constexpr int kImgPerBlock = 8;
+
+__global__ __launch_bounds__(kVThreads) void vertex_visibility_kernel(const double *__restrict__ xyz,
+                                                                      const double *__restrict__ cam_mats,
+                                                                      const uint16_t *__restrict__ depth,
+                                                                      VertexArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * kVThreads + threadIdx.x;
+    const bool live = i < a.n_points;
+    const int64_t ic = live ? i : a.n_points - 1;
+    const int lane = threadIdx.x & 63;
+    const double x = xyz[ic * a.point_stride];
+    const double y = xyz[ic * a.point_stride + a.comp_stride];
+    const double z = xyz[ic * a.point_stride + 2 * a.comp_stride];
+    const int img0 = blockIdx.y * kImgPerBlock;
+    const int img1 = min(img0 + kImgPerBlock, a.n_images);
+    const int64_t dpix = (int64_t)a.dh * a.dw;
+
+    for (int img = img0; img < img1; ++img) {
+        const double *__restrict__ Einv = cam_mats + (int64_t)img * 32;
+        const double *__restrict__ K = Einv + 16;
+        const uint16_t *__restrict__ dimg = depth + (int64_t)img * dpix;
+        // IH:57-69
+        const double qx = affine_row(Einv + 0, x, y, z);
+        const double qy = affine_row(Einv + 4, x, y, z);
+        const double qz = affine_row(Einv + 8, x, y, z);
+        const double ix = affine_row(K + 0, qx, qy, qz);
+        const double iy = affine_row(K + 4, qx, qy, qz);
+        const double iz = affine_row(K + 8, qx, qy, qz);
+        const double u = ix / iz, v = iy / iz;
+        int xi, yi;
+        const bool vis = depth_test(live, u, v, qz, dimg, a.dh, a.dw, a.H, a.W, a.sx, a.sy, xi, yi);
+
+        const unsigned long long word = __ballot(vis);
+        if (lane == 0) {
+            if (a.bits && (i < a.n_points)) a.bits[(int64_t)img * a.n_words + (i >> 6)] = word;
+            if (a.count) {
+                const int c = __popcll(word);
+                if (c) atomicAdd(a.count + img, c);
+            }
+        }
+        if (live) {
+            const int64_t o = (int64_t)img * a.n_points + i;
+            if (a.mask) a.mask[o] = vis ? 1 : 0;
+            if (a.uv) {
+                a.uv[2 * o + 0] = u;
+                a.uv[2 * o + 1] = v;
+            }
+            if (a.depth_out) a.depth_out[o] = qz;
+        }
+    }
+}
+
+}  // namespace mspa
+
+using namespace mspa;
+
+extern "C" int mspa_vertex_visibility(const double *xyz, int64_t n_points, int64_t point_stride,
+                                      int64_t comp_stride, const double *cam_mats, int32_t n_images,
+                                      const uint16_t *depth, int32_t dh, int32_t dw, int32_t H, int32_t W,
+                                      uint64_t *out_bits, uint8_t *out_mask, double *out_uv,
+                                      double *out_depth, int32_t *out_count, mspa_stream_t stream) {
+    if (!xyz || !cam_mats || !depth) return fail(MSPA_EINVAL, "mspa_vertex_visibility: null input pointer");
+    if (n_points < 0 || n_images < 0 || point_stride <= 0 || comp_stride <= 0)
+        return fail(MSPA_EINVAL, "mspa_vertex_visibility: bad count or stride");
+    if (dh < 2 || dw < 2 || H < 2 || W < 2 || dh > 32767 || dw > 32767 || H > 32767 || W > 32767)
+        return fail(MSPA_EINVAL, "mspa_vertex_visibility: image size out of range [2, 32767]");
+    hipStream_t s = (hipStream_t)stream;
+    if (out_count && n_images > 0) {
+        int rc = check_hip(hipMemsetAsync(out_count, 0, sizeof(int32_t) * n_images, s), "hipMemsetAsync(count)");
+        if (rc) return rc;
+    }
+    if (n_points == 0 || n_images == 0) return MSPA_OK;
+    VertexArgs a;
+    a.n_points = n_points; a.point_stride = point_stride; a.comp_stride = comp_stride;
+    a.n_images = n_images; a.dh = dh; a.dw = dw; a.H = H; a.W = W;
+    a.sx = (double)dw / (double)W;
+    a.sy = (double)dh / (double)H;
+    a.n_words = (n_points + 63) / 64;
+    a.bits = out_bits; a.mask = out_mask; a.uv = out_uv; a.depth_out = out_depth; a.count = out_count;
+    const int64_t bx = (n_points + kVThreads - 1) / kVThreads;
+    const int64_t by = (n_images + kImgPerBlock - 1) / kImgPerBlock;
+    if (bx > 0x7fffffffLL || by > 65535) return fail(MSPA_EINVAL, "mspa_vertex_visibility: batch too large; split it");
+    hipLaunchKernelGGL(vertex_visibility_kernel, dim3((uint32_t)bx, (uint32_t)by), dim3(kVThreads), 0, s, xyz, cam_mats, depth, a);
+    return check_hip(hipGetLastError(), "vertex_visibility_kernel launch");
+}

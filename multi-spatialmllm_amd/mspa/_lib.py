@@ -1,0 +1,79 @@
+"""ctypes binding of libmspa.so.  Fails loudly: no library, no engine."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_void_p, POINTER
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.environ.get("MSPA_LIB", os.path.join(_PKG_ROOT, "libmspa.so"))
+
+MSPA_OK, MSPA_EINVAL, MSPA_EHIP, MSPA_EUNSUPPORTED = 0, -1, -2, -3
+MAT_KINV, MAT_E, MAT_A, MAT_EINV_ALIGNED, MAT_K, FRAME_MATS = 0, 1, 2, 3, 4, 5
+
+
+class MspaError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libmspa error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/mspa.h one to one
+_SIGNATURES = {
+    "mspa_version": (c_int, []),
+    "mspa_last_error_string": (c_char_p, []),
+    "mspa_device_info": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int64), POINTER(c_int),
+                                 c_char_p, c_int]),
+    "mspa_pair_reproject": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64,
+                                    c_int32, c_int32, c_int32, c_int32,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
+    "mspa_vertex_visibility": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p,
+                                       c_int32, c_int32, c_int32, c_int32,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mspa_pair_overlap": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]),
+}
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"libmspa.so not found at {LIB_PATH}. Build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the geometry kernels.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError here = header and library out of sync
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return list(_SIGNATURES.keys())
+
+
+def check(rc: int):
+    if rc != MSPA_OK:
+        msg = load().mspa_last_error_string()
+        raise MspaError(rc, msg.decode() if msg else "unknown")
+
+
+def version() -> int:
+    return load().mspa_version()
+
+
+def device_info(device: int = 0) -> dict:
+    n_cu, wave, clock = c_int(0), c_int(0), c_int(0)
+    hbm = c_int64(0)
+    name = ctypes.create_string_buffer(64)
+    check(load().mspa_device_info(device, ctypes.byref(n_cu), ctypes.byref(wave), ctypes.byref(hbm),
+                                  ctypes.byref(clock), name, 64))
+    return {"name": name.value.decode(), "n_cu": n_cu.value, "wave_size": wave.value,
+            "hbm_bytes": hbm.value, "clock_khz": clock.value}

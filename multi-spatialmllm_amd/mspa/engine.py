@@ -1,0 +1,184 @@
+"""PyTorch-ROCm front end of the geometry kernels.
+
+torch is plumbing here: it owns device memory and the stream; every computation is a call into
+libmspa.so through ``data_ptr()``.  Host-side matrix preparation (``np.linalg.inv``, ``A @ E``)
+uses the very NumPy routines the reference uses (IH:57, IH:113-124, OPS:313) so that what reaches
+the kernels is bit-identical to what the reference would multiply with.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_AFFINE_ROW = np.array([0.0, 0.0, 0.0, 1.0])
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("mspa.engine needs a ROCm GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback -- the CPU restatement under oracle/ is test-only")
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensors only"
+    return t.data_ptr()
+
+
+def check_affine(name: str, m: np.ndarray):
+    """The kernels take affine matrices with finite entries (include/mspa.h); the reference drops
+    frames with non-finite poses before any projection (IH:409-418)."""
+    m = np.asarray(m, dtype=np.float64)
+    if m.shape != (4, 4) or not np.all(np.isfinite(m)):
+        raise ValueError(f"{name}: expected a finite 4x4 matrix")
+    if not np.array_equal(m[3], _AFFINE_ROW):
+        raise ValueError(f"{name}: last row must be exactly [0, 0, 0, 1], got {m[3]}")
+    return m
+
+
+def frame_matrices(K: np.ndarray, A: Optional[np.ndarray], E_list: Sequence[np.ndarray]) -> np.ndarray:
+    """[F, 5, 16] float64 frame records for mspa_pair_reproject (slot order of include/mspa.h)."""
+    K = check_affine("K", K)
+    A = np.eye(4) if A is None else check_affine("A", A)
+    Kinv = check_affine("inv(K)", np.linalg.inv(K))                       # OPS:313
+    out = np.empty((len(E_list), _lib.FRAME_MATS, 16), dtype=np.float64)
+    for f, E in enumerate(E_list):
+        E = check_affine(f"E[{f}]", E)
+        Einv_al = check_affine(f"inv(A@E[{f}])", np.linalg.inv(A @ E))  # IH:113-124, IH:57
+        out[f, _lib.MAT_KINV] = Kinv.reshape(16)
+        out[f, _lib.MAT_E] = E.reshape(16)
+        out[f, _lib.MAT_A] = A.reshape(16)
+        out[f, _lib.MAT_EINV_ALIGNED] = Einv_al.reshape(16)
+        out[f, _lib.MAT_K] = K.reshape(16)
+    return out
+
+
+def camera_matrices(K: np.ndarray, E_aligned_list: Sequence[np.ndarray]) -> np.ndarray:
+    """[n, 2, 16] float64 records for mspa_vertex_visibility: inv(E_aligned), K."""
+    K = check_affine("K", K)
+    out = np.empty((len(E_aligned_list), 2, 16), dtype=np.float64)
+    for f, E in enumerate(E_aligned_list):
+        E = check_affine(f"E_aligned[{f}]", E)
+        out[f, 0] = check_affine("inv(E_aligned)", np.linalg.inv(E)).reshape(16)   # IH:57
+        out[f, 1] = K.reshape(16)
+    return out
+
+
+def depth_to_device(depth: np.ndarray, device="cuda") -> torch.Tensor:
+    """uint16 depth frames -> device int16 tensor holding the same bits (torch has few uint16 ops)."""
+    d = np.ascontiguousarray(depth, dtype=np.uint16)
+    return torch.from_numpy(d.view(np.int16)).to(device)
+
+
+PAIR_OUTPUTS = ("vis_bits", "vis_u8", "valid_u8", "pix_i16", "xyz_f32", "rgba", "xyz_f64", "uv_f64",
+                "depth_f64", "counts")
+
+
+def alloc_pair_outputs(n_pairs: int, image_hw: Tuple[int, int], outputs: Iterable[str], device="cuda"):
+    H, W = image_hw
+    P = H * W
+    shapes = {
+        "vis_bits": ((n_pairs, (P + 63) // 64), torch.int64),
+        "vis_u8": ((n_pairs, P), torch.uint8),
+        "valid_u8": ((n_pairs, P), torch.uint8),
+        "pix_i16": ((n_pairs, P, 2), torch.int16),
+        "xyz_f32": ((n_pairs, P, 3), torch.float32),
+        "rgba": ((n_pairs, P), torch.int32),
+        "xyz_f64": ((n_pairs, P, 3), torch.float64),
+        "uv_f64": ((n_pairs, P, 2), torch.float64),
+        "depth_f64": ((n_pairs, P), torch.float64),
+        "counts": ((n_pairs, 2), torch.int32),
+    }
+    out = {}
+    for name in outputs:
+        if name not in shapes:
+            raise ValueError(f"unknown pair output {name!r}; choose from {PAIR_OUTPUTS}")
+        shape, dtype = shapes[name]
+        out[name] = torch.empty(shape, dtype=dtype, device=device)
+    return out
+
+
+def pair_reproject(depth: torch.Tensor, mats: torch.Tensor, pairs: torch.Tensor, image_hw: Tuple[int, int],
+                   out: Dict[str, torch.Tensor], rgb: Optional[torch.Tensor] = None, flags: int = 0):
+    """Enqueue K3 on the current stream.  depth [F,DH,DW] int16(bits of uint16), mats [F,5,16] f64,
+    pairs [B,2] int32, rgb [F,H,W,3] uint8 (only for out['rgba']).  ``out`` comes from
+    alloc_pair_outputs and is filled in place."""
+    _require_gpu()
+    lib = _lib.load()
+    assert depth.dtype in (torch.int16, torch.uint16) and depth.dim() == 3
+    assert mats.dtype == torch.float64 and mats.shape[1:] == (_lib.FRAME_MATS, 16)
+    assert pairs.dtype == torch.int32 and pairs.dim() == 2 and pairs.shape[1] == 2
+    F, DH, DW = depth.shape
+    assert mats.shape[0] == F
+    H, W = image_hw
+    if rgb is not None:
+        assert rgb.dtype == torch.uint8 and tuple(rgb.shape) == (F, H, W, 3)
+    g = lambda k: _ptr(out.get(k))
+    _lib.check(lib.mspa_pair_reproject(
+        _ptr(depth), _ptr(rgb), _ptr(mats), F, _ptr(pairs), pairs.shape[0], DH, DW, H, W,
+        g("vis_bits"), g("vis_u8"), g("valid_u8"), g("pix_i16"), g("xyz_f32"), g("rgba"),
+        g("xyz_f64"), g("uv_f64"), g("depth_f64"), g("counts"), flags, _stream_ptr()))
+    return out
+
+
+def vertex_visibility(xyz: torch.Tensor, cam_mats: torch.Tensor, depth: torch.Tensor, image_hw: Tuple[int, int],
+                      want: Iterable[str] = ("bits", "count")) -> Dict[str, torch.Tensor]:
+    """Enqueue K1.  xyz [N,3] or [N,C>=3] float64 rows (or a [3,N] SoA tensor with soa=True layout
+    given as xyz.t()); cam_mats [I,2,16]; depth [I,DH,DW].  Returns the requested outputs."""
+    _require_gpu()
+    lib = _lib.load()
+    assert xyz.dtype == torch.float64 and xyz.dim() == 2 and xyz.is_cuda
+    n = xyz.shape[0]
+    ps, cs = xyz.stride(0), xyz.stride(1)
+    assert xyz.shape[1] >= 3 and ps > 0 and cs > 0
+    I, DH, DW = depth.shape
+    assert cam_mats.dtype == torch.float64 and tuple(cam_mats.shape) == (I, 2, 16)
+    H, W = image_hw
+    dev = xyz.device
+    out: Dict[str, torch.Tensor] = {}
+    want = tuple(want)
+    if "bits" in want:
+        out["bits"] = torch.empty((I, (n + 63) // 64), dtype=torch.int64, device=dev)
+    if "mask" in want:
+        out["mask"] = torch.empty((I, n), dtype=torch.uint8, device=dev)
+    if "uv" in want:
+        out["uv"] = torch.empty((I, n, 2), dtype=torch.float64, device=dev)
+    if "depth" in want:
+        out["depth"] = torch.empty((I, n), dtype=torch.float64, device=dev)
+    if "count" in want:
+        out["count"] = torch.empty((I,), dtype=torch.int32, device=dev)
+    assert cam_mats.is_contiguous() and depth.is_contiguous()
+    _lib.check(lib.mspa_vertex_visibility(
+        xyz.data_ptr(), n, ps, cs, cam_mats.data_ptr(), I, depth.data_ptr(), DH, DW, H, W,
+        _ptr(out.get("bits")), _ptr(out.get("mask")), _ptr(out.get("uv")), _ptr(out.get("depth")),
+        _ptr(out.get("count")), _stream_ptr()))
+    return out
+
+
+def all_pairs(n: int, device="cuda") -> torch.Tensor:
+    """(i, j), i < j, in the row-major order of the reference's nested loops (CFR:176-178)."""
+    return torch.triu_indices(n, n, offset=1, device=device).t().contiguous().to(torch.int32)
+
+
+def pair_overlap(bits: torch.Tensor, pairs: torch.Tensor, want_counts: bool = False):
+    """Enqueue K2 on K1's bitsets.  Returns overlap [n_pairs] f64 (+ inter, union int32)."""
+    _require_gpu()
+    lib = _lib.load()
+    assert bits.dtype == torch.int64 and bits.dim() == 2 and bits.is_contiguous()
+    assert pairs.dtype == torch.int32 and pairs.dim() == 2 and pairs.shape[1] == 2 and pairs.is_contiguous()
+    n_pairs = pairs.shape[0]
+    overlap = torch.empty((n_pairs,), dtype=torch.float64, device=bits.device)
+    inter = torch.empty((n_pairs,), dtype=torch.int32, device=bits.device) if want_counts else None
+    uni = torch.empty((n_pairs,), dtype=torch.int32, device=bits.device) if want_counts else None
+    _lib.check(lib.mspa_pair_overlap(bits.data_ptr(), bits.shape[0], bits.shape[1], pairs.data_ptr(), n_pairs,
+                                     overlap.data_ptr(), _ptr(inter), _ptr(uni), _stream_ptr()))
+    return (overlap, inter, uni) if want_counts else overlap

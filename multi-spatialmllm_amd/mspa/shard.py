@@ -1,0 +1,104 @@
+"""One process per GPU: shard frame pairs / scenes across ranks, collate records over RCCL.
+
+The geometry path shards embarrassingly: frame pairs (K3), (scene, image)
+projections (K1) and scenes (K2, which needs all bitsets of one scene) share nothing, so there is
+NO collective on the data path.  The one exchange step is the collation of the per-pair / per-scene
+numeric records at the end: an all_gather of the record counts followed by an all_gather of the
+padded fixed-width record tensors (RCCL over xGMI when the backend is "nccl"; the same code runs on
+gloo/CPU tensors for the world_size-2 tests).  Text templating happens on the host after it.
+"""
+from __future__ import annotations
+
+import dataclasses
+import datetime
+import os
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+@dataclasses.dataclass
+class DistContext:
+    rank: int
+    world: int
+    device: torch.device
+    group: object = None
+    owns_process_group: bool = False
+
+    def barrier(self):
+        if self.device.type == "cuda":
+            dist.barrier(group=self.group, device_ids=[self.device.index])
+        else:
+            dist.barrier(group=self.group)
+
+    def max_over_ranks(self, x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def close(self):
+        if self.owns_process_group and dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def init_distributed(device: torch.device, backend: str = None, timeout_s: int = 600) -> DistContext:
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run)."""
+    backend = backend or ("nccl" if device.type == "cuda" else "gloo")   # "nccl" IS RCCL on ROCm
+    owns = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kwargs = {}
+        if device.type == "cuda":
+            kwargs["device_id"] = device
+        dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
+        owns = True
+    return DistContext(dist.get_rank(), dist.get_world_size(), device, None, owns)
+
+
+def partition(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced [start, stop) range of a flat work list (config-2 style pair lists)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def lpt_assign(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Longest-processing-time-first assignment of scenes to ranks (cost ~ F^2*N/64 + F*N)."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0.0] * world
+    bins: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        bins[r].append(i)
+        load[r] += costs[i]
+    for b in bins:
+        b.sort()
+    return bins
+
+
+def scene_cost(n_frames: int, n_points: int) -> float:
+    return float(n_frames) ** 2 * n_points / 64.0 + float(n_frames) * n_points
+
+
+def collate_records(local: torch.Tensor, ctx: DistContext) -> torch.Tensor:
+    """all_gather a [n_local, k] record tensor whose n_local may differ per rank.
+
+    Two collectives: counts (one int64 per rank), then the records padded to the largest count.
+    Returns the concatenation in rank order, identical on every rank."""
+    assert local.dim() == 2
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros_like(n_local) for _ in range(ctx.world)]
+    dist.all_gather(counts, n_local, group=ctx.group)
+    counts = [int(c.item()) for c in counts]
+    n_max = max(counts)
+    if n_max == local.shape[0]:
+        padded = local.contiguous()
+    else:
+        padded = torch.zeros((n_max, local.shape[1]), dtype=local.dtype, device=local.device)
+        padded[:local.shape[0]] = local
+    gathered = torch.empty((ctx.world * n_max, local.shape[1]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, padded, group=ctx.group)
+    if all(c == n_max for c in counts):
+        return gathered
+    return torch.cat([gathered[r * n_max:r * n_max + c] for r, c in enumerate(counts)], dim=0)

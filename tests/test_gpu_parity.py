@@ -1,0 +1,324 @@
+"""HIP path (through the C ABI of include/mspa.h) against the oracles and the frozen reference outputs.
+
+Bars (BASELINE.json north_star): visibility masks, pixel indices, counts and overlap ratios are
+bit-exact; float64 products are bit-identical to the C oracle (same operation order) and within
+1e-9 relative (bar: 1e-5) of the NumPy oracle / reference; float32 points equal float32(oracle).
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import GoldenScene, close_f64, same_f64
+from mspa import engine, synth, _lib
+from oracle import c_oracle as C
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def nan_equal_bits(a, b):
+    """Bit-identical where finite/inf, NaN where NaN (NaN payload/sign is not part of the contract)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    na, nb = np.isnan(a), np.isnan(b)
+    return a.shape == b.shape and np.array_equal(na, nb) and \
+        np.array_equal(np.where(na, 0.0, a).view(np.int64), np.where(nb, 0.0, b).view(np.int64))
+
+
+def upload_scene(g, frame_ids):
+    depth = engine.depth_to_device(np.stack([g.depth[i] for i in frame_ids]), DEV)
+    mats = torch.from_numpy(engine.frame_matrices(g.K, g.A, [g.E[i] for i in frame_ids])).to(DEV)
+    rgb = None
+    if g.color:
+        rgb = torch.from_numpy(np.stack([g.color[i] for i in frame_ids])).to(DEV)
+    return depth, mats, rgb
+
+
+ALL_OUT = ("vis_bits", "vis_u8", "valid_u8", "pix_i16", "xyz_f32", "xyz_f64", "uv_f64", "depth_f64", "counts")
+
+
+def run_pairs(g, frame_ids, pair_idx, outputs=ALL_OUT):
+    depth, mats, rgb = upload_scene(g, frame_ids)
+    pairs = torch.tensor(pair_idx, dtype=torch.int32, device=DEV).reshape(-1, 2)
+    outs = tuple(outputs) + (("rgba",) if rgb is not None else ())
+    out = engine.alloc_pair_outputs(len(pair_idx), g.color_hw, outs, DEV)
+    for t in out.values():
+        t.fill_(0x5A if t.dtype in (torch.uint8,) else 0)   # poison: every element must be written
+    engine.pair_reproject(depth, mats, pairs, g.color_hw, out, rgb=rgb)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def unpack_bits(words, n):
+    b = np.unpackbits(words.view(np.uint8), bitorder="little")
+    return b[:n].astype(bool)
+
+
+def check_pair_against(res, n, ref_c, ref_np, image_hw, color=None):
+    H, W = image_hw
+    P = H * W
+    valid = ref_c["valid"]
+    assert np.array_equal(res["valid_u8"][n].astype(bool), valid)
+    assert np.array_equal(res["vis_u8"][n].astype(bool), ref_c["vis"])
+    assert np.array_equal(res["vis_u8"][n].astype(bool), ref_np["vis"])
+    assert np.array_equal(unpack_bits(res["vis_bits"][n], P), ref_np["vis"])
+    assert not unpack_bits(res["vis_bits"][n], res["vis_bits"][n].size * 64)[P:].any()
+    assert tuple(res["counts"][n]) == (ref_np["n_valid"], ref_np["n_vis"])
+    pix = res["pix_i16"][n]
+    assert np.array_equal(pix[valid, 0], ref_np["xi"][valid]) and np.array_equal(pix[valid, 1], ref_np["yi"][valid])
+    assert (pix[~valid] == -1).all()
+    # float64: bit-identical to the C oracle, tight against NumPy
+    assert nan_equal_bits(res["xyz_f64"][n], ref_c["xyz"])
+    assert nan_equal_bits(res["uv_f64"][n], ref_c["uv2"])
+    assert nan_equal_bits(res["depth_f64"][n], ref_c["depth2"])
+    assert close_f64(res["xyz_f64"][n], ref_np["xyz"], rtol=1e-9, scale=1e-3)
+    assert close_f64(res["uv_f64"][n][valid], ref_np["uv2"][valid], rtol=1e-9, scale=1e-3)
+    assert close_f64(res["depth_f64"][n], ref_np["depth2"], rtol=1e-9, scale=1e-3)
+    f32 = res["xyz_f32"][n]
+    assert np.array_equal(f32[valid], ref_c["xyz"][valid].astype(np.float32))
+    assert np.isnan(f32[~valid]).all()
+    if color is not None and "rgba" in res:
+        rgba = res["rgba"][n].view(np.uint32)
+        exp = color.reshape(-1, 3).astype(np.uint32)
+        exp = exp[:, 0] | (exp[:, 1] << 8) | (exp[:, 2] << 16) | np.where(valid, 0xFF000000, 0).astype(np.uint32)
+        assert np.array_equal(rgba, exp)
+
+
+@pytest.mark.parametrize("name", ["scene_ident", "scene_scaled"])
+def test_pair_reproject_golden(name):
+    """K3 against the reference's frozen outputs (tests/golden) and both oracles."""
+    g = GoldenScene(name)
+    ids = g.valid_image_ids
+    fidx = {i: n for n, i in enumerate(ids)}
+    pair_ids = [(str(a), str(b)) for a, b in g["pair_ids"]]
+    res = run_pairs(g, ids, [(fidx[a], fidx[b]) for a, b in pair_ids])
+    H, W = g.color_hw
+    for n, (id1, id2) in enumerate(pair_ids):
+        col = g.color.get(id1)
+        ref_np = O.frame_pair(g.depth[id1], g.depth[id2], g.K, g.E[id1], g.E[id2], g.A, g.color_hw,
+                              col if col is not None else np.zeros((H, W, 3), np.uint8))
+        ref_c = C.frame_pair(g.depth[id1], g.depth[id2], g.K, g.E[id1], g.E[id2], g.A, g.color_hw)
+        check_pair_against(res, n, ref_c, ref_np, g.color_hw, col)
+        # and straight against the reference arrays
+        v = res["valid_u8"][n].astype(bool)
+        assert np.array_equal(res["vis_u8"][n].astype(bool)[v], g[f"pair{n}_vis"])
+        assert close_f64(res["xyz_f64"][n][v], g[f"pair{n}_xyzrgb"][:, :3], rtol=1e-9, scale=1e-3)
+        assert close_f64(res["uv_f64"][n][v], g[f"pair{n}_uv"], rtol=1e-9, scale=1e-3)
+        assert close_f64(res["depth_f64"][n][v], g[f"pair{n}_depth"], rtol=1e-9, scale=1e-3)
+
+
+@pytest.mark.parametrize("color_hw,depth_hw", [((480, 640), (480, 640)), ((968, 1296), (480, 640)),
+                                               ((61, 83), (37, 53))])
+def test_pair_reproject_seeded(color_hw, depth_hw):
+    """Seeded scenes at BASELINE sizes (and an odd ragged size): every output of every pixel."""
+    sc = synth.make_scene(1003, n_points=64, n_frames=4, color_hw=color_hw, depth_hw=depth_hw,
+                          invalid_pose_frac=0.0, with_color=(color_hw[0] <= 480))
+    ids = sc.valid_image_ids
+    pair_idx = [(0, 1), (2, 0), (3, 3)]
+    res = run_pairs(sc, ids, pair_idx)
+    H, W = color_hw
+    for n, (a, b) in enumerate(pair_idx):
+        id1, id2 = ids[a], ids[b]
+        col = sc.color.get(id1)
+        ref_np = O.frame_pair(sc.depth[id1], sc.depth[id2], sc.K, sc.E[id1], sc.E[id2], sc.A, color_hw,
+                              col if col is not None else np.zeros((H, W, 3), np.uint8))
+        ref_c = C.frame_pair(sc.depth[id1], sc.depth[id2], sc.K, sc.E[id1], sc.E[id2], sc.A, color_hw)
+        check_pair_against(res, n, ref_c, ref_np, color_hw, col)
+        assert ref_np["n_vis"] > 0
+
+
+def test_pair_reproject_minimal_outputs_and_empty():
+    sc = synth.make_scene(1004, n_points=64, n_frames=3, color_hw=(48, 64), depth_hw=(48, 64), invalid_pose_frac=0)
+    ids = sc.valid_image_ids
+    res = run_pairs(sc, ids, [(0, 1), (1, 2)], outputs=("vis_bits", "counts"))
+    full = run_pairs(sc, ids, [(0, 1), (1, 2)])
+    assert np.array_equal(res["vis_bits"], full["vis_bits"]) and np.array_equal(res["counts"], full["counts"])
+    # zero pairs is a no-op, not an error
+    depth, mats, rgb = upload_scene(sc, ids)
+    out = engine.alloc_pair_outputs(0, sc.color_hw, ("vis_bits", "counts"), DEV)
+    engine.pair_reproject(depth, mats, torch.zeros((0, 2), dtype=torch.int32, device=DEV), sc.color_hw, out)
+    torch.cuda.synchronize()
+
+
+def test_pair_reproject_errors():
+    sc = synth.make_scene(1004, n_points=64, n_frames=2, color_hw=(48, 64), depth_hw=(48, 64), invalid_pose_frac=0)
+    ids = sc.valid_image_ids
+    depth, mats, rgb = upload_scene(sc, ids)
+    pairs = torch.tensor([[0, 1]], dtype=torch.int32, device=DEV)
+    out = engine.alloc_pair_outputs(1, sc.color_hw, ("rgba",), DEV)
+    with pytest.raises(_lib.MspaError) as e:
+        engine.pair_reproject(depth, mats, pairs, sc.color_hw, out, rgb=None)       # rgba without rgb
+    assert e.value.code == _lib.MSPA_EINVAL
+    out = engine.alloc_pair_outputs(1, sc.color_hw, ("counts",), DEV)
+    with pytest.raises(_lib.MspaError) as e:
+        engine.pair_reproject(depth, mats, pairs, sc.color_hw, out, flags=1 << 7)   # unknown flag
+    assert e.value.code == _lib.MSPA_EINVAL
+    bad = sc.E[ids[0]].copy()
+    bad[3, 0] = 1e-9
+    with pytest.raises(ValueError):
+        engine.frame_matrices(sc.K, sc.A, [bad])
+    with pytest.raises(ValueError):
+        engine.frame_matrices(sc.K, sc.A, [np.full((4, 4), -np.inf)])
+
+
+# ------------------------------------------------------------------------------------------
+# K1 vertex visibility
+# ------------------------------------------------------------------------------------------
+def run_vertices(points_t, K, A, E_list, depth_list, image_hw, want=("bits", "mask", "uv", "depth", "count")):
+    cam = torch.from_numpy(engine.camera_matrices(K, [A @ E for E in E_list])).to(DEV)
+    depth = engine.depth_to_device(np.stack(depth_list), DEV)
+    out = engine.vertex_visibility(points_t, cam, depth, image_hw, want)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("name", ["scene_ident", "scene_scaled", "ties"])
+@pytest.mark.parametrize("layout", ["rows3", "rows6", "soa"])
+def test_vertex_visibility_golden(name, layout):
+    g = GoldenScene(name)
+    ids = g.valid_image_ids
+    pts = g.points
+    if layout == "rows3":
+        t = torch.from_numpy(np.ascontiguousarray(pts[:, :3])).to(DEV)
+    elif layout == "rows6":
+        t = torch.from_numpy(np.ascontiguousarray(pts)).to(DEV)[:, :3]          # aligned_points.npy as is
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(pts[:, :3].T)).to(DEV).t()     # [3,N] storage
+    res = run_vertices(t, g.K, g.A, [g.E[i] for i in ids], [g.depth[i] for i in ids], g.color_hw)
+    n = pts.shape[0]
+    for k, image_id in enumerate(ids):
+        ref_vis = g["ref_vis"][k] if g["ref_vis"].ndim == 2 else g["ref_vis"]
+        ref_uv = g["ref_uv"][k] if g["ref_uv"].ndim == 3 else g["ref_uv"]
+        ref_d = g["ref_depth"][k] if g["ref_depth"].ndim == 2 else g["ref_depth"]
+        assert np.array_equal(res["mask"][k].astype(bool), ref_vis)
+        assert np.array_equal(unpack_bits(res["bits"][k], n), ref_vis)
+        assert not unpack_bits(res["bits"][k], res["bits"][k].size * 64)[n:].any()
+        assert res["count"][k] == int(ref_vis.sum())
+        mc, uvc, dc = C.vertex_visibility(pts[:, :3], g.K, g.A @ g.E[image_id], g.depth[image_id], g.color_hw)
+        assert nan_equal_bits(res["uv"][k], uvc) and nan_equal_bits(res["depth"][k], dc)
+        fin = np.isfinite(ref_uv).all(axis=1)
+        assert close_f64(res["uv"][k][fin], ref_uv[fin], rtol=1e-9, scale=1e-3)
+        assert close_f64(res["depth"][k], ref_d, rtol=1e-9, scale=1e-3)
+        if name == "ties":   # exact arithmetic: bit-identical to the reference itself, inf/nan included
+            assert nan_equal_bits(res["uv"][k], ref_uv) and nan_equal_bits(res["depth"][k], ref_d)
+
+
+def test_vertex_visibility_scene_products():
+    """CFR.process_scene / MVI.process_scene rebuilt from K1 + K2 equal the reference's tables."""
+    g = GoldenScene("scene_ident")
+    ids = g.valid_image_ids
+    t = torch.from_numpy(np.ascontiguousarray(g.points[:, :3])).to(DEV)
+    cam = torch.from_numpy(engine.camera_matrices(g.K, [g.A @ g.E[i] for i in ids])).to(DEV)
+    depth = engine.depth_to_device(np.stack([g.depth[i] for i in ids]), DEV)
+    out = engine.vertex_visibility(t, cam, depth, g.color_hw, ("bits", "mask"))
+    pairs = engine.all_pairs(len(ids), DEV)
+    overlap, inter, uni = engine.pair_overlap(out["bits"], pairs, want_counts=True)
+    torch.cuda.synchronize()
+    keys = [(ids[i], ids[j]) for i, j in pairs.cpu().numpy()]
+    assert keys == [tuple(str(s) for s in k) for k in g["cfr_pairs"]]
+    assert same_f64(overlap.cpu().numpy(), g["cfr_values"][:, 0])
+    ref = g.json("mvi_json")
+    mask = out["mask"].cpu().numpy().astype(bool)
+    for k, image_id in enumerate(ids):
+        assert np.where(mask[k])[0].tolist() == ref["image_to_points"][image_id]
+
+
+def test_vertex_visibility_large_and_edge():
+    sc = synth.make_scene(1005, n_points=131072 + 37, n_frames=11, color_hw=(480, 640), invalid_pose_frac=0,
+                          with_color=False)
+    ids = sc.valid_image_ids
+    t = torch.from_numpy(np.ascontiguousarray(sc.points[:, :3])).to(DEV)
+    res = run_vertices(t, sc.K, sc.A, [sc.E[i] for i in ids], [sc.depth[i] for i in ids], sc.color_hw,
+                       want=("bits", "count", "mask"))
+    n = sc.points.shape[0]
+    for k, image_id in enumerate(ids):
+        m, _, _ = O.vertex_visibility(sc.points[:, :3], sc.K, sc.A @ sc.E[image_id], sc.depth[image_id], sc.color_hw)
+        assert np.array_equal(res["mask"][k].astype(bool), m)
+        assert np.array_equal(unpack_bits(res["bits"][k], n), m)
+        assert res["count"][k] == int(m.sum()) > 0
+    # empty inputs are no-ops
+    cam = torch.from_numpy(engine.camera_matrices(sc.K, [sc.A @ sc.E[ids[0]]])).to(DEV)
+    depth = engine.depth_to_device(sc.depth[ids[0]][None], DEV)
+    out = engine.vertex_visibility(torch.zeros((0, 3), dtype=torch.float64, device=DEV), cam, depth, sc.color_hw,
+                                   ("bits", "count"))
+    torch.cuda.synchronize()
+    assert out["bits"].shape == (1, 0) and int(out["count"][0]) == 0
+
+
+# ------------------------------------------------------------------------------------------
+# K2 pair overlap
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_bits", [64, 700, 4096 + 64, 131072])
+def test_pair_overlap(n_bits):
+    rng = np.random.default_rng(n_bits)
+    F = 9
+    masks = rng.random((F, n_bits)) < rng.random((F, 1)) * 0.4
+    masks[3] = False
+    masks[5] = False                       # an empty union -> NaN (CFR:136)
+    n_words = (n_bits + 63) // 64
+    padded = np.zeros((F, n_words * 64), dtype=bool)
+    padded[:, :n_bits] = masks
+    words = np.packbits(padded, axis=1, bitorder="little").view(np.int64)
+    bits = torch.from_numpy(np.ascontiguousarray(words)).to(DEV)
+    pairs = engine.all_pairs(F, DEV)
+    overlap, inter, uni = engine.pair_overlap(bits, pairs, want_counts=True)
+    torch.cuda.synchronize()
+    overlap, inter, uni = overlap.cpu().numpy(), inter.cpu().numpy(), uni.cpu().numpy()
+    for p, (i, j) in enumerate(pairs.cpu().numpy()):
+        ref = O.calculate_camera_overlap(masks[i], masks[j])
+        c, ci, cu = C.pair_overlap(masks[i], masks[j])
+        assert inter[p] == ci == int((masks[i] & masks[j]).sum()) and uni[p] == cu
+        if np.isnan(ref):
+            assert np.isnan(overlap[p]) and (i, j) == (3, 5)
+        else:
+            assert same_f64(overlap[p], ref)
+
+
+# ------------------------------------------------------------------------------------------
+# size-independent properties at BASELINE.json's full configuration (config 2: 1k 640x480 pairs)
+# ------------------------------------------------------------------------------------------
+def test_full_size_properties():
+    sc = synth.make_scene(1006, n_points=64, n_frames=12, color_hw=(480, 640), invalid_pose_frac=0, with_color=False)
+    ids = sc.valid_image_ids
+    depth, mats, _ = upload_scene(sc, ids)
+    rng = np.random.default_rng(0)
+    n_pairs = 1000
+    pair_np = rng.integers(0, len(ids), size=(n_pairs, 2)).astype(np.int32)
+    pair_np[:len(ids)] = np.arange(len(ids))[:, None]            # identity pairs first
+    pairs = torch.from_numpy(pair_np).to(DEV)
+    P = 480 * 640
+    out = engine.alloc_pair_outputs(n_pairs, sc.color_hw, ("vis_bits", "pix_i16", "counts", "valid_u8"), DEV)
+    engine.pair_reproject(depth, mats, pairs, sc.color_hw, out)
+    # shard the same batch in two launches: results must not depend on batching / block mapping
+    out2 = engine.alloc_pair_outputs(n_pairs, sc.color_hw, ("vis_bits", "counts"), DEV)
+    h = 373
+    o_a = {k: v[:h] for k, v in out2.items()}
+    o_b = {k: v[h:] for k, v in out2.items()}
+    engine.pair_reproject(depth, mats, pairs[:h].contiguous(), sc.color_hw, o_a)
+    engine.pair_reproject(depth, mats, pairs[h:].contiguous(), sc.color_hw, o_b)
+    torch.cuda.synchronize()
+    assert torch.equal(out["vis_bits"], out2["vis_bits"]) and torch.equal(out["counts"], out2["counts"])
+    counts = out["counts"].cpu().numpy()
+    bits = out["vis_bits"].cpu().numpy()
+    pop = np.unpackbits(bits.view(np.uint8), axis=1).sum(axis=1)
+    assert np.array_equal(pop, counts[:, 1])                      # checksum of the bitset == counter
+    assert (counts[:, 1] <= counts[:, 0]).all() and (counts[:, 0] <= P).all()
+    valid = out["valid_u8"].cpu().numpy()
+    assert np.array_equal(valid.sum(axis=1), counts[:, 0])
+    # valid count only depends on frame 1
+    zero_frac = np.array([(sc.depth[i] == 0).mean() for i in ids])
+    assert np.allclose(1 - counts[:, 0] / P, zero_frac[pair_np[:, 0]], atol=1e-12)
+    # identity pairs: every valid pixel reprojects onto itself
+    pix = out["pix_i16"][:len(ids)].cpu().numpy()
+    my, mx = np.divmod(np.arange(P), 640)
+    for k in range(len(ids)):
+        v = valid[k].astype(bool)
+        assert np.array_equal(pix[k][v, 0], mx[v]) and np.array_equal(pix[k][v, 1], my[v])
+    # spot-check three random pairs of the big batch against the oracle
+    for p in (len(ids) + 1, 500, 999):
+        a, b = ids[pair_np[p, 0]], ids[pair_np[p, 1]]
+        ref = C.frame_pair(sc.depth[a], sc.depth[b], sc.K, sc.E[a], sc.E[b], sc.A, sc.color_hw)
+        assert np.array_equal(unpack_bits(bits[p], P), ref["vis"])
+        assert tuple(counts[p]) == (ref["n_valid"], ref["n_vis"])

@@ -1,0 +1,135 @@
+"""Host-side logic that needs no GPU: the C-ABI surface, matrix preparation, sharding + collation."""
+import ctypes
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from mspa import _lib, engine, shard, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mspa.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(mspa_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no declarations parsed from include/mspa.h"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mspa.h but not exported by libmspa.so"
+    assert sorted(_lib.exported_symbols()) == declared, "mspa/_lib.py signatures out of sync with the header"
+    assert _lib.version() == int(re.search(r"#define MSPA_VERSION (\d+)", header).group(1))
+
+
+def test_error_reporting_without_gpu_calls():
+    lib = _lib.load()
+    # argument validation happens before any HIP call, so it is checkable on a CPU-only box
+    rc = lib.mspa_pair_overlap(None, 1, 1, None, 0, None, None, None, None)
+    assert rc == _lib.MSPA_EINVAL and b"null pointer" in lib.mspa_last_error_string()
+    rc = lib.mspa_pair_reproject(None, None, None, 1, None, 0, 480, 640, 480, 640, *([None] * 10), 0, None)
+    assert rc == _lib.MSPA_EINVAL
+    with pytest.raises(_lib.MspaError):
+        _lib.check(rc)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_engine_refuses_to_run_without_gpu():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        engine.pair_overlap(torch.zeros((2, 2), dtype=torch.int64), torch.zeros((1, 2), dtype=torch.int32))
+
+
+def test_matrix_preparation_matches_numpy():
+    sc = synth.make_scene(5, n_points=16, n_frames=3, color_hw=(24, 32), depth_hw=(24, 32), invalid_pose_frac=0,
+                          with_color=False)
+    E = [sc.E[i] for i in sc.valid_image_ids]
+    m = engine.frame_matrices(sc.K, sc.A, E)
+    assert m.shape == (3, 5, 16) and m.dtype == np.float64
+    for f in range(3):
+        assert np.array_equal(m[f, _lib.MAT_KINV].reshape(4, 4), np.linalg.inv(sc.K))
+        assert np.array_equal(m[f, _lib.MAT_E].reshape(4, 4), E[f])
+        assert np.array_equal(m[f, _lib.MAT_EINV_ALIGNED].reshape(4, 4), np.linalg.inv(sc.A @ E[f]))
+    c = engine.camera_matrices(sc.K, [sc.A @ e for e in E])
+    assert np.array_equal(c[1, 0].reshape(4, 4), np.linalg.inv(sc.A @ E[1]))
+    with pytest.raises(ValueError):
+        engine.frame_matrices(sc.K, sc.A, [np.full((4, 4), np.nan)])
+
+
+def test_partition_and_lpt():
+    for n in (0, 1, 7, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [shard.partition(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    costs = [shard.scene_cost(f, 131072) for f in (300, 20, 64, 64, 500, 90, 10, 250, 250)]
+    bins = shard.lpt_assign(costs, 3)
+    assert sorted(i for b in bins for i in b) == list(range(len(costs)))
+    loads = [sum(costs[i] for i in b) for b in bins]
+    assert max(loads) <= sum(costs) / 3 + max(costs)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p in (os.path.join(ROOT, "multi-spatialmllm_amd"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from mspa import shard as S, synth as Y
+    from oracle import np_oracle as O
+    ctx = S.init_distributed(torch.device("cpu"))
+    sc = Y.make_scene(31, n_points=16, n_frames=5, color_hw=(24, 32), depth_hw=(24, 32), invalid_pose_frac=0,
+                      with_color=False)
+    ids = sc.valid_image_ids
+    all_pairs = [(i, j) for i in range(len(ids)) for j in range(len(ids)) if i != j][:13]   # 13: uneven split
+    lo, hi = S.partition(len(all_pairs), world, rank)
+    recs = []
+    col = np.zeros((24, 32, 3), np.uint8)
+    for (i, j) in all_pairs[lo:hi]:      # the CPU stand-in for the per-rank kernel launch (tests only)
+        r = O.frame_pair(sc.depth[ids[i]], sc.depth[ids[j]], sc.K, sc.E[ids[i]], sc.E[ids[j]], sc.A, (24, 32), col)
+        recs.append([i, j, r["n_valid"], r["n_vis"]])
+    local = torch.tensor(recs, dtype=torch.int32).reshape(-1, 4)
+    full = S.collate_records(local, ctx)
+    t = ctx.max_over_ranks(float(rank + 1))
+    ctx.barrier()
+    q.put((rank, full.numpy().tolist(), t))
+    ctx.close()
+
+
+def test_shard_and_collate_gloo_world2():
+    import torch.multiprocessing as mp
+    from oracle import np_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sc = synth.make_scene(31, n_points=16, n_frames=5, color_hw=(24, 32), depth_hw=(24, 32), invalid_pose_frac=0,
+                          with_color=False)
+    ids = sc.valid_image_ids
+    all_pairs = [(i, j) for i in range(len(ids)) for j in range(len(ids)) if i != j][:13]
+    col = np.zeros((24, 32, 3), np.uint8)
+    expect = []
+    for (i, j) in all_pairs:
+        r = O.frame_pair(sc.depth[ids[i]], sc.depth[ids[j]], sc.K, sc.E[ids[i]], sc.E[ids[j]], sc.A, (24, 32), col)
+        expect.append([i, j, r["n_valid"], r["n_vis"]])
+    for rank, full, t in results:
+        assert full == expect, f"rank {rank}: collated records differ from the single-process table"
+        assert t == 2.0
