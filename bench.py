@@ -52,9 +52,13 @@ def parse_args():
     ap.add_argument("--frames", type=int, default=2048, help="distinct device-resident frames per GPU")
     ap.add_argument("--base-frames", type=int, default=24, help="frames rendered on the host per GPU")
     ap.add_argument("--variant", choices=sorted(VARIANTS), default="corr")
+    ap.add_argument("--mode", choices=("fast", "exact"), default="fast",
+                    help="fast: MSPA_PAIR_FAST (bit-exact integers via guarded composed matrices); exact: the "
+                         "reference's own operation order")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--also", default="dense", help="comma list of extra variants timed briefly (rank 0 report)")
+    ap.add_argument("--also", default="corr:exact,dense:fast,dense:exact,minimal:fast",
+                    help="comma list of extra variant:mode legs timed briefly on rank 0")
     return ap.parse_args()
 
 
@@ -81,7 +85,7 @@ def build_inputs(args, rank, device):
         depth[r * nb:(r + 1) * nb] = d.to(torch.int16)      # same 16 bits; the kernels read them as uint16
     mats = torch.from_numpy(np.tile(base_mats, (reps, 1, 1))).to(device)
     rgb = None
-    if VARIANTS[args.variant]["rgb"] or any(VARIANTS[v]["rgb"] for v in args.also.split(",") if v):
+    if VARIANTS[args.variant]["rgb"] or any(VARIANTS[v.split(":")[0]]["rgb"] for v in args.also.split(",") if v):
         rgb = torch.randint(0, 256, (n_frames, H, W, 3), generator=g, device=device, dtype=torch.uint8)
     # pairs: two different views of the same replica, walking through all replicas
     rng = np.random.default_rng(77 + rank)
@@ -93,12 +97,14 @@ def build_inputs(args, rank, device):
     return sc, ids, depth, mats, rgb, pairs, pairs_np, nb
 
 
-def time_variant(variant, depth, mats, rgb, pairs, steps, warmup, dist_ctx):
+def time_variant(variant, mode, depth, mats, rgb, pairs, steps, warmup, dist_ctx):
     """Returns (wall seconds for `steps` steps, mean kernel ms from HIP events, outputs)."""
     import torch
     from mspa import engine, shard
 
+    from mspa import _lib
     spec = VARIANTS[variant]
+    flags = _lib.PAIR_FAST if mode == "fast" else 0
     out = engine.alloc_pair_outputs(pairs.shape[0], (H, W), spec["outputs"], depth.device)
     rgb_in = rgb if spec["rgb"] else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -106,7 +112,7 @@ def time_variant(variant, depth, mats, rgb, pairs, steps, warmup, dist_ctx):
     def step(k=None):
         if k is not None:
             ev[k][0].record()
-        engine.pair_reproject(depth, mats, pairs, (H, W), out, rgb=rgb_in)
+        engine.pair_reproject(depth, mats, pairs, (H, W), out, rgb=rgb_in, flags=flags)
         if k is not None:
             ev[k][1].record()
         if dist_ctx is not None:
@@ -169,7 +175,8 @@ def main():
     dist_ctx = shard.init_distributed(device) if world > 1 else None
 
     sc, ids, depth, mats, rgb, pairs, pairs_np, nb = build_inputs(args, rank, device)
-    wall, kern_ms, out = time_variant(args.variant, depth, mats, rgb, pairs, args.steps, args.warmup, dist_ctx)
+    wall, kern_ms, out = time_variant(args.variant, args.mode, depth, mats, rgb, pairs, args.steps, args.warmup,
+                                      dist_ctx)
     if dist_ctx is not None:
         wall = dist_ctx.max_over_ranks(wall)
     pairs_per_step = args.pairs * world
@@ -180,10 +187,11 @@ def main():
 
     extra = {}
     if rank == 0:
-        for v in [v for v in args.also.split(",") if v and v != args.variant]:
-            w2, k2, _ = time_variant(v, depth, mats, rgb, pairs, max(3, args.steps // 4), 1, None)
+        for leg in [v for v in args.also.split(",") if v and v != f"{args.variant}:{args.mode}"]:
+            v, m = leg.split(":")
+            w2, k2, _ = time_variant(v, m, depth, mats, rgb, pairs, max(3, args.steps // 4), 1, None)
             b2 = VARIANTS[v]["bytes_per_px"] * P * args.pairs
-            extra[v] = {"pairs_per_s_1gpu": round(args.pairs / (k2 * 1e-3), 1), "kernel_ms": round(k2, 4),
+            extra[leg] = {"pairs_per_s_1gpu": round(args.pairs / (k2 * 1e-3), 1), "kernel_ms": round(k2, 4),
                         "achieved_GBs": round(b2 / (k2 * 1e-3) / 1e9, 1),
                         "frac": round(b2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "bytes_per_pair": int(VARIANTS[v]["bytes_per_px"] * P)}
@@ -209,15 +217,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": "visual_correspondence unproject+reproject+occlusion kernel (K3) on "
                                    f"{args.pairs} 640x480 frame pairs per GPU per step (BASELINE.json configs[1])",
-                       "variant": args.variant, "outputs": list(spec["outputs"]),
+                       "variant": args.variant, "mode": args.mode, "outputs": list(spec["outputs"]),
                        "pairs_per_step_per_gpu": args.pairs, "distinct_frames_per_gpu": int(depth.shape[0]),
                        "image": "640x480 depth u16 (+rgb u8x3 for dense)", "parallelism": f"dp{world}",
                        "collation": "RCCL all_gather of per-pair records" if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "mspa::pair_reproject_kernel", "kernel_ms": round(kern_ms, 4),
-                         "bytes_per_pair": int(spec["bytes_per_px"] * P),
-                         "note": "exact float64 chain: ~100 FP64 VALU ops/pixel, FP64-VALU co-limited (DESIGN.md)"},
+                         "kernel": "mspa::pair_fast_kernel" if args.mode == "fast" else "mspa::pair_exact_kernel",
+                         "kernel_ms": round(kern_ms, 4), "bytes_per_pair": int(spec["bytes_per_px"] * P)},
             "cpu_baseline": cpu,
             "variants": extra,
             "device": info,

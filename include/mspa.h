@@ -52,10 +52,16 @@ typedef void *mspa_stream_t;        /* hipStream_t */
 #define MSPA_MAT_A 2                /* A, world->aligned OPS:319-320 (identity when absent) */
 #define MSPA_MAT_EINV_ALIGNED 3     /* inv(A @ E)        IH:113-124, IH:57 */
 #define MSPA_MAT_K 4                /* K                 IH:66 */
-#define MSPA_FRAME_MATS 5
+#define MSPA_MAT_UNPROJ 5           /* A @ E @ inv(K)    composed on the host (fast path only) */
+#define MSPA_MAT_REPROJ 6           /* K @ inv(A @ E)    composed on the host (fast path only) */
+#define MSPA_FRAME_MATS 7
 
 /* flags of mspa_pair_reproject */
-#define MSPA_PAIR_FAST 1u           /* reserved: composed-matrix fast path with exact fallback */
+#define MSPA_PAIR_FAST 1u           /* composed-matrix evaluation with exact re-evaluation of every
+                                       lane near a decision boundary: masks, pixel indices and counters
+                                       stay bit-exact, float32 points agree to ~1e-12 relative.  Needs
+                                       slots 5/6 filled and K's third row == 0 0 1 0 (pinhole); ignored
+                                       when any float64 output is requested. */
 
 int mspa_version(void);
 const char *mspa_last_error_string(void);

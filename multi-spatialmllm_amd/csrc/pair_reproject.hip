@@ -1,19 +1,30 @@
 // K3: frame-pair back-projection -> reprojection -> depth-buffer visibility (see include/mspa.h).
 //
 // Mapping.  A workgroup of 256 threads (4 waves) owns a strip of kIters*256 consecutive pixels of
-// ONE pair; lanes take consecutive pixels so every depth/colour read and every output write is a
-// contiguous run per wave.  Blocks of one pair are numbered so that they land on one XCD
-// (hardware dispatches block b to XCD b % 8): the frame-2 depth image the pair gathers from
-// (600 KB) then stays in that XCD's 4 MB L2.  The five 3x4 matrices of the pair are read through
-// wave-uniform addresses (scalar loads into SGPRs, the operand v_fma_f64 takes for free); the
-// per-pixel chain lives in VGPRs.  No MFMA: this is point geometry, HBM/FP64-VALU bound.
+// ONE pair; lanes take consecutive pixels, so every depth/colour read and every output write is a
+// contiguous run per wave.  Blocks of one pair are numbered so that they land on one XCD (the
+// hardware dispatches block b to XCD b % 8): the frame-2 depth image the pair gathers from (600 KB)
+// then stays in that XCD's 4 MB L2.  Camera matrices are read through wave-uniform addresses, i.e.
+// as scalar loads into SGPRs -- the one operand v_fma_f64 takes for free -- while the per-pixel
+// chain lives in VGPRs.  No MFMA: this is point geometry, bound by HBM and the FP64 VALU.
+//
+// Two kernels behind one entry point:
+//   * pair_exact_kernel -- the reference's own operation order (five sequential 3x4 products, IEEE
+//     division).  Float64 outputs are bit-identical to the C oracle.  ~100 FP64 VALU ops / pixel,
+//     so it is FP64-issue bound, not HBM bound.
+//   * pair_fast_kernel (MSPA_PAIR_FAST) -- one composed 3x4 product + reciprocal (~35 ops/pixel).
+//     Every lane whose integer decisions (half-to-even rounding of the pixel index, the image
+//     bounds, the strict depth comparison) sit within a guard band of a decision boundary is
+//     re-evaluated with the exact chain, so masks, pixel indices and counters stay bit-exact; the
+//     guard (1e-6 px / 1e-9 m) is ~5 orders of magnitude wider than the worst rounding
+//     difference between the two evaluation orders ("Fast path").
 #include "mspa_common.h"
 
 namespace mspa {
 
 // Inputs are separate `const T *__restrict__` kernel parameters (not struct members) on purpose:
 // only then can the compiler prove the wave-uniform matrix/pair reads are never clobbered by the
-// kernel's own stores and issue them as scalar loads (s_load_dwordx8 -> SGPRs).
+// kernel's own stores and issue them as scalar loads (s_load_dwordx8/x16 -> SGPRs).
 struct PairArgs {
     int64_t n_pairs;
     int dh, dw, H, W;
@@ -33,39 +44,334 @@ struct PairArgs {
     int32_t *counts;
 };
 
+// Output sets.  A kernel instantiated with GENERIC = true tests every output pointer at run time
+// (wave-uniform branches); the specialised instances know their set at compile time, which frees
+// ~20 SGPRs of pointers and removes the dead stores' address arithmetic.
+enum : uint32_t {
+    O_VIS_BITS = 1u << 0, O_VIS_U8 = 1u << 1, O_VALID_U8 = 1u << 2, O_PIX = 1u << 3, O_XYZ32 = 1u << 4,
+    O_RGBA = 1u << 5, O_XYZ64 = 1u << 6, O_UV64 = 1u << 7, O_DEPTH64 = 1u << 8, O_COUNTS = 1u << 9,
+};
+constexpr uint32_t kSetCorr = O_VIS_BITS | O_PIX | O_COUNTS;                         // correspondence
+constexpr uint32_t kSetDense = O_VIS_U8 | O_PIX | O_XYZ32 | O_RGBA | O_COUNTS;       // coloured point cloud
+constexpr uint32_t kSetMinimal = O_VIS_BITS | O_COUNTS;                              // overlap only
+
+template <uint32_t SET, bool GENERIC>
+struct Outs {
+    template <uint32_t BIT, typename T>
+    static __device__ __forceinline__ bool has(T *ptr) {
+        return GENERIC ? (ptr != nullptr) : ((SET & BIT) != 0);
+    }
+};
+
 constexpr int kThreads = 256;
 constexpr int kIters = 16;                       // 4096 pixels per workgroup
 constexpr int kStrip = kThreads * kIters;
+constexpr int kGroup = 4;                        // pixels per lane processed between matrix reloads
 
-template <bool IDENT>
-__global__ __launch_bounds__(kThreads) void pair_reproject_kernel(const uint16_t *__restrict__ depth,
-                                                                  const uint8_t *__restrict__ rgb,
-                                                                  const double *__restrict__ mats,
-                                                                  const int32_t *__restrict__ pairs, PairArgs a) {
-    // XCD-aware decode: xcd = b % 8 picks the pair within a group of 8, the rest walks the strips.
+constexpr double kGuardPx = 1e-6;                // fast path: distance to a rounding/bounds boundary
+constexpr double kGuardZ = 1e-9;                 // fast path: distance to a depth-test boundary (m)
+
+// Makes a wave-uniform pointer opaque to LICM: loads through the result cannot be hoisted out of
+// the pixel loop, so at most one stage's matrices are live in SGPRs at a time (all five would
+// need 120 SGPRs; beyond ~100 the compiler spills them to VGPR lanes and every FMA pays a
+// v_readlane).
+// (The asm launders an SGPR *offset*, not the pointer: the pointer keeps its kernel-argument
+// provenance -- global address space, noalias -- so the loads stay scalar.)
+// `after` is a value the previous stage produced: the (empty) asm cannot issue before it exists,
+// which pins the matrix loads between the two stages instead of at the top of the loop body.
+__device__ __forceinline__ const double *opaque(const double *p, double after) {
+    int zero = 0;
+    asm volatile("" : "+s"(zero) : "v"(after));
+    return p + zero;
+}
+
+struct Pixel {
+    double ax, ay, az;     // aligned world point
+    double u, v, qz;       // projection into frame 2, camera-2 depth
+    int xi, yi;            // clipped depth-2 pixel index
+    bool vis;
+};
+
+// The exact chain (OPS:303-320, IH:57-69), one 3x4 product at a time over a group of kGroup pixels
+// so that only ONE matrix (24 SGPRs) has to be live at any point of the loop.
+template <int G>
+__device__ __forceinline__ void apply_affine(const double *m, double (&x)[G], double (&y)[G], double (&z)[G]) {
+    // sched_barrier: the machine scheduler must not interleave two products, or it keeps several
+    // matrices live and spills SGPRs to VGPR lanes (v_writelane/v_readlane on every operand).
+    __builtin_amdgcn_sched_barrier(0);
+    const double *__restrict__ mm = opaque(m, x[G - 1]);
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const double nx = affine_row(mm + 0, x[j], y[j], z[j]);
+        const double ny = affine_row(mm + 4, x[j], y[j], z[j]);
+        const double nz = affine_row(mm + 8, x[j], y[j], z[j]);
+        x[j] = nx;
+        y[j] = ny;
+        z[j] = nz;
+    }
+    // pin the results here: without this the optimiser sinks the products of pixels 1..G-1 past the
+    // next stages (down to their first use), which again keeps every matrix live across the body
+#pragma unroll
+    for (int j = 0; j < G; ++j) asm volatile("" : "+v"(x[j]), "+v"(y[j]), "+v"(z[j]));
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// single-pixel forms (cold path of the fast kernel)
+__device__ __forceinline__ void exact_unproject(const double *__restrict__ m1, double mxd, double myd, double d,
+                                                double &ax, double &ay, double &az) {
+    double x[1] = {mxd * d}, y[1] = {myd * d}, z[1] = {d};
+    apply_affine<1>(m1 + MSPA_MAT_KINV * 16, x, y, z);      // OPS:313
+    apply_affine<1>(m1 + MSPA_MAT_E * 16, x, y, z);         // OPS:316
+    apply_affine<1>(m1 + MSPA_MAT_A * 16, x, y, z);         // OPS:319-320
+    ax = x[0];
+    ay = y[0];
+    az = z[0];
+}
+
+__device__ __forceinline__ void exact_project(const double *__restrict__ m2, double ax, double ay, double az,
+                                              double &u, double &v, double &qz) {
+    double x[1] = {ax}, y[1] = {ay}, z[1] = {az};
+    apply_affine<1>(m2 + MSPA_MAT_EINV_ALIGNED * 16, x, y, z);   // IH:57-60
+    qz = z[0];                                                    // IH:63
+    apply_affine<1>(m2 + MSPA_MAT_K * 16, x, y, z);              // IH:66
+    u = x[0] / z[0];                                              // IH:69
+    v = y[0] / z[0];
+}
+
+struct Ctx {
+    const uint16_t *__restrict__ depth1;
+    const uint16_t *__restrict__ depth2;
+    const uint8_t *__restrict__ rgb1;
+    int64_t obase;
+    int64_t words_per_pair;
+    int64_t pair;
+    int lane;
+};
+
+// All per-pixel stores.  Every branch on an output pointer is wave-uniform (or compile-time).
+template <typename O>
+__device__ __forceinline__ void store_pixel(const PairArgs &a, const Ctx &c, uint32_t i, bool in_img, bool valid,
+                                            const Pixel &p) {
+    if (O::template has<O_VIS_BITS>(a.vis_bits)) {
+        const unsigned long long vmask = __ballot(p.vis);
+        if (c.lane == 0 && (i - c.lane) < a.P) a.vis_bits[c.pair * c.words_per_pair + ((i - c.lane) >> 6)] = vmask;
+    }
+    if (!in_img) return;
+    const int64_t o = c.obase + i;
+    if (O::template has<O_VIS_U8>(a.vis_u8)) a.vis_u8[o] = p.vis ? 1 : 0;
+    if (O::template has<O_VALID_U8>(a.valid_u8)) a.valid_u8[o] = valid ? 1 : 0;
+    if (O::template has<O_PIX>(a.pix_i16)) {
+        const uint32_t packed = valid ? ((uint32_t)(uint16_t)p.xi | ((uint32_t)(uint16_t)p.yi << 16)) : 0xFFFFFFFFu;
+        reinterpret_cast<uint32_t *>(a.pix_i16)[o] = packed;
+    }
+    if (O::template has<O_XYZ32>(a.xyz_f32)) {
+        float *q = a.xyz_f32 + 3 * o;
+        const float fn = __builtin_nanf("");
+        q[0] = valid ? (float)p.ax : fn;
+        q[1] = valid ? (float)p.ay : fn;
+        q[2] = valid ? (float)p.az : fn;
+    }
+    if (O::template has<O_RGBA>(a.rgba)) {
+        uint32_t col = 0;
+        if (c.rgb1) {
+            const uint8_t *s = c.rgb1 + 3 * (int64_t)i;
+            col = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
+        }
+        a.rgba[o] = col | (valid ? 0xFF000000u : 0u);
+    }
+    const double nan = __builtin_nan("");
+    if (O::template has<O_XYZ64>(a.xyz_f64)) {
+        double *q = a.xyz_f64 + 3 * o;
+        q[0] = valid ? p.ax : nan;
+        q[1] = valid ? p.ay : nan;
+        q[2] = valid ? p.az : nan;
+    }
+    if (O::template has<O_UV64>(a.uv_f64)) {
+        a.uv_f64[2 * o + 0] = valid ? p.u : nan;
+        a.uv_f64[2 * o + 1] = valid ? p.v : nan;
+    }
+    if (O::template has<O_DEPTH64>(a.depth_f64)) a.depth_f64[o] = valid ? p.qz : nan;
+}
+
+// wave reduce (bpermute shuffles), one LDS step, two atomics per workgroup
+template <typename O>
+__device__ __forceinline__ void flush_counts(const PairArgs &a, int64_t pair, int lane, int n_valid, int n_vis) {
+    if (!O::template has<O_COUNTS>(a.counts)) return;
+    for (int off = 32; off > 0; off >>= 1) {
+        n_valid += __shfl_down(n_valid, off);
+        n_vis += __shfl_down(n_vis, off);
+    }
+    __shared__ int red[2][kThreads / kWave];
+    const int w = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][w] = n_valid;
+        red[1][w] = n_vis;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sv = 0, ss = 0;
+        for (int j = 0; j < kThreads / kWave; ++j) {
+            sv += red[0][j];
+            ss += red[1][j];
+        }
+        atomicAdd(a.counts + 2 * pair + 0, sv);
+        atomicAdd(a.counts + 2 * pair + 1, ss);
+    }
+}
+
+// XCD-aware decode: xcd = b % 8 picks the pair within a group of 8, the rest walks the strips.
+__device__ __forceinline__ bool decode_block(const PairArgs &a, int64_t &pair, uint32_t &strip) {
     const uint32_t b = blockIdx.x;
     const uint32_t xcd = b & 7u;
     const uint32_t k = b >> 3;
-    const uint32_t strip = k % (uint32_t)a.strips;
-    const int64_t pair = (int64_t)(k / (uint32_t)a.strips) * 8 + xcd;
-    if (pair >= a.n_pairs) return;
+    strip = k % (uint32_t)a.strips;
+    pair = (int64_t)(k / (uint32_t)a.strips) * 8 + xcd;
+    return pair < a.n_pairs;
+}
 
+// depth sample of frame 1 under colour pixel (mx, my): OPS:272-294
+template <bool IDENT>
+__device__ __forceinline__ uint32_t sample_depth1(const PairArgs &a, const uint16_t *__restrict__ depth1, uint32_t ic,
+                                                  uint32_t mx, uint32_t my) {
+    if (IDENT) return depth1[ic];
+    const int dy = round_clip((double)my * a.sy, a.dh - 1);
+    const int dx = round_clip((double)mx * a.sx, a.dw - 1);
+    return depth1[dy * a.dw + dx];
+}
+
+template <bool IDENT>
+__global__ __launch_bounds__(kThreads) void pair_exact_kernel(const uint16_t *__restrict__ depth,
+                                                              const uint8_t *__restrict__ rgb,
+                                                              const double *__restrict__ mats,
+                                                              const int32_t *__restrict__ pairs, PairArgs a) {
+    int64_t pair;
+    uint32_t strip;
+    if (!decode_block(a, pair, strip)) return;
     const int f1 = pairs[2 * pair + 0];
     const int f2 = pairs[2 * pair + 1];
-    const double *__restrict__ m1 = mats + (int64_t)f1 * (MSPA_FRAME_MATS * 16);
-    const double *__restrict__ m2 = mats + (int64_t)f2 * (MSPA_FRAME_MATS * 16);
-    const double *__restrict__ Kinv = m1 + MSPA_MAT_KINV * 16;
-    const double *__restrict__ E1 = m1 + MSPA_MAT_E * 16;
-    const double *__restrict__ A = m1 + MSPA_MAT_A * 16;
-    const double *__restrict__ Einv2 = m2 + MSPA_MAT_EINV_ALIGNED * 16;
-    const double *__restrict__ K = m2 + MSPA_MAT_K * 16;
-
+    const double *m1 = mats + (int64_t)f1 * (MSPA_FRAME_MATS * 16);
+    const double *m2 = mats + (int64_t)f2 * (MSPA_FRAME_MATS * 16);
     const int64_t dpix = (int64_t)a.dh * a.dw;
-    const uint16_t *__restrict__ depth1 = depth + (int64_t)f1 * dpix;
-    const uint16_t *__restrict__ depth2 = depth + (int64_t)f2 * dpix;
-    const uint8_t *__restrict__ rgb1 = rgb ? rgb + (int64_t)f1 * a.P * 3 : nullptr;
-    const int64_t obase = pair * (int64_t)a.P;
-    const int lane = threadIdx.x & 63;
+    Ctx c;
+    c.depth1 = depth + (int64_t)f1 * dpix;
+    c.depth2 = depth + (int64_t)f2 * dpix;
+    c.rgb1 = rgb ? rgb + (int64_t)f1 * a.P * 3 : nullptr;
+    c.obase = pair * (int64_t)a.P;
+    c.words_per_pair = (a.P + 63) >> 6;
+    c.pair = pair;
+    c.lane = threadIdx.x & 63;
+
+    int n_valid = 0, n_vis = 0;
+    const uint32_t i0 = strip * (uint32_t)kStrip + threadIdx.x;
+    for (int g = 0; g < kIters; g += kGroup) {
+        double x[kGroup], y[kGroup], z[kGroup];
+        bool in_img[kGroup], valid[kGroup];
+        Pixel px[kGroup];
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) {
+            const uint32_t i = i0 + (uint32_t)(g + j) * kThreads;
+            in_img[j] = i < a.P;
+            const uint32_t ic = in_img[j] ? i : a.P - 1;
+            const uint32_t my = __umulhi(ic, a.div_magic);
+            const uint32_t mx = ic - my * (uint32_t)a.W;
+            const uint32_t d16 = sample_depth1<IDENT>(a, c.depth1, ic, mx, my);
+            const double d = (double)d16 * 0.001;                     // OPS:292-294
+            valid[j] = in_img[j] && (d > 0.0);                        // OPS:297
+            x[j] = (double)mx * d;                                    // OPS:303-310
+            y[j] = (double)my * d;
+            z[j] = d;
+        }
+        apply_affine<kGroup>(m1 + MSPA_MAT_KINV * 16, x, y, z);      // OPS:313
+        apply_affine<kGroup>(m1 + MSPA_MAT_E * 16, x, y, z);         // OPS:316
+        apply_affine<kGroup>(m1 + MSPA_MAT_A * 16, x, y, z);         // OPS:319-320
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) {
+            px[j].ax = x[j];
+            px[j].ay = y[j];
+            px[j].az = z[j];
+        }
+        apply_affine<kGroup>(m2 + MSPA_MAT_EINV_ALIGNED * 16, x, y, z);   // IH:57-60
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) px[j].qz = z[j];                  // IH:63
+        apply_affine<kGroup>(m2 + MSPA_MAT_K * 16, x, y, z);              // IH:66
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) {
+            px[j].u = x[j] / z[j];                                         // IH:69
+            px[j].v = y[j] / z[j];
+            px[j].vis = depth_test(valid[j], px[j].u, px[j].v, px[j].qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy,
+                                   px[j].xi, px[j].yi);
+            n_valid += valid[j] ? 1 : 0;
+            n_vis += px[j].vis ? 1 : 0;
+            store_pixel<Outs<0, true>>(a, c, i0 + (uint32_t)(g + j) * kThreads, in_img[j], valid[j], px[j]);
+        }
+    }
+    flush_counts<Outs<0, true>>(a, pair, c.lane, n_valid, n_vis);
+}
+
+// --------------------------------------------------------------------------------------------
+// fast path
+// --------------------------------------------------------------------------------------------
+// row r of (3x4 affine X) * (3x4 affine Y), both row-major 4x4 storage; plain float64 FMAs
+__device__ __forceinline__ void compose_row(const double *__restrict__ X, const double *__restrict__ Y, int r,
+                                            double out[4]) {
+#pragma unroll
+    for (int cidx = 0; cidx < 4; ++cidx) {
+        double acc = X[4 * r + 0] * Y[0 + cidx];
+        acc = __builtin_fma(X[4 * r + 1], Y[4 + cidx], acc);
+        acc = __builtin_fma(X[4 * r + 2], Y[8 + cidx], acc);
+        if (cidx == 3) acc += X[4 * r + 3];
+        out[cidx] = acc;
+    }
+}
+
+__device__ __forceinline__ double uniform(double v) {   // VGPR holding a wave-uniform value -> SGPR pair
+    const unsigned long long b = __double_as_longlong(v);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+template <bool IDENT, uint32_t SET, bool GENERIC>
+__global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__restrict__ depth,
+                                                             const uint8_t *__restrict__ rgb,
+                                                             const double *__restrict__ mats,
+                                                             const int32_t *__restrict__ pairs, PairArgs a) {
+    using O = Outs<SET, GENERIC>;
+    constexpr bool WANT_XYZ = GENERIC || (SET & O_XYZ32);
+    int64_t pair;
+    uint32_t strip;
+    if (!decode_block(a, pair, strip)) return;
+    const int f1 = pairs[2 * pair + 0];
+    const int f2 = pairs[2 * pair + 1];
+    const double *m1 = mats + (int64_t)f1 * (MSPA_FRAME_MATS * 16);
+    const double *m2 = mats + (int64_t)f2 * (MSPA_FRAME_MATS * 16);
+    const int64_t dpix = (int64_t)a.dh * a.dw;
+    Ctx c;
+    c.depth1 = depth + (int64_t)f1 * dpix;
+    c.depth2 = depth + (int64_t)f2 * dpix;
+    c.rgb1 = rgb ? rgb + (int64_t)f1 * a.P * 3 : nullptr;
+    c.obase = pair * (int64_t)a.P;
+    c.words_per_pair = (a.P + 63) >> 6;
+    c.pair = pair;
+    c.lane = threadIdx.x & 63;
+
+    // Per-pair composed matrices: U = A*E1*Kinv (host, per frame), M = (K*inv(A*E2)) * U.
+    // 36 FMAs per wave, once per 4096-pixel strip; results parked in SGPRs.
+    const double *__restrict__ U = m1 + MSPA_MAT_UNPROJ * 16;
+    const double *__restrict__ N = m2 + MSPA_MAT_REPROJ * 16;
+    double M[3][4], Ur[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double row[4];
+        compose_row(N, U, r, row);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) M[r][k] = uniform(row[k]);
+        if (WANT_XYZ) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Ur[r][k] = U[4 * r + k];
+        }
+    }
+    const double Wd = (double)a.W, Hd = (double)a.H;
 
     int n_valid = 0, n_vis = 0;
     const uint32_t i0 = strip * (uint32_t)kStrip + threadIdx.x;
@@ -76,107 +382,67 @@ __global__ __launch_bounds__(kThreads) void pair_reproject_kernel(const uint16_t
         const uint32_t ic = in_img ? i : a.P - 1;
         const uint32_t my = __umulhi(ic, a.div_magic);
         const uint32_t mx = ic - my * (uint32_t)a.W;
+        const uint32_t d16 = sample_depth1<IDENT>(a, c.depth1, ic, mx, my);
+        const double d = (double)d16 * 0.001;
+        const bool valid = in_img && (d > 0.0);
+        const double mxd = (double)mx, myd = (double)my;
 
-        uint32_t d16;
-        if (IDENT) {
-            d16 = depth1[ic];
+        // (ix, iy, iz) = M * (mx*d, my*d, d, 1) = d * (M[:, :3] * (mx, my, 1)) + M[:, 3]
+        const double tx = __builtin_fma(M[0][0], mxd, __builtin_fma(M[0][1], myd, M[0][2]));
+        const double ty = __builtin_fma(M[1][0], mxd, __builtin_fma(M[1][1], myd, M[1][2]));
+        const double tz = __builtin_fma(M[2][0], mxd, __builtin_fma(M[2][1], myd, M[2][2]));
+        const double ix = __builtin_fma(tx, d, M[0][3]);
+        const double iy = __builtin_fma(ty, d, M[1][3]);
+        const double iz = __builtin_fma(tz, d, M[2][3]);       // == camera-2 depth (K row 2 is 0 0 1 0)
+        // reciprocal: hardware estimate + two Newton steps (each squares the relative error)
+        double rz = __builtin_amdgcn_rcp(iz);
+        rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
+        rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
+        Pixel p;
+        p.u = ix * rz;
+        p.v = iy * rz;
+        p.qz = iz;
+        const double us = IDENT ? p.u : p.u * a.sx;
+        const double vs = IDENT ? p.v : p.v * a.sy;
+        const double ru = __builtin_rint(us), rv = __builtin_rint(vs);
+        const bool inb = (p.u >= 0.0) && (p.u < Wd) && (p.v >= 0.0) && (p.v < Hd);
+        // clip (NaN / overflow semantics of round_clip are only reachable through the exact path)
+        p.xi = (int)__builtin_fmin(__builtin_fmax(ru, 0.0), (double)(a.dw - 1));
+        p.yi = (int)__builtin_fmin(__builtin_fmax(rv, 0.0), (double)(a.dh - 1));
+        double dv = 0.0;
+        if (valid && inb && iz > 0.0) dv = (double)c.depth2[p.yi * a.dw + p.xi] * 0.001;
+        p.vis = valid && inb && (iz > 0.0) && (iz < dv);
+
+        // guard band: any decision closer than the guard to its boundary is redone exactly
+        const double fu = __builtin_fabs(__builtin_fabs(us - ru) - 0.5);
+        const double fv = __builtin_fabs(__builtin_fabs(vs - rv) - 0.5);
+        const double bu = __builtin_fmin(__builtin_fabs(p.u), __builtin_fabs(p.u - Wd));
+        const double bv = __builtin_fmin(__builtin_fabs(p.v), __builtin_fabs(p.v - Hd));
+        const double gpx = __builtin_fmin(__builtin_fmin(fu, fv), __builtin_fmin(bu, bv));
+        const double gz = __builtin_fmin(__builtin_fabs(iz - dv), __builtin_fabs(iz));
+        // !(x > g) also catches NaN / inf from iz == 0
+        const bool risky = valid && (!(gpx > kGuardPx) || !(gz > kGuardZ) || !(__builtin_fabs(us) < 1e9) ||
+                                     !(__builtin_fabs(vs) < 1e9));
+        if (WANT_XYZ) {
+            const double sx3 = __builtin_fma(Ur[0][0], mxd, __builtin_fma(Ur[0][1], myd, Ur[0][2]));
+            const double sy3 = __builtin_fma(Ur[1][0], mxd, __builtin_fma(Ur[1][1], myd, Ur[1][2]));
+            const double sz3 = __builtin_fma(Ur[2][0], mxd, __builtin_fma(Ur[2][1], myd, Ur[2][2]));
+            p.ax = __builtin_fma(sx3, d, Ur[0][3]);
+            p.ay = __builtin_fma(sy3, d, Ur[1][3]);
+            p.az = __builtin_fma(sz3, d, Ur[2][3]);
         } else {
-            const int dy = round_clip((double)my * a.sy, a.dh - 1);   // OPS:285-290
-            const int dx = round_clip((double)mx * a.sx, a.dw - 1);
-            d16 = depth1[dy * a.dw + dx];
+            p.ax = p.ay = p.az = 0.0;
         }
-        const double d = (double)d16 * 0.001;                         // OPS:292-294
-        const bool valid = in_img && (d > 0.0);                       // OPS:297
-
-        // OPS:303-320: pixel ray -> camera -> world -> aligned
-        const double px = (double)mx * d, py = (double)my * d;
-        const double cx = affine_row(Kinv + 0, px, py, d);
-        const double cy = affine_row(Kinv + 4, px, py, d);
-        const double cz = affine_row(Kinv + 8, px, py, d);
-        const double wx = affine_row(E1 + 0, cx, cy, cz);
-        const double wy = affine_row(E1 + 4, cx, cy, cz);
-        const double wz = affine_row(E1 + 8, cx, cy, cz);
-        const double ax = affine_row(A + 0, wx, wy, wz);
-        const double ay = affine_row(A + 4, wx, wy, wz);
-        const double az = affine_row(A + 8, wx, wy, wz);
-        // IH:57-69: aligned world -> camera 2 -> image 2
-        const double qx = affine_row(Einv2 + 0, ax, ay, az);
-        const double qy = affine_row(Einv2 + 4, ax, ay, az);
-        const double qz = affine_row(Einv2 + 8, ax, ay, az);
-        const double ix = affine_row(K + 0, qx, qy, qz);
-        const double iy = affine_row(K + 4, qx, qy, qz);
-        const double iz = affine_row(K + 8, qx, qy, qz);
-        const double u = ix / iz, v = iy / iz;
-
-        int xi, yi;
-        const bool vis = depth_test(valid, u, v, qz, depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, xi, yi);
+        if (risky) {   // cold: exact chain for this lane, everything recomputed
+            exact_unproject(m1, mxd, myd, d, p.ax, p.ay, p.az);
+            exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
+            p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi);
+        }
         n_valid += valid ? 1 : 0;
-        n_vis += vis ? 1 : 0;
-
-        const unsigned long long vmask = __ballot(vis);
-        if (a.vis_bits && lane == 0 && (i - lane) < a.P)
-            a.vis_bits[pair * (int64_t)((a.P + 63) >> 6) + ((i - lane) >> 6)] = vmask;
-        if (in_img) {
-            const int64_t o = obase + i;
-            const double nan = __builtin_nan("");
-            if (a.vis_u8) a.vis_u8[o] = vis ? 1 : 0;
-            if (a.valid_u8) a.valid_u8[o] = valid ? 1 : 0;
-            if (a.pix_i16) {
-                const uint32_t packed = valid ? ((uint32_t)(uint16_t)xi | ((uint32_t)(uint16_t)yi << 16)) : 0xFFFFFFFFu;
-                reinterpret_cast<uint32_t *>(a.pix_i16)[o] = packed;
-            }
-            if (a.xyz_f32) {
-                float *q = a.xyz_f32 + 3 * o;
-                const float fn = __builtin_nanf("");
-                q[0] = valid ? (float)ax : fn;
-                q[1] = valid ? (float)ay : fn;
-                q[2] = valid ? (float)az : fn;
-            }
-            if (a.rgba) {
-                uint32_t c = 0;
-                if (rgb1) {
-                    const uint8_t *s = rgb1 + 3 * (int64_t)i;
-                    c = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
-                }
-                a.rgba[o] = c | (valid ? 0xFF000000u : 0u);
-            }
-            if (a.xyz_f64) {
-                double *q = a.xyz_f64 + 3 * o;
-                q[0] = valid ? ax : nan;
-                q[1] = valid ? ay : nan;
-                q[2] = valid ? az : nan;
-            }
-            if (a.uv_f64) {
-                a.uv_f64[2 * o + 0] = valid ? u : nan;
-                a.uv_f64[2 * o + 1] = valid ? v : nan;
-            }
-            if (a.depth_f64) a.depth_f64[o] = valid ? qz : nan;
-        }
+        n_vis += p.vis ? 1 : 0;
+        store_pixel<O>(a, c, i, in_img, valid, p);
     }
-
-    if (a.counts) {
-        // wave reduce (DPP/bpermute shuffles), then one LDS step and two atomics per workgroup
-        for (int off = 32; off > 0; off >>= 1) {
-            n_valid += __shfl_down(n_valid, off);
-            n_vis += __shfl_down(n_vis, off);
-        }
-        __shared__ int red[2][kThreads / kWave];
-        const int w = threadIdx.x >> 6;
-        if (lane == 0) {
-            red[0][w] = n_valid;
-            red[1][w] = n_vis;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int sv = 0, ss = 0;
-            for (int j = 0; j < kThreads / kWave; ++j) {
-                sv += red[0][j];
-                ss += red[1][j];
-            }
-            atomicAdd(a.counts + 2 * pair + 0, sv);
-            atomicAdd(a.counts + 2 * pair + 1, ss);
-        }
-    }
+    flush_counts<O>(a, pair, c.lane, n_valid, n_vis);
 }
 
 }  // namespace mspa
@@ -198,7 +464,6 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
     if (P * (uint64_t)W >= (1ull << 32)) return fail(MSPA_EINVAL, "mspa_pair_reproject: H*W*W must be < 2^32");
     if (out_rgba && !rgb) return fail(MSPA_EINVAL, "mspa_pair_reproject: out_rgba needs rgb");
     if (flags & ~MSPA_PAIR_FAST) return fail(MSPA_EINVAL, "mspa_pair_reproject: unknown flag");
-    if (flags & MSPA_PAIR_FAST) return fail(MSPA_EUNSUPPORTED, "mspa_pair_reproject: MSPA_PAIR_FAST not built yet");
     if (n_pairs == 0) return MSPA_OK;
     hipStream_t s = (hipStream_t)stream;
 
@@ -220,10 +485,32 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
     const int64_t groups = (n_pairs + 7) / 8;
     const int64_t blocks = groups * 8 * a.strips;
     if (blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_pair_reproject: too many workgroups; split the batch");
+    const dim3 grid((uint32_t)blocks), block(kThreads);
     const bool ident = (dh == H && dw == W);
-    if (ident)
-        hipLaunchKernelGGL(pair_reproject_kernel<true>, dim3((uint32_t)blocks), dim3(kThreads), 0, s, depth, rgb, frame_mats, pairs, a);
-    else
-        hipLaunchKernelGGL(pair_reproject_kernel<false>, dim3((uint32_t)blocks), dim3(kThreads), 0, s, depth, rgb, frame_mats, pairs, a);
-    return check_hip(hipGetLastError(), "pair_reproject_kernel launch");
+    // float64 outputs are defined as the reference's own operation order: they force the exact kernel
+    const bool fast = (flags & MSPA_PAIR_FAST) && !out_xyz_f64 && !out_uv_f64 && !out_depth_f64;
+    if (!fast) {
+        if (ident) hipLaunchKernelGGL(pair_exact_kernel<true>, grid, block, 0, s, depth, rgb, frame_mats, pairs, a);
+        else hipLaunchKernelGGL(pair_exact_kernel<false>, grid, block, 0, s, depth, rgb, frame_mats, pairs, a);
+    } else {
+        uint32_t set = 0;
+        set |= out_vis_bits ? O_VIS_BITS : 0; set |= out_vis_u8 ? O_VIS_U8 : 0; set |= out_valid_u8 ? O_VALID_U8 : 0;
+        set |= out_pix_i16 ? O_PIX : 0; set |= out_xyz_f32 ? O_XYZ32 : 0; set |= out_rgba ? O_RGBA : 0;
+        set |= out_counts ? O_COUNTS : 0;
+#define MSPA_LAUNCH_FAST(ID, SET_, GEN) \
+    hipLaunchKernelGGL((pair_fast_kernel<ID, SET_, GEN>), grid, block, 0, s, depth, rgb, frame_mats, pairs, a)
+        if (ident) {
+            if (set == kSetCorr) MSPA_LAUNCH_FAST(true, kSetCorr, false);
+            else if (set == kSetDense) MSPA_LAUNCH_FAST(true, kSetDense, false);
+            else if (set == kSetMinimal) MSPA_LAUNCH_FAST(true, kSetMinimal, false);
+            else MSPA_LAUNCH_FAST(true, 0u, true);
+        } else {
+            if (set == kSetCorr) MSPA_LAUNCH_FAST(false, kSetCorr, false);
+            else if (set == kSetDense) MSPA_LAUNCH_FAST(false, kSetDense, false);
+            else if (set == kSetMinimal) MSPA_LAUNCH_FAST(false, kSetMinimal, false);
+            else MSPA_LAUNCH_FAST(false, 0u, true);
+        }
+#undef MSPA_LAUNCH_FAST
+    }
+    return check_hip(hipGetLastError(), "pair_reproject kernel launch");
 }

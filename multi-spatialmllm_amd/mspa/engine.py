@@ -46,7 +46,7 @@ def check_affine(name: str, m: np.ndarray):
 
 
 def frame_matrices(K: np.ndarray, A: Optional[np.ndarray], E_list: Sequence[np.ndarray]) -> np.ndarray:
-    """[F, 5, 16] float64 frame records for mspa_pair_reproject (slot order of include/mspa.h)."""
+    """[F, 7, 16] float64 frame records for mspa_pair_reproject (slot order of include/mspa.h)."""
     K = check_affine("K", K)
     A = np.eye(4) if A is None else check_affine("A", A)
     Kinv = check_affine("inv(K)", np.linalg.inv(K))                       # OPS:313
@@ -59,7 +59,16 @@ def frame_matrices(K: np.ndarray, A: Optional[np.ndarray], E_list: Sequence[np.n
         out[f, _lib.MAT_A] = A.reshape(16)
         out[f, _lib.MAT_EINV_ALIGNED] = Einv_al.reshape(16)
         out[f, _lib.MAT_K] = K.reshape(16)
+        # composed products for MSPA_PAIR_FAST (any float64 evaluation order will do: lanes near a
+        # decision boundary are re-evaluated with the exact chain inside the kernel)
+        out[f, _lib.MAT_UNPROJ] = (A @ E @ Kinv).reshape(16)
+        out[f, _lib.MAT_REPROJ] = (K @ Einv_al).reshape(16)
     return out
+
+
+def fast_path_ok(K: np.ndarray) -> bool:
+    """MSPA_PAIR_FAST reads the camera-2 depth off the third image row: K[2] must be 0 0 1 0."""
+    return bool(np.array_equal(np.asarray(K, dtype=np.float64)[2], np.array([0.0, 0.0, 1.0, 0.0])))
 
 
 def camera_matrices(K: np.ndarray, E_aligned_list: Sequence[np.ndarray]) -> np.ndarray:
@@ -109,7 +118,7 @@ def alloc_pair_outputs(n_pairs: int, image_hw: Tuple[int, int], outputs: Iterabl
 
 def pair_reproject(depth: torch.Tensor, mats: torch.Tensor, pairs: torch.Tensor, image_hw: Tuple[int, int],
                    out: Dict[str, torch.Tensor], rgb: Optional[torch.Tensor] = None, flags: int = 0):
-    """Enqueue K3 on the current stream.  depth [F,DH,DW] int16(bits of uint16), mats [F,5,16] f64,
+    """Enqueue K3 on the current stream.  depth [F,DH,DW] int16(bits of uint16), mats [F,7,16] f64,
     pairs [B,2] int32, rgb [F,H,W,3] uint8 (only for out['rgba']).  ``out`` comes from
     alloc_pair_outputs and is filled in place."""
     _require_gpu()

@@ -39,14 +39,17 @@ def upload_scene(g, frame_ids):
 ALL_OUT = ("vis_bits", "vis_u8", "valid_u8", "pix_i16", "xyz_f32", "xyz_f64", "uv_f64", "depth_f64", "counts")
 
 
-def run_pairs(g, frame_ids, pair_idx, outputs=ALL_OUT):
+FAST_OUT = ("vis_bits", "vis_u8", "valid_u8", "pix_i16", "xyz_f32", "counts")
+
+
+def run_pairs(g, frame_ids, pair_idx, outputs=ALL_OUT, flags=0):
     depth, mats, rgb = upload_scene(g, frame_ids)
     pairs = torch.tensor(pair_idx, dtype=torch.int32, device=DEV).reshape(-1, 2)
     outs = tuple(outputs) + (("rgba",) if rgb is not None else ())
     out = engine.alloc_pair_outputs(len(pair_idx), g.color_hw, outs, DEV)
     for t in out.values():
         t.fill_(0x5A if t.dtype in (torch.uint8,) else 0)   # poison: every element must be written
-    engine.pair_reproject(depth, mats, pairs, g.color_hw, out, rgb=rgb)
+    engine.pair_reproject(depth, mats, pairs, g.color_hw, out, rgb=rgb, flags=flags)
     torch.cuda.synchronize()
     return {k: v.cpu().numpy() for k, v in out.items()}
 
@@ -69,6 +72,16 @@ def check_pair_against(res, n, ref_c, ref_np, image_hw, color=None):
     pix = res["pix_i16"][n]
     assert np.array_equal(pix[valid, 0], ref_np["xi"][valid]) and np.array_equal(pix[valid, 1], ref_np["yi"][valid])
     assert (pix[~valid] == -1).all()
+    if color is not None and "rgba" in res:
+        rgba = res["rgba"][n].view(np.uint32)
+        exp = color.reshape(-1, 3).astype(np.uint32)
+        exp = exp[:, 0] | (exp[:, 1] << 8) | (exp[:, 2] << 16) | np.where(valid, 0xFF000000, 0).astype(np.uint32)
+        assert np.array_equal(rgba, exp)
+    f32 = res["xyz_f32"][n]
+    assert np.isnan(f32[~valid]).all()
+    if "xyz_f64" not in res:      # fast path: integers exact (above), float32 points to ~1 ulp of float32
+        assert np.allclose(f32[valid], ref_c["xyz"][valid], rtol=2e-7, atol=1e-7)
+        return
     # float64: bit-identical to the C oracle, tight against NumPy
     assert nan_equal_bits(res["xyz_f64"][n], ref_c["xyz"])
     assert nan_equal_bits(res["uv_f64"][n], ref_c["uv2"])
@@ -76,24 +89,22 @@ def check_pair_against(res, n, ref_c, ref_np, image_hw, color=None):
     assert close_f64(res["xyz_f64"][n], ref_np["xyz"], rtol=1e-9, scale=1e-3)
     assert close_f64(res["uv_f64"][n][valid], ref_np["uv2"][valid], rtol=1e-9, scale=1e-3)
     assert close_f64(res["depth_f64"][n], ref_np["depth2"], rtol=1e-9, scale=1e-3)
-    f32 = res["xyz_f32"][n]
     assert np.array_equal(f32[valid], ref_c["xyz"][valid].astype(np.float32))
-    assert np.isnan(f32[~valid]).all()
-    if color is not None and "rgba" in res:
-        rgba = res["rgba"][n].view(np.uint32)
-        exp = color.reshape(-1, 3).astype(np.uint32)
-        exp = exp[:, 0] | (exp[:, 1] << 8) | (exp[:, 2] << 16) | np.where(valid, 0xFF000000, 0).astype(np.uint32)
-        assert np.array_equal(rgba, exp)
 
 
+MODES = [("exact", 0, ALL_OUT), ("fast", _lib.PAIR_FAST, FAST_OUT)]
+
+
+@pytest.mark.parametrize("mode,flags,outs", MODES, ids=["exact", "fast"])
 @pytest.mark.parametrize("name", ["scene_ident", "scene_scaled"])
-def test_pair_reproject_golden(name):
+def test_pair_reproject_golden(name, mode, flags, outs):
     """K3 against the reference's frozen outputs (tests/golden) and both oracles."""
     g = GoldenScene(name)
+    assert engine.fast_path_ok(g.K)
     ids = g.valid_image_ids
     fidx = {i: n for n, i in enumerate(ids)}
     pair_ids = [(str(a), str(b)) for a, b in g["pair_ids"]]
-    res = run_pairs(g, ids, [(fidx[a], fidx[b]) for a, b in pair_ids])
+    res = run_pairs(g, ids, [(fidx[a], fidx[b]) for a, b in pair_ids], outputs=outs, flags=flags)
     H, W = g.color_hw
     for n, (id1, id2) in enumerate(pair_ids):
         col = g.color.get(id1)
@@ -104,21 +115,26 @@ def test_pair_reproject_golden(name):
         # and straight against the reference arrays
         v = res["valid_u8"][n].astype(bool)
         assert np.array_equal(res["vis_u8"][n].astype(bool)[v], g[f"pair{n}_vis"])
+        if mode == "fast":
+            assert np.allclose(res["xyz_f32"][n][v], g[f"pair{n}_xyzrgb"][:, :3], rtol=2e-7, atol=1e-7)
+            continue
         assert close_f64(res["xyz_f64"][n][v], g[f"pair{n}_xyzrgb"][:, :3], rtol=1e-9, scale=1e-3)
         assert close_f64(res["uv_f64"][n][v], g[f"pair{n}_uv"], rtol=1e-9, scale=1e-3)
         assert close_f64(res["depth_f64"][n][v], g[f"pair{n}_depth"], rtol=1e-9, scale=1e-3)
 
 
+@pytest.mark.parametrize("mode,flags,outs", MODES, ids=["exact", "fast"])
 @pytest.mark.parametrize("color_hw,depth_hw", [((480, 640), (480, 640)), ((968, 1296), (480, 640)),
                                                ((61, 83), (37, 53))])
-def test_pair_reproject_seeded(color_hw, depth_hw):
+def test_pair_reproject_seeded(color_hw, depth_hw, mode, flags, outs):
     """Seeded scenes at BASELINE sizes (and an odd ragged size): every output of every pixel."""
     sc = synth.make_scene(1003, n_points=64, n_frames=4, color_hw=color_hw, depth_hw=depth_hw,
                           invalid_pose_frac=0.0, with_color=(color_hw[0] <= 480))
     ids = sc.valid_image_ids
     pair_idx = [(0, 1), (2, 0), (3, 3)]
-    res = run_pairs(sc, ids, pair_idx)
+    res = run_pairs(sc, ids, pair_idx, outputs=outs, flags=flags)
     H, W = color_hw
+    total_vis = 0
     for n, (a, b) in enumerate(pair_idx):
         id1, id2 = ids[a], ids[b]
         col = sc.color.get(id1)
@@ -126,15 +142,51 @@ def test_pair_reproject_seeded(color_hw, depth_hw):
                               col if col is not None else np.zeros((H, W, 3), np.uint8))
         ref_c = C.frame_pair(sc.depth[id1], sc.depth[id2], sc.K, sc.E[id1], sc.E[id2], sc.A, color_hw)
         check_pair_against(res, n, ref_c, ref_np, color_hw, col)
-        assert ref_np["n_vis"] > 0
+        total_vis += ref_np["n_vis"]
+    assert total_vis > 0
+
+
+@pytest.mark.parametrize("mode,flags,outs", MODES, ids=["exact", "fast"])
+def test_pair_reproject_half_pixel_ties(mode, flags, outs):
+    """Every reprojected coordinate is an exact .5 tie (dyadic geometry): half-to-even must win."""
+    H, W = 48, 64
+    K = np.eye(4)
+    K[0, 0] = K[1, 1] = 64.0
+    K[0, 2], K[1, 2] = 32.0, 24.0
+    A = np.eye(4)
+    A[:3, 3] = [1.0, -2.0, 0.5]
+    E1 = np.eye(4)
+    E2 = np.eye(4)
+    E2[:3, 3] = [1.0 / 64.0, -1.0 / 64.0, 0.0]       # 0.5 px at z = 2, 1 px at z = 1, 0.25 px at z = 4
+    rng = np.random.default_rng(3)
+    depth1 = rng.choice(np.array([0, 1000, 2000, 2000, 2000, 4000], dtype=np.uint16), size=(H, W))
+    depth2 = np.full((H, W), 2000, dtype=np.uint16)
+    depth2[::3] = 2001
+    sc = synth.SynthScene("ties_pair", K, A, {"00000": E1, "00005": E2}, np.zeros((1, 6)),
+                          {"00000": depth1, "00005": depth2}, {}, (H, W), (H, W), np.zeros((0, 2, 3)))
+    res = run_pairs(sc, ["00000", "00005"], [(0, 1), (1, 0)], outputs=outs, flags=flags)
+    for n, (a, b) in enumerate([("00000", "00005"), ("00005", "00000")]):
+        ref_np = O.frame_pair(sc.depth[a], sc.depth[b], K, sc.E[a], sc.E[b], A, (H, W), np.zeros((H, W, 3), np.uint8))
+        ref_c = C.frame_pair(sc.depth[a], sc.depth[b], K, sc.E[a], sc.E[b], A, (H, W))
+        frac = np.abs(ref_np["uv2"][ref_np["valid"]] % 1.0)
+        assert (frac == 0.5).mean() > 0.3                      # the ties are really there
+        check_pair_against(res, n, ref_c, ref_np, (H, W), None)
 
 
 def test_pair_reproject_minimal_outputs_and_empty():
-    sc = synth.make_scene(1004, n_points=64, n_frames=3, color_hw=(48, 64), depth_hw=(48, 64), invalid_pose_frac=0)
+    sc = synth.make_scene(1004, n_points=64, n_frames=3, color_hw=(48, 64), depth_hw=(48, 64), invalid_pose_frac=0,
+                          with_color=False)
     ids = sc.valid_image_ids
-    res = run_pairs(sc, ids, [(0, 1), (1, 2)], outputs=("vis_bits", "counts"))
     full = run_pairs(sc, ids, [(0, 1), (1, 2)])
-    assert np.array_equal(res["vis_bits"], full["vis_bits"]) and np.array_equal(res["counts"], full["counts"])
+    for flags in (0, _lib.PAIR_FAST):       # specialised output sets of the fast kernel included
+        for outs in (("vis_bits", "counts"), ("vis_bits", "pix_i16", "counts"), ("vis_bits",),
+                     ("vis_u8", "pix_i16", "xyz_f32", "counts")):
+            res = run_pairs(sc, ids, [(0, 1), (1, 2)], outputs=outs, flags=flags)
+            for k in outs:
+                if k == "xyz_f32":
+                    assert np.allclose(res[k], full[k], rtol=2e-7, atol=1e-7, equal_nan=True)
+                else:
+                    assert np.array_equal(res[k], full[k]), (flags, outs, k)
     # zero pairs is a no-op, not an error
     depth, mats, rgb = upload_scene(sc, ids)
     out = engine.alloc_pair_outputs(0, sc.color_hw, ("vis_bits", "counts"), DEV)
@@ -291,6 +343,12 @@ def test_full_size_properties():
     P = 480 * 640
     out = engine.alloc_pair_outputs(n_pairs, sc.color_hw, ("vis_bits", "pix_i16", "counts", "valid_u8"), DEV)
     engine.pair_reproject(depth, mats, pairs, sc.color_hw, out)
+    # the fast path must reproduce every integer product of the exact kernel, pixel for pixel
+    outf = engine.alloc_pair_outputs(n_pairs, sc.color_hw, ("vis_bits", "pix_i16", "counts"), DEV)
+    engine.pair_reproject(depth, mats, pairs, sc.color_hw, outf, flags=_lib.PAIR_FAST)
+    torch.cuda.synchronize()
+    for k in outf:
+        assert torch.equal(out[k], outf[k]), f"fast path differs from exact kernel in {k}"
     # shard the same batch in two launches: results must not depend on batching / block mapping
     out2 = engine.alloc_pair_outputs(n_pairs, sc.color_hw, ("vis_bits", "counts"), DEV)
     h = 373
