@@ -31,7 +31,9 @@ struct PairArgs {
     uint32_t P;            // H*W
     uint32_t div_magic;    // floor(2^32 / W) + 1 : i / W == umulhi(i, magic) for i*W < 2^32
     double sx, sy;         // dw / W, dh / H  (IH:359-360, OPS:272-273)
-    int strips;            // strips per pair
+    int strips;            // exact kernel: 4096-pixel strips per pair;  fast kernel: groups of 4 wave tiles
+    int n_stripes, n_tiles;   // fast kernel: 64-column stripes per row band, wave tiles per pair
+    uint32_t stripe_magic;    // floor(2^32 / n_stripes) + 1
     uint64_t *vis_bits;
     uint8_t *vis_u8;
     uint8_t *valid_u8;
@@ -149,10 +151,10 @@ struct Ctx {
 };
 
 // All per-pixel stores.  Every branch on an output pointer is wave-uniform (or compile-time).
-template <typename O>
+template <typename O, bool SKIP_BITS = false>
 __device__ __forceinline__ void store_pixel(const PairArgs &a, const Ctx &c, uint32_t i, bool in_img, bool valid,
                                             const Pixel &p) {
-    if (O::template has<O_VIS_BITS>(a.vis_bits)) {
+    if (!SKIP_BITS && O::template has<O_VIS_BITS>(a.vis_bits)) {
         const unsigned long long vmask = __ballot(p.vis);
         if (c.lane == 0 && (i - c.lane) < a.P) a.vis_bits[c.pair * c.words_per_pair + ((i - c.lane) >> 6)] = vmask;
     }
@@ -331,6 +333,11 @@ __device__ __forceinline__ double uniform(double v) {   // VGPR holding a wave-u
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
+constexpr int kTileRows = 16;                    // a wave owns a 64-column x 16-row tile
+
+// Fast kernel mapping: lane <-> image column, the wave walks down kTileRows rows.  The column is
+// loop-invariant per lane and the row is wave-uniform, so the pixel-coordinate half of the composed
+// product (M[:,0]*mx + M[:,2]) is computed once per lane and no integer division is needed.
 template <bool IDENT, uint32_t SET, bool GENERIC>
 __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__restrict__ depth,
                                                              const uint8_t *__restrict__ rgb,
@@ -339,8 +346,8 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
     using O = Outs<SET, GENERIC>;
     constexpr bool WANT_XYZ = GENERIC || (SET & O_XYZ32);
     int64_t pair;
-    uint32_t strip;
-    if (!decode_block(a, pair, strip)) return;
+    uint32_t tgroup;
+    if (!decode_block(a, pair, tgroup)) return;
     const int f1 = pairs[2 * pair + 0];
     const int f2 = pairs[2 * pair + 1];
     const double *m1 = mats + (int64_t)f1 * (MSPA_FRAME_MATS * 16);
@@ -356,93 +363,153 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
     c.lane = threadIdx.x & 63;
 
     // Per-pair composed matrices: U = A*E1*Kinv (host, per frame), M = (K*inv(A*E2)) * U.
-    // 36 FMAs per wave, once per 4096-pixel strip; results parked in SGPRs.
+    // 36 FMAs per wave, once per tile; results parked in SGPRs.  The depth scale 0.001 (OPS:292) is
+    // folded into the columns that multiply the raw millimetre sample.
     const double *__restrict__ U = m1 + MSPA_MAT_UNPROJ * 16;
     const double *__restrict__ N = m2 + MSPA_MAT_REPROJ * 16;
-    double M[3][4], Ur[3][4];
+    double M[3][4], Us[3][4];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         double row[4];
         compose_row(N, U, r, row);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) M[r][k] = uniform(row[k]);
+        for (int k = 0; k < 4; ++k) M[r][k] = uniform(k < 3 ? row[k] * 0.001 : row[k]);
         if (WANT_XYZ) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) Ur[r][k] = U[4 * r + k];
+            for (int k = 0; k < 4; ++k) Us[r][k] = k < 3 ? U[4 * r + k] * 0.001 : U[4 * r + k];
         }
     }
+
+    // wave tile -> (row band, column stripe); both wave-uniform
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = tgroup * (kThreads / kWave) + wave;
+    const uint32_t band = __umulhi(tile, a.stripe_magic);
+    const uint32_t stripe = tile - band * (uint32_t)a.n_stripes;
+    const bool tile_ok = tile < (uint32_t)a.n_tiles;
+    const uint32_t col = stripe * 64u + (uint32_t)c.lane;
+    const bool col_ok = tile_ok && col < (uint32_t)a.W;
+    const uint32_t colc = col_ok ? col : 0u;
+    const uint32_t row0 = band * (uint32_t)kTileRows;
+    const double mxd = (double)colc;
+    // column half of the product: a_r = M[r][0]*mx + M[r][2]
+    const double a0 = __builtin_fma(M[0][0], mxd, M[0][2]);
+    const double a1 = __builtin_fma(M[1][0], mxd, M[1][2]);
+    const double a2 = __builtin_fma(M[2][0], mxd, M[2][2]);
+    double b0 = 0, b1 = 0, b2 = 0;
+    if (WANT_XYZ) {
+        b0 = __builtin_fma(Us[0][0], mxd, Us[0][2]);
+        b1 = __builtin_fma(Us[1][0], mxd, Us[1][2]);
+        b2 = __builtin_fma(Us[2][0], mxd, Us[2][2]);
+    }
+    int dx1 = 0;
+    if (!IDENT) dx1 = round_clip((double)colc * a.sx, a.dw - 1);   // OPS:286-290, column part
     const double Wd = (double)a.W, Hd = (double)a.H;
+    const bool words_aligned = (a.W & 63) == 0;
 
-    int n_valid = 0, n_vis = 0;
-    const uint32_t i0 = strip * (uint32_t)kStrip + threadIdx.x;
-#pragma unroll 2
-    for (int it = 0; it < kIters; ++it) {
-        const uint32_t i = i0 + (uint32_t)it * kThreads;
-        const bool in_img = i < a.P;
-        const uint32_t ic = in_img ? i : a.P - 1;
-        const uint32_t my = __umulhi(ic, a.div_magic);
-        const uint32_t mx = ic - my * (uint32_t)a.W;
-        const uint32_t d16 = sample_depth1<IDENT>(a, c.depth1, ic, mx, my);
-        const double d = (double)d16 * 0.001;
-        const bool valid = in_img && (d > 0.0);
-        const double mxd = (double)mx, myd = (double)my;
+    int n_valid = 0, n_vis = 0;          // wave totals, kept uniform (SALU popcounts of ballots)
+    if (tile_ok) {
+        for (int r = 0; r < kTileRows; ++r) {
+            const uint32_t row = row0 + (uint32_t)r;
+            if (row >= (uint32_t)a.H) break;                         // wave-uniform
+            const bool in_img = col_ok;
+            const uint32_t i = row * (uint32_t)a.W + colc;
+            const double myd = (double)row;
+            uint32_t d16;
+            if (IDENT) {
+                d16 = c.depth1[i];
+            } else {
+                const int dy = round_clip(myd * a.sy, a.dh - 1);
+                d16 = c.depth1[dy * a.dw + dx1];
+            }
+            const bool valid = in_img && (d16 != 0u);                // OPS:297 (d16*0.001 > 0 <=> d16 != 0)
+            const double dmm = (double)d16;
 
-        // (ix, iy, iz) = M * (mx*d, my*d, d, 1) = d * (M[:, :3] * (mx, my, 1)) + M[:, 3]
-        const double tx = __builtin_fma(M[0][0], mxd, __builtin_fma(M[0][1], myd, M[0][2]));
-        const double ty = __builtin_fma(M[1][0], mxd, __builtin_fma(M[1][1], myd, M[1][2]));
-        const double tz = __builtin_fma(M[2][0], mxd, __builtin_fma(M[2][1], myd, M[2][2]));
-        const double ix = __builtin_fma(tx, d, M[0][3]);
-        const double iy = __builtin_fma(ty, d, M[1][3]);
-        const double iz = __builtin_fma(tz, d, M[2][3]);       // == camera-2 depth (K row 2 is 0 0 1 0)
-        // reciprocal: hardware estimate + two Newton steps (each squares the relative error)
-        double rz = __builtin_amdgcn_rcp(iz);
-        rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
-        rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
-        Pixel p;
-        p.u = ix * rz;
-        p.v = iy * rz;
-        p.qz = iz;
-        const double us = IDENT ? p.u : p.u * a.sx;
-        const double vs = IDENT ? p.v : p.v * a.sy;
-        const double ru = __builtin_rint(us), rv = __builtin_rint(vs);
-        const bool inb = (p.u >= 0.0) && (p.u < Wd) && (p.v >= 0.0) && (p.v < Hd);
-        // clip (NaN / overflow semantics of round_clip are only reachable through the exact path)
-        p.xi = (int)__builtin_fmin(__builtin_fmax(ru, 0.0), (double)(a.dw - 1));
-        p.yi = (int)__builtin_fmin(__builtin_fmax(rv, 0.0), (double)(a.dh - 1));
-        double dv = 0.0;
-        if (valid && inb && iz > 0.0) dv = (double)c.depth2[p.yi * a.dw + p.xi] * 0.001;
-        p.vis = valid && inb && (iz > 0.0) && (iz < dv);
+            // (ix, iy, iz) = M * (mx*d, my*d, d, 1) = d * (M[:, :3] * (mx, my, 1)) + M[:, 3]
+            const double ix = __builtin_fma(__builtin_fma(M[0][1], myd, a0), dmm, M[0][3]);
+            const double iy = __builtin_fma(__builtin_fma(M[1][1], myd, a1), dmm, M[1][3]);
+            const double iz = __builtin_fma(__builtin_fma(M[2][1], myd, a2), dmm, M[2][3]);   // camera-2 depth
+            // reciprocal: hardware estimate + one Newton step (squares the relative error; the
+            // guard band only needs ~1e-9 relative)
+            double rz = __builtin_amdgcn_rcp(iz);
+            rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
+            Pixel p;
+            p.u = ix * rz;
+            p.v = iy * rz;
+            p.qz = iz;
+            const double us = IDENT ? p.u : p.u * a.sx;
+            const double vs = IDENT ? p.v : p.v * a.sy;
+            const double ru = __builtin_rint(us), rv = __builtin_rint(vs);
+            const bool inb = (p.u >= 0.0) && (p.u < Wd) && (p.v >= 0.0) && (p.v < Hd);
+            // saturating conversion, then an integer clamp (NaN -> 0; overflow is caught by the guard)
+            p.xi = min(max((int)ru, 0), a.dw - 1);
+            p.yi = min(max((int)rv, 0), a.dh - 1);
+            double dv = 0.0;
+            const bool test = valid && inb && (iz > 0.0);
+            if (test) dv = (double)c.depth2[p.yi * a.dw + p.xi] * 0.001;
+            p.vis = test && (iz < dv);
 
-        // guard band: any decision closer than the guard to its boundary is redone exactly
-        const double fu = __builtin_fabs(__builtin_fabs(us - ru) - 0.5);
-        const double fv = __builtin_fabs(__builtin_fabs(vs - rv) - 0.5);
-        const double bu = __builtin_fmin(__builtin_fabs(p.u), __builtin_fabs(p.u - Wd));
-        const double bv = __builtin_fmin(__builtin_fabs(p.v), __builtin_fabs(p.v - Hd));
-        const double gpx = __builtin_fmin(__builtin_fmin(fu, fv), __builtin_fmin(bu, bv));
-        const double gz = __builtin_fmin(__builtin_fabs(iz - dv), __builtin_fabs(iz));
-        // !(x > g) also catches NaN / inf from iz == 0
-        const bool risky = valid && (!(gpx > kGuardPx) || !(gz > kGuardZ) || !(__builtin_fabs(us) < 1e9) ||
-                                     !(__builtin_fabs(vs) < 1e9));
-        if (WANT_XYZ) {
-            const double sx3 = __builtin_fma(Ur[0][0], mxd, __builtin_fma(Ur[0][1], myd, Ur[0][2]));
-            const double sy3 = __builtin_fma(Ur[1][0], mxd, __builtin_fma(Ur[1][1], myd, Ur[1][2]));
-            const double sz3 = __builtin_fma(Ur[2][0], mxd, __builtin_fma(Ur[2][1], myd, Ur[2][2]));
-            p.ax = __builtin_fma(sx3, d, Ur[0][3]);
-            p.ay = __builtin_fma(sy3, d, Ur[1][3]);
-            p.az = __builtin_fma(sz3, d, Ur[2][3]);
-        } else {
-            p.ax = p.ay = p.az = 0.0;
+            // Guard band.  With t = us - rint(us) in [-0.5, 0.5], a decision can flip only if |t| is
+            // within the guard of 0.5 (rounding tie) or of 0 (u at an integer: the image bounds 0 and
+            // W are integers), i.e. unless guard < |t| < 0.5 - guard  <=>  ||t| - 0.25| < 0.25 - guard.
+            // Huge |us| gives t = 0 and NaN fails the ordered compare, so both end up "risky".
+            const double wu = __builtin_fabs(us - ru) - 0.25;
+            const double wv = __builtin_fabs(vs - rv) - 0.25;
+            bool risky = !(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx);
+            risky = risky || !(__builtin_fabs(iz) > kGuardZ) || (test && !(__builtin_fabs(iz - dv) > kGuardZ));
+            if (!IDENT) {   // bounds live in colour-pixel units here, not at integers of the depth grid
+                const double bu = __builtin_fmin(__builtin_fabs(p.u), __builtin_fabs(p.u - Wd));
+                const double bv = __builtin_fmin(__builtin_fabs(p.v), __builtin_fabs(p.v - Hd));
+                risky = risky || !(__builtin_fmin(bu, bv) > kGuardPx);
+            }
+            risky = risky && valid;
+            if (WANT_XYZ) {
+                p.ax = __builtin_fma(__builtin_fma(Us[0][1], myd, b0), dmm, Us[0][3]);
+                p.ay = __builtin_fma(__builtin_fma(Us[1][1], myd, b1), dmm, Us[1][3]);
+                p.az = __builtin_fma(__builtin_fma(Us[2][1], myd, b2), dmm, Us[2][3]);
+            } else {
+                p.ax = p.ay = p.az = 0.0;
+            }
+            if (risky) {   // cold: the reference's own chain for this lane, everything recomputed
+                const double d = dmm * 0.001;
+                exact_unproject(m1, mxd, myd, d, p.ax, p.ay, p.az);
+                exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
+                p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi);
+            }
+            const unsigned long long vmask = __ballot(p.vis);
+            n_vis += __popcll(vmask);
+            n_valid += __popcll(__ballot(valid));
+            if (O::template has<O_VIS_BITS>(a.vis_bits)) {
+                const uint64_t bit0 = (uint64_t)row * (uint64_t)a.W + (uint64_t)stripe * 64u;
+                uint64_t *wp = a.vis_bits + pair * c.words_per_pair + (int64_t)(bit0 >> 6);
+                if (words_aligned) {
+                    if (c.lane == 0) *wp = vmask;
+                } else if (c.lane == 0 && vmask) {   // stripes straddle words: OR into the zeroed bitset
+                    const uint32_t sh = (uint32_t)(bit0 & 63u);
+                    atomicOr((unsigned long long *)wp, vmask << sh);
+                    if (sh && (vmask >> (64u - sh))) atomicOr((unsigned long long *)wp + 1, vmask >> (64u - sh));
+                }
+            }
+            store_pixel<O, true>(a, c, i, in_img, valid, p);
         }
-        if (risky) {   // cold: exact chain for this lane, everything recomputed
-            exact_unproject(m1, mxd, myd, d, p.ax, p.ay, p.az);
-            exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
-            p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi);
-        }
-        n_valid += valid ? 1 : 0;
-        n_vis += p.vis ? 1 : 0;
-        store_pixel<O>(a, c, i, in_img, valid, p);
     }
-    flush_counts<O>(a, pair, c.lane, n_valid, n_vis);
+    // one LDS step and two atomics per workgroup (lane 0 of each wave holds the wave totals)
+    if (O::template has<O_COUNTS>(a.counts)) {
+        __shared__ int red[2][kThreads / kWave];
+        if (c.lane == 0) {
+            red[0][wave] = n_valid;
+            red[1][wave] = n_vis;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int sv = 0, ss = 0;
+            for (int j = 0; j < kThreads / kWave; ++j) {
+                sv += red[0][j];
+                ss += red[1][j];
+            }
+            atomicAdd(a.counts + 2 * pair + 0, sv);
+            atomicAdd(a.counts + 2 * pair + 1, ss);
+        }
+    }
 }
 
 }  // namespace mspa
@@ -456,8 +523,9 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
                                    float *out_xyz_f32, uint32_t *out_rgba, double *out_xyz_f64,
                                    double *out_uv_f64, double *out_depth_f64, int32_t *out_counts,
                                    uint32_t flags, mspa_stream_t stream) {
-    if (!depth || !frame_mats || !pairs) return fail(MSPA_EINVAL, "mspa_pair_reproject: null input pointer");
     if (n_frames <= 0 || n_pairs < 0) return fail(MSPA_EINVAL, "mspa_pair_reproject: bad frame/pair count");
+    if (!depth || !frame_mats || (!pairs && n_pairs > 0))
+        return fail(MSPA_EINVAL, "mspa_pair_reproject: null input pointer");
     if (dh < 2 || dw < 2 || H < 2 || W < 2 || dh > 32767 || dw > 32767 || H > 32767 || W > 32767)
         return fail(MSPA_EINVAL, "mspa_pair_reproject: image size out of range [2, 32767]");
     const uint64_t P = (uint64_t)H * (uint64_t)W;
@@ -482,13 +550,27 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
         int rc = check_hip(hipMemsetAsync(out_counts, 0, sizeof(int32_t) * 2 * n_pairs, s), "hipMemsetAsync(counts)");
         if (rc) return rc;
     }
+    const bool ident = (dh == H && dw == W);
+    // float64 outputs are defined as the reference's own operation order: they force the exact kernel
+    const bool fast = (flags & MSPA_PAIR_FAST) && !out_xyz_f64 && !out_uv_f64 && !out_depth_f64;
+    if (fast) {
+        a.n_stripes = (W + 63) / 64;
+        a.n_tiles = a.n_stripes * ((H + kTileRows - 1) / kTileRows);
+        a.stripe_magic = (uint32_t)((1ull << 32) / (uint64_t)a.n_stripes) + 1u;
+        a.strips = (a.n_tiles + (kThreads / kWave) - 1) / (kThreads / kWave);
+        if (out_vis_bits && (W & 63)) {   // stripes straddle bitset words: the kernel ORs into zeros
+            int rc = check_hip(hipMemsetAsync(out_vis_bits, 0, sizeof(uint64_t) * ((P + 63) / 64) * n_pairs, s),
+                               "hipMemsetAsync(vis_bits)");
+            if (rc) return rc;
+        }
+    } else {
+        a.n_stripes = a.n_tiles = 0;
+        a.stripe_magic = 0;
+    }
     const int64_t groups = (n_pairs + 7) / 8;
     const int64_t blocks = groups * 8 * a.strips;
     if (blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_pair_reproject: too many workgroups; split the batch");
     const dim3 grid((uint32_t)blocks), block(kThreads);
-    const bool ident = (dh == H && dw == W);
-    // float64 outputs are defined as the reference's own operation order: they force the exact kernel
-    const bool fast = (flags & MSPA_PAIR_FAST) && !out_xyz_f64 && !out_uv_f64 && !out_depth_f64;
     if (!fast) {
         if (ident) hipLaunchKernelGGL(pair_exact_kernel<true>, grid, block, 0, s, depth, rgb, frame_mats, pairs, a);
         else hipLaunchKernelGGL(pair_exact_kernel<false>, grid, block, 0, s, depth, rgb, frame_mats, pairs, a);
