@@ -334,6 +334,7 @@ __device__ __forceinline__ double uniform(double v) {   // VGPR holding a wave-u
 }
 
 constexpr int kTileRows = 16;                    // a wave owns a 64-column x 16-row tile
+constexpr int kRowGroup = 4;                     // rows whose loads/gathers are in flight together
 
 // Fast kernel mapping: lane <-> image column, the wave walks down kTileRows rows.  The column is
 // loop-invariant per lane and the row is wave-uniform, so the pixel-coordinate half of the composed
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
     // wave tile -> (row band, column stripe); both wave-uniform
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t tile = tgroup * (kThreads / kWave) + wave;
-    const uint32_t band = __umulhi(tile, a.stripe_magic);
+    const uint32_t band = a.n_stripes == 1 ? tile : __umulhi(tile, a.stripe_magic);   // magic overflows for 1
     const uint32_t stripe = tile - band * (uint32_t)a.n_stripes;
     const bool tile_ok = tile < (uint32_t)a.n_tiles;
     const uint32_t col = stripe * 64u + (uint32_t)c.lane;
@@ -408,88 +409,110 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 
     int n_valid = 0, n_vis = 0;          // wave totals, kept uniform (SALU popcounts of ballots)
     if (tile_ok) {
-        for (int r = 0; r < kTileRows; ++r) {
-            const uint32_t row = row0 + (uint32_t)r;
-            if (row >= (uint32_t)a.H) break;                         // wave-uniform
-            const bool in_img = col_ok;
-            const uint32_t i = row * (uint32_t)a.W + colc;
-            const double myd = (double)row;
-            uint32_t d16;
-            if (IDENT) {
-                d16 = c.depth1[i];
-            } else {
-                const int dy = round_clip(myd * a.sy, a.dh - 1);
-                d16 = c.depth1[dy * a.dw + dx1];
-            }
-            const bool valid = in_img && (d16 != 0u);                // OPS:297 (d16*0.001 > 0 <=> d16 != 0)
-            const double dmm = (double)d16;
-
-            // (ix, iy, iz) = M * (mx*d, my*d, d, 1) = d * (M[:, :3] * (mx, my, 1)) + M[:, 3]
-            const double ix = __builtin_fma(__builtin_fma(M[0][1], myd, a0), dmm, M[0][3]);
-            const double iy = __builtin_fma(__builtin_fma(M[1][1], myd, a1), dmm, M[1][3]);
-            const double iz = __builtin_fma(__builtin_fma(M[2][1], myd, a2), dmm, M[2][3]);   // camera-2 depth
-            // reciprocal: hardware estimate + one Newton step (squares the relative error; the
-            // guard band only needs ~1e-9 relative)
-            double rz = __builtin_amdgcn_rcp(iz);
-            rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
-            Pixel p;
-            p.u = ix * rz;
-            p.v = iy * rz;
-            p.qz = iz;
-            const double us = IDENT ? p.u : p.u * a.sx;
-            const double vs = IDENT ? p.v : p.v * a.sy;
-            const double ru = __builtin_rint(us), rv = __builtin_rint(vs);
-            const bool inb = (p.u >= 0.0) && (p.u < Wd) && (p.v >= 0.0) && (p.v < Hd);
-            // saturating conversion, then an integer clamp (NaN -> 0; overflow is caught by the guard)
-            p.xi = min(max((int)ru, 0), a.dw - 1);
-            p.yi = min(max((int)rv, 0), a.dh - 1);
-            double dv = 0.0;
-            const bool test = valid && inb && (iz > 0.0);
-            if (test) dv = (double)c.depth2[p.yi * a.dw + p.xi] * 0.001;
-            p.vis = test && (iz < dv);
-
-            // Guard band.  With t = us - rint(us) in [-0.5, 0.5], a decision can flip only if |t| is
-            // within the guard of 0.5 (rounding tie) or of 0 (u at an integer: the image bounds 0 and
-            // W are integers), i.e. unless guard < |t| < 0.5 - guard  <=>  ||t| - 0.25| < 0.25 - guard.
-            // Huge |us| gives t = 0 and NaN fails the ordered compare, so both end up "risky".
-            const double wu = __builtin_fabs(us - ru) - 0.25;
-            const double wv = __builtin_fabs(vs - rv) - 0.25;
-            bool risky = !(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx);
-            risky = risky || !(__builtin_fabs(iz) > kGuardZ) || (test && !(__builtin_fabs(iz - dv) > kGuardZ));
-            if (!IDENT) {   // bounds live in colour-pixel units here, not at integers of the depth grid
-                const double bu = __builtin_fmin(__builtin_fabs(p.u), __builtin_fabs(p.u - Wd));
-                const double bv = __builtin_fmin(__builtin_fabs(p.v), __builtin_fabs(p.v - Hd));
-                risky = risky || !(__builtin_fmin(bu, bv) > kGuardPx);
-            }
-            risky = risky && valid;
-            if (WANT_XYZ) {
-                p.ax = __builtin_fma(__builtin_fma(Us[0][1], myd, b0), dmm, Us[0][3]);
-                p.ay = __builtin_fma(__builtin_fma(Us[1][1], myd, b1), dmm, Us[1][3]);
-                p.az = __builtin_fma(__builtin_fma(Us[2][1], myd, b2), dmm, Us[2][3]);
-            } else {
-                p.ax = p.ay = p.az = 0.0;
-            }
-            if (risky) {   // cold: the reference's own chain for this lane, everything recomputed
-                const double d = dmm * 0.001;
-                exact_unproject(m1, mxd, myd, d, p.ax, p.ay, p.az);
-                exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
-                p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi);
-            }
-            const unsigned long long vmask = __ballot(p.vis);
-            n_vis += __popcll(vmask);
-            n_valid += __popcll(__ballot(valid));
-            if (O::template has<O_VIS_BITS>(a.vis_bits)) {
-                const uint64_t bit0 = (uint64_t)row * (uint64_t)a.W + (uint64_t)stripe * 64u;
-                uint64_t *wp = a.vis_bits + pair * c.words_per_pair + (int64_t)(bit0 >> 6);
-                if (words_aligned) {
-                    if (c.lane == 0) *wp = vmask;
-                } else if (c.lane == 0 && vmask) {   // stripes straddle words: OR into the zeroed bitset
-                    const uint32_t sh = (uint32_t)(bit0 & 63u);
-                    atomicOr((unsigned long long *)wp, vmask << sh);
-                    if (sh && (vmask >> (64u - sh))) atomicOr((unsigned long long *)wp + 1, vmask >> (64u - sh));
+        // Rows are processed kRowGroup at a time in three straight-line phases so that the kRowGroup
+        // depth-1 loads, and then the kRowGroup depth-2 gathers, are in flight together: with one row
+        // at a time a wave pays two dependent memory round trips per row and the kernel is latency
+        // bound at ~30 % of HBM bandwidth.
+        for (int r0 = 0; r0 < kTileRows; r0 += kRowGroup) {
+            uint32_t i[kRowGroup], d16[kRowGroup], dv16[kRowGroup];
+            bool in_img[kRowGroup], valid[kRowGroup], test[kRowGroup], risky[kRowGroup];
+            double myd[kRowGroup], us[kRowGroup], vs[kRowGroup];
+            Pixel px[kRowGroup];
+            // phase A: depth-1 samples
+#pragma unroll
+            for (int g = 0; g < kRowGroup; ++g) {
+                const uint32_t row = row0 + (uint32_t)(r0 + g);
+                const bool row_ok = row < (uint32_t)a.H;                     // wave-uniform
+                const uint32_t rowc = row_ok ? row : (uint32_t)a.H - 1u;
+                in_img[g] = col_ok && row_ok;
+                i[g] = rowc * (uint32_t)a.W + colc;
+                myd[g] = (double)rowc;
+                if (IDENT) {
+                    d16[g] = c.depth1[i[g]];
+                } else {
+                    const int dy = round_clip(myd[g] * a.sy, a.dh - 1);
+                    d16[g] = c.depth1[dy * a.dw + dx1];
                 }
             }
-            store_pixel<O, true>(a, c, i, in_img, valid, p);
+            // phase B: composed projection, pixel index, gather issue
+#pragma unroll
+            for (int g = 0; g < kRowGroup; ++g) {
+                valid[g] = in_img[g] && (d16[g] != 0u);                      // OPS:297 (d16*0.001 > 0 <=> d16 != 0)
+                const double dmm = (double)d16[g];
+                // (ix, iy, iz) = M * (mx*d, my*d, d, 1) = d * (M[:, :3] * (mx, my, 1)) + M[:, 3]
+                const double ix = __builtin_fma(__builtin_fma(M[0][1], myd[g], a0), dmm, M[0][3]);
+                const double iy = __builtin_fma(__builtin_fma(M[1][1], myd[g], a1), dmm, M[1][3]);
+                const double iz = __builtin_fma(__builtin_fma(M[2][1], myd[g], a2), dmm, M[2][3]);   // camera-2 depth
+                // reciprocal: hardware estimate + one Newton step (squares the relative error; the
+                // guard band only needs ~1e-9 relative)
+                double rz = __builtin_amdgcn_rcp(iz);
+                rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
+                Pixel &p = px[g];
+                p.u = ix * rz;
+                p.v = iy * rz;
+                p.qz = iz;
+                us[g] = IDENT ? p.u : p.u * a.sx;
+                vs[g] = IDENT ? p.v : p.v * a.sy;
+                const double ru = __builtin_rint(us[g]), rv = __builtin_rint(vs[g]);
+                const bool inb = (p.u >= 0.0) && (p.u < Wd) && (p.v >= 0.0) && (p.v < Hd);
+                // saturating conversion, then an integer clamp (NaN -> 0; overflow is caught by the guard)
+                p.xi = min(max((int)ru, 0), a.dw - 1);
+                p.yi = min(max((int)rv, 0), a.dh - 1);
+                test[g] = valid[g] && inb && (iz > 0.0);
+                // unconditional gather (pixel 0 for lanes that cannot pass) keeps the code straight-line
+                dv16[g] = c.depth2[test[g] ? (p.yi * a.dw + p.xi) : 0];
+                // Guard band, coordinate part.  With t = us - rint(us) in [-0.5, 0.5], a decision can
+                // flip only if |t| is within the guard of 0.5 (rounding tie) or of 0 (u at an integer:
+                // the image bounds 0 and W are integers), i.e. unless guard < |t| < 0.5 - guard  <=>
+                // ||t| - 0.25| < 0.25 - guard.  Huge |us| gives t = 0 and NaN fails the ordered
+                // compare, so both end up "risky".
+                const double wu = __builtin_fabs(us[g] - ru) - 0.25;
+                const double wv = __builtin_fabs(vs[g] - rv) - 0.25;
+                bool rk = !(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx);
+                rk = rk || !(__builtin_fabs(iz) > kGuardZ);
+                if (!IDENT) {   // bounds live in colour-pixel units here, not at integers of the depth grid
+                    const double bu = __builtin_fmin(__builtin_fabs(p.u), __builtin_fabs(p.u - Wd));
+                    const double bv = __builtin_fmin(__builtin_fabs(p.v), __builtin_fabs(p.v - Hd));
+                    rk = rk || !(__builtin_fmin(bu, bv) > kGuardPx);
+                }
+                risky[g] = rk;
+                if (WANT_XYZ) {
+                    p.ax = __builtin_fma(__builtin_fma(Us[0][1], myd[g], b0), dmm, Us[0][3]);
+                    p.ay = __builtin_fma(__builtin_fma(Us[1][1], myd[g], b1), dmm, Us[1][3]);
+                    p.az = __builtin_fma(__builtin_fma(Us[2][1], myd[g], b2), dmm, Us[2][3]);
+                } else {
+                    p.ax = p.ay = p.az = 0.0;
+                }
+            }
+            // phase C: depth test, guard, stores
+#pragma unroll
+            for (int g = 0; g < kRowGroup; ++g) {
+                Pixel &p = px[g];
+                const double dv = (double)dv16[g] * 0.001;
+                p.vis = test[g] && (p.qz < dv);
+                const bool rk = valid[g] && (risky[g] || (test[g] && !(__builtin_fabs(p.qz - dv) > kGuardZ)));
+                if (rk) {   // cold: the reference's own chain for this lane, everything recomputed
+                    const double d = (double)d16[g] * 0.001;
+                    exact_unproject(m1, mxd, myd[g], d, p.ax, p.ay, p.az);
+                    exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
+                    p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi);
+                }
+                const unsigned long long vmask = __ballot(p.vis);
+                n_vis += __popcll(vmask);
+                n_valid += __popcll(__ballot(valid[g]));
+                if (O::template has<O_VIS_BITS>(a.vis_bits) && (row0 + (uint32_t)(r0 + g)) < (uint32_t)a.H) {
+                    const uint64_t bit0 = (uint64_t)(row0 + (uint32_t)(r0 + g)) * (uint64_t)a.W + (uint64_t)stripe * 64u;
+                    uint64_t *wp = a.vis_bits + pair * c.words_per_pair + (int64_t)(bit0 >> 6);
+                    if (words_aligned) {
+                        if (c.lane == 0) *wp = vmask;
+                    } else if (c.lane == 0 && vmask) {   // stripes straddle words: OR into the zeroed bitset
+                        const uint32_t sh = (uint32_t)(bit0 & 63u);
+                        atomicOr((unsigned long long *)wp, vmask << sh);
+                        if (sh && (vmask >> (64u - sh))) atomicOr((unsigned long long *)wp + 1, vmask >> (64u - sh));
+                    }
+                }
+                store_pixel<O, true>(a, c, i[g], in_img[g], valid[g], p);
+            }
         }
     }
     // one LDS step and two atomics per workgroup (lane 0 of each wave holds the wave totals)
