@@ -87,9 +87,10 @@ extern "C" int mspa_vertex_visibility(const double *xyz, int64_t n_points, int64
                                       const uint16_t *depth, int32_t dh, int32_t dw, int32_t H, int32_t W,
                                       uint64_t *out_bits, uint8_t *out_mask, double *out_uv,
                                       double *out_depth, int32_t *out_count, mspa_stream_t stream) {
-    if (!xyz || !cam_mats || !depth) return fail(MSPA_EINVAL, "mspa_vertex_visibility: null input pointer");
     if (n_points < 0 || n_images < 0 || point_stride <= 0 || comp_stride <= 0)
         return fail(MSPA_EINVAL, "mspa_vertex_visibility: bad count or stride");
+    if ((!xyz && n_points > 0) || ((!cam_mats || !depth) && n_images > 0))
+        return fail(MSPA_EINVAL, "mspa_vertex_visibility: null input pointer");
     if (dh < 2 || dw < 2 || H < 2 || W < 2 || dh > 32767 || dw > 32767 || H > 32767 || W > 32767)
         return fail(MSPA_EINVAL, "mspa_vertex_visibility: image size out of range [2, 32767]");
     hipStream_t s = (hipStream_t)stream;
