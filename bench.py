@@ -43,6 +43,10 @@ VARIANTS = {
 }
 
 
+def _legs(spec):
+    return [v for v in spec.replace("'", "").replace('"', "").split(",") if v and v != "none"]
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,7 +62,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--also", default="corr:exact,dense:fast,dense:exact,minimal:fast",
-                    help="comma list of extra variant:mode legs timed briefly on rank 0")
+                    help="comma list of extra variant:mode legs timed briefly on rank 0 ('none' = skip)")
     return ap.parse_args()
 
 
@@ -85,7 +89,7 @@ def build_inputs(args, rank, device):
         depth[r * nb:(r + 1) * nb] = d.to(torch.int16)      # same 16 bits; the kernels read them as uint16
     mats = torch.from_numpy(np.tile(base_mats, (reps, 1, 1))).to(device)
     rgb = None
-    if VARIANTS[args.variant]["rgb"] or any(VARIANTS[v.split(":")[0]]["rgb"] for v in args.also.split(",") if v):
+    if VARIANTS[args.variant]["rgb"] or any(VARIANTS[v.split(":")[0]]["rgb"] for v in _legs(args.also)):
         rgb = torch.randint(0, 256, (n_frames, H, W, 3), generator=g, device=device, dtype=torch.uint8)
     # pairs: two different views of the same replica, walking through all replicas
     rng = np.random.default_rng(77 + rank)
@@ -187,7 +191,7 @@ def main():
 
     extra = {}
     if rank == 0:
-        for leg in [v for v in args.also.split(",") if v and v != f"{args.variant}:{args.mode}"]:
+        for leg in [v for v in _legs(args.also) if v != f"{args.variant}:{args.mode}"]:
             v, m = leg.split(":")
             w2, k2, _ = time_variant(v, m, depth, mats, rgb, pairs, max(3, args.steps // 4), 1, None)
             b2 = VARIANTS[v]["bytes_per_px"] * P * args.pairs
