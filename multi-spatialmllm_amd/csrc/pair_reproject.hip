@@ -334,11 +334,20 @@ __device__ __forceinline__ double uniform(double v) {   // VGPR holding a wave-u
 }
 
 constexpr int kTileRows = 16;                    // a wave owns a 64-column x 16-row tile
-constexpr int kRowGroup = 4;                     // rows whose loads/gathers are in flight together
+constexpr int kRowGroup = 4;                     // rows whose depth-2 gathers are in flight together
 
-// Fast kernel mapping: lane <-> image column, the wave walks down kTileRows rows.  The column is
-// loop-invariant per lane and the row is wave-uniform, so the pixel-coordinate half of the composed
-// product (M[:,0]*mx + M[:,2]) is computed once per lane and no integer division is needed.
+// Fast kernel.
+//  * Mapping: lane <-> image column, the wave walks down kTileRows rows.  The column is loop-invariant
+//    per lane and the row is wave-uniform, so the pixel-coordinate half of the composed product
+//    (M[:,0]*mx + M[:,2]) is computed once per lane, the row half is one add per row, and no integer
+//    division is needed.
+//  * Memory-level parallelism: all kTileRows depth-1 samples of the tile are requested before any
+//    arithmetic (one 128-byte line per wave-row, kTileRows lines in flight per wave); depth-2 gathers
+//    are issued kRowGroup rows at a time.  With one row at a time a wave pays two dependent memory
+//    round trips per row and the kernel sits at ~30 % of HBM bandwidth (profiles/r01).
+//  * The hot loop is branch-free.  Lanes whose decisions fall inside the guard band only set a bit in
+//    a per-lane row mask; one cold loop after the tile re-evaluates those pixels with the exact chain
+//    and patches the outputs (pixel index store, bit flip by atomicXor, counter delta).
 template <bool IDENT, uint32_t SET, bool GENERIC>
 __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__restrict__ depth,
                                                              const uint8_t *__restrict__ rgb,
@@ -391,117 +400,124 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
     const bool col_ok = tile_ok && col < (uint32_t)a.W;
     const uint32_t colc = col_ok ? col : 0u;
     const uint32_t row0 = band * (uint32_t)kTileRows;
-    const double mxd = (double)colc;
-    // column half of the product: a_r = M[r][0]*mx + M[r][2]
-    const double a0 = __builtin_fma(M[0][0], mxd, M[0][2]);
-    const double a1 = __builtin_fma(M[1][0], mxd, M[1][2]);
-    const double a2 = __builtin_fma(M[2][0], mxd, M[2][2]);
-    double b0 = 0, b1 = 0, b2 = 0;
-    if (WANT_XYZ) {
-        b0 = __builtin_fma(Us[0][0], mxd, Us[0][2]);
-        b1 = __builtin_fma(Us[1][0], mxd, Us[1][2]);
-        b2 = __builtin_fma(Us[2][0], mxd, Us[2][2]);
-    }
-    int dx1 = 0;
-    if (!IDENT) dx1 = round_clip((double)colc * a.sx, a.dw - 1);   // OPS:286-290, column part
-    const double Wd = (double)a.W, Hd = (double)a.H;
     const bool words_aligned = (a.W & 63) == 0;
 
     int n_valid = 0, n_vis = 0;          // wave totals, kept uniform (SALU popcounts of ballots)
     if (tile_ok) {
-        // Rows are processed kRowGroup at a time in three straight-line phases so that the kRowGroup
-        // depth-1 loads, and then the kRowGroup depth-2 gathers, are in flight together: with one row
-        // at a time a wave pays two dependent memory round trips per row and the kernel is latency
-        // bound at ~30 % of HBM bandwidth.
+        int dx1 = 0;
+        if (!IDENT) dx1 = round_clip((double)colc * a.sx, a.dw - 1);   // OPS:286-290, column part
+        // depth-1 sample of (tile row g, this lane's column); rows past the image are clamped
+        auto load_d1 = [&](int g) -> uint32_t {
+            const uint32_t row = min(row0 + (uint32_t)g, (uint32_t)a.H - 1u);
+            if (IDENT) return c.depth1[row * (uint32_t)a.W + colc];
+            const int dy = round_clip((double)row * a.sy, a.dh - 1);
+            return c.depth1[dy * a.dw + dx1];
+        };
+        uint32_t d16n[kRowGroup];                   // samples of the NEXT row group (software prefetch)
+#pragma unroll
+        for (int j = 0; j < kRowGroup; ++j) d16n[j] = load_d1(j);
+        const double mxd = (double)colc;
+        const double myd0 = (double)row0;
+        // t_r = M[r][0]*mx + M[r][1]*my + M[r][2]; advanced by M[r][1] per row
+        double t0 = __builtin_fma(M[0][1], myd0, __builtin_fma(M[0][0], mxd, M[0][2]));
+        double t1 = __builtin_fma(M[1][1], myd0, __builtin_fma(M[1][0], mxd, M[1][2]));
+        double t2 = __builtin_fma(M[2][1], myd0, __builtin_fma(M[2][0], mxd, M[2][2]));
+        double s0 = 0, s1 = 0, s2 = 0;
+        if (WANT_XYZ) {
+            s0 = __builtin_fma(Us[0][1], myd0, __builtin_fma(Us[0][0], mxd, Us[0][2]));
+            s1 = __builtin_fma(Us[1][1], myd0, __builtin_fma(Us[1][0], mxd, Us[1][2]));
+            s2 = __builtin_fma(Us[2][1], myd0, __builtin_fma(Us[2][0], mxd, Us[2][2]));
+        }
+        const double Wd = (double)a.W, Hd = (double)a.H;
+        uint32_t risky_rows = 0, vis_rows = 0;       // per-lane row masks for the cold loop
+
+#pragma unroll 1
         for (int r0 = 0; r0 < kTileRows; r0 += kRowGroup) {
-            uint32_t i[kRowGroup], d16[kRowGroup], dv16[kRowGroup];
-            bool in_img[kRowGroup], valid[kRowGroup], test[kRowGroup], risky[kRowGroup];
-            double myd[kRowGroup], us[kRowGroup], vs[kRowGroup];
-            Pixel px[kRowGroup];
-            // phase A: depth-1 samples
+            uint32_t d16[kRowGroup];
 #pragma unroll
-            for (int g = 0; g < kRowGroup; ++g) {
-                const uint32_t row = row0 + (uint32_t)(r0 + g);
-                const bool row_ok = row < (uint32_t)a.H;                     // wave-uniform
-                const uint32_t rowc = row_ok ? row : (uint32_t)a.H - 1u;
-                in_img[g] = col_ok && row_ok;
-                i[g] = rowc * (uint32_t)a.W + colc;
-                myd[g] = (double)rowc;
-                if (IDENT) {
-                    d16[g] = c.depth1[i[g]];
-                } else {
-                    const int dy = round_clip(myd[g] * a.sy, a.dh - 1);
-                    d16[g] = c.depth1[dy * a.dw + dx1];
-                }
+            for (int j = 0; j < kRowGroup; ++j) d16[j] = d16n[j];
+            if (r0 + kRowGroup < kTileRows) {       // wave-uniform: request the next group's samples now
+#pragma unroll
+                for (int j = 0; j < kRowGroup; ++j) d16n[j] = load_d1(r0 + kRowGroup + j);
             }
-            // phase B: composed projection, pixel index, gather issue
+            double qz[kRowGroup];
+            float fx[kRowGroup], fy[kRowGroup], fz[kRowGroup];
+            int pix[kRowGroup];
+            uint32_t dv16[kRowGroup];
+            bool valid[kRowGroup], test[kRowGroup], risky[kRowGroup];
+            // ---- projection + gather issue ---------------------------------------------------
 #pragma unroll
-            for (int g = 0; g < kRowGroup; ++g) {
-                valid[g] = in_img[g] && (d16[g] != 0u);                      // OPS:297 (d16*0.001 > 0 <=> d16 != 0)
-                const double dmm = (double)d16[g];
+            for (int j = 0; j < kRowGroup; ++j) {
+                const int g = r0 + j;
+                const bool in_img = col_ok && (row0 + (uint32_t)g) < (uint32_t)a.H;
+                valid[j] = in_img & (d16[j] != 0u);                          // OPS:297
+                const double dmm = (double)d16[j];
                 // (ix, iy, iz) = M * (mx*d, my*d, d, 1) = d * (M[:, :3] * (mx, my, 1)) + M[:, 3]
-                const double ix = __builtin_fma(__builtin_fma(M[0][1], myd[g], a0), dmm, M[0][3]);
-                const double iy = __builtin_fma(__builtin_fma(M[1][1], myd[g], a1), dmm, M[1][3]);
-                const double iz = __builtin_fma(__builtin_fma(M[2][1], myd[g], a2), dmm, M[2][3]);   // camera-2 depth
+                const double ix = __builtin_fma(t0, dmm, M[0][3]);
+                const double iy = __builtin_fma(t1, dmm, M[1][3]);
+                const double iz = __builtin_fma(t2, dmm, M[2][3]);          // camera-2 depth
+                if (WANT_XYZ) {
+                    fx[j] = (float)__builtin_fma(s0, dmm, Us[0][3]);
+                    fy[j] = (float)__builtin_fma(s1, dmm, Us[1][3]);
+                    fz[j] = (float)__builtin_fma(s2, dmm, Us[2][3]);
+                    s0 += Us[0][1];
+                    s1 += Us[1][1];
+                    s2 += Us[2][1];
+                }
+                t0 += M[0][1];
+                t1 += M[1][1];
+                t2 += M[2][1];
                 // reciprocal: hardware estimate + one Newton step (squares the relative error; the
                 // guard band only needs ~1e-9 relative)
                 double rz = __builtin_amdgcn_rcp(iz);
                 rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
-                Pixel &p = px[g];
-                p.u = ix * rz;
-                p.v = iy * rz;
-                p.qz = iz;
-                us[g] = IDENT ? p.u : p.u * a.sx;
-                vs[g] = IDENT ? p.v : p.v * a.sy;
-                const double ru = __builtin_rint(us[g]), rv = __builtin_rint(vs[g]);
-                const bool inb = (p.u >= 0.0) && (p.u < Wd) && (p.v >= 0.0) && (p.v < Hd);
+                const double u = ix * rz, v = iy * rz;
+                const double us = IDENT ? u : u * a.sx;
+                const double vs = IDENT ? v : v * a.sy;
+                const double ru = __builtin_rint(us), rv = __builtin_rint(vs);
+                const bool inb = (u >= 0.0) & (u < Wd) & (v >= 0.0) & (v < Hd);
                 // saturating conversion, then an integer clamp (NaN -> 0; overflow is caught by the guard)
-                p.xi = min(max((int)ru, 0), a.dw - 1);
-                p.yi = min(max((int)rv, 0), a.dh - 1);
-                test[g] = valid[g] && inb && (iz > 0.0);
+                const int xi = min(max((int)ru, 0), a.dw - 1);
+                const int yi = min(max((int)rv, 0), a.dh - 1);
+                test[j] = valid[j] & inb & (iz > 0.0);           // bitwise: no short-circuit branches
                 // unconditional gather (pixel 0 for lanes that cannot pass) keeps the code straight-line
-                dv16[g] = c.depth2[test[g] ? (p.yi * a.dw + p.xi) : 0];
+                dv16[j] = c.depth2[test[j] ? (yi * a.dw + xi) : 0];
+                pix[j] = (int)((uint32_t)xi | ((uint32_t)yi << 16));
+                qz[j] = iz;
                 // Guard band, coordinate part.  With t = us - rint(us) in [-0.5, 0.5], a decision can
                 // flip only if |t| is within the guard of 0.5 (rounding tie) or of 0 (u at an integer:
                 // the image bounds 0 and W are integers), i.e. unless guard < |t| < 0.5 - guard  <=>
                 // ||t| - 0.25| < 0.25 - guard.  Huge |us| gives t = 0 and NaN fails the ordered
                 // compare, so both end up "risky".
-                const double wu = __builtin_fabs(us[g] - ru) - 0.25;
-                const double wv = __builtin_fabs(vs[g] - rv) - 0.25;
+                const double wu = __builtin_fabs(us - ru) - 0.25;
+                const double wv = __builtin_fabs(vs - rv) - 0.25;
                 bool rk = !(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx);
-                rk = rk || !(__builtin_fabs(iz) > kGuardZ);
+                rk = rk | !(__builtin_fabs(iz) > kGuardZ);
                 if (!IDENT) {   // bounds live in colour-pixel units here, not at integers of the depth grid
-                    const double bu = __builtin_fmin(__builtin_fabs(p.u), __builtin_fabs(p.u - Wd));
-                    const double bv = __builtin_fmin(__builtin_fabs(p.v), __builtin_fabs(p.v - Hd));
-                    rk = rk || !(__builtin_fmin(bu, bv) > kGuardPx);
+                    const double bu = __builtin_fmin(__builtin_fabs(u), __builtin_fabs(u - Wd));
+                    const double bv = __builtin_fmin(__builtin_fabs(v), __builtin_fabs(v - Hd));
+                    rk = rk | !(__builtin_fmin(bu, bv) > kGuardPx);
                 }
-                risky[g] = rk;
-                if (WANT_XYZ) {
-                    p.ax = __builtin_fma(__builtin_fma(Us[0][1], myd[g], b0), dmm, Us[0][3]);
-                    p.ay = __builtin_fma(__builtin_fma(Us[1][1], myd[g], b1), dmm, Us[1][3]);
-                    p.az = __builtin_fma(__builtin_fma(Us[2][1], myd[g], b2), dmm, Us[2][3]);
-                } else {
-                    p.ax = p.ay = p.az = 0.0;
-                }
+                risky[j] = rk;
             }
-            // phase C: depth test, guard, stores
+            // ---- depth test, outputs ----------------------------------------------------------
 #pragma unroll
-            for (int g = 0; g < kRowGroup; ++g) {
-                Pixel &p = px[g];
-                const double dv = (double)dv16[g] * 0.001;
-                p.vis = test[g] && (p.qz < dv);
-                const bool rk = valid[g] && (risky[g] || (test[g] && !(__builtin_fabs(p.qz - dv) > kGuardZ)));
-                if (rk) {   // cold: the reference's own chain for this lane, everything recomputed
-                    const double d = (double)d16[g] * 0.001;
-                    exact_unproject(m1, mxd, myd[g], d, p.ax, p.ay, p.az);
-                    exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
-                    p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi);
-                }
-                const unsigned long long vmask = __ballot(p.vis);
+            for (int j = 0; j < kRowGroup; ++j) {
+                const int g = r0 + j;
+                const uint32_t row = row0 + (uint32_t)g;
+                const bool row_ok = row < (uint32_t)a.H;                      // wave-uniform
+                const bool in_img = col_ok && row_ok;
+                const double dv = (double)dv16[j] * 0.001;
+                const bool vis = test[j] & (qz[j] < dv);
+                const bool rk = valid[j] & (risky[j] | (test[j] & !(__builtin_fabs(qz[j] - dv) > kGuardZ)));
+                risky_rows |= (uint32_t)rk << g;
+                vis_rows |= (uint32_t)vis << g;
+                const unsigned long long vmask = __ballot(vis);
                 n_vis += __popcll(vmask);
-                n_valid += __popcll(__ballot(valid[g]));
-                if (O::template has<O_VIS_BITS>(a.vis_bits) && (row0 + (uint32_t)(r0 + g)) < (uint32_t)a.H) {
-                    const uint64_t bit0 = (uint64_t)(row0 + (uint32_t)(r0 + g)) * (uint64_t)a.W + (uint64_t)stripe * 64u;
+                n_valid += __popcll(__ballot(valid[j]));
+                if (!row_ok) continue;
+                if (O::template has<O_VIS_BITS>(a.vis_bits)) {
+                    const uint64_t bit0 = (uint64_t)row * (uint64_t)a.W + (uint64_t)stripe * 64u;
                     uint64_t *wp = a.vis_bits + pair * c.words_per_pair + (int64_t)(bit0 >> 6);
                     if (words_aligned) {
                         if (c.lane == 0) *wp = vmask;
@@ -511,8 +527,65 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
                         if (sh && (vmask >> (64u - sh))) atomicOr((unsigned long long *)wp + 1, vmask >> (64u - sh));
                     }
                 }
-                store_pixel<O, true>(a, c, i[g], in_img[g], valid[g], p);
+                if (in_img) {
+                    const int64_t o = c.obase + (int64_t)(row * (uint32_t)a.W + colc);
+                    if (O::template has<O_VIS_U8>(a.vis_u8)) a.vis_u8[o] = vis ? 1 : 0;
+                    if (O::template has<O_VALID_U8>(a.valid_u8)) a.valid_u8[o] = valid[j] ? 1 : 0;
+                    if (O::template has<O_PIX>(a.pix_i16))
+                        reinterpret_cast<int *>(a.pix_i16)[o] = valid[j] ? pix[j] : -1;
+                    if (O::template has<O_XYZ32>(a.xyz_f32)) {
+                        float *q = a.xyz_f32 + 3 * o;
+                        const float fn = __builtin_nanf("");
+                        q[0] = valid[j] ? fx[j] : fn;
+                        q[1] = valid[j] ? fy[j] : fn;
+                        q[2] = valid[j] ? fz[j] : fn;
+                    }
+                    if (O::template has<O_RGBA>(a.rgba)) {
+                        uint32_t colr = 0;
+                        if (c.rgb1) {
+                            const uint8_t *s = c.rgb1 + 3 * (int64_t)(row * (uint32_t)a.W + colc);
+                            colr = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
+                        }
+                        a.rgba[o] = colr | (valid[j] ? 0xFF000000u : 0u);
+                    }
+                }
             }
+        }
+
+        // ---- cold loop: exact re-evaluation of the guarded pixels ---------------------------------
+        if (__ballot(risky_rows != 0u)) {
+            __builtin_amdgcn_s_waitcnt(0);            // the fast path's stores have reached L2
+            int delta = 0;
+            while (risky_rows) {
+                const int g = __builtin_ctz(risky_rows);
+                risky_rows &= risky_rows - 1u;
+                const uint32_t row = row0 + (uint32_t)g;
+                const uint32_t i = row * (uint32_t)a.W + colc;
+                uint32_t dd;
+                if (IDENT) {
+                    dd = c.depth1[i];
+                } else {
+                    const int dy = round_clip((double)row * a.sy, a.dh - 1);
+                    dd = c.depth1[dy * a.dw + dx1];
+                }
+                Pixel p;
+                exact_unproject(m1, mxd, (double)row, (double)dd * 0.001, p.ax, p.ay, p.az);
+                exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
+                p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi);
+                const bool was = (vis_rows >> g) & 1u;
+                if (p.vis != was) {
+                    delta += p.vis ? 1 : -1;
+                    if (O::template has<O_VIS_BITS>(a.vis_bits)) {
+                        const uint64_t bit = (uint64_t)row * (uint64_t)a.W + (uint64_t)col;
+                        atomicXor((unsigned long long *)(a.vis_bits + pair * c.words_per_pair + (int64_t)(bit >> 6)),
+                                  1ull << (bit & 63u));
+                    }
+                }
+                store_pixel<O, true>(a, c, i, true, true, p);
+            }
+            // wave-reduce the visible-count corrections (rare path)
+            for (int off = 32; off > 0; off >>= 1) delta += __shfl_down(delta, off);
+            n_vis += __builtin_amdgcn_readfirstlane(delta);
         }
     }
     // one LDS step and two atomics per workgroup (lane 0 of each wave holds the wave totals)
