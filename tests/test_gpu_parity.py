@@ -322,8 +322,9 @@ def test_pair_overlap(n_bits):
         ref = O.calculate_camera_overlap(masks[i], masks[j])
         c, ci, cu = C.pair_overlap(masks[i], masks[j])
         assert inter[p] == ci == int((masks[i] & masks[j]).sum()) and uni[p] == cu
-        if np.isnan(ref):
-            assert np.isnan(overlap[p]) and (i, j) == (3, 5)
+        assert np.isnan(ref) == (cu == 0)
+        if np.isnan(ref):                  # empty union (both masks empty), e.g. the pair (3, 5)
+            assert np.isnan(overlap[p]) and cu == 0
         else:
             assert same_f64(overlap[p], ref)
 
