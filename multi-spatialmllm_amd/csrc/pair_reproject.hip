@@ -348,7 +348,9 @@ constexpr int kRowGroup = 4;                     // rows whose depth-2 gathers a
 //  * The hot loop is branch-free.  Lanes whose decisions fall inside the guard band only set a bit in
 //    a per-lane row mask; one cold loop after the tile re-evaluates those pixels with the exact chain
 //    and patches the outputs (pixel index store, bit flip by atomicXor, counter delta).
-template <bool IDENT, uint32_t SET, bool GENERIC>
+//  * TIGHT = the image is a whole number of tiles (W % 64 == 0, H % kTileRows == 0, true for 640x480):
+//    no edge predicates, bitset words coincide with wave rows.
+template <bool IDENT, bool TIGHT, uint32_t SET, bool GENERIC>
 __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__restrict__ depth,
                                                              const uint8_t *__restrict__ rgb,
                                                              const double *__restrict__ mats,
@@ -397,10 +399,10 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
     const uint32_t stripe = tile - band * (uint32_t)a.n_stripes;
     const bool tile_ok = tile < (uint32_t)a.n_tiles;
     const uint32_t col = stripe * 64u + (uint32_t)c.lane;
-    const bool col_ok = tile_ok && col < (uint32_t)a.W;
+    const bool col_ok = TIGHT ? true : (tile_ok && col < (uint32_t)a.W);
     const uint32_t colc = col_ok ? col : 0u;
     const uint32_t row0 = band * (uint32_t)kTileRows;
-    const bool words_aligned = (a.W & 63) == 0;
+    const bool words_aligned = TIGHT || (a.W & 63) == 0;
 
     int n_valid = 0, n_vis = 0;          // wave totals, kept uniform (SALU popcounts of ballots)
     if (tile_ok) {
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
         if (!IDENT) dx1 = round_clip((double)colc * a.sx, a.dw - 1);   // OPS:286-290, column part
         // depth-1 sample of (tile row g, this lane's column); rows past the image are clamped
         auto load_d1 = [&](int g) -> uint32_t {
-            const uint32_t row = min(row0 + (uint32_t)g, (uint32_t)a.H - 1u);
+            const uint32_t row = TIGHT ? row0 + (uint32_t)g : min(row0 + (uint32_t)g, (uint32_t)a.H - 1u);
             if (IDENT) return c.depth1[row * (uint32_t)a.W + colc];
             const int dy = round_clip((double)row * a.sy, a.dh - 1);
             return c.depth1[dy * a.dw + dx1];
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 #pragma unroll
             for (int j = 0; j < kRowGroup; ++j) {
                 const int g = r0 + j;
-                const bool in_img = col_ok && (row0 + (uint32_t)g) < (uint32_t)a.H;
+                const bool in_img = TIGHT ? true : (col_ok && (row0 + (uint32_t)g) < (uint32_t)a.H);
                 valid[j] = in_img & (d16[j] != 0u);                          // OPS:297
                 const double dmm = (double)d16[j];
                 // (ix, iy, iz) = M * (mx*d, my*d, d, 1) = d * (M[:, :3] * (mx, my, 1)) + M[:, 3]
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
             for (int j = 0; j < kRowGroup; ++j) {
                 const int g = r0 + j;
                 const uint32_t row = row0 + (uint32_t)g;
-                const bool row_ok = row < (uint32_t)a.H;                      // wave-uniform
+                const bool row_ok = TIGHT ? true : row < (uint32_t)a.H;       // wave-uniform
                 const bool in_img = col_ok && row_ok;
                 const double dv = (double)dv16[j] * 0.001;
                 const bool vis = test[j] & (qz[j] < dv);
@@ -675,18 +677,18 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
         set |= out_vis_bits ? O_VIS_BITS : 0; set |= out_vis_u8 ? O_VIS_U8 : 0; set |= out_valid_u8 ? O_VALID_U8 : 0;
         set |= out_pix_i16 ? O_PIX : 0; set |= out_xyz_f32 ? O_XYZ32 : 0; set |= out_rgba ? O_RGBA : 0;
         set |= out_counts ? O_COUNTS : 0;
-#define MSPA_LAUNCH_FAST(ID, SET_, GEN) \
-    hipLaunchKernelGGL((pair_fast_kernel<ID, SET_, GEN>), grid, block, 0, s, depth, rgb, frame_mats, pairs, a)
-        if (ident) {
-            if (set == kSetCorr) MSPA_LAUNCH_FAST(true, kSetCorr, false);
-            else if (set == kSetDense) MSPA_LAUNCH_FAST(true, kSetDense, false);
-            else if (set == kSetMinimal) MSPA_LAUNCH_FAST(true, kSetMinimal, false);
-            else MSPA_LAUNCH_FAST(true, 0u, true);
+#define MSPA_LAUNCH_FAST(ID, TI, SET_, GEN) \
+    hipLaunchKernelGGL((pair_fast_kernel<ID, TI, SET_, GEN>), grid, block, 0, s, depth, rgb, frame_mats, pairs, a)
+        const bool tight = (W % 64 == 0) && (H % kTileRows == 0);
+        if (ident && tight) {           // the BASELINE shape: 640x480 colour == depth
+            if (set == kSetCorr) MSPA_LAUNCH_FAST(true, true, kSetCorr, false);
+            else if (set == kSetDense) MSPA_LAUNCH_FAST(true, true, kSetDense, false);
+            else if (set == kSetMinimal) MSPA_LAUNCH_FAST(true, true, kSetMinimal, false);
+            else MSPA_LAUNCH_FAST(true, true, 0u, true);
+        } else if (ident) {
+            MSPA_LAUNCH_FAST(true, false, 0u, true);
         } else {
-            if (set == kSetCorr) MSPA_LAUNCH_FAST(false, kSetCorr, false);
-            else if (set == kSetDense) MSPA_LAUNCH_FAST(false, kSetDense, false);
-            else if (set == kSetMinimal) MSPA_LAUNCH_FAST(false, kSetMinimal, false);
-            else MSPA_LAUNCH_FAST(false, 0u, true);
+            MSPA_LAUNCH_FAST(false, false, 0u, true);
         }
 #undef MSPA_LAUNCH_FAST
     }
