@@ -137,6 +137,46 @@ int mspa_pair_overlap(const uint64_t *bits, int32_t n_images, int64_t n_words, c
                       int64_t n_pairs, double *out_overlap, int32_t *out_inter, int32_t *out_union,
                       mspa_stream_t stream);
 
+/*
+ * K4 -- per-pair camera relations: the distance / yaw / pitch columns of CFR.process_scene's pair
+ * table (CFR:176-189) and the relative-pose translation of CME.build_training_sample (CME:185-190).
+ *
+ *   E_aligned, Einv_aligned  [n_frames, 16] float64: A @ E and its inverse (host, numpy.linalg.inv)
+ *   yaw, pitch               [n_frames] float64 degrees, extract_yaw_pitch (CFR:86-100) on the host
+ *   pairs                    [n_pairs, 2] int32 (i, j)
+ *   out                      [n_pairs, 6] float64: ||t_j - t_i||, yaw_j - yaw_i, pitch_j - pitch_i,
+ *                            then the translation column of inv(E_i) @ E_j (camera-i axes)
+ */
+int mspa_pair_pose(const double *E_aligned, const double *Einv_aligned, const double *yaw,
+                   const double *pitch, int32_t n_frames, const int32_t *pairs, int64_t n_pairs,
+                   double *out, mspa_stream_t stream);
+
+/*
+ * K5a -- TAPVid-3D tracks: camera->world (OM_C:446-454) and the normalised pinhole projection with
+ * its validity test (TwoFrameVideoQAEngine.project_point, OM_C:293-315) for every (frame, point).
+ *
+ *   tracks_xyz  [T, P, 3] float64 camera-space      c2w  [T, 16] float64 = inv(extrinsics_w2c) (host)
+ *   fx_fy_cx_cy_host  4 float64 on the HOST          H, W image size
+ *   out_world [T, P, 3] f64,  out_uvn [T, P, 2] f64 (u/W, v/H),  out_ok [T, P] u8
+ *   (1 = the reference would return coordinates, 0 = it returns None); each optional.
+ */
+int mspa_track_to_world(const double *tracks_xyz, const double *c2w, int32_t T, int32_t P,
+                        const double *fx_fy_cx_cy_host, int32_t H, int32_t W, double *out_world,
+                        double *out_uvn, uint8_t *out_ok, mspa_stream_t stream);
+
+/*
+ * K5b -- object displacement between two frames of one track point (OM_C:324-356) and the pair
+ * distance used for binning (OM_C:484-498), for a list of (frame1, frame2, point) triples.
+ *
+ *   world [T, P, 3] f64 (K5a),  w2c / c2w [T, 16] f64,  triples [n, 3] int32
+ *   out   [n, 5] f64: distance (0 when below obj_threshold), displacement in camera-1 axes (x, y, z;
+ *         zeroed likewise), np.linalg.norm(axis=1)-form pair distance
+ *   out_flags [n, 2] u8: point_moving, cam_moving
+ */
+int mspa_track_displacement(const double *world, const double *w2c, const double *c2w, int32_t T,
+                            int32_t P, const int32_t *triples, int64_t n, double obj_threshold,
+                            double cam_threshold, double *out, uint8_t *out_flags, mspa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -191,3 +191,69 @@ def pair_overlap(bits: torch.Tensor, pairs: torch.Tensor, want_counts: bool = Fa
     _lib.check(lib.mspa_pair_overlap(bits.data_ptr(), bits.shape[0], bits.shape[1], pairs.data_ptr(), n_pairs,
                                      overlap.data_ptr(), _ptr(inter), _ptr(uni), _stream_ptr()))
     return (overlap, inter, uni) if want_counts else overlap
+
+
+def extract_yaw_pitch_host(E_aligned_list: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
+    """Per-frame angles exactly as CFR:86-100 computes them (NumPy on the host: F values per scene,
+    and the reference's own libm calls are the only way to be bit-identical with it)."""
+    yaw, pitch = [], []
+    for E in E_aligned_list:
+        z = np.asarray(E)[:3, 2]
+        yaw.append(np.degrees(np.arctan2(z[1], z[0])))
+        pitch.append(np.degrees(np.arcsin(z[2] / np.linalg.norm(z))))
+    return np.array(yaw, dtype=np.float64), np.array(pitch, dtype=np.float64)
+
+
+def pair_pose(E_aligned: torch.Tensor, Einv_aligned: torch.Tensor, yaw: torch.Tensor, pitch: torch.Tensor,
+              pairs: torch.Tensor) -> torch.Tensor:
+    """Enqueue K4.  E_aligned / Einv_aligned [F,16] f64, yaw / pitch [F] f64, pairs [n,2] i32 ->
+    [n,6] f64: distance, dyaw, dpitch, translation of inv(E_i) @ E_j."""
+    _require_gpu()
+    lib = _lib.load()
+    F = E_aligned.shape[0]
+    for t in (E_aligned, Einv_aligned):
+        assert t.dtype == torch.float64 and tuple(t.shape) == (F, 16)
+    assert yaw.dtype == torch.float64 and pitch.dtype == torch.float64 and pairs.dtype == torch.int32
+    out = torch.empty((pairs.shape[0], 6), dtype=torch.float64, device=E_aligned.device)
+    _lib.check(lib.mspa_pair_pose(_ptr(E_aligned), _ptr(Einv_aligned), _ptr(yaw), _ptr(pitch), F, _ptr(pairs),
+                                  pairs.shape[0], _ptr(out), _stream_ptr()))
+    return out
+
+
+def track_to_world(tracks_xyz: torch.Tensor, c2w: Optional[torch.Tensor], fx_fy_cx_cy: Sequence[float],
+                   image_hw: Tuple[int, int], want=("world", "uvn", "ok")) -> Dict[str, torch.Tensor]:
+    """Enqueue K5a.  tracks_xyz [T,P,3] f64, c2w [T,16] f64 (np.linalg.inv(extrinsics_w2c) on the host)."""
+    _require_gpu()
+    lib = _lib.load()
+    import ctypes
+    T, P, _ = tracks_xyz.shape
+    assert tracks_xyz.dtype == torch.float64 and tracks_xyz.is_contiguous()
+    dev = tracks_xyz.device
+    out = {}
+    if "world" in want:
+        out["world"] = torch.empty((T, P, 3), dtype=torch.float64, device=dev)
+    if "uvn" in want:
+        out["uvn"] = torch.empty((T, P, 2), dtype=torch.float64, device=dev)
+    if "ok" in want:
+        out["ok"] = torch.empty((T, P), dtype=torch.uint8, device=dev)
+    intr = (ctypes.c_double * 4)(*[float(v) for v in fx_fy_cx_cy])
+    H, W = image_hw
+    _lib.check(lib.mspa_track_to_world(_ptr(tracks_xyz), _ptr(c2w), T, P, intr, H, W, _ptr(out.get("world")),
+                                       _ptr(out.get("uvn")), _ptr(out.get("ok")), _stream_ptr()))
+    return out
+
+
+def track_displacement(world: torch.Tensor, w2c: torch.Tensor, c2w: torch.Tensor, triples: torch.Tensor,
+                       obj_threshold: float = 0.01, cam_threshold: float = 0.01):
+    """Enqueue K5b.  Returns ([n,5] f64: distance, dx, dy, dz (camera-1 axes), binning distance;
+    [n,2] u8: point_moving, cam_moving)."""
+    _require_gpu()
+    lib = _lib.load()
+    T, P, _ = world.shape
+    assert triples.dtype == torch.int32 and triples.dim() == 2 and triples.shape[1] == 3
+    n = triples.shape[0]
+    out = torch.empty((n, 5), dtype=torch.float64, device=world.device)
+    flags = torch.empty((n, 2), dtype=torch.uint8, device=world.device)
+    _lib.check(lib.mspa_track_displacement(_ptr(world), _ptr(w2c), _ptr(c2w), T, P, _ptr(triples), n,
+                                           obj_threshold, cam_threshold, _ptr(out), _ptr(flags), _stream_ptr()))
+    return out, flags

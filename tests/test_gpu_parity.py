@@ -381,3 +381,81 @@ def test_full_size_properties():
         ref = C.frame_pair(sc.depth[a], sc.depth[b], sc.K, sc.E[a], sc.E[b], sc.A, sc.color_hw)
         assert np.array_equal(unpack_bits(bits[p], P), ref["vis"])
         assert tuple(counts[p]) == (ref["n_valid"], ref["n_vis"])
+
+
+# ------------------------------------------------------------------------------------------
+# K4 pair pose / K5 track geometry
+# ------------------------------------------------------------------------------------------
+def f64_ok(a, b):
+    return same_f64(a, b) or close_f64(a, b, rtol=1e-12, scale=1e-6)
+
+
+@pytest.mark.parametrize("name", ["scene_ident", "scene_scaled"])
+def test_pair_pose_golden(name):
+    """K4 against the reference's CFR pair table and CME relative-pose answers (tests/golden)."""
+    g = GoldenScene(name)
+    ids = g.valid_image_ids
+    Ea = [g.A @ g.E[i] for i in ids]
+    yaw, pitch = engine.extract_yaw_pitch_host(Ea)
+    E_t = torch.from_numpy(np.stack(Ea).reshape(-1, 16)).to(DEV)
+    Einv_t = torch.from_numpy(np.stack([np.linalg.inv(e) for e in Ea]).reshape(-1, 16)).to(DEV)
+    pairs = engine.all_pairs(len(ids), DEV)
+    both = torch.cat([pairs, pairs.flip(1)], dim=0).contiguous()         # (i, j) and the swapped (j, i)
+    out = engine.pair_pose(E_t, Einv_t, torch.from_numpy(yaw).to(DEV), torch.from_numpy(pitch).to(DEV), both)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    n = pairs.shape[0]
+    ref = g["cfr_values"]
+    assert f64_ok(out[:n, 0], ref[:, 1])                                   # distance  CFR:183
+    assert same_f64(out[:n, 1], ref[:, 2]) and same_f64(out[:n, 2], ref[:, 3])   # yaw / pitch differences
+    for p, (swap, ans) in enumerate(zip(g["cme_swap"], g["cme_answers_json"])):
+        a = json.loads(str(ans))
+        d = out[p + n, 3:6] if swap else out[p, 3:6]
+        assert f64_ok(d, a["displacement_vector"])
+        assert [int(v * 1000) for v in d] == [a["x_value"], a["y_value"], a["z_value"]]      # CME:221-223
+        assert int(np.linalg.norm(d) * 1000) == a["total_distance"]
+
+
+def test_track_geometry_golden():
+    """K5 against the reference's TAPVid records (tests/golden/tracks.npz) and the oracle."""
+    import os
+    from golden_util import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, "tracks.npz"))
+    T, P, _ = z["tracks_XYZ"].shape
+    hw = tuple(int(v) for v in z["image_hw"])
+    tracks = torch.from_numpy(np.ascontiguousarray(z["tracks_XYZ"])).to(DEV)
+    w2c_np = np.ascontiguousarray(z["extrinsics_w2c"])
+    c2w_np = np.linalg.inv(w2c_np)                                          # OM_C:448, on the host
+    c2w = torch.from_numpy(c2w_np.reshape(T, 16)).to(DEV)
+    w2c = torch.from_numpy(w2c_np.reshape(T, 16)).to(DEV)
+    res = engine.track_to_world(tracks, c2w, z["fx_fy_cx_cy"], hw)
+    trip_np = np.ascontiguousarray(z["pairs"].astype(np.int32))
+    disp, flags = engine.track_displacement(res["world"], w2c, c2w, torch.from_numpy(trip_np).to(DEV))
+    torch.cuda.synchronize()
+    world = res["world"].cpu().numpy()
+    assert f64_ok(world, z["ref_world"])
+    uvn, ok = res["uvn"].cpu().numpy(), res["ok"].cpu().numpy().astype(bool)
+    for t in range(T):
+        for p in range(0, P, 5):
+            r = O.project_point(z["tracks_XYZ"][t, p], z["fx_fy_cx_cy"], hw[0], hw[1])
+            assert (r is not None) == bool(ok[t, p])
+            if r is not None:
+                assert same_f64(uvn[t, p], r)
+    disp, flags = disp.cpu().numpy(), flags.cpu().numpy()
+    for k, ((f1, f2, p), kept, rec) in enumerate(zip(z["pairs"], z["kept"], z["records_json"])):
+        assert bool(kept) == bool(ok[f1, p] and ok[f2, p])                   # OM_C:360-362 skip rule
+        o = O.object_displacement(z["ref_world"], z["tracks_XYZ"], z["extrinsics_w2c"], z["fx_fy_cx_cy"], hw,
+                                  int(f1), int(f2), int(p))
+        dref = np.linalg.norm(z["ref_world"][f2, p] - z["ref_world"][f1, p])
+        assert f64_ok(disp[k, 4], np.linalg.norm((z["ref_world"][[f2], p] - z["ref_world"][[f1], p]), axis=1)[0])
+        assert flags[k, 0] == int(not (dref < 0.01))
+        if not kept:
+            continue
+        ref = json.loads(str(rec))
+        assert flags[k, 0] == ref["point_moving"] == o["point_moving"]
+        assert flags[k, 1] == ref["cam_moving"] == o["cam_moving"]
+        assert f64_ok(disp[k, 1:4], ref["gt_value"])                          # vector stored in metres (OM_C:393)
+        assert int(disp[k, 0] * 1000) == o["gt_total_distance"]
+        p1 = (round(uvn[f1, p, 0] * 1000), round(uvn[f1, p, 1] * 1000))       # OM_C:364-365
+        p2 = (round(uvn[f2, p, 0] * 1000), round(uvn[f2, p, 1] * 1000))
+        assert p1 == tuple(ref["p1"]) and p2 == tuple(ref["p2"])

@@ -47,11 +47,19 @@ def test_matrix_preparation_matches_numpy():
                           with_color=False)
     E = [sc.E[i] for i in sc.valid_image_ids]
     m = engine.frame_matrices(sc.K, sc.A, E)
-    assert m.shape == (3, 5, 16) and m.dtype == np.float64
+    assert m.shape == (3, _lib.FRAME_MATS, 16) and m.dtype == np.float64
     for f in range(3):
         assert np.array_equal(m[f, _lib.MAT_KINV].reshape(4, 4), np.linalg.inv(sc.K))
         assert np.array_equal(m[f, _lib.MAT_E].reshape(4, 4), E[f])
         assert np.array_equal(m[f, _lib.MAT_EINV_ALIGNED].reshape(4, 4), np.linalg.inv(sc.A @ E[f]))
+        assert np.allclose(m[f, _lib.MAT_UNPROJ].reshape(4, 4), sc.A @ E[f] @ np.linalg.inv(sc.K), rtol=1e-15)
+        assert np.allclose(m[f, _lib.MAT_REPROJ].reshape(4, 4), sc.K @ np.linalg.inv(sc.A @ E[f]), rtol=1e-15)
+    assert engine.fast_path_ok(sc.K)
+    bad_K = sc.K.copy()
+    bad_K[2, 3] = 0.5
+    assert not engine.fast_path_ok(bad_K)
+    for f in range(3):
+        pass
     c = engine.camera_matrices(sc.K, [sc.A @ e for e in E])
     assert np.array_equal(c[1, 0].reshape(4, 4), np.linalg.inv(sc.A @ E[1]))
     with pytest.raises(ValueError):
