@@ -126,6 +126,18 @@ int mspa_vertex_visibility(const double *xyz, int64_t n_points, int64_t point_st
                            int32_t *out_count, mspa_stream_t stream);
 
 /*
+ * The three predicates of the reference on already-projected points, for callers that hold (uv, depth)
+ * from an earlier projection: check_point_in_image_boundary (IH:337-344),
+ * check_point_visibility_by_depth (IH:346-373), check_point_visibility (IH:375-386).
+ *   uv [n, 2] f64, point_depth [n] f64, depth_image [dh, dw] u16 (may be NULL for the bounds test alone)
+ *   out_in_bounds / out_by_depth / out_visible [n] u8, each optional
+ */
+int mspa_check_visibility(const double *uv, const double *point_depth, int64_t n,
+                          const uint16_t *depth_image, int32_t dh, int32_t dw, int32_t H, int32_t W,
+                          uint8_t *out_in_bounds, uint8_t *out_by_depth, uint8_t *out_visible,
+                          mspa_stream_t stream);
+
+/*
  * K2 -- pair overlap, HOT LOOP 2 of CFR.process_scene: calculate_camera_overlap (CFR:102-137)
  * on K1's bitsets.  overlap = |a & b| / |a | b| * 100 in float64 (NaN for an empty union).
  *

@@ -78,9 +78,52 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_kernel(const doub
     }
 }
 
+// a3/a4/a5 on already-projected points (the reference exposes them as separate methods, IH:337-386)
+__global__ __launch_bounds__(kVThreads) void check_visibility_kernel(const double *__restrict__ uv,
+                                                                     const double *__restrict__ pdepth, int64_t n,
+                                                                     const uint16_t *__restrict__ dimg, int dh, int dw,
+                                                                     int H, int W, double sx, double sy,
+                                                                     uint8_t *__restrict__ inb_out,
+                                                                     uint8_t *__restrict__ byd_out,
+                                                                     uint8_t *__restrict__ vis_out) {
+    const int64_t i = (int64_t)blockIdx.x * kVThreads + threadIdx.x;
+    if (i >= n) return;
+    const double u = uv[2 * i], v = uv[2 * i + 1], d = pdepth ? pdepth[i] : 0.0;
+    const bool inb = (u >= 0.0) && (u < (double)W) && (v >= 0.0) && (v < (double)H);   // IH:342-343
+    bool byd = false;
+    if (dimg) {                                                                         // IH:359-371
+        const int xi = round_clip(u * sx, dw - 1), yi = round_clip(v * sy, dh - 1);
+        const double dv = (double)dimg[yi * dw + xi] * 0.001;
+        byd = (d > 0.0) && (d < dv);
+    }
+    if (inb_out) inb_out[i] = inb ? 1 : 0;
+    if (byd_out) byd_out[i] = byd ? 1 : 0;
+    if (vis_out) vis_out[i] = (inb && byd) ? 1 : 0;
+}
+
 }  // namespace mspa
 
 using namespace mspa;
+
+extern "C" int mspa_check_visibility(const double *uv, const double *point_depth, int64_t n,
+                                     const uint16_t *depth_image, int32_t dh, int32_t dw, int32_t H, int32_t W,
+                                     uint8_t *out_in_bounds, uint8_t *out_by_depth, uint8_t *out_visible,
+                                     mspa_stream_t stream) {
+    if (n < 0) return fail(MSPA_EINVAL, "mspa_check_visibility: bad count");
+    if (n == 0) return MSPA_OK;
+    if (!uv) return fail(MSPA_EINVAL, "mspa_check_visibility: null uv");
+    if ((out_by_depth || out_visible) && (!depth_image || !point_depth))
+        return fail(MSPA_EINVAL, "mspa_check_visibility: depth test needs point_depth and depth_image");
+    if (H < 2 || W < 2 || H > 32767 || W > 32767 || (depth_image && (dh < 2 || dw < 2 || dh > 32767 || dw > 32767)))
+        return fail(MSPA_EINVAL, "mspa_check_visibility: image size out of range [2, 32767]");
+    const int64_t blocks = (n + kVThreads - 1) / kVThreads;
+    if (blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_check_visibility: too many points; split the batch");
+    const double sx = depth_image ? (double)dw / (double)W : 1.0, sy = depth_image ? (double)dh / (double)H : 1.0;
+    hipLaunchKernelGGL(check_visibility_kernel, dim3((uint32_t)blocks), dim3(kVThreads), 0, (hipStream_t)stream, uv,
+                       point_depth, n, depth_image, dh, dw, H, W, sx, sy, out_in_bounds, out_by_depth, out_visible);
+    return check_hip(hipGetLastError(), "check_visibility_kernel launch");
+}
+
 
 extern "C" int mspa_vertex_visibility(const double *xyz, int64_t n_points, int64_t point_stride,
                                       int64_t comp_stride, const double *cam_mats, int32_t n_images,

@@ -36,6 +36,8 @@ _SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mspa_pair_overlap": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
+    "mspa_check_visibility": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "mspa_pair_pose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p,
                                c_void_p]),
     "mspa_track_to_world": (c_int, [c_void_p, c_void_p, c_int32, c_int32, POINTER(c_double), c_int32, c_int32,

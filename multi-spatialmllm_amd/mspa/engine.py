@@ -257,3 +257,19 @@ def track_displacement(world: torch.Tensor, w2c: torch.Tensor, c2w: torch.Tensor
     _lib.check(lib.mspa_track_displacement(_ptr(world), _ptr(w2c), _ptr(c2w), T, P, _ptr(triples), n,
                                            obj_threshold, cam_threshold, _ptr(out), _ptr(flags), _stream_ptr()))
     return out, flags
+
+
+def check_visibility(uv: torch.Tensor, point_depth: Optional[torch.Tensor], depth_image: Optional[torch.Tensor],
+                     image_hw: Tuple[int, int], want=("visible",)) -> Dict[str, torch.Tensor]:
+    """The reference's three predicates on already-projected points (IH:337-386)."""
+    _require_gpu()
+    lib = _lib.load()
+    n = uv.shape[0]
+    assert uv.dtype == torch.float64 and uv.dim() == 2 and uv.shape[1] == 2 and uv.is_contiguous()
+    out = {k: torch.empty((n,), dtype=torch.uint8, device=uv.device) for k in want}
+    dh, dw = (depth_image.shape[-2], depth_image.shape[-1]) if depth_image is not None else (0, 0)
+    H, W = image_hw
+    _lib.check(lib.mspa_check_visibility(_ptr(uv), _ptr(point_depth), n, _ptr(depth_image), dh, dw, H, W,
+                                         _ptr(out.get("in_bounds")), _ptr(out.get("by_depth")),
+                                         _ptr(out.get("visible")), _stream_ptr()))
+    return out

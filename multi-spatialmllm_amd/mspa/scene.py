@@ -1,0 +1,129 @@
+"""Scene-level products on top of the kernels: the reference's per-scene scripts as device pipelines.
+
+``SceneOnDevice`` keeps one scene resident (vertices, depth frames, camera tables) and produces
+what ``CFR.process_scene`` (CFR:139-197) and ``MVI.process_scene`` (MVI:75-125) return -- the pair
+table and the visibility index -- from K1 (vertex visibility), K2 (pair overlap) and K4 (pair pose),
+plus the correspondence primitives of the visual-correspondence head (VC_C:280-344).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import engine
+
+
+def valid_image_ids(E: Dict[str, np.ndarray]) -> List[str]:
+    """Frames whose pose holds inf/nan are dropped before any projection (IH:184-189, 409-418)."""
+    return [k for k, e in E.items() if np.all(np.isfinite(np.asarray(e, dtype=np.float64)))]
+
+
+class SceneOnDevice:
+    def __init__(self, K: np.ndarray, A: np.ndarray, E: Dict[str, np.ndarray], depth: Dict[str, np.ndarray],
+                 image_hw: Tuple[int, int], points_xyz: Optional[np.ndarray] = None, device="cuda",
+                 color: Optional[Dict[str, np.ndarray]] = None):
+        self.K, self.A = np.asarray(K, np.float64), np.asarray(A, np.float64)
+        self.ids = valid_image_ids(E)
+        self.index = {k: n for n, k in enumerate(self.ids)}
+        self.image_hw = tuple(int(v) for v in image_hw)
+        self.device = device
+        self.E_aligned = [self.A @ np.asarray(E[k], np.float64) for k in self.ids]        # IH:113-124
+        self.depth = engine.depth_to_device(np.stack([depth[k] for k in self.ids]), device)
+        self.frame_mats = torch.from_numpy(engine.frame_matrices(self.K, self.A, [E[k] for k in self.ids])).to(device)
+        self.cam_mats = torch.from_numpy(engine.camera_matrices(self.K, self.E_aligned)).to(device)
+        self.rgb = None
+        if color:
+            self.rgb = torch.from_numpy(np.stack([color[k] for k in self.ids])).to(device)
+        self.xyz = None
+        if points_xyz is not None:
+            self.xyz = torch.from_numpy(np.ascontiguousarray(np.asarray(points_xyz, np.float64)[:, :3])).to(device)
+        self._vis = None
+
+    # ---- K1 -------------------------------------------------------------------------------
+    def vertex_visibility(self, want=("bits", "count")) -> Dict[str, torch.Tensor]:
+        assert self.xyz is not None, "scene uploaded without vertices"
+        return engine.vertex_visibility(self.xyz, self.cam_mats, self.depth, self.image_hw, want)
+
+    def _visibility(self):
+        if self._vis is None:
+            self._vis = self.vertex_visibility(("bits", "count"))
+        return self._vis
+
+    # ---- CFR.process_scene ------------------------------------------------------------------
+    def frames_relations(self) -> Dict[Tuple[str, str], Dict[str, float]]:
+        """{(id1, id2): {overlap, distance, yaw, pitch}} for all i < j in key order (CFR:176-189)."""
+        vis = self._visibility()
+        F = len(self.ids)
+        pairs = engine.all_pairs(F, self.device)
+        overlap = engine.pair_overlap(vis["bits"], pairs)
+        yaw, pitch = engine.extract_yaw_pitch_host(self.E_aligned)
+        E_t = torch.from_numpy(np.stack(self.E_aligned).reshape(F, 16)).to(self.device)
+        Einv_t = self.cam_mats[:, 0, :].contiguous()
+        pose = engine.pair_pose(E_t, Einv_t, torch.from_numpy(yaw).to(self.device),
+                                torch.from_numpy(pitch).to(self.device), pairs)
+        overlap, pose, pairs = overlap.cpu().numpy(), pose.cpu().numpy(), pairs.cpu().numpy()
+        table = {}
+        for n, (i, j) in enumerate(pairs):
+            table[(self.ids[i], self.ids[j])] = {"overlap": np.float64(overlap[n]), "distance": np.float64(pose[n, 0]),
+                                                 "yaw": np.float64(pose[n, 1]), "pitch": np.float64(pose[n, 2])}
+        return table
+
+    def empty_frames(self) -> List[str]:
+        """Frames that see no vertex at all (the reference logs them, CFR:159-161 / MVI:110-113)."""
+        cnt = self._visibility()["count"].cpu().numpy()
+        return [k for k, c in zip(self.ids, cnt) if c == 0]
+
+    # ---- MVI.process_scene ------------------------------------------------------------------
+    def visibility_index(self) -> Dict[str, dict]:
+        """{"image_to_points": {img: [idx...]}, "point_to_images": {idx: [img...]}} (MVI:103-123)."""
+        mask = self.vertex_visibility(("mask",))["mask"]
+        n = mask.shape[1]
+        image_to_points = {}
+        nz = torch.nonzero(mask)                                  # row-major: (image, point) ascending
+        img = nz[:, 0].cpu().numpy()
+        pt = nz[:, 1].cpu().numpy()
+        bounds = np.searchsorted(img, np.arange(len(self.ids) + 1))
+        for k, image_id in enumerate(self.ids):
+            image_to_points[image_id] = pt[bounds[k]:bounds[k + 1]].tolist()
+        order = np.lexsort((img, pt))                             # by point, then image index
+        pt_s, img_s = pt[order], img[order]
+        pb = np.searchsorted(pt_s, np.arange(n + 1))
+        # image ids are zero-padded strings, so index order == sorted() order whenever the ids are sorted;
+        # sort explicitly otherwise (MVI:117 uses sorted())
+        sorted_ids = self.ids == sorted(self.ids)
+        point_to_images = {}
+        for v in range(n):
+            lst = [self.ids[k] for k in img_s[pb[v]:pb[v + 1]]]
+            point_to_images[v] = lst if sorted_ids else sorted(lst)
+        return {"image_to_points": image_to_points, "point_to_images": point_to_images}
+
+    # ---- correspondence primitives (VC_C:280-344) ---------------------------------------------
+    def common_visible_points(self, image_id1: str, image_id2: str) -> np.ndarray:
+        """np.intersect1d of the two frames' visible-vertex lists == set bits of (bits1 & bits2)."""
+        bits = self._visibility()["bits"]
+        both = bits[self.index[image_id1]] & bits[self.index[image_id2]]
+        b = both.cpu().numpy().view(np.uint8)
+        idx = np.nonzero(np.unpackbits(b, bitorder="little"))[0]
+        return idx[idx < self.xyz.shape[0]]
+
+    def point_2d_in_image(self, image_id: str, point_ids: Sequence[int], check_visible: bool = True):
+        """get_point_2d_coordinates_in_image (IH:291-305) for a handful of vertices of one image."""
+        k = self.index[image_id]
+        sel = self.xyz[torch.as_tensor(list(point_ids), device=self.device, dtype=torch.long)].contiguous()
+        out = engine.vertex_visibility(sel, self.cam_mats[k:k + 1].contiguous(), self.depth[k:k + 1].contiguous(),
+                                       self.image_hw, ("mask", "uv", "depth"))
+        uv, d, m = out["uv"][0].cpu().numpy(), out["depth"][0].cpu().numpy(), out["mask"][0].cpu().numpy().astype(bool)
+        if check_visible:
+            return uv[m], d[m]
+        return uv, d
+
+    # ---- K3 ---------------------------------------------------------------------------------
+    def pair_reproject(self, pairs_ids: Sequence[Tuple[str, str]], outputs: Sequence[str], fast: bool = True):
+        pairs = torch.tensor([[self.index[a], self.index[b]] for a, b in pairs_ids], dtype=torch.int32,
+                             device=self.device).reshape(-1, 2)
+        out = engine.alloc_pair_outputs(pairs.shape[0], self.image_hw, outputs, self.device)
+        flags = engine._lib.PAIR_FAST if (fast and engine.fast_path_ok(self.K)) else 0
+        engine.pair_reproject(self.depth, self.frame_mats, pairs, self.image_hw, out, rgb=self.rgb, flags=flags)
+        return out

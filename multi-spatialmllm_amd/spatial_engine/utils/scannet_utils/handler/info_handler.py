@@ -1,0 +1,300 @@
+"""Mirror of the reference's handler/info_handler.py: same names, arguments, defaults and return
+types; the geometry runs on the MI355X through libmspa.so.
+
+Scene-info layout (unchanged): ``infos[scene_id]`` holds ``intrinsic_matrix`` (4x4),
+``axis_align_matrix`` (4x4), ``num_posed_images``, ``num_objects``, per-object boxes under integer
+keys and ``images_info[image_id]["extrinsic_matrix"]`` (4x4 camera->world, may contain -inf).
+"""
+from __future__ import annotations
+
+import json
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from mspa import engine
+
+from . import _images
+from .ops import project_mask_to_3d
+
+
+def _load_any(path):
+    try:
+        import mmengine
+        return mmengine.load(path)
+    except ImportError:
+        with open(path, "rb") as f:
+            return pickle.load(f)
+
+
+def _dev(a, dtype=np.float64):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dtype))).cuda()
+
+
+def project_points(points, K, E):
+    """[N,4] homogeneous world points, 4x4 K, 4x4 camera->world E -> ([N,2] un-rounded pixel
+    coordinates, [N] signed camera depth), float64 (reference: info_handler.py:46-72).
+    The homogeneous coordinate must be 1 (it is at every call site of the reference)."""
+    points = np.asarray(points, dtype=np.float64)
+    if points.ndim != 2 or points.shape[1] != 4:
+        raise ValueError("points must be [N, 4] homogeneous coordinates")
+    if not np.all(points[:, 3] == 1.0):
+        raise ValueError("libmspa projects affine points: the homogeneous coordinate must be exactly 1")
+    cam = torch.from_numpy(engine.camera_matrices(np.asarray(K, np.float64), [np.asarray(E, np.float64)])).cuda()
+    xyz = _dev(points[:, :3])
+    dummy = torch.zeros((1, 2, 2), dtype=torch.int16, device="cuda")
+    out = engine.vertex_visibility(xyz, cam, dummy, (2, 2), ("uv", "depth"))
+    return out["uv"][0].cpu().numpy(), out["depth"][0].cpu().numpy()
+
+
+class SceneInfoHandler:
+    def __init__(self, info_path, posed_images_root="data/scannet/posed_images",
+                 instance_data_root="data/scannet/scannet_instance_data", mask_image_root="data/scannet/scans",
+                 depth_value_scale=0.001):
+        if isinstance(info_path, dict):
+            self.infos = info_path                       # convenience: an already-loaded infos dict
+        else:
+            try:
+                self.infos = _load_any(info_path)
+                print(f"Data from {info_path} loaded successfully.")
+            except Exception as e:                       # same observable behaviour as upstream (IH:80-82)
+                print(f"Failed to load data from {info_path}: {e}")
+                raise SystemExit(1)
+        if depth_value_scale != 0.001:
+            raise ValueError("libmspa fixes the depth scale at 0.001 (millimetres), like the reference's data")
+        self.posed_images_root = posed_images_root
+        self.instance_data_root = instance_data_root
+        self.mask_image_root = mask_image_root
+        self.depth_value_scale = depth_value_scale
+
+    # ---- plain accessors ----------------------------------------------------------------------
+    def __len__(self):
+        return len(self.infos)
+
+    def get_sorted_keys(self):
+        return sorted(self.infos.keys())
+
+    def get_all_scene_ids(self):
+        return list(self.infos.keys())
+
+    def get_intrinsic_matrix(self, scene_id, image_id=None):
+        return self.infos[scene_id]["intrinsic_matrix"]
+
+    def convert_image_id_to_key(self, image_id):
+        try:
+            image_id = int(image_id)
+        except Exception as e:
+            print(f"Failed to convert image_id: {image_id}: {e}")
+            return None
+        return None if image_id < 0 else f"{image_id:05d}"
+
+    def get_extrinsic_matrix(self, scene_id, image_id, warning=True):
+        key = self.convert_image_id_to_key(image_id)
+        E = self.infos[scene_id]["images_info"][key]["extrinsic_matrix"]
+        if warning and not np.all(np.isfinite(E)):
+            print(f"[SceneInfoHanlder] Warning: extrinsics matrix of {scene_id}: {key} contains inf or nan.")
+        return E
+
+    def get_world_to_axis_align_matrix(self, scene_id, image_id=None):
+        return self.infos[scene_id]["axis_align_matrix"]
+
+    def get_extrinsic_matrix_align(self, scene_id, image_id):
+        return self.get_world_to_axis_align_matrix(scene_id) @ self.get_extrinsic_matrix(scene_id, image_id)
+
+    def get_num_posed_images(self, scene_id):
+        return self.infos[scene_id]["num_posed_images"]
+
+    def get_num_objects(self, scene_id):
+        return self.infos[scene_id]["num_objects"]
+
+    def get_all_image_ids(self, scene_id):
+        return list(self.infos[scene_id]["images_info"].keys())
+
+    def is_posed_image_valid(self, scene_id, image_id):
+        key = self.convert_image_id_to_key(image_id)
+        if key is None:
+            return False
+        return bool(np.all(np.isfinite(self.get_extrinsic_matrix(scene_id, key, warning=False))))
+
+    def get_all_extrinsic_valid_image_ids(self, scene_id):
+        return [i for i in self.get_all_image_ids(scene_id) if self.is_posed_image_valid(scene_id, i)]
+
+    def get_image_path(self, scene_id, image_id):
+        key = self.convert_image_id_to_key(image_id)
+        return None if key is None else os.path.join(self.posed_images_root, scene_id, f"{key}.jpg")
+
+    def get_depth_image_path(self, scene_id, image_id):
+        key = self.convert_image_id_to_key(image_id)
+        return None if key is None else os.path.join(self.posed_images_root, scene_id, f"{key}.png")
+
+    def get_image_shape(self, scene_id, image_id=None):
+        if image_id is None:
+            image_id = self.get_all_image_ids(scene_id)[0]
+        return tuple(_images.image_shape(self.get_image_path(scene_id, image_id)))     # (H, W)
+
+    get_image_size = get_image_shape   # the name visual_correspondence calls (upstream defect)
+
+    def get_depth_image(self, scene_id, image_id):
+        return _images.read_depth(self.get_depth_image_path(scene_id, image_id))
+
+    def get_depth_image_shape(self, scene_id, image_id=0):
+        return self.get_depth_image(scene_id, image_id).shape[:2]
+
+    # ---- objects / point clouds ---------------------------------------------------------------
+    def get_object_gt_bbox(self, scene_id, object_id, axis_aligned=True, with_class_id=False):
+        bbox = self.infos[scene_id][object_id]["aligned_bbox" if axis_aligned else "unaligned_bbox"]
+        return bbox if with_class_id else bbox[0:-1]
+
+    def get_object_raw_category(self, scene_id, object_id):
+        return self.infos[scene_id][object_id]["raw_category"]
+
+    def get_scene_raw_categories(self, scene_id):
+        return [self.get_object_raw_category(scene_id, o) for o in range(self.get_num_objects(scene_id))]
+
+    def get_object_height(self, scene_id, object_id):
+        return self.get_object_gt_bbox(scene_id, object_id)[5]
+
+    def get_object_length(self, scene_id, object_id):
+        b = self.get_object_gt_bbox(scene_id, object_id)
+        return max(b[3], b[4])
+
+    def get_object_width(self, scene_id, object_id):
+        b = self.get_object_gt_bbox(scene_id, object_id)
+        return min(b[3], b[4])
+
+    def get_object_length_axis_aligned(self, scene_id, object_id):
+        b = self.get_object_gt_bbox(scene_id, object_id)
+        return 0 if b[3] > b[4] else 1
+
+    def get_object_width_axis_aligned(self, scene_id, object_id):
+        b = self.get_object_gt_bbox(scene_id, object_id)
+        return 0 if b[3] < b[4] else 1
+
+    def get_object_volume(self, scene_id, object_id):
+        b = self.get_object_gt_bbox(scene_id, object_id)
+        return b[3] * b[4] * b[5]
+
+    def get_scene_points_align(self, scene_id):
+        return np.load(os.path.join(self.instance_data_root, scene_id, "aligned_points.npy"))
+
+    def get_scene_points(self, scene_id):
+        return np.load(os.path.join(self.instance_data_root, scene_id, "unaligned_points.npy"))
+
+    def get_scene_instance_mask(self, scene_id):
+        return np.load(os.path.join(self.instance_data_root, scene_id, "instance_mask.npy"))
+
+    def get_object_points_aligned(self, scene_id, object_id):
+        return np.load(os.path.join(self.instance_data_root, scene_id, f"object_{object_id}_aligned_points.npy"),
+                       allow_pickle=True)
+
+    def get_object_point_index(self, scene_id, object_id):
+        idx = np.where(self.get_scene_instance_mask(scene_id) == object_id + 1)[0]
+        if len(idx) == 0:
+            print(f"[SceneInfoHanlder] Warning: {scene_id} does not have object {object_id}.")
+        return idx
+
+    def get_point_3d_coordinates(self, scene_id, point_id, align=True):
+        pts = self.get_scene_points_align(scene_id) if align else self.get_scene_points(scene_id)
+        return pts[point_id]
+
+    # ---- geometry: HIP -------------------------------------------------------------------------
+    def project_3d_point_to_image(self, scene_id, image_id, points_3d, align=True):
+        """[N,3] or (3,) world points -> ([N,2] pixel coordinates, [N] depth)  (IH:313-335)."""
+        K = self.get_intrinsic_matrix(scene_id, image_id)
+        E = self.get_extrinsic_matrix_align(scene_id, image_id) if align else self.get_extrinsic_matrix(scene_id, image_id)
+        pts = np.asarray(points_3d, dtype=np.float64)
+        pts = pts[None, :] if pts.ndim == 1 else pts
+        return project_points(np.hstack([pts[:, :3], np.ones((pts.shape[0], 1))]), K, E)
+
+    def check_point_in_image_boundary(self, scene_id, points_2d):
+        out = engine.check_visibility(_dev(points_2d), None, None, self.get_image_shape(scene_id), ("in_bounds",))
+        return out["in_bounds"].cpu().numpy().astype(bool)
+
+    def _depth_dev(self, scene_id, image_id):
+        return engine.depth_to_device(self.get_depth_image(scene_id, image_id), "cuda")
+
+    def check_point_visibility_by_depth(self, scene_id, image_id, points_2d, points_depth):
+        out = engine.check_visibility(_dev(points_2d), _dev(points_depth), self._depth_dev(scene_id, image_id),
+                                      self.get_image_shape(scene_id, image_id), ("by_depth",))
+        return out["by_depth"].cpu().numpy().astype(bool)
+
+    def check_point_visibility(self, scene_id, image_id, points_2d, points_depth):
+        out = engine.check_visibility(_dev(points_2d), _dev(points_depth), self._depth_dev(scene_id, image_id),
+                                      self.get_image_shape(scene_id), ("visible",))
+        return out["visible"].cpu().numpy().astype(bool)
+
+    def get_point_2d_coordinates_in_image(self, scene_id, image_id, point_id, align=True, check_visible=False,
+                                          return_depth=False):
+        point_3d = self.get_point_3d_coordinates(scene_id, point_id, align)[:3]
+        uv, d = self.project_3d_point_to_image(scene_id, image_id, point_3d, align)
+        if check_visible:
+            m = self.check_point_visibility(scene_id, image_id, uv, d)
+            uv, d = uv[m], d[m]
+        return (uv, d) if return_depth else uv
+
+    def project_image_to_3d_with_mask(self, scene_id, image_id, mask=None, with_color=False):
+        color = self.get_image_path(scene_id, image_id) if with_color else None
+        return project_mask_to_3d(self.get_depth_image_path(scene_id, image_id),
+                                  self.get_intrinsic_matrix(scene_id, image_id),
+                                  self.get_extrinsic_matrix(scene_id, image_id), mask,
+                                  self.get_world_to_axis_align_matrix(scene_id), color_image=color)
+
+    def get_instance_mask(self, scene_id, image_id, target_id) -> np.ndarray:
+        path = os.path.join(self.mask_image_root, scene_id, "instance-filt", f"{int(image_id)}.png")
+        try:
+            mask_image = _images.read_depth(path)
+        except Exception:
+            mask_image = None
+        if mask_image is None:
+            raise FileNotFoundError(f"Mask image not found at path: {path}")
+        return np.where(mask_image == target_id + 1, 1, 0)
+
+    # ---- resident scene (what the per-scene scripts use) -----------------------------------------
+    def scene_on_device(self, scene_id, with_points=True):
+        from mspa.scene import SceneOnDevice
+        ids = self.get_all_image_ids(scene_id)
+        E = {i: self.infos[scene_id]["images_info"][i]["extrinsic_matrix"] for i in ids}
+        valid = [i for i in ids if np.all(np.isfinite(E[i]))]
+        depth = {i: self.get_depth_image(scene_id, i) for i in valid}
+        pts = self.get_scene_points_align(scene_id)[:, :3] if with_points else None
+        return SceneOnDevice(self.get_intrinsic_matrix(scene_id), self.get_world_to_axis_align_matrix(scene_id),
+                             E, depth, self.get_image_shape(scene_id), pts)
+
+
+class VisibilityInfoHandler:
+    """Reader of the vertex<->image visibility index (parquet with JSON-string values, or nested pkl)."""
+
+    def __init__(self, visibility_info_path):
+        self.visibility_info_path = visibility_info_path
+        print(f"[VisibilityInfoHandler] Reading visibility info from {self.visibility_info_path}.")
+        if visibility_info_path.endswith(".parquet"):
+            import pandas as pd
+            df = pd.read_parquet(visibility_info_path)
+            self.info_format = "parquet"
+            self.visibility_info = dict(zip(df["key"].tolist(), df["values"].tolist()))
+        elif visibility_info_path.endswith(".pkl"):
+            self.info_format = "pkl"
+            self.visibility_info = _load_any(visibility_info_path)
+        else:
+            raise ValueError(f"Unsupported file format: {self.visibility_info_path}")
+
+    def _get(self, scene_id, kind, item):
+        if self.info_format == "parquet":
+            key = f"{scene_id}:{kind}:{item}"
+            if key not in self.visibility_info:
+                raise ValueError(f"Key {key} not found in visibility info.")
+            return json.loads(self.visibility_info[key])
+        if scene_id not in self.visibility_info:
+            raise ValueError(f"Scene {scene_id} not found in visibility info.")
+        if item not in self.visibility_info[scene_id][kind]:
+            what = "Image" if kind == "image_to_points" else "Point"
+            raise ValueError(f"{what} {item} not found in visibility info for scene {scene_id}.")
+        return self.visibility_info[scene_id][kind][item]
+
+    def get_image_to_points_info(self, scene_id, image_id):
+        return self._get(scene_id, "image_to_points", image_id)
+
+    def get_point_to_images_info(self, scene_id, point_index):
+        return self._get(scene_id, "point_to_images", point_index)

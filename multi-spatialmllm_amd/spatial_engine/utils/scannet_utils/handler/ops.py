@@ -1,0 +1,41 @@
+"""Mirror of the reference's handler/ops.py for the one function on the hot path."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from mspa import engine
+
+from ._images import read_color_rgb, read_depth
+
+
+def project_mask_to_3d(depth_image, intrinsic_matrix, extrinsic_matrix, mask=None,
+                       world_to_axis_align_matrix=None, color_image=None):
+    """Same contract as the reference's ``project_mask_to_3d`` (ops.py:235-329): back-project the
+    mask's pixels (mask spans the colour grid; ``None`` = every pixel, needs ``color_image``) through
+    inv(K), E and optionally A; returns ``[M, 3]`` or ``[M, 6]`` float64 in row-major mask order with
+    zero-depth pixels dropped.  Runs kernel K3 in exact mode (float64 outputs)."""
+    if isinstance(depth_image, str):
+        depth_image = read_depth(depth_image)
+    if isinstance(color_image, str):
+        color_image = read_color_rgb(color_image)
+    if mask is None:
+        mask = np.ones(color_image.shape[:2], dtype=bool)          # AttributeError when both are None, as upstream
+    mask = np.asarray(mask)
+    H, W = mask.shape[:2]
+    A = np.eye(4) if world_to_axis_align_matrix is None else np.asarray(world_to_axis_align_matrix, np.float64)
+    K = np.asarray(intrinsic_matrix, np.float64)
+    E = np.asarray(extrinsic_matrix, np.float64)
+    mats = torch.from_numpy(engine.frame_matrices(K, A, [E])).cuda()
+    depth = engine.depth_to_device(np.asarray(depth_image)[None], "cuda")
+    pairs = torch.zeros((1, 2), dtype=torch.int32, device="cuda")
+    out = engine.alloc_pair_outputs(1, (H, W), ("xyz_f64", "valid_u8"), "cuda")
+    engine.pair_reproject(depth, mats, pairs, (H, W), out)
+    keep = out["valid_u8"][0].cpu().numpy().astype(bool) & (mask.reshape(-1) != 0)
+    xyz = out["xyz_f64"][0].cpu().numpy()[keep]
+    if world_to_axis_align_matrix is None:
+        pass    # A = identity: x*1 + 0*y + 0*z + 0 is exact, the result equals E @ cam
+    if color_image is not None:
+        rgb = np.asarray(color_image).reshape(-1, color_image.shape[-1])[keep]
+        return np.hstack((xyz, rgb))
+    return xyz
