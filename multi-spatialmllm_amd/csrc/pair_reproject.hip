@@ -610,6 +610,250 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// fast path, whole-tile images (the BASELINE shape 640x480: W % 64 == 0, H % kTightRows == 0)
+// --------------------------------------------------------------------------------------------
+// Same arithmetic and guard as pair_fast_kernel, trimmed for VALU issue, which is what bounds the
+// fast path (profiles/r01c: VALU pipe 75 % busy, every VALU instruction ~4 cycles on gfx950 whether
+// it is 64- or 32-bit, so the lever is the instruction COUNT per pixel):
+//   * depth reads, gathers and pixel-index stores go through buffer resources (SGPR base + SGPR row
+//     offset + one loop-invariant VGPR column offset): no 64-bit address arithmetic in the vector pipe;
+//   * the gather is issued for every lane (the clamped index is always a valid address), no select;
+//   * clamps are single v_med3_i32; decisions stay in SGPR masks (s_and/s_or are free next to the
+//     vector pipe); risky rows are recorded per wave (ballot -> LDS) instead of per-lane bit masks;
+//   * 24 rows per wave tile amortise the per-tile matrix composition.
+constexpr int kTightRows = 24;
+
+__device__ __forceinline__ int med3_0(int x, int hi) {   // clamp(x, 0, hi), hi wave-uniform
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+    return r;
+}
+
+template <uint32_t SET>
+__global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
+                                                                   const uint8_t *__restrict__ rgb,
+                                                                   const double *__restrict__ mats,
+                                                                   const int32_t *__restrict__ pairs, PairArgs a) {
+    using O = Outs<SET, false>;
+    constexpr bool WANT_XYZ = (SET & O_XYZ32) != 0;
+    int64_t pair;
+    uint32_t tgroup;
+    if (!decode_block(a, pair, tgroup)) return;
+    const int f1 = pairs[2 * pair + 0];
+    const int f2 = pairs[2 * pair + 1];
+    const double *m1 = mats + (int64_t)f1 * (MSPA_FRAME_MATS * 16);
+    const double *m2 = mats + (int64_t)f2 * (MSPA_FRAME_MATS * 16);
+    const int64_t dpix = (int64_t)a.dh * a.dw;
+    Ctx c;
+    c.depth1 = depth + (int64_t)f1 * dpix;
+    c.depth2 = depth + (int64_t)f2 * dpix;
+    c.rgb1 = rgb ? rgb + (int64_t)f1 * a.P * 3 : nullptr;
+    c.obase = pair * (int64_t)a.P;
+    c.words_per_pair = (a.P + 63) >> 6;
+    c.pair = pair;
+    c.lane = threadIdx.x & 63;
+
+    const double *__restrict__ U = m1 + MSPA_MAT_UNPROJ * 16;
+    const double *__restrict__ N = m2 + MSPA_MAT_REPROJ * 16;
+    double M[3][4], Us[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double row[4];
+        compose_row(N, U, r, row);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) M[r][k] = uniform(k < 3 ? row[k] * 0.001 : row[k]);
+        if (WANT_XYZ) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Us[r][k] = k < 3 ? U[4 * r + k] * 0.001 : U[4 * r + k];
+        }
+    }
+
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = tgroup * (kThreads / kWave) + wave;
+    const uint32_t band = a.n_stripes == 1 ? tile : __umulhi(tile, a.stripe_magic);
+    const uint32_t stripe = tile - band * (uint32_t)a.n_stripes;
+    const bool tile_ok = tile < (uint32_t)a.n_tiles;
+    const uint32_t col = stripe * 64u + (uint32_t)c.lane;
+    const uint32_t row0 = band * (uint32_t)kTightRows;
+
+    __shared__ unsigned long long lds_rb[kThreads / kWave][kTightRows];   // risky-lane ballots of flagged rows
+    __shared__ unsigned long long lds_vm[kThreads / kWave][kTightRows];   // their fast-path visibility ballots
+    int n_valid = 0, n_vis = 0;
+    if (tile_ok) {
+        const uint32_t Wb = (uint32_t)a.W;
+        // buffer resources: SGPR base + byte count; raw addressing = base + voffset (VGPR) + soffset (SGPR)
+        const int kRsrcFlags = 0x00020000;
+        __amdgpu_buffer_rsrc_t rs_d1 = __builtin_amdgcn_make_buffer_rsrc((void *)c.depth1, 0, (int)(dpix * 2), kRsrcFlags);
+        __amdgpu_buffer_rsrc_t rs_d2 = __builtin_amdgcn_make_buffer_rsrc((void *)c.depth2, 0, (int)(dpix * 2), kRsrcFlags);
+        __amdgpu_buffer_rsrc_t rs_pix = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.pix_i16 ? a.pix_i16 + 2 * c.obase : nullptr), 0, O::template has<O_PIX>(a.pix_i16) ? (int)(a.P * 4) : 0,
+            kRsrcFlags);
+        const int col2 = (int)(col * 2u), col4 = (int)(col * 4u);
+        const int hi_x = a.dw - 1, hi_y = a.dh - 1;
+
+        uint32_t d16n[kRowGroup];
+#pragma unroll
+        for (int j = 0; j < kRowGroup; ++j)
+            d16n[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_d1, col2, (int)((row0 + (uint32_t)j) * Wb * 2u), 0);
+
+        const double mxd = (double)col;
+        const double myd0 = (double)row0;
+        double t0 = __builtin_fma(M[0][1], myd0, __builtin_fma(M[0][0], mxd, M[0][2]));
+        double t1 = __builtin_fma(M[1][1], myd0, __builtin_fma(M[1][0], mxd, M[1][2]));
+        double t2 = __builtin_fma(M[2][1], myd0, __builtin_fma(M[2][0], mxd, M[2][2]));
+        double s0 = 0, s1 = 0, s2 = 0;
+        if (WANT_XYZ) {
+            s0 = __builtin_fma(Us[0][1], myd0, __builtin_fma(Us[0][0], mxd, Us[0][2]));
+            s1 = __builtin_fma(Us[1][1], myd0, __builtin_fma(Us[1][0], mxd, Us[1][2]));
+            s2 = __builtin_fma(Us[2][1], myd0, __builtin_fma(Us[2][0], mxd, Us[2][2]));
+        }
+        const double Wd = (double)a.W, Hd = (double)a.H;
+        uint32_t risky_rows = 0;                     // wave-uniform: rows with at least one guarded lane
+
+#pragma unroll 1
+        for (int r0 = 0; r0 < kTightRows; r0 += kRowGroup) {
+            uint32_t d16[kRowGroup];
+#pragma unroll
+            for (int j = 0; j < kRowGroup; ++j) d16[j] = d16n[j];
+            if (r0 + kRowGroup < kTightRows) {
+#pragma unroll
+                for (int j = 0; j < kRowGroup; ++j)
+                    d16n[j] = __builtin_amdgcn_raw_buffer_load_b16(
+                        rs_d1, col2, (int)((row0 + (uint32_t)(r0 + kRowGroup + j)) * Wb * 2u), 0);
+            }
+            double qz[kRowGroup];
+            float fx[kRowGroup], fy[kRowGroup], fz[kRowGroup];
+            int pix[kRowGroup];
+            uint32_t dv16[kRowGroup];
+            bool valid[kRowGroup], test[kRowGroup], risky[kRowGroup];
+#pragma unroll
+            for (int j = 0; j < kRowGroup; ++j) {
+                valid[j] = d16[j] != 0u;                                     // OPS:297
+                const double dmm = (double)d16[j];
+                const double ix = __builtin_fma(t0, dmm, M[0][3]);
+                const double iy = __builtin_fma(t1, dmm, M[1][3]);
+                const double iz = __builtin_fma(t2, dmm, M[2][3]);
+                if (WANT_XYZ) {
+                    fx[j] = (float)__builtin_fma(s0, dmm, Us[0][3]);
+                    fy[j] = (float)__builtin_fma(s1, dmm, Us[1][3]);
+                    fz[j] = (float)__builtin_fma(s2, dmm, Us[2][3]);
+                    s0 += Us[0][1];
+                    s1 += Us[1][1];
+                    s2 += Us[2][1];
+                }
+                t0 += M[0][1];
+                t1 += M[1][1];
+                t2 += M[2][1];
+                double rz = __builtin_amdgcn_rcp(iz);
+                rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
+                const double u = ix * rz, v = iy * rz;
+                const double ru = __builtin_rint(u), rv = __builtin_rint(v);
+                const bool inb = (u >= 0.0) & (u < Wd) & (v >= 0.0) & (v < Hd);
+                const int xi = med3_0((int)ru, hi_x);
+                const int yi = med3_0((int)rv, hi_y);
+                test[j] = inb & (iz > 0.0);
+                // every lane gathers: the clamped index is always inside the image
+                dv16[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, (yi * a.dw + xi) * 2, 0, 0);
+                pix[j] = (int)((uint32_t)xi | ((uint32_t)yi << 16));
+                qz[j] = iz;
+                const double wu = __builtin_fabs(u - ru) - 0.25;
+                const double wv = __builtin_fabs(v - rv) - 0.25;
+                risky[j] = !(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx) |
+                           !(__builtin_fabs(iz) > kGuardZ);
+            }
+#pragma unroll
+            for (int j = 0; j < kRowGroup; ++j) {
+                const int g = r0 + j;
+                const uint32_t row = row0 + (uint32_t)g;
+                const double dv = (double)dv16[j] * 0.001;
+                const bool vis = valid[j] & test[j] & (qz[j] < dv);
+                const bool rk = valid[j] & (risky[j] | (test[j] & !(__builtin_fabs(qz[j] - dv) > kGuardZ)));
+                const unsigned long long vmask = __ballot(vis);
+                const unsigned long long rb = __ballot(rk);
+                n_vis += __popcll(vmask);
+                n_valid += __popcll(__ballot(valid[j]));
+                if (rb) {                                            // wave-uniform, rare
+                    if (c.lane == 0) {
+                        lds_rb[wave][g] = rb;
+                        lds_vm[wave][g] = vmask;
+                    }
+                    risky_rows |= 1u << g;
+                }
+                const uint32_t i = row * Wb + col;
+                if (O::template has<O_VIS_BITS>(a.vis_bits)) {
+                    if (c.lane == 0) a.vis_bits[pair * c.words_per_pair + (int64_t)(i >> 6)] = vmask;
+                }
+                if (O::template has<O_PIX>(a.pix_i16))
+                    __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(valid[j] ? pix[j] : -1), rs_pix, col4,
+                                                          (int)(row * Wb * 4u), 0);
+                const int64_t o = c.obase + (int64_t)i;
+                if (O::template has<O_VIS_U8>(a.vis_u8)) a.vis_u8[o] = vis ? 1 : 0;
+                if (O::template has<O_VALID_U8>(a.valid_u8)) a.valid_u8[o] = valid[j] ? 1 : 0;
+                if (O::template has<O_XYZ32>(a.xyz_f32)) {
+                    float *q = a.xyz_f32 + 3 * o;
+                    const float fn = __builtin_nanf("");
+                    q[0] = valid[j] ? fx[j] : fn;
+                    q[1] = valid[j] ? fy[j] : fn;
+                    q[2] = valid[j] ? fz[j] : fn;
+                }
+                if (O::template has<O_RGBA>(a.rgba)) {
+                    uint32_t colr = 0;
+                    if (c.rgb1) {
+                        const uint8_t *s = c.rgb1 + 3 * (int64_t)i;
+                        colr = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
+                    }
+                    a.rgba[o] = colr | (valid[j] ? 0xFF000000u : 0u);
+                }
+            }
+        }
+
+        // ---- cold loop: rows with guarded lanes are re-evaluated with the exact chain ---------------
+        if (risky_rows) {
+            __builtin_amdgcn_s_waitcnt(0);                 // the fast path's stores are in L2, LDS writes landed
+            while (risky_rows) {                            // wave-uniform
+                const int g = __builtin_ctz(risky_rows);
+                risky_rows &= risky_rows - 1u;
+                const unsigned long long rb = lds_rb[wave][g];
+                const unsigned long long old = lds_vm[wave][g];
+                const uint32_t row = row0 + (uint32_t)g;
+                const uint32_t i = row * Wb + col;
+                const bool mine = (rb >> c.lane) & 1ull;
+                bool vis = (old >> c.lane) & 1ull;
+                if (mine) {
+                    Pixel p;
+                    exact_unproject(m1, mxd, (double)row, (double)c.depth1[i] * 0.001, p.ax, p.ay, p.az);
+                    exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
+                    p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi);
+                    vis = p.vis;
+                    store_pixel<O, true>(a, c, i, true, true, p);
+                }
+                const unsigned long long fresh = __ballot(vis);
+                n_vis += __popcll(fresh) - __popcll(old);
+                if (O::template has<O_VIS_BITS>(a.vis_bits) && c.lane == 0)
+                    a.vis_bits[pair * c.words_per_pair + (int64_t)(i >> 6)] = fresh;
+            }
+        }
+    }
+    if (O::template has<O_COUNTS>(a.counts)) {
+        __shared__ int red[2][kThreads / kWave];
+        if (c.lane == 0) {
+            red[0][wave] = n_valid;
+            red[1][wave] = n_vis;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int sv = 0, ss = 0;
+            for (int j = 0; j < kThreads / kWave; ++j) {
+                sv += red[0][j];
+                ss += red[1][j];
+            }
+            atomicAdd(a.counts + 2 * pair + 0, sv);
+            atomicAdd(a.counts + 2 * pair + 1, ss);
+        }
+    }
+}
+
 }  // namespace mspa
 
 using namespace mspa;
@@ -651,9 +895,16 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
     const bool ident = (dh == H && dw == W);
     // float64 outputs are defined as the reference's own operation order: they force the exact kernel
     const bool fast = (flags & MSPA_PAIR_FAST) && !out_xyz_f64 && !out_uv_f64 && !out_depth_f64;
+    uint32_t set = 0;
+    set |= out_vis_bits ? O_VIS_BITS : 0; set |= out_vis_u8 ? O_VIS_U8 : 0; set |= out_valid_u8 ? O_VALID_U8 : 0;
+    set |= out_pix_i16 ? O_PIX : 0; set |= out_xyz_f32 ? O_XYZ32 : 0; set |= out_rgba ? O_RGBA : 0;
+    set |= out_counts ? O_COUNTS : 0;
+    const bool tight24 = fast && ident && (W % 64 == 0) && (H % kTightRows == 0) && (P * 4 < (1ull << 31)) &&
+                         (set == kSetCorr || set == kSetDense || set == kSetMinimal);
     if (fast) {
+        const int tile_rows = tight24 ? kTightRows : kTileRows;
         a.n_stripes = (W + 63) / 64;
-        a.n_tiles = a.n_stripes * ((H + kTileRows - 1) / kTileRows);
+        a.n_tiles = a.n_stripes * ((H + tile_rows - 1) / tile_rows);
         a.stripe_magic = (uint32_t)((1ull << 32) / (uint64_t)a.n_stripes) + 1u;
         a.strips = (a.n_tiles + (kThreads / kWave) - 1) / (kThreads / kWave);
         if (out_vis_bits && (W & 63)) {   // stripes straddle bitset words: the kernel ORs into zeros
@@ -672,11 +923,14 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
     if (!fast) {
         if (ident) hipLaunchKernelGGL(pair_exact_kernel<true>, grid, block, 0, s, depth, rgb, frame_mats, pairs, a);
         else hipLaunchKernelGGL(pair_exact_kernel<false>, grid, block, 0, s, depth, rgb, frame_mats, pairs, a);
+    } else if (tight24) {
+#define MSPA_LAUNCH_TIGHT(SET_) \
+    hipLaunchKernelGGL((pair_fast_tight_kernel<SET_>), grid, block, 0, s, depth, rgb, frame_mats, pairs, a)
+        if (set == kSetCorr) MSPA_LAUNCH_TIGHT(kSetCorr);
+        else if (set == kSetDense) MSPA_LAUNCH_TIGHT(kSetDense);
+        else MSPA_LAUNCH_TIGHT(kSetMinimal);
+#undef MSPA_LAUNCH_TIGHT
     } else {
-        uint32_t set = 0;
-        set |= out_vis_bits ? O_VIS_BITS : 0; set |= out_vis_u8 ? O_VIS_U8 : 0; set |= out_valid_u8 ? O_VALID_U8 : 0;
-        set |= out_pix_i16 ? O_PIX : 0; set |= out_xyz_f32 ? O_XYZ32 : 0; set |= out_rgba ? O_RGBA : 0;
-        set |= out_counts ? O_COUNTS : 0;
 #define MSPA_LAUNCH_FAST(ID, TI, SET_, GEN) \
     hipLaunchKernelGGL((pair_fast_kernel<ID, TI, SET_, GEN>), grid, block, 0, s, depth, rgb, frame_mats, pairs, a)
         const bool tight = (W % 64 == 0) && (H % kTileRows == 0);
