@@ -227,7 +227,7 @@ def main():
                        "collation": "RCCL all_gather of per-pair records" if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "mspa::pair_fast_kernel" if args.mode == "fast" else "mspa::pair_exact_kernel",
+                         "kernel": "mspa::pair_fast_tight_kernel" if args.mode == "fast" else "mspa::pair_exact_kernel",
                          "kernel_ms": round(kern_ms, 4), "bytes_per_pair": int(spec["bytes_per_px"] * P)},
             "cpu_baseline": cpu,
             "variants": extra,
