@@ -61,6 +61,7 @@ def parse_args():
                          "reference's own operation order")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scene-legs", action="store_true", help="skip the K1/K2 informational legs")
     ap.add_argument("--also", default="corr:exact,dense:fast,dense:exact,minimal:fast",
                     help="comma list of extra variant:mode legs timed briefly on rank 0 ('none' = skip)")
     return ap.parse_args()
@@ -138,6 +139,47 @@ def time_variant(variant, mode, depth, mats, rgb, pairs, steps, warmup, dist_ctx
     return wall, kern_ms, out
 
 
+def time_scene_kernels(device, n_points=131072, n_frames=64, reps=5):
+    """K1 (vertex visibility) + K2 (all-pairs overlap) + K4 (pair pose) on one synthetic scene:
+    the per-scene work of CFR.process_scene.  Informational legs with their own byte formulas
+    (DESIGN.md section 4): K1 24*N + 2*DW*DH + N/8 per image, K2 2*N/8 + 8 per pair."""
+    import torch
+    from mspa import engine, synth
+
+    sc = synth.make_scene(4000, n_points=n_points, n_frames=8, color_hw=(H, W), depth_hw=(H, W),
+                          invalid_pose_frac=0.0, with_color=False)
+    ids = sc.valid_image_ids
+    reps_f = n_frames // len(ids)
+    Ea = [sc.A @ sc.E[i] for i in ids] * reps_f
+    cam = torch.from_numpy(engine.camera_matrices(sc.K, Ea)).to(device)
+    depth = engine.depth_to_device(np.stack([sc.depth[i] for i in ids] * reps_f), device)
+    xyz = torch.from_numpy(np.ascontiguousarray(sc.points[:, :3])).to(device)
+    F = len(Ea)
+    pairs = engine.all_pairs(F, device)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t1 = t2 = 0.0
+    for r in range(reps + 1):
+        ev[0].record()
+        vis = engine.vertex_visibility(xyz, cam, depth, (H, W), ("bits", "count"))
+        ev[1].record()
+        ov = engine.pair_overlap(vis["bits"], pairs)
+        ev[2].record()
+        torch.cuda.synchronize()
+        if r:
+            t1 += ev[0].elapsed_time(ev[1])
+            t2 += ev[1].elapsed_time(ev[2])
+    t1, t2 = t1 / reps, t2 / reps
+    b1 = F * (24 * n_points + 2 * H * W + n_points // 8)
+    b2 = pairs.shape[0] * (2 * n_points // 8 + 8)
+    return {"K1_vertex_visibility": {"images": F, "vertices": n_points, "kernel_ms": round(t1, 4),
+                                     "images_per_s": round(F / (t1 * 1e-3), 1),
+                                     "achieved_GBs": round(b1 / (t1 * 1e-3) / 1e9, 1),
+                                     "frac": round(b1 / (t1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "K2_pair_overlap": {"pairs": int(pairs.shape[0]), "kernel_ms": round(t2, 4),
+                                "pairs_per_s": round(pairs.shape[0] / (t2 * 1e-3), 1),
+                                "streaming_GBs": round(b2 / (t2 * 1e-3) / 1e9, 1)}}
+
+
 def cpu_baseline(sc, ids, pairs_np, nb, budget_s):
     """Time the NumPy restatement of the reference path on a bounded sample of the same pairs."""
     from oracle import np_oracle as O
@@ -199,8 +241,8 @@ def main():
                         "achieved_GBs": round(b2 / (k2 * 1e-3) / 1e9, 1),
                         "frac": round(b2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "bytes_per_pair": int(VARIANTS[v]["bytes_per_px"] * P)}
-    elif dist_ctx is not None:
-        pass
+        if world == 1 and not args.no_scene_legs:
+            extra["scene"] = time_scene_kernels(device)
 
     if rank == 0:
         cpu, traffic = None, None
@@ -210,7 +252,7 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             t = json.load(open(tfile))
-            if t.get("variant") == args.variant and t.get("pairs") == args.pairs:
+            if t.get("variant") == args.variant and t.get("pairs") == args.pairs and t.get("mode") == args.mode:
                 traffic = t.get("hbm_bytes_per_launch")
         info = _lib.device_info(local_rank)
         line = {
