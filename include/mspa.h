@@ -85,8 +85,9 @@ int mspa_device_info(int device, int *n_cu, int *wave_size, int64_t *hbm_bytes, 
  *   out_vis_bits  [n_pairs, ceil(P/64)] uint64   bit (i & 63) of word (i >> 6) = pixel i visible
  *   out_vis_u8    [n_pairs, P] uint8             1 = visible in f2, 0 otherwise
  *   out_valid_u8  [n_pairs, P] uint8             1 = depth sample of f1 > 0 (OPS:297)
- *   out_pix_i16   [n_pairs, P, 2] int16          clipped depth-pixel index (xi, yi) in f2
- *                                                (IH:362-366); (-1,-1) where the f1 sample is 0
+ *   out_pix_i16   [n_pairs, P, 2] int16          depth-pixel index (xi, yi) in f2 (IH:362-366) where the
+ *                                                point lands inside f2 in front of its camera (the
+ *                                                candidate correspondence); (-1,-1) otherwise
  *   out_xyz_f32   [n_pairs, P, 3] float32        aligned world point, NaN where invalid
  *   out_rgba      [n_pairs, P] uint32            r | g<<8 | b<<16 | (valid ? 255 : 0)<<24
  *   out_xyz_f64   [n_pairs, P, 3], out_uv_f64 [n_pairs, P, 2], out_depth_f64 [n_pairs, P]

@@ -41,13 +41,16 @@ __device__ __forceinline__ int round_clip(double v, int hi) {
 }
 
 // IH:337-386 for one projected point; the depth gather is skipped for lanes that cannot pass.
+// `inview` reports the two tests that do not involve the depth buffer (inside the image, in front of
+// the camera): it is the condition under which (xi, yi) is a meaningful correspondence.
 __device__ __forceinline__ bool depth_test(bool enable, double u, double v, double d,
                                            const uint16_t *__restrict__ depth_img, int dh, int dw, int H, int W,
-                                           double sx, double sy, int &xi, int &yi) {
+                                           double sx, double sy, int &xi, int &yi, bool *inview = nullptr) {
     bool inb = (u >= 0.0) && (u < (double)W) && (v >= 0.0) && (v < (double)H);
     xi = round_clip(u * sx, dw - 1);
     yi = round_clip(v * sy, dh - 1);
     bool vis = false;
+    if (inview) *inview = enable && inb && d > 0.0;
     if (enable && inb && d > 0.0) {
         double dv = (double)depth_img[yi * dw + xi] * 0.001;
         vis = d < dv;

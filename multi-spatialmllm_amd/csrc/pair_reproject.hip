@@ -92,6 +92,7 @@ struct Pixel {
     double u, v, qz;       // projection into frame 2, camera-2 depth
     int xi, yi;            // clipped depth-2 pixel index
     bool vis;
+    bool inview;           // inside frame 2 and in front of camera 2 (before the depth-buffer test)
 };
 
 // The exact chain (OPS:303-320, IH:57-69), one 3x4 product at a time over a group of kGroup pixels
@@ -163,7 +164,8 @@ __device__ __forceinline__ void store_pixel(const PairArgs &a, const Ctx &c, uin
     if (O::template has<O_VIS_U8>(a.vis_u8)) a.vis_u8[o] = p.vis ? 1 : 0;
     if (O::template has<O_VALID_U8>(a.valid_u8)) a.valid_u8[o] = valid ? 1 : 0;
     if (O::template has<O_PIX>(a.pix_i16)) {
-        const uint32_t packed = valid ? ((uint32_t)(uint16_t)p.xi | ((uint32_t)(uint16_t)p.yi << 16)) : 0xFFFFFFFFu;
+        const uint32_t packed =
+            (valid && p.inview) ? ((uint32_t)(uint16_t)p.xi | ((uint32_t)(uint16_t)p.yi << 16)) : 0xFFFFFFFFu;
         reinterpret_cast<uint32_t *>(a.pix_i16)[o] = packed;
     }
     if (O::template has<O_XYZ32>(a.xyz_f32)) {
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(kThreads) void pair_exact_kernel(const uint16_t *__
             px[j].u = x[j] / z[j];                                         // IH:69
             px[j].v = y[j] / z[j];
             px[j].vis = depth_test(valid[j], px[j].u, px[j].v, px[j].qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy,
-                                   px[j].xi, px[j].yi);
+                                   px[j].xi, px[j].yi, &px[j].inview);
             n_valid += valid[j] ? 1 : 0;
             n_vis += px[j].vis ? 1 : 0;
             store_pixel<Outs<0, true>>(a, c, i0 + (uint32_t)(g + j) * kThreads, in_img[j], valid[j], px[j]);
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
                     if (O::template has<O_VIS_U8>(a.vis_u8)) a.vis_u8[o] = vis ? 1 : 0;
                     if (O::template has<O_VALID_U8>(a.valid_u8)) a.valid_u8[o] = valid[j] ? 1 : 0;
                     if (O::template has<O_PIX>(a.pix_i16))
-                        reinterpret_cast<int *>(a.pix_i16)[o] = valid[j] ? pix[j] : -1;
+                        reinterpret_cast<int *>(a.pix_i16)[o] = test[j] ? pix[j] : -1;
                     if (O::template has<O_XYZ32>(a.xyz_f32)) {
                         float *q = a.xyz_f32 + 3 * o;
                         const float fn = __builtin_nanf("");
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
                 Pixel p;
                 exact_unproject(m1, mxd, (double)row, (double)dd * 0.001, p.ax, p.ay, p.az);
                 exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
-                p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi);
+                p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi, &p.inview);
                 const bool was = (vis_rows >> g) & 1u;
                 if (p.vis != was) {
                     delta += p.vis ? 1 : -1;
@@ -621,8 +623,9 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 //   * the gather is issued for every lane (the clamped index is always a valid address), no select;
 //   * clamps are single v_med3_i32; decisions stay in SGPR masks (s_and/s_or are free next to the
 //     vector pipe); risky rows are recorded per wave (ballot -> LDS) instead of per-lane bit masks;
-//   * 24 rows per wave tile amortise the per-tile matrix composition.
-constexpr int kTightRows = 24;
+//   * 48 rows per wave tile amortise the per-tile matrix composition;
+//   * a group of 4 rows none of whose 256 pixels can land in frame 2 skips gather, guard and depth test.
+constexpr int kTightRows = 48;
 
 __device__ __forceinline__ int med3_0(int x, int hi) {   // clamp(x, 0, hi), hi wave-uniform
     int r;
@@ -722,11 +725,13 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                     d16n[j] = __builtin_amdgcn_raw_buffer_load_b16(
                         rs_d1, col2, (int)((row0 + (uint32_t)(r0 + kRowGroup + j)) * Wb * 2u), 0);
             }
-            double qz[kRowGroup];
+            // ---- stage 1: project; "in view" with the guard band folded into the comparison constants:
+            // a lane the reference would accept (0 <= u < W, 0 <= v < H, depth > 0) always passes, and a lane
+            // that passes without being accepted sits inside a guard band and is re-evaluated exactly.
+            double u[kRowGroup], v[kRowGroup], qz[kRowGroup];
             float fx[kRowGroup], fy[kRowGroup], fz[kRowGroup];
-            int pix[kRowGroup];
-            uint32_t dv16[kRowGroup];
-            bool valid[kRowGroup], test[kRowGroup], risky[kRowGroup];
+            bool valid[kRowGroup], inview[kRowGroup];
+            unsigned long long any = 0;
 #pragma unroll
             for (int j = 0; j < kRowGroup; ++j) {
                 valid[j] = d16[j] != 0u;                                     // OPS:297
@@ -747,28 +752,74 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                 t2 += M[2][1];
                 double rz = __builtin_amdgcn_rcp(iz);
                 rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
-                const double u = ix * rz, v = iy * rz;
-                const double ru = __builtin_rint(u), rv = __builtin_rint(v);
-                const bool inb = (u >= 0.0) & (u < Wd) & (v >= 0.0) & (v < Hd);
+                u[j] = ix * rz;
+                v[j] = iy * rz;
+                qz[j] = iz;
+                inview[j] = valid[j] & (u[j] > -kGuardPx) & (u[j] < Wd + kGuardPx) & (v[j] > -kGuardPx) &
+                            (v[j] < Hd + kGuardPx) & (iz > -kGuardZ);
+                any |= __ballot(inview[j]);
+            }
+            if (any == 0) {
+                // ---- nothing of these 4 x 64 pixels can land in frame 2: no gather, no depth test ----
+#pragma unroll
+                for (int j = 0; j < kRowGroup; ++j) {
+                    const uint32_t row = row0 + (uint32_t)(r0 + j);
+                    const uint32_t i = row * Wb + col;
+                    n_valid += __popcll(__ballot(valid[j]));
+                    if (O::template has<O_VIS_BITS>(a.vis_bits)) {
+                        if (c.lane == 0) a.vis_bits[pair * c.words_per_pair + (int64_t)(i >> 6)] = 0ull;
+                    }
+                    if (O::template has<O_PIX>(a.pix_i16))
+                        __builtin_amdgcn_raw_buffer_store_b32(0xFFFFFFFFu, rs_pix, col4, (int)(row * Wb * 4u), 0);
+                    const int64_t o = c.obase + (int64_t)i;
+                    if (O::template has<O_VIS_U8>(a.vis_u8)) a.vis_u8[o] = 0;
+                    if (O::template has<O_VALID_U8>(a.valid_u8)) a.valid_u8[o] = valid[j] ? 1 : 0;
+                    if (O::template has<O_XYZ32>(a.xyz_f32)) {
+                        float *q = a.xyz_f32 + 3 * o;
+                        const float fn = __builtin_nanf("");
+                        q[0] = valid[j] ? fx[j] : fn;
+                        q[1] = valid[j] ? fy[j] : fn;
+                        q[2] = valid[j] ? fz[j] : fn;
+                    }
+                    if (O::template has<O_RGBA>(a.rgba)) {
+                        uint32_t colr = 0;
+                        if (c.rgb1) {
+                            const uint8_t *s = c.rgb1 + 3 * (int64_t)i;
+                            colr = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
+                        }
+                        a.rgba[o] = colr | (valid[j] ? 0xFF000000u : 0u);
+                    }
+                }
+                continue;
+            }
+            // ---- stage 2: pixel index, gather, guard ---------------------------------------------
+            int pix[kRowGroup];
+            uint32_t dv16[kRowGroup];
+            bool risky[kRowGroup];
+#pragma unroll
+            for (int j = 0; j < kRowGroup; ++j) {
+                const double ru = __builtin_rint(u[j]), rv = __builtin_rint(v[j]);
                 const int xi = med3_0((int)ru, hi_x);
                 const int yi = med3_0((int)rv, hi_y);
-                test[j] = inb & (iz > 0.0);
                 // every lane gathers: the clamped index is always inside the image
                 dv16[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, (yi * a.dw + xi) * 2, 0, 0);
                 pix[j] = (int)((uint32_t)xi | ((uint32_t)yi << 16));
-                qz[j] = iz;
-                const double wu = __builtin_fabs(u - ru) - 0.25;
-                const double wv = __builtin_fabs(v - rv) - 0.25;
+                // With t = u - rint(u) in [-0.5, 0.5] a decision can flip only if |t| is within the guard of
+                // 0.5 (rounding tie) or of 0 (u at an integer: the image bounds are integers), i.e. unless
+                // guard < |t| < 0.5 - guard  <=>  ||t| - 0.25| < 0.25 - guard.  NaN fails the ordered compare.
+                const double wu = __builtin_fabs(u[j] - ru) - 0.25;
+                const double wv = __builtin_fabs(v[j] - rv) - 0.25;
                 risky[j] = !(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx) |
-                           !(__builtin_fabs(iz) > kGuardZ);
+                           !(qz[j] > kGuardZ);
             }
+            // ---- stage 3: depth test, outputs -------------------------------------------------------
 #pragma unroll
             for (int j = 0; j < kRowGroup; ++j) {
                 const int g = r0 + j;
                 const uint32_t row = row0 + (uint32_t)g;
                 const double dv = (double)dv16[j] * 0.001;
-                const bool vis = valid[j] & test[j] & (qz[j] < dv);
-                const bool rk = valid[j] & (risky[j] | (test[j] & !(__builtin_fabs(qz[j] - dv) > kGuardZ)));
+                const bool vis = inview[j] & (qz[j] < dv);
+                const bool rk = inview[j] & (risky[j] | !(__builtin_fabs(qz[j] - dv) > kGuardZ));
                 const unsigned long long vmask = __ballot(vis);
                 const unsigned long long rb = __ballot(rk);
                 n_vis += __popcll(vmask);
@@ -785,7 +836,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                     if (c.lane == 0) a.vis_bits[pair * c.words_per_pair + (int64_t)(i >> 6)] = vmask;
                 }
                 if (O::template has<O_PIX>(a.pix_i16))
-                    __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(valid[j] ? pix[j] : -1), rs_pix, col4,
+                    __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(inview[j] ? pix[j] : -1), rs_pix, col4,
                                                           (int)(row * Wb * 4u), 0);
                 const int64_t o = c.obase + (int64_t)i;
                 if (O::template has<O_VIS_U8>(a.vis_u8)) a.vis_u8[o] = vis ? 1 : 0;
@@ -824,7 +875,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                     Pixel p;
                     exact_unproject(m1, mxd, (double)row, (double)c.depth1[i] * 0.001, p.ax, p.ay, p.az);
                     exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
-                    p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi);
+                    p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi, &p.inview);
                     vis = p.vis;
                     store_pixel<O, true>(a, c, i, true, true, p);
                 }

@@ -70,8 +70,11 @@ def check_pair_against(res, n, ref_c, ref_np, image_hw, color=None):
     assert not unpack_bits(res["vis_bits"][n], res["vis_bits"][n].size * 64)[P:].any()
     assert tuple(res["counts"][n]) == (ref_np["n_valid"], ref_np["n_vis"])
     pix = res["pix_i16"][n]
-    assert np.array_equal(pix[valid, 0], ref_np["xi"][valid]) and np.array_equal(pix[valid, 1], ref_np["yi"][valid])
-    assert (pix[~valid] == -1).all()
+    with np.errstate(invalid="ignore"):     # candidate correspondences: inside frame 2, in front of camera 2
+        inview = valid & O.check_point_in_image_boundary(ref_np["uv2"], image_hw) & (ref_np["depth2"] > 0)
+    assert np.array_equal(pix[inview, 0], ref_np["xi"][inview]) and np.array_equal(pix[inview, 1], ref_np["yi"][inview])
+    assert (pix[~inview] == -1).all()
+    assert not ref_np["vis"][~inview].any()
     if color is not None and "rgba" in res:
         rgba = res["rgba"][n].view(np.uint32)
         exp = color.reshape(-1, 3).astype(np.uint32)
@@ -373,8 +376,10 @@ def test_full_size_properties():
     pix = out["pix_i16"][:len(ids)].cpu().numpy()
     my, mx = np.divmod(np.arange(P), 640)
     for k in range(len(ids)):
-        v = valid[k].astype(bool)
+        v = valid[k].astype(bool) & (pix[k][:, 0] >= 0)      # border pixels may round to just outside the image
         assert np.array_equal(pix[k][v, 0], mx[v]) and np.array_equal(pix[k][v, 1], my[v])
+        interior = valid[k].astype(bool) & (mx > 0) & (mx < 639) & (my > 0) & (my < 479)
+        assert (pix[k][interior, 0] >= 0).all()
     # spot-check three random pairs of the big batch against the oracle
     for p in (len(ids) + 1, 500, 999):
         a, b = ids[pair_np[p, 0]], ids[pair_np[p, 1]]
