@@ -680,6 +680,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
     const uint32_t col = stripe * 64u + (uint32_t)c.lane;
     const uint32_t row0 = band * (uint32_t)kTightRows;
 
+    static_assert(kTightRows <= 64, "risky_rows is a 64-bit row mask");
     __shared__ unsigned long long lds_rb[kThreads / kWave][kTightRows];   // risky-lane ballots of flagged rows
     __shared__ unsigned long long lds_vm[kThreads / kWave][kTightRows];   // their fast-path visibility ballots
     int n_valid = 0, n_vis = 0;
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
             s2 = __builtin_fma(Us[2][1], myd0, __builtin_fma(Us[2][0], mxd, Us[2][2]));
         }
         const double Wd = (double)a.W, Hd = (double)a.H;
-        uint32_t risky_rows = 0;                     // wave-uniform: rows with at least one guarded lane
+        unsigned long long risky_rows = 0;           // wave-uniform: rows with at least one guarded lane
 
 #pragma unroll 1
         for (int r0 = 0; r0 < kTightRows; r0 += kRowGroup) {
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                         lds_rb[wave][g] = rb;
                         lds_vm[wave][g] = vmask;
                     }
-                    risky_rows |= 1u << g;
+                    risky_rows |= 1ull << g;
                 }
                 const uint32_t i = row * Wb + col;
                 if (O::template has<O_VIS_BITS>(a.vis_bits)) {
@@ -863,8 +864,8 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
         if (risky_rows) {
             __builtin_amdgcn_s_waitcnt(0);                 // the fast path's stores are in L2, LDS writes landed
             while (risky_rows) {                            // wave-uniform
-                const int g = __builtin_ctz(risky_rows);
-                risky_rows &= risky_rows - 1u;
+                const int g = __builtin_ctzll(risky_rows);
+                risky_rows &= risky_rows - 1ull;
                 const unsigned long long rb = lds_rb[wave][g];
                 const unsigned long long old = lds_vm[wave][g];
                 const uint32_t row = row0 + (uint32_t)g;
