@@ -657,6 +657,32 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
     c.pair = pair;
     c.lane = threadIdx.x & 63;
 
+    // wave tile -> (row band, column stripe); both wave-uniform
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = tgroup * (kThreads / kWave) + wave;
+    const uint32_t band = a.n_stripes == 1 ? tile : __umulhi(tile, a.stripe_magic);
+    const uint32_t stripe = tile - band * (uint32_t)a.n_stripes;
+    const bool tile_ok = tile < (uint32_t)a.n_tiles;
+    const uint32_t col = stripe * 64u + (uint32_t)c.lane;
+    const uint32_t row0 = band * (uint32_t)kTightRows;
+
+    // The tile's depth-1 samples (48 rows x 128 B) go HBM -> LDS by LDS-DMA, two rows per wave
+    // instruction (lanes 0-31 fetch row 2k, lanes 32-63 row 2k+1, 4 bytes = 2 pixels each): all 24
+    // requests are in flight before any arithmetic and cost no VGPRs; their latency hides behind the
+    // matrix composition below.  (A register prefetch one row group ahead left the kernel latency
+    // bound once skipped groups made an iteration shorter than a memory round trip.)
+    __shared__ uint16_t lds_d1[kThreads / kWave][kTightRows * 64];
+    if (tile_ok) {
+        typedef __attribute__((address_space(1))) const void gvoid_t;
+        typedef __attribute__((address_space(3))) void lvoid_t;
+        const uint16_t *src = c.depth1 + (int64_t)(row0 + (uint32_t)(c.lane >> 5)) * a.W + stripe * 64u +
+                              (uint32_t)(c.lane & 31) * 2u;
+#pragma unroll
+        for (int k = 0; k < kTightRows / 2; ++k)
+            __builtin_amdgcn_global_load_lds((gvoid_t *)(src + (int64_t)(2 * k) * a.W),
+                                             (lvoid_t *)&lds_d1[wave][k * 128], 4, 0, 0);
+    }
+
     const double *__restrict__ U = m1 + MSPA_MAT_UNPROJ * 16;
     const double *__restrict__ N = m2 + MSPA_MAT_REPROJ * 16;
     double M[3][4], Us[3][4];
@@ -672,14 +698,6 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
         }
     }
 
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = tgroup * (kThreads / kWave) + wave;
-    const uint32_t band = a.n_stripes == 1 ? tile : __umulhi(tile, a.stripe_magic);
-    const uint32_t stripe = tile - band * (uint32_t)a.n_stripes;
-    const bool tile_ok = tile < (uint32_t)a.n_tiles;
-    const uint32_t col = stripe * 64u + (uint32_t)c.lane;
-    const uint32_t row0 = band * (uint32_t)kTightRows;
-
     static_assert(kTightRows <= 64, "risky_rows is a 64-bit row mask");
     __shared__ unsigned long long lds_rb[kThreads / kWave][kTightRows];   // risky-lane ballots of flagged rows
     __shared__ unsigned long long lds_vm[kThreads / kWave][kTightRows];   // their fast-path visibility ballots
@@ -688,18 +706,12 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
         const uint32_t Wb = (uint32_t)a.W;
         // buffer resources: SGPR base + byte count; raw addressing = base + voffset (VGPR) + soffset (SGPR)
         const int kRsrcFlags = 0x00020000;
-        __amdgpu_buffer_rsrc_t rs_d1 = __builtin_amdgcn_make_buffer_rsrc((void *)c.depth1, 0, (int)(dpix * 2), kRsrcFlags);
         __amdgpu_buffer_rsrc_t rs_d2 = __builtin_amdgcn_make_buffer_rsrc((void *)c.depth2, 0, (int)(dpix * 2), kRsrcFlags);
         __amdgpu_buffer_rsrc_t rs_pix = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(a.pix_i16 ? a.pix_i16 + 2 * c.obase : nullptr), 0, O::template has<O_PIX>(a.pix_i16) ? (int)(a.P * 4) : 0,
             kRsrcFlags);
-        const int col2 = (int)(col * 2u), col4 = (int)(col * 4u);
+        const int col4 = (int)(col * 4u);
         const int hi_x = a.dw - 1, hi_y = a.dh - 1;
-
-        uint32_t d16n[kRowGroup];
-#pragma unroll
-        for (int j = 0; j < kRowGroup; ++j)
-            d16n[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_d1, col2, (int)((row0 + (uint32_t)j) * Wb * 2u), 0);
 
         const double mxd = (double)col;
         const double myd0 = (double)row0;
@@ -714,18 +726,13 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
         }
         const double Wd = (double)a.W, Hd = (double)a.H;
         unsigned long long risky_rows = 0;           // wave-uniform: rows with at least one guarded lane
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's depth-1 samples have landed in LDS
 
 #pragma unroll 1
         for (int r0 = 0; r0 < kTightRows; r0 += kRowGroup) {
             uint32_t d16[kRowGroup];
 #pragma unroll
-            for (int j = 0; j < kRowGroup; ++j) d16[j] = d16n[j];
-            if (r0 + kRowGroup < kTightRows) {
-#pragma unroll
-                for (int j = 0; j < kRowGroup; ++j)
-                    d16n[j] = __builtin_amdgcn_raw_buffer_load_b16(
-                        rs_d1, col2, (int)((row0 + (uint32_t)(r0 + kRowGroup + j)) * Wb * 2u), 0);
-            }
+            for (int j = 0; j < kRowGroup; ++j) d16[j] = lds_d1[wave][(r0 + j) * 64 + c.lane];
             // ---- stage 1: project; "in view" with the guard band folded into the comparison constants:
             // a lane the reference would accept (0 <= u < W, 0 <= v < H, depth > 0) always passes, and a lane
             // that passes without being accepted sits inside a guard band and is re-evaluated exactly.
