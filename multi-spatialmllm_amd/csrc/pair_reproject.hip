@@ -626,6 +626,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 //   * 48 rows per wave tile amortise the per-tile matrix composition;
 //   * a group of 4 rows none of whose 256 pixels can land in frame 2 skips gather, guard and depth test.
 constexpr int kTightRows = 48;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int med3_0(int x, int hi) {   // clamp(x, 0, hi), hi wave-uniform
     int r;
@@ -698,6 +699,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
         }
     }
 
+    __shared__ uint32_t lds_px[kThreads / kWave][kRowGroup * 64];        // pixel-index transpose stage
     static_assert(kTightRows <= 64, "risky_rows is a 64-bit row mask");
     __shared__ unsigned long long lds_rb[kThreads / kWave][kTightRows];   // risky-lane ballots of flagged rows
     __shared__ unsigned long long lds_vm[kThreads / kWave][kTightRows];   // their fast-path visibility ballots
@@ -710,7 +712,15 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
         __amdgpu_buffer_rsrc_t rs_pix = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(a.pix_i16 ? a.pix_i16 + 2 * c.obase : nullptr), 0, O::template has<O_PIX>(a.pix_i16) ? (int)(a.P * 4) : 0,
             kRsrcFlags);
-        const int col4 = (int)(col * 4u);
+        __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.vis_bits ? a.vis_bits + pair * c.words_per_pair : nullptr), 0,
+            O::template has<O_VIS_BITS>(a.vis_bits) ? (int)(c.words_per_pair * 8) : 0, kRsrcFlags);
+        // Stores are issued per ROW GROUP, 16 bytes per lane: four dword-per-lane stores per group left the
+        // kernel store-issue bound (~3.6 B/clk/CU).  The 4 x 64 pixel indices of a group are transposed
+        // through 1 KB of LDS so that lane L owns 4 consecutive pixels of row L / 16.
+        const int pix_voff = (int)((((uint32_t)c.lane >> 4) * Wb + stripe * 64u + ((uint32_t)c.lane & 15u) * 4u) * 4u);
+        const uint32_t wpr = Wb >> 6;                                   // bitset words per image row
+        const int bits_voff = (int)(((uint32_t)c.lane & 3u) * wpr * 8u); // lanes 0..3 store the 4 row words
         const int hi_x = a.dw - 1, hi_y = a.dh - 1;
 
         const double mxd = (double)col;
@@ -769,16 +779,22 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
             }
             if (any == 0) {
                 // ---- nothing of these 4 x 64 pixels can land in frame 2: no gather, no depth test ----
+                const uint32_t rowg = row0 + (uint32_t)r0;
+#pragma unroll
+                for (int j = 0; j < kRowGroup; ++j) n_valid += __popcll(__ballot(valid[j]));
+                if (O::template has<O_VIS_BITS>(a.vis_bits)) {
+                    if (c.lane < kRowGroup)
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rs_bits, bits_voff, (int)((rowg * wpr + stripe) * 8u), 0);
+                }
+                if (O::template has<O_PIX>(a.pix_i16)) {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 none = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                    __builtin_amdgcn_raw_buffer_store_b128(none, rs_pix, pix_voff, (int)(rowg * Wb * 4u), 0);
+                }
 #pragma unroll
                 for (int j = 0; j < kRowGroup; ++j) {
-                    const uint32_t row = row0 + (uint32_t)(r0 + j);
+                    const uint32_t row = rowg + (uint32_t)j;
                     const uint32_t i = row * Wb + col;
-                    n_valid += __popcll(__ballot(valid[j]));
-                    if (O::template has<O_VIS_BITS>(a.vis_bits)) {
-                        if (c.lane == 0) a.vis_bits[pair * c.words_per_pair + (int64_t)(i >> 6)] = 0ull;
-                    }
-                    if (O::template has<O_PIX>(a.pix_i16))
-                        __builtin_amdgcn_raw_buffer_store_b32(0xFFFFFFFFu, rs_pix, col4, (int)(row * Wb * 4u), 0);
                     const int64_t o = c.obase + (int64_t)i;
                     if (O::template has<O_VIS_U8>(a.vis_u8)) a.vis_u8[o] = 0;
                     if (O::template has<O_VALID_U8>(a.valid_u8)) a.valid_u8[o] = valid[j] ? 1 : 0;
@@ -821,6 +837,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                            !(qz[j] > kGuardZ);
             }
             // ---- stage 3: depth test, outputs -------------------------------------------------------
+            unsigned long long vm[kRowGroup];
 #pragma unroll
             for (int j = 0; j < kRowGroup; ++j) {
                 const int g = r0 + j;
@@ -828,24 +845,19 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                 const double dv = (double)dv16[j] * 0.001;
                 const bool vis = inview[j] & (qz[j] < dv);
                 const bool rk = inview[j] & (risky[j] | !(__builtin_fabs(qz[j] - dv) > kGuardZ));
-                const unsigned long long vmask = __ballot(vis);
+                vm[j] = __ballot(vis);
                 const unsigned long long rb = __ballot(rk);
-                n_vis += __popcll(vmask);
+                n_vis += __popcll(vm[j]);
                 n_valid += __popcll(__ballot(valid[j]));
                 if (rb) {                                            // wave-uniform, rare
                     if (c.lane == 0) {
                         lds_rb[wave][g] = rb;
-                        lds_vm[wave][g] = vmask;
+                        lds_vm[wave][g] = vm[j];
                     }
                     risky_rows |= 1ull << g;
                 }
+                if (O::template has<O_PIX>(a.pix_i16)) lds_px[wave][j * 64 + c.lane] = (uint32_t)(inview[j] ? pix[j] : -1);
                 const uint32_t i = row * Wb + col;
-                if (O::template has<O_VIS_BITS>(a.vis_bits)) {
-                    if (c.lane == 0) a.vis_bits[pair * c.words_per_pair + (int64_t)(i >> 6)] = vmask;
-                }
-                if (O::template has<O_PIX>(a.pix_i16))
-                    __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(inview[j] ? pix[j] : -1), rs_pix, col4,
-                                                          (int)(row * Wb * 4u), 0);
                 const int64_t o = c.obase + (int64_t)i;
                 if (O::template has<O_VIS_U8>(a.vis_u8)) a.vis_u8[o] = vis ? 1 : 0;
                 if (O::template has<O_VALID_U8>(a.valid_u8)) a.valid_u8[o] = valid[j] ? 1 : 0;
@@ -863,6 +875,20 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                         colr = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
                     }
                     a.rgba[o] = colr | (valid[j] ? 0xFF000000u : 0u);
+                }
+            }
+            {
+                const uint32_t rowg = row0 + (uint32_t)r0;
+                if (O::template has<O_VIS_BITS>(a.vis_bits)) {
+                    static_assert(kRowGroup == 4, "lanes 0..3 each store one row word");
+                    const unsigned long long w = c.lane == 0 ? vm[0] : c.lane == 1 ? vm[1] : c.lane == 2 ? vm[2] : vm[3];
+                    if (c.lane < kRowGroup)
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)w, (uint32_t)(w >> 32)}, rs_bits, bits_voff, (int)((rowg * wpr + stripe) * 8u), 0);
+                }
+                if (O::template has<O_PIX>(a.pix_i16)) {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 q = *reinterpret_cast<const u32x4 *>(&lds_px[wave][c.lane * 4]);
+                    __builtin_amdgcn_raw_buffer_store_b128(q, rs_pix, pix_voff, (int)(rowg * Wb * 4u), 0);
                 }
             }
         }
