@@ -130,6 +130,20 @@ def import_reference():
         if p in sys.path:
             sys.path.remove(p)
         sys.path.insert(0, p)
+    # The reference tree has no __init__.py files (namespace package); a regular package of the same
+    # name anywhere on sys.path would shadow it, so the façade's root is taken off the path while the
+    # reference modules are imported (they stay in sys.modules under their own names afterwards).
+    facade_roots = [q for q in sys.path
+                    if os.path.isfile(os.path.join(q or ".", "spatial_engine", "__init__.py"))]
+    saved_path = list(sys.path)
+    sys.path[:] = [q for q in sys.path if q not in facade_roots]
+    try:
+        return _import_reference_modules()
+    finally:
+        sys.path[:] = saved_path
+
+
+def _import_reference_modules():
     ns = types.SimpleNamespace()
     ns.IH = importlib.import_module("spatial_engine.utils.scannet_utils.handler.info_handler")
     ns.OPS = importlib.import_module("spatial_engine.utils.scannet_utils.handler.ops")
