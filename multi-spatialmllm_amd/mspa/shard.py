@@ -81,6 +81,18 @@ def scene_cost(n_frames: int, n_points: int) -> float:
     return float(n_frames) ** 2 * n_points / 64.0 + float(n_frames) * n_points
 
 
+def collate_records_async(local: torch.Tensor, ctx: DistContext, out: torch.Tensor = None):
+    """Fixed-size collation (every rank contributes the same number of records, e.g. the bench's
+    per-step batches): ONE all_gather, enqueued asynchronously -- no count exchange, no host
+    synchronisation.  Returns (gathered [world*n, k], work); ``work.wait()`` orders the caller's stream
+    after the collective (it does not block the host on RCCL)."""
+    assert local.dim() == 2 and local.is_contiguous()
+    if out is None:
+        out = torch.empty((ctx.world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(out, local, group=ctx.group, async_op=True)
+    return out, work
+
+
 def collate_records(local: torch.Tensor, ctx: DistContext) -> torch.Tensor:
     """all_gather a [n_local, k] record tensor whose n_local may differ per rank.
 

@@ -110,6 +110,11 @@ def _worker(rank, world, port, q):
         recs.append([i, j, r["n_valid"], r["n_vis"]])
     local = torch.tensor(recs, dtype=torch.int32).reshape(-1, 4)
     full = S.collate_records(local, ctx)
+    # fixed-size asynchronous form used by bench.py (one all_gather, no count exchange)
+    fixed = torch.full((5, 2), rank + 1, dtype=torch.int32)
+    g, work = S.collate_records_async(fixed, ctx)
+    work.wait()
+    assert g.shape == (5 * world, 2) and all(int(g[5 * r, 0]) == r + 1 for r in range(world))
     t = ctx.max_over_ranks(float(rank + 1))
     ctx.barrier()
     q.put((rank, full.numpy().tolist(), t))
