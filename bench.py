@@ -238,7 +238,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     _lib.load()
-    dist_ctx = shard.init_distributed(device) if world > 1 else None
+    # MSPA_BENCH_FORCE_DIST=1 exercises the RCCL collation path with a single rank (1-GPU boxes)
+    dist_ctx = shard.init_distributed(device) if (world > 1 or os.environ.get("MSPA_BENCH_FORCE_DIST")) else None
 
     sc, ids, depth, mats, rgb, pairs, pairs_np, nb = build_inputs(args, rank, device)
     wall, kern_ms, out = time_variant(args.variant, args.mode, depth, mats, rgb, pairs, args.steps, args.warmup,
