@@ -190,6 +190,28 @@ int mspa_track_displacement(const double *world, const double *w2c, const double
                             int32_t P, const int32_t *triples, int64_t n, double obj_threshold,
                             double cam_threshold, double *out, uint8_t *out_flags, mspa_stream_t stream);
 
+/*
+ * K6a -- correspondence extraction on K1's bitsets: for every selection (image1, image2, j) the j-th
+ * vertex (ascending index) visible in both images, i.e. element j of np.intersect1d(points1, points2)
+ * (visual correspondence, VC_C:303-313); with image1 == image2 it is element j of that image's
+ * visible-vertex list (depth heads, DE_C:190-198).  -1 when fewer than j+1 vertices qualify.
+ *   bits [n_images, n_words] uint64,  selections [n, 3] int32,  out_vertex [n] int32
+ */
+int mspa_select_common_point(const uint64_t *bits, int32_t n_images, int64_t n_words,
+                             const int32_t *selections, int64_t n, int32_t *out_vertex,
+                             mspa_stream_t stream);
+
+/*
+ * K6b -- SceneInfoHandler.get_point_2d_coordinates_in_image (IH:291-305) for a batch of
+ * (vertex, image) samples: un-rounded (u, v), camera depth and the check_point_visibility flag.
+ *   xyz as in mspa_vertex_visibility; cam_mats [n_images, 2, 16]; depth [n_images, dh, dw]
+ *   samples [n, 2] int32 (vertex, image);  out_uv [n, 2] f64, out_depth [n] f64, out_visible [n] u8
+ */
+int mspa_project_samples(const double *xyz, int64_t n_points, int64_t point_stride, int64_t comp_stride,
+                         const double *cam_mats, int32_t n_images, const uint16_t *depth, int32_t dh,
+                         int32_t dw, int32_t H, int32_t W, const int32_t *samples, int64_t n,
+                         double *out_uv, double *out_depth, uint8_t *out_visible, mspa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

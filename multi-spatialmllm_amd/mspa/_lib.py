@@ -42,6 +42,10 @@ _SIGNATURES = {
                                c_void_p]),
     "mspa_track_to_world": (c_int, [c_void_p, c_void_p, c_int32, c_int32, POINTER(c_double), c_int32, c_int32,
                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mspa_select_common_point": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mspa_project_samples": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_int32,
+                                     c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
     "mspa_track_displacement": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64,
                                         c_double, c_double, c_void_p, c_void_p, c_void_p]),
 }

@@ -273,3 +273,37 @@ def check_visibility(uv: torch.Tensor, point_depth: Optional[torch.Tensor], dept
                                          _ptr(out.get("in_bounds")), _ptr(out.get("by_depth")),
                                          _ptr(out.get("visible")), _stream_ptr()))
     return out
+
+
+def select_common_point(bits: torch.Tensor, selections: torch.Tensor) -> torch.Tensor:
+    """Enqueue K6a.  bits [F, n_words] int64 (K1), selections [n, 3] int32 (image1, image2, j) ->
+    [n] int32 vertex index: element j of np.intersect1d of the two visible lists (-1 if out of range)."""
+    _require_gpu()
+    lib = _lib.load()
+    assert bits.dtype == torch.int64 and bits.dim() == 2 and bits.is_contiguous()
+    assert selections.dtype == torch.int32 and selections.dim() == 2 and selections.shape[1] == 3
+    out = torch.empty((selections.shape[0],), dtype=torch.int32, device=bits.device)
+    _lib.check(lib.mspa_select_common_point(_ptr(bits), bits.shape[0], bits.shape[1], _ptr(selections.contiguous()),
+                                            selections.shape[0], _ptr(out), _stream_ptr()))
+    return out
+
+
+def project_samples(xyz: torch.Tensor, cam_mats: torch.Tensor, depth: torch.Tensor, image_hw: Tuple[int, int],
+                    samples: torch.Tensor):
+    """Enqueue K6b.  samples [n, 2] int32 (vertex, image) -> (uv [n,2] f64, depth [n] f64, visible [n] u8)."""
+    _require_gpu()
+    lib = _lib.load()
+    assert xyz.dtype == torch.float64 and xyz.dim() == 2 and xyz.shape[1] >= 3
+    assert samples.dtype == torch.int32 and samples.dim() == 2 and samples.shape[1] == 2
+    I, DH, DW = depth.shape
+    assert tuple(cam_mats.shape) == (I, 2, 16) and cam_mats.is_contiguous() and depth.is_contiguous()
+    n = samples.shape[0]
+    dev = xyz.device
+    uv = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    d = torch.empty((n,), dtype=torch.float64, device=dev)
+    vis = torch.empty((n,), dtype=torch.uint8, device=dev)
+    H, W = image_hw
+    _lib.check(lib.mspa_project_samples(xyz.data_ptr(), xyz.shape[0], xyz.stride(0), xyz.stride(1), _ptr(cam_mats), I,
+                                        _ptr(depth), DH, DW, H, W, _ptr(samples.contiguous()), n, _ptr(uv), _ptr(d),
+                                        _ptr(vis), _stream_ptr()))
+    return uv, d, vis

@@ -1,0 +1,382 @@
+"""Task heads: QA records in the reference's InternVL chat schema, numerics from the HIP kernels.
+
+Each head is split in two:
+  * a **numeric stage** that runs on the GPU for a whole batch (K4 pair pose, K6a/K6b correspondence
+    selection + projection, K5 track geometry) and returns plain arrays;
+  * a **record stage**, pure Python, that draws from ``random`` in exactly the order the reference's
+    scripts do and fills the templates (schemas, ids, integer formatting).
+The record stage never computes geometry; handing it the reference's template tables and seeds
+reproduces the reference's JSONL byte for byte (tests/test_heads_vs_reference.py checks that with
+numerics supplied by the oracle, tests/test_gpu_heads.py checks the numeric stages on the MI355X).
+
+Reference scripts mirrored (paths under spatial_engine/): camera_movement/
+camera_movement_engine_train_val.py (CME), visual_correspondence/
+visual_correspondence_qa_engine_coor_2_coor.py (VC_C), depth_perception/
+depth_estimation_coor_engine.py (DE_C), object_movement/single_object_movement_engine_coord.py (OM_C).
+"""
+from __future__ import annotations
+
+import json
+import random as _random
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import templates as T
+
+
+# --------------------------------------------------------------------------------------------
+# shared helpers
+# --------------------------------------------------------------------------------------------
+def to_eval_sample(train_sample: dict) -> dict:
+    """Train record -> eval record: the conversation collapses into ``text`` (CME:247-269)."""
+    conversation = train_sample.pop("conversations")
+    train_sample["text"] = conversation[0]["value"]
+    return train_sample
+
+
+def write_jsonl(path: str, records: Iterable[dict]):
+    with open(path, "w") as f:
+        for r in records:
+            f.write(json.dumps(r) + "\n")
+
+
+def sample_indices(n: int, k: int, rng=_random) -> List[int]:
+    """Positions ``random.sample(seq_of_len_n, k)`` would pick: the draw depends only on n and k, so
+    sampling ``range(n)`` consumes the generator identically and yields the positions themselves."""
+    return rng.sample(range(n), k)
+
+
+# --------------------------------------------------------------------------------------------
+# camera movement (CME:153-245)
+# --------------------------------------------------------------------------------------------
+def camera_movement_answer_values(d, yaw_angle: float, pitch_angle: float) -> dict:
+    """The 15 answer fields from the camera-1-frame displacement ``d`` and the (already swapped and
+    wrapped) angles: sign words and truncated integers exactly as CME:209-225."""
+    d = np.asarray(d, dtype=np.float64)
+    return {
+        "x_movement": "right" if d[0] > 0 else "left",
+        "y_movement": "down" if d[1] > 0 else "up",
+        "z_movement": "forward" if d[2] > 0 else "backward",
+        "yaw_movement": "left" if yaw_angle > 0 else "right",
+        "pitch_movement": "up" if pitch_angle > 0 else "down",
+        "x_distance": int(abs(d[0]) * 1000),
+        "y_distance": int(abs(d[1]) * 1000),
+        "z_distance": int(abs(d[2]) * 1000),
+        "yaw_angle": int(abs(yaw_angle)),
+        "pitch_angle": int(abs(pitch_angle)),
+        "x_value": int(d[0] * 1000),
+        "y_value": int(d[1] * 1000),
+        "z_value": int(d[2] * 1000),
+        "total_distance": int(np.linalg.norm(d) * 1000),
+        "displacement_vector": d.tolist(),
+    }
+
+
+def camera_movement_record(row: dict, idx: int, question_type: str, rel_t_12, rel_t_21, image_hw: Tuple[int, int],
+                           templates: T.TemplateSet = T.CAMERA_MOVEMENT, rng=_random) -> dict:
+    """One record of the camera-movement head.  ``row`` has scene_id, image_id1, image_id2, overlap, yaw,
+    pitch, distance (a row of the pair table); ``rel_t_12`` / ``rel_t_21`` are the translation columns of
+    inv(E1)@E2 and inv(E2)@E1 (K4 computes both directions)."""
+    scene_id, image1, image2 = row["scene_id"], row["image_id1"], row["image_id2"]
+    overlap, yaw_angle, pitch_angle = float(row["overlap"]), float(row["yaw"]), float(row["pitch"])
+    d = np.asarray(rel_t_12, dtype=np.float64)
+    if rng.random() < 0.5:                                   # CME:163-166
+        yaw_angle, pitch_angle = -yaw_angle, -pitch_angle
+        image1, image2 = image2, image1
+        d = np.asarray(rel_t_21, dtype=np.float64)
+    if abs(yaw_angle) > 180:                                 # CME:168-172
+        yaw_angle = yaw_angle - 360 if yaw_angle > 0 else yaw_angle + 360
+    distance = np.linalg.norm(d)
+    assert abs(distance - row["distance"]) < 0.1, \
+        f"distance is not close to the distance from df for {scene_id} {image1} {image2}."     # CME:193
+    task_description = rng.choice(templates.task_description)
+    if overlap < 0.1:
+        raise NotImplementedError("overlap < 0.1 is not supported yet.")                       # CME:199-201
+    question = rng.choice(templates.questions[question_type])
+    answer_template = rng.choice(templates.answers[question_type])
+    answer_values = camera_movement_answer_values(d, yaw_angle, pitch_angle)
+    H, W = image_hw
+    return {
+        "id": idx,
+        "image": [f"{scene_id}/{image1}.jpg", f"{scene_id}/{image2}.jpg"],
+        "conversations": [{"from": "human", "value": f"{task_description}\n{question}"},
+                          {"from": "gpt", "value": answer_template.format(**answer_values)}],
+        "height_list": [H] * 2,
+        "width_list": [W] * 2,
+        "answer_values": answer_values,
+        "question_type": question_type,
+        "gt_value": answer_values[question_type],
+    }
+
+
+def camera_movement_numeric(scene, rows: Sequence[dict]):
+    """GPU stage: K4 for every row in both directions -> ([n,3] rel_t_12, [n,3] rel_t_21)."""
+    import torch
+    from . import engine
+    F = len(scene.ids)
+    idx = np.array([[scene.index[r["image_id1"]], scene.index[r["image_id2"]]] for r in rows], dtype=np.int32)
+    both = torch.from_numpy(np.concatenate([idx, idx[:, ::-1]], axis=0).copy()).to(scene.device)
+    yaw, pitch = engine.extract_yaw_pitch_host(scene.E_aligned)
+    E_t = torch.from_numpy(np.stack(scene.E_aligned).reshape(F, 16)).to(scene.device)
+    out = engine.pair_pose(E_t, scene.cam_mats[:, 0, :].contiguous(), torch.from_numpy(yaw).to(scene.device),
+                           torch.from_numpy(pitch).to(scene.device), both).cpu().numpy()
+    n = len(rows)
+    return out[:n, 3:6], out[n:, 3:6]
+
+
+def camera_movement_records(scene, rows: Sequence[dict], question_type: str, image_hw, start_idx: int = 0,
+                            templates: T.TemplateSet = T.CAMERA_MOVEMENT, rng=_random) -> List[dict]:
+    t12, t21 = camera_movement_numeric(scene, rows)
+    return [camera_movement_record(r, start_idx + k, question_type, t12[k], t21[k], image_hw, templates, rng)
+            for k, r in enumerate(rows)]
+
+
+# --------------------------------------------------------------------------------------------
+# visual correspondence, coordinate -> coordinate (VC_C:264-394)
+# --------------------------------------------------------------------------------------------
+def normalised(uv_row, image_hw) -> Tuple[int, int]:
+    """round(u / W * 1000), round(v / H * 1000) with Python's banker's rounding (VC_C:341-344)."""
+    H, W = image_hw
+    return round((uv_row[0] / W) * 1000), round((uv_row[1] / H) * 1000)
+
+
+def visual_correspondence_draws(rows: Sequence[dict], n_common: Sequence[int], templates: T.TemplateSet,
+                                rng=_random, max_points_per_pair: int = 1):
+    """Every random decision of VC_C.build_training_sample for a batch, in the reference's order, given only
+    the number of common visible vertices per pair: swap coin, position(s) inside the sorted intersection,
+    template picks.  Returns a list of dicts (None for pairs without common vertices, VC_C:304-309)."""
+    draws = []
+    for row, n in zip(rows, n_common):
+        swap = rng.random() < 0.5                                        # VC_C:280
+        if n == 0:
+            draws.append(None)
+            continue
+        if n >= max_points_per_pair:                                     # VC_C:312-315
+            pos = sample_indices(int(n), max_points_per_pair, rng)
+        else:
+            pos = [rng.choice(range(int(n))) for _ in range(max_points_per_pair)]
+        picks = [(rng.choice(range(len(templates.task_description))),
+                  rng.choice(range(len(templates.questions["default"]))),
+                  rng.choice(range(len(templates.answers["default"])))) for _ in pos]
+        draws.append({"swap": swap, "positions": pos, "picks": picks})
+    return draws
+
+
+def visual_correspondence_record(row: dict, idx: int, draw: dict, uv1: np.ndarray, uv2: np.ndarray, image_hw,
+                                 templates: T.TemplateSet = T.VISUAL_CORRESPONDENCE) -> dict:
+    """Record stage.  uv1/uv2: [k,2] projections of the selected vertices into the (post-swap) first and
+    second image."""
+    scene_id, image1, image2 = row["scene_id"], row["image_id1"], row["image_id2"]
+    if draw["swap"]:
+        image1, image2 = image2, image1
+    H, W = image_hw
+    conversation, p1_list, p2_list = [], [], []
+    for k, (ti, qi, ai) in enumerate(draw["picks"]):
+        x1, y1 = normalised(uv1[k], image_hw)
+        x2, y2 = normalised(uv2[k], image_hw)
+        question = templates.questions["default"][qi].format(x1=x1, y1=y1, x2=x2, y2=y2)
+        answer = templates.answers["default"][ai].format(x1=x1, y1=y1, x2=x2, y2=y2)
+        if not conversation:
+            conversation = [{"from": "human", "value": f"{templates.task_description[ti]}\n{question}"},
+                            {"from": "gpt", "value": answer}]
+        else:
+            conversation += [{"from": "human", "value": question}, {"from": "gpt", "value": answer}]
+        p1_list.append((x1, y1))
+        p2_list.append((x2, y2))
+    return {
+        "id": f"{scene_id}_{image1}_{image2}_{idx}",
+        "image": [f"{scene_id}/{image1}.jpg", f"{scene_id}/{image2}.jpg"],
+        "conversations": conversation,
+        "height_list": [H, H],
+        "width_list": [W, W],
+        "question_type": "visual_correspondence_coor_2_coor",
+        "p1_list": p1_list,
+        "p2_list": p2_list,
+        "gt_value": list(p2_list[0]),
+    }
+
+
+def visual_correspondence_records(scene, rows: Sequence[dict], image_hw, start_idx: int = 0,
+                                  templates: T.TemplateSet = T.VISUAL_CORRESPONDENCE, rng=_random) -> List[dict]:
+    """Whole head for one scene: K2 intersection sizes -> host draws -> K6a selection -> K6b projection."""
+    import torch
+    from . import engine
+    bits = scene._visibility()["bits"]
+    dev = scene.device
+    idx = np.array([[scene.index[r["image_id1"]], scene.index[r["image_id2"]]] for r in rows], dtype=np.int32)
+    _, inter, _ = engine.pair_overlap(bits, torch.from_numpy(idx).to(dev), want_counts=True)
+    n_common = inter.cpu().numpy()
+    draws = visual_correspondence_draws(rows, n_common, templates, rng)
+    sel, owner = [], []
+    for k, dr in enumerate(draws):
+        if dr is None:
+            continue
+        for j in dr["positions"]:
+            sel.append([idx[k, 0], idx[k, 1], j])
+            owner.append(k)
+    records = []
+    if sel:
+        sel_t = torch.tensor(sel, dtype=torch.int32, device=dev)
+        vert = engine.select_common_point(bits, sel_t)
+        first = torch.tensor([idx[k, 1] if draws[k]["swap"] else idx[k, 0] for k in owner], dtype=torch.int32, device=dev)
+        second = torch.tensor([idx[k, 0] if draws[k]["swap"] else idx[k, 1] for k in owner], dtype=torch.int32, device=dev)
+        samples = torch.cat([torch.stack([vert, first], 1), torch.stack([vert, second], 1)], 0).contiguous()
+        uv, _, vis = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw, samples)
+        uv, vis = uv.cpu().numpy(), vis.cpu().numpy().astype(bool)
+        m = len(owner)
+        assert vis.all(), "a vertex taken from both visibility lists failed the visibility re-check (IH:297-300)"
+        by_row: Dict[int, List[int]] = {}
+        for s, k in enumerate(owner):
+            by_row.setdefault(k, []).append(s)
+        for k, ss in by_row.items():
+            records.append(visual_correspondence_record(rows[k], start_idx + k, draws[k], uv[ss], uv[[s + m for s in ss]],
+                                                        image_hw, templates))
+    return records
+
+
+# --------------------------------------------------------------------------------------------
+# depth estimation by coordinate (DE_C:175-254)
+# --------------------------------------------------------------------------------------------
+def depth_estimation_draws(image_ids: Sequence[str], n_visible: Dict[str, int], max_samples: int,
+                           templates: T.TemplateSet, rng=_random, max_n_points_per_image: int = 1):
+    """Random decisions of DE_C.generate_qa_training_single_scene: which images, which visible-vertex
+    positions, which templates (question, answer, task description -- in that order, DE_C:224-230)."""
+    n_images = min(max_samples, len(image_ids)) if max_samples > 0 else len(image_ids)
+    sampled = rng.sample(list(image_ids), n_images)                       # DE_C:187
+    draws = []
+    for image_id in sampled:
+        n = int(n_visible[image_id])
+        if n < max_n_points_per_image:                                    # DE_C:195-198
+            pos = rng.choices(range(n), k=max_n_points_per_image)
+        else:
+            pos = sample_indices(n, max_n_points_per_image, rng)
+        picks = [(rng.choice(range(len(templates.questions["default"]))),
+                  rng.choice(range(len(templates.answers["default"]))),
+                  rng.choice(range(len(templates.task_description)))) for _ in pos]
+        draws.append({"image_id": image_id, "positions": pos, "picks": picks})
+    return draws
+
+
+def depth_estimation_record(scene_id: str, image_id: str, vertex: int, uv_row, depth_m: float, pick, image_hw,
+                            templates: T.TemplateSet = T.DEPTH_ESTIMATION) -> dict:
+    H, W = image_hw
+    x, y = normalised(uv_row, image_hw)
+    depth = round(depth_m * 1000)                                         # DE_C:218
+    qi, ai, ti = pick
+    question = templates.questions["default"][qi].format(x1=x, y1=y)
+    answer = templates.answers["default"][ai].format(x1=x, y1=y, depth=depth)
+    return {
+        "id": f"{scene_id}_{image_id}_point{vertex}",
+        "image": [f"{scene_id}/{image_id}.jpg"],
+        "conversations": [{"from": "human", "value": f"{templates.task_description[ti]}\n{question}"},
+                          {"from": "gpt", "value": answer}],
+        "height_list": [H],
+        "width_list": [W],
+        "question_type": "depth_estimation_coor",
+        "gt_value": depth,
+        "ori_coordinates": [int(uv_row[0]), int(uv_row[1])],
+    }
+
+
+def depth_estimation_records(scene, scene_id: str, image_hw, max_samples: int = -1,
+                             templates: T.TemplateSet = T.DEPTH_ESTIMATION, rng=_random) -> List[dict]:
+    import torch
+    from . import engine
+    vis = scene._visibility()
+    counts = vis["count"].cpu().numpy()
+    n_visible = {k: int(c) for k, c in zip(scene.ids, counts)}
+    draws = depth_estimation_draws(scene.ids, n_visible, max_samples, templates, rng)
+    sel = [[scene.index[d["image_id"]], scene.index[d["image_id"]], j] for d in draws for j in d["positions"]]
+    if not sel:
+        return []
+    dev = scene.device
+    sel_t = torch.tensor(sel, dtype=torch.int32, device=dev)
+    vert = engine.select_common_point(vis["bits"], sel_t)
+    samples = torch.stack([vert, sel_t[:, 0]], 1).contiguous()
+    uv, d, ok = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw, samples)
+    uv, d, ok, vert = uv.cpu().numpy(), d.cpu().numpy(), ok.cpu().numpy().astype(bool), vert.cpu().numpy()
+    records, s = [], 0
+    for dr in draws:
+        for pick in dr["picks"]:
+            if ok[s]:
+                records.append(depth_estimation_record(scene_id, dr["image_id"], int(vert[s]), uv[s], float(d[s]), pick,
+                                                       image_hw, templates))
+            s += 1
+    return records
+
+
+# --------------------------------------------------------------------------------------------
+# object movement on TAPVid-3D tracks (OM_C:317-404)
+# --------------------------------------------------------------------------------------------
+def object_movement_record(scene_id: str, frame1: int, frame2: int, point_index: int, question_type: str,
+                           numeric: dict, image_hw, templates: T.TemplateSet = T.OBJECT_MOVEMENT, rng=_random) -> Optional[dict]:
+    """numeric: distance, vector (camera-1 axes, metres), point_moving, cam_moving, p1n/p2n (normalised
+    projections or None) -- K5's outputs for this (frame1, frame2, point)."""
+    if numeric["p1n"] is None or numeric["p2n"] is None:                  # OM_C:360-362
+        return None
+    H, W = image_hw
+    x1, y1 = round(numeric["p1n"][0] * 1000), round(numeric["p1n"][1] * 1000)
+    x2, y2 = round(numeric["p2n"][0] * 1000), round(numeric["p2n"][1] * 1000)
+    task_description = rng.choice(templates.task_description)             # OM_C:367-375
+    question = rng.choice(templates.questions[question_type]).format(x1=x1, y1=y1)
+    vec = numeric["vector"]
+    answer_text = rng.choice(templates.answers[question_type]).format(
+        total_distance=round(numeric["distance"] * 1000), x_value=round(vec[0] * 1000), y_value=round(vec[1] * 1000),
+        z_value=round(vec[2] * 1000))
+    if not numeric["point_moving"]:
+        answer_text = "The point did not move. " + answer_text
+    images = [f"{scene_id}/{frame:05d}.jpg" for frame in [frame1, frame2]]
+    return {
+        "id": f"{scene_id}_{frame1}_{frame2}_{point_index}",
+        "image": images,
+        "conversations": [{"from": "human", "value": f"{task_description}\n{question}"},
+                          {"from": "gpt", "value": answer_text}],
+        "height_list": [H] * 2,
+        "width_list": [W] * 2,
+        "gt_value": int(numeric["distance"] * 1000) if "total_distance" in question_type else list(vec),
+        "question_type": question_type,
+        "point_moving": int(numeric["point_moving"]),
+        "cam_moving": int(numeric["cam_moving"]),
+        "p1": (x1, y1),
+        "p2": (x2, y2),
+    }
+
+
+def object_movement_numeric(tracks_xyz: np.ndarray, extrinsics_w2c: np.ndarray, fx_fy_cx_cy, image_hw,
+                            triples: np.ndarray, device="cuda") -> List[dict]:
+    """GPU stage: K5a + K5b for a list of (frame1, frame2, point) triples."""
+    import torch
+    from . import engine
+    T_, P, _ = tracks_xyz.shape
+    tr = torch.from_numpy(np.ascontiguousarray(tracks_xyz, dtype=np.float64)).to(device)
+    w2c_np = np.ascontiguousarray(extrinsics_w2c, dtype=np.float64)
+    c2w = torch.from_numpy(np.linalg.inv(w2c_np).reshape(T_, 16)).to(device)          # OM_C:448, host LAPACK
+    w2c = torch.from_numpy(w2c_np.reshape(T_, 16)).to(device)
+    res = engine.track_to_world(tr, c2w, fx_fy_cx_cy, image_hw)
+    trip = torch.from_numpy(np.ascontiguousarray(triples, dtype=np.int32)).to(device)
+    disp, flags = engine.track_displacement(res["world"], w2c, c2w, trip)
+    uvn, ok = res["uvn"].cpu().numpy(), res["ok"].cpu().numpy().astype(bool)
+    disp, flags = disp.cpu().numpy(), flags.cpu().numpy()
+    out = []
+    for k, (f1, f2, p) in enumerate(np.asarray(triples)):
+        out.append({"distance": float(disp[k, 0]), "vector": disp[k, 1:4].tolist(),
+                    "point_moving": bool(flags[k, 0]), "cam_moving": bool(flags[k, 1]),
+                    "p1n": uvn[f1, p].tolist() if ok[f1, p] else None,
+                    "p2n": uvn[f2, p].tolist() if ok[f2, p] else None})
+    return out
+
+
+def object_movement_records(scene_id: str, tracks_xyz, extrinsics_w2c, fx_fy_cx_cy, image_hw, sample_pairs: Sequence[dict],
+                            question_type: str, templates: T.TemplateSet = T.OBJECT_MOVEMENT, rng=_random,
+                            device="cuda") -> List[dict]:
+    """format_training_samples (OM_C:317-404) for already chosen {frame1, frame2, point_index} samples."""
+    triples = np.array([[s["frame1"], s["frame2"], s["point_index"]] for s in sample_pairs], dtype=np.int32).reshape(-1, 3)
+    numeric = object_movement_numeric(tracks_xyz, extrinsics_w2c, fx_fy_cx_cy, image_hw, triples, device)
+    records = []
+    for s, num in zip(sample_pairs, numeric):
+        r = object_movement_record(scene_id, int(s["frame1"]), int(s["frame2"]), int(s["point_index"]), question_type, num,
+                                   image_hw, templates, rng)
+        if r is not None:
+            records.append(r)
+    return records

@@ -153,6 +153,7 @@ def _import_reference_modules():
     ns.OM_C = importlib.import_module("spatial_engine.object_movement.single_object_movement_engine_coord")
     ns.VC_C = importlib.import_module(
         "spatial_engine.visual_correspondence.visual_correspondence_qa_engine_coor_2_coor")
+    ns.DE_C = importlib.import_module("spatial_engine.depth_perception.depth_estimation_coor_engine")
     assert ns.IH.__file__.startswith(REFERENCE_ROOT), ns.IH.__file__
     return ns
 
@@ -177,4 +178,10 @@ def make_handler(ns, scenes, root=None):
     info_path = os.path.join(root, "infos.pkl")
     _INFOS[info_path] = infos
     handler = ns.IH.SceneInfoHandler(info_path, posed_images_root=posed, instance_data_root=inst)
+    handler._mspa_info_path, handler._mspa_root = info_path, root
     return handler
+
+
+def register_pickle(path, obj):
+    """Make ``mmengine.load(path)`` (stub) return ``obj`` -- e.g. a visibility-info dict."""
+    _INFOS[path] = obj

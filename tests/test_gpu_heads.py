@@ -1,0 +1,163 @@
+"""Numeric stages of the task heads on the MI355X (K4, K5, K6a, K6b) and the heads end to end.
+
+End-to-end check: the records the GPU heads emit equal the records the pure-Python record stage
+builds from ORACLE numerics with the same seed -- and that record stage is pinned to the reference in
+tests/test_heads_vs_reference.py, so the chain reference -> record stage -> GPU heads is closed.
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import same_f64, close_f64
+from mspa import engine, heads, synth
+from mspa import templates as T
+from mspa.scene import SceneOnDevice
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def world():
+    sc = synth.make_scene(3001, n_points=3000, n_frames=7, color_hw=(96, 128), depth_hw=(96, 128),
+                          invalid_pose_frac=0.15, with_color=False)
+    scene = SceneOnDevice(sc.K, sc.A, sc.E, sc.depth, sc.color_hw, sc.points, DEV)
+    table = O.frames_relations_scene(sc.points[:, :3], sc.K, sc.A, sc.E, sc.depth, sc.color_hw)
+    vis = O.visibility_index_scene(sc.points[:, :3], sc.K, sc.A, sc.E, sc.depth, sc.color_hw)
+    rows = [{"scene_id": sc.scene_id, "image_id1": a, "image_id2": b, "overlap": max(float(v["overlap"]), 1.0),
+             "distance": float(v["distance"]), "yaw": float(v["yaw"]), "pitch": float(v["pitch"])}
+            for (a, b), v in table.items()]
+    return sc, scene, rows, vis
+
+
+def test_select_common_point_and_project_samples(world):
+    sc, scene, rows, vis = world
+    bits = scene._visibility()["bits"]
+    rng = np.random.default_rng(0)
+    sel, expect = [], []
+    ids = scene.ids
+    for _ in range(400):
+        a, b = rng.integers(0, len(ids), 2)
+        if rng.random() < 0.2:
+            b = a                                                       # one image's own visible list
+        common = np.intersect1d(vis["image_to_points"][ids[a]], vis["image_to_points"][ids[b]])
+        j = int(rng.integers(0, len(common) + 3))                       # sometimes past the end
+        sel.append([a, b, j])
+        expect.append(int(common[j]) if j < len(common) else -1)
+    got = engine.select_common_point(bits, torch.tensor(sel, dtype=torch.int32, device=DEV)).cpu().numpy()
+    assert np.array_equal(got, np.array(expect))
+    assert (got >= 0).sum() > 50
+    # K6b on the hits, both images of the selection
+    hit = [(v, s[0]) for v, s in zip(got, sel) if v >= 0] + [(v, s[1]) for v, s in zip(got, sel) if v >= 0]
+    samples = torch.tensor(hit, dtype=torch.int32, device=DEV)
+    uv, d, ok = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw, samples)
+    uv, d, ok = uv.cpu().numpy(), d.cpu().numpy(), ok.cpu().numpy().astype(bool)
+    assert ok.all()                                                     # taken from the visible lists
+    for k in range(0, len(hit), 7):
+        v, img = hit[k]
+        ruv, rd = O.point_2d_in_image(sc.points[v], sc.K, sc.A @ sc.E[ids[img]], sc.depth[ids[img]], sc.color_hw,
+                                      check_visible=False)
+        assert (same_f64(uv[k], ruv[0]) or close_f64(uv[k], ruv[0], rtol=1e-12, scale=1e-6))
+        assert close_f64(d[k], rd[0], rtol=1e-12, scale=1e-9)
+    # a vertex that is NOT visible reports so
+    unseen = [int(np.setdiff1d(np.arange(sc.points.shape[0]), vis["image_to_points"][ids[0]])[0]), 0]
+    _, _, ok2 = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw,
+                                       torch.tensor([unseen], dtype=torch.int32, device=DEV))
+    assert not bool(ok2[0])
+
+
+def test_camera_movement_head(world):
+    sc, scene, rows, _ = world
+    for qt in ("displacement_vector", "total_distance", "yaw_movement"):
+        random.seed(3)
+        got = heads.camera_movement_records(scene, rows, qt, sc.color_hw)
+        random.seed(3)
+        want = []
+        for n, row in enumerate(rows):
+            E1, E2 = sc.A @ sc.E[row["image_id1"]], sc.A @ sc.E[row["image_id2"]]
+            want.append(heads.camera_movement_record(row, n, qt, (np.linalg.inv(E1) @ E2)[:3, 3],
+                                                     (np.linalg.inv(E2) @ E1)[:3, 3], sc.color_hw))
+        assert len(got) == len(want) == len(rows)
+        for g, w in zip(got, want):
+            gv, wv = g["answer_values"].pop("displacement_vector"), w["answer_values"].pop("displacement_vector")
+            if qt == "displacement_vector":
+                g.pop("gt_value"), w.pop("gt_value")
+            assert g == w
+            assert same_f64(gv, wv) or close_f64(gv, wv, rtol=1e-12, scale=1e-9)
+
+
+def test_visual_correspondence_head(world):
+    sc, scene, rows, vis = world
+    random.seed(9)
+    got = heads.visual_correspondence_records(scene, rows, sc.color_hw)
+    n_common = [len(np.intersect1d(vis["image_to_points"][r["image_id1"]], vis["image_to_points"][r["image_id2"]]))
+                for r in rows]
+    random.seed(9)
+    draws = heads.visual_correspondence_draws(rows, n_common, T.VISUAL_CORRESPONDENCE)
+    want = []
+    for n, (row, dr) in enumerate(zip(rows, draws)):
+        if dr is None:
+            continue
+        first, second = (row["image_id2"], row["image_id1"]) if dr["swap"] else (row["image_id1"], row["image_id2"])
+        common = np.intersect1d(vis["image_to_points"][first], vis["image_to_points"][second])
+        verts = [int(common[j]) for j in dr["positions"]]
+        uv1 = np.stack([O.point_2d_in_image(sc.points[v], sc.K, sc.A @ sc.E[first], sc.depth[first], sc.color_hw)[0][0]
+                        for v in verts])
+        uv2 = np.stack([O.point_2d_in_image(sc.points[v], sc.K, sc.A @ sc.E[second], sc.depth[second], sc.color_hw)[0][0]
+                        for v in verts])
+        want.append(heads.visual_correspondence_record(row, n, dr, uv1, uv2, sc.color_hw))
+    assert len(want) > 3 and sorted(got, key=lambda r: r["id"]) == sorted(want, key=lambda r: r["id"])
+
+
+def test_depth_estimation_head(world):
+    sc, scene, rows, vis = world
+    random.seed(13)
+    got = heads.depth_estimation_records(scene, sc.scene_id, sc.color_hw, max_samples=5)
+    ids = O.valid_image_ids(sc.E)
+    random.seed(13)
+    draws = heads.depth_estimation_draws(ids, {k: len(vis["image_to_points"][k]) for k in ids}, 5, T.DEPTH_ESTIMATION)
+    want = []
+    for dr in draws:
+        for j, pick in zip(dr["positions"], dr["picks"]):
+            v = vis["image_to_points"][dr["image_id"]][j]
+            uv, d = O.point_2d_in_image(sc.points[v], sc.K, sc.A @ sc.E[dr["image_id"]], sc.depth[dr["image_id"]],
+                                        sc.color_hw)
+            want.append(heads.depth_estimation_record(sc.scene_id, dr["image_id"], v, uv[0], float(d[0]), pick,
+                                                      sc.color_hw))
+    assert got == want and len(got) == 5
+
+
+def test_object_movement_head():
+    tr = synth.make_tracks(21, T=18, P=30)
+    world = O.tracks_cam_to_world(tr.tracks_XYZ, tr.extrinsics_w2c)
+    rng = np.random.default_rng(2)
+    pairs = [{"frame1": int(a), "frame2": int(b), "point_index": int(p)}
+             for a, b, p in zip(rng.integers(0, 18, 40), rng.integers(0, 18, 40), rng.integers(0, 30, 40))]
+    H, W = tr.image_hw
+    for qt in T.OBJECT_MOVEMENT_TYPES:
+        random.seed(5)
+        got = heads.object_movement_records(tr.scene_id, tr.tracks_XYZ, tr.extrinsics_w2c, tr.fx_fy_cx_cy, tr.image_hw,
+                                            pairs, qt)
+        random.seed(5)
+        want = []
+        for s in pairs:
+            o = O.object_displacement(world, tr.tracks_XYZ, tr.extrinsics_w2c, tr.fx_fy_cx_cy, tr.image_hw,
+                                      s["frame1"], s["frame2"], s["point_index"])
+            if o is None:
+                continue
+            dist = np.linalg.norm(world[s["frame2"], s["point_index"]] - world[s["frame1"], s["point_index"]])
+            num = {"distance": float(dist) if o["point_moving"] else 0, "vector": o["gt_vector"],
+                   "point_moving": bool(o["point_moving"]), "cam_moving": bool(o["cam_moving"]),
+                   "p1n": O.project_point(tr.tracks_XYZ[s["frame1"], s["point_index"]], tr.fx_fy_cx_cy, H, W),
+                   "p2n": O.project_point(tr.tracks_XYZ[s["frame2"], s["point_index"]], tr.fx_fy_cx_cy, H, W)}
+            want.append(heads.object_movement_record(tr.scene_id, s["frame1"], s["frame2"], s["point_index"], qt, num,
+                                                     tr.image_hw))
+        assert len(got) == len(want) > 10
+        for g, w in zip(got, want):
+            if "vector" in qt:
+                gv, wv = g.pop("gt_value"), w.pop("gt_value")
+                assert same_f64(gv, wv) or close_f64(gv, wv, rtol=1e-12, scale=1e-9)
+            assert g == w
