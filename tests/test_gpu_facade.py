@@ -172,3 +172,66 @@ def test_visibility_info_handler_roundtrip(setup, tmp_path):
     assert vp.get_point_to_images_info(sid, 3) == ref["point_to_images"]["3"]
     with pytest.raises(ValueError):
         ns.IH.VisibilityInfoHandler(str(tmp_path / "vis.txt"))
+
+
+def test_head_wrappers(setup, tmp_path):
+    """Reference-signature record builders of the façade against the frozen reference answers."""
+    import random
+    ns, g, h, sid = setup
+    CME = importlib.import_module("spatial_engine.camera_movement.camera_movement_engine_train_val")
+    VC = importlib.import_module("spatial_engine.visual_correspondence.visual_correspondence_qa_engine_coor_2_coor")
+    keys = [tuple(str(x) for x in k) for k in g["cfr_pairs"]]
+    for n, ((id1, id2), vals, (yaw, pitch), ans) in enumerate(zip(keys, g["cfr_values"], g["cme_yaw_pitch"],
+                                                                 g["cme_answers_json"])):
+        row = {"scene_id": sid, "image_id1": id1, "image_id2": id2, "overlap": 20.0, "distance": float(vals[1]),
+               "yaw": float(yaw), "pitch": float(pitch)}
+        random.seed(1000 + n)                      # the seed oracle/gen_golden.py used for this row
+        rec = CME.build_training_sample(h, row, n, "total_distance")
+        ref = json.loads(str(ans))
+        dv_ref, dv = ref.pop("displacement_vector"), rec["answer_values"].pop("displacement_vector")
+        assert rec["answer_values"] == ref and f64_ok(dv, dv_ref)
+        assert rec["gt_value"] == ref["total_distance"] and rec["id"] == n and len(rec["image"]) == 2
+        assert rec["height_list"] == [g.color_hw[0]] * 2
+    # visual correspondence through the façade == record stage fed with the reference's frozen projections
+    from mspa import heads
+    from mspa import templates as T
+    mvi = g.json("mvi_json")
+    vis_dict = {sid: {"image_to_points": mvi["image_to_points"]}}
+    row = {"scene_id": sid, "image_id1": keys[0][0], "image_id2": keys[0][1]}
+    random.seed(4)
+    rec = VC.build_training_sample(h, row, 7, vis_dict, str(tmp_path / "w.txt"))
+    common = np.intersect1d(mvi["image_to_points"][keys[0][0]], mvi["image_to_points"][keys[0][1]])
+    random.seed(4)
+    draw = heads.visual_correspondence_draws([row], [len(common)], T.VISUAL_CORRESPONDENCE)[0]
+    if draw is None:
+        assert rec is None
+    else:
+        first, second = (row["image_id2"], row["image_id1"]) if draw["swap"] else (row["image_id1"], row["image_id2"])
+        v = int(common[draw["positions"][0]])
+        k1, k2 = g.valid_image_ids.index(first), g.valid_image_ids.index(second)
+        want = heads.visual_correspondence_record(row, 7, draw, g["ref_uv"][k1][[v]], g["ref_uv"][k2][[v]], g.color_hw)
+        assert rec == want
+    assert VC.build_training_sample(h, dict(row, scene_id="nope"), 0, vis_dict, str(tmp_path / "w.txt")) is None
+
+
+def test_object_movement_wrapper():
+    import random
+    facade()
+    OM = importlib.import_module("spatial_engine.object_movement.single_object_movement_engine_coord")
+    from golden_util import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, "tracks.npz"))
+    eng = OM.TwoFrameVideoQAEngine("tapvid3d_displacement_vector", "adt")
+    H, W = (int(v) for v in z["image_hw"])
+    pairs = [{"frame1": int(a), "frame2": int(b), "point_index": int(p)} for a, b, p in z["pairs"]]
+    recs = eng.format_training_samples(pairs, z["fx_fy_cx_cy"], "golden_tracks", z["ref_world"], z["tracks_XYZ"], H, W,
+                                       z["extrinsics_w2c"])
+    kept = [json.loads(str(r)) for r, k in zip(z["records_json"], z["kept"]) if k]
+    assert len(recs) == len(kept)
+    for r, ref in zip(recs, kept):
+        assert tuple(r["p1"]) == tuple(ref["p1"]) and tuple(r["p2"]) == tuple(ref["p2"])
+        assert r["point_moving"] == ref["point_moving"] and r["cam_moving"] == ref["cam_moving"]
+        assert f64_ok(r["gt_value"], ref["gt_value"])
+    assert eng.project_point(np.array([0.1, 0.2, -2.0]), z["fx_fy_cx_cy"], H, W) is None
+    p = eng.project_point(np.array([0.1, 0.2, 2.0]), z["fx_fy_cx_cy"], H, W)
+    fx, fy, cx, cy = z["fx_fy_cx_cy"]
+    assert same_f64(p, [((fx * 0.1 / (2.0 + 1e-8)) + cx) / W, ((fy * 0.2 / (2.0 + 1e-8)) + cy) / H])
