@@ -159,7 +159,7 @@ def time_variant(variant, mode, depth, mats, rgb, pairs, steps, warmup, dist_ctx
     return wall, kern_ms, outs[(state["n"] - 1) % n_buf]
 
 
-def time_scene_kernels(device, n_points=131072, n_frames=64, reps=5):
+def time_scene_kernels(device, n_points=131072, n_frames=320, reps=5):
     """K1 (vertex visibility) + K2 (all-pairs overlap) + K4 (pair pose) on one synthetic scene:
     the per-scene work of CFR.process_scene.  Informational legs with their own byte formulas
     (DESIGN.md section 4): K1 24*N + 2*DW*DH + N/8 per image, K2 2*N/8 + 8 per pair."""
@@ -176,19 +176,25 @@ def time_scene_kernels(device, n_points=131072, n_frames=64, reps=5):
     xyz = torch.from_numpy(np.ascontiguousarray(sc.points[:, :3])).to(device)
     F = len(Ea)
     pairs = engine.all_pairs(F, device)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    t1 = t2 = 0.0
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    yaw, pitch = engine.extract_yaw_pitch_host(Ea)
+    E_t = torch.from_numpy(np.stack(Ea).reshape(F, 16)).to(device)
+    yaw_t, pitch_t = torch.from_numpy(yaw).to(device), torch.from_numpy(pitch).to(device)
+    t1 = t2 = t3 = 0.0
     for r in range(reps + 1):
         ev[0].record()
         vis = engine.vertex_visibility(xyz, cam, depth, (H, W), ("bits", "count"))
         ev[1].record()
         ov = engine.pair_overlap(vis["bits"], pairs)
         ev[2].record()
+        pose = engine.pair_pose(E_t, cam[:, 0, :].contiguous(), yaw_t, pitch_t, pairs)
+        ev[3].record()
         torch.cuda.synchronize()
         if r:
             t1 += ev[0].elapsed_time(ev[1])
             t2 += ev[1].elapsed_time(ev[2])
-    t1, t2 = t1 / reps, t2 / reps
+            t3 += ev[2].elapsed_time(ev[3])
+    t1, t2, t3 = t1 / reps, t2 / reps, t3 / reps
     b1 = F * (24 * n_points + 2 * H * W + n_points // 8)
     b2 = pairs.shape[0] * (2 * n_points // 8 + 8)
     return {"K1_vertex_visibility": {"images": F, "vertices": n_points, "kernel_ms": round(t1, 4),
@@ -197,7 +203,10 @@ def time_scene_kernels(device, n_points=131072, n_frames=64, reps=5):
                                      "frac": round(b1 / (t1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "K2_pair_overlap": {"pairs": int(pairs.shape[0]), "kernel_ms": round(t2, 4),
                                 "pairs_per_s": round(pairs.shape[0] / (t2 * 1e-3), 1),
-                                "streaming_GBs": round(b2 / (t2 * 1e-3) / 1e9, 1)}}
+                                "streaming_GBs": round(b2 / (t2 * 1e-3) / 1e9, 1)},
+            "K4_pair_pose": {"pairs": int(pairs.shape[0]), "kernel_ms": round(t3, 4)},
+            "scene_total": {"frames": F, "vertices": n_points, "ms": round(t1 + t2 + t3, 4),
+                            "note": "CFR.process_scene for one ScanNet-sized scene (every-5th-frame average)"}}
 
 
 def cpu_baseline(sc, ids, pairs_np, nb, budget_s):
