@@ -67,13 +67,26 @@ def parse_args():
     return ap.parse_args()
 
 
-def build_inputs(args, rank, device):
-    """Render a few frames on the host, expand them on the device into `frames` distinct frames."""
-    import torch
-    from mspa import engine, synth
-
+def make_base_scene(args, rank):
+    """Host-only part of the inputs: the seeded synthetic scene and the step's pair list."""
+    from mspa import synth
     sc = synth.make_scene(1000 + rank, n_points=64, n_frames=args.base_frames, color_hw=(H, W),
                           depth_hw=(H, W), invalid_pose_frac=0.0, with_color=False)
+    nb = len(sc.valid_image_ids)
+    reps = max(1, args.frames // nb)
+    rng = np.random.default_rng(77 + rank)
+    rep = np.arange(args.pairs) % reps
+    b1 = rng.integers(0, nb, args.pairs)
+    b2 = (b1 + rng.integers(1, min(4, nb), args.pairs)) % nb
+    pairs_np = np.stack([rep * nb + b1, rep * nb + b2], axis=1).astype(np.int32)
+    return sc, pairs_np
+
+
+def build_inputs(args, rank, device, sc, pairs_np):
+    """Expand the host-rendered frames on the device into `frames` distinct frames."""
+    import torch
+    from mspa import engine
+
     ids = sc.valid_image_ids
     nb = len(ids)
     base_depth = np.stack([sc.depth[i] for i in ids])
@@ -92,14 +105,9 @@ def build_inputs(args, rank, device):
     rgb = None
     if VARIANTS[args.variant]["rgb"] or any(VARIANTS[v.split(":")[0]]["rgb"] for v in _legs(args.also)):
         rgb = torch.randint(0, 256, (n_frames, H, W, 3), generator=g, device=device, dtype=torch.uint8)
-    # pairs: two different views of the same replica, walking through all replicas
-    rng = np.random.default_rng(77 + rank)
-    rep = np.arange(args.pairs) % reps
-    b1 = rng.integers(0, nb, args.pairs)
-    b2 = (b1 + rng.integers(1, min(4, nb), args.pairs)) % nb
-    pairs_np = np.stack([rep * nb + b1, rep * nb + b2], axis=1).astype(np.int32)
+    # pairs: two different views of the same replica, walking through all replicas (make_base_scene)
     pairs = torch.from_numpy(pairs_np).to(device)
-    return sc, ids, depth, mats, rgb, pairs, pairs_np, nb
+    return ids, depth, mats, rgb, pairs, nb
 
 
 def time_variant(variant, mode, depth, mats, rgb, pairs, steps, warmup, dist_ctx):
@@ -209,25 +217,62 @@ def time_scene_kernels(device, n_points=131072, n_frames=320, reps=5):
                             "note": "CFR.process_scene for one ScanNet-sized scene (every-5th-frame average)"}}
 
 
-def cpu_baseline(sc, ids, pairs_np, nb, budget_s):
-    """Time the NumPy restatement of the reference path on a bounded sample of the same pairs."""
-    from oracle import np_oracle as O
+_CPU_SCENE = None
 
-    color = np.zeros((H, W, 3), dtype=np.uint8)
+
+def _cpu_pair(job):
+    """One frame pair through the NumPy restatement of the reference path (worker side)."""
+    from oracle import np_oracle as O
+    sc, ids, color = _CPU_SCENE
+    a, b = job
+    r = O.frame_pair(sc.depth[ids[a]], sc.depth[ids[b]], sc.K, sc.E[ids[a]], sc.E[ids[b]], sc.A, (H, W), color)
+    return r["n_vis"]
+
+
+def _cpu_worker_init():
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)                 # one BLAS thread per worker, as OMP_NUM_THREADS=1 would
+    except Exception:
+        pass
+
+
+def cpu_baseline(sc, pairs_np, budget_s):
+    """Time the NumPy restatement of the reference path (oracle/np_oracle.frame_pair) on a bounded sample
+    of the step's pairs: (i) one process, (ii) multiprocessing.Pool(min(25, cores)) -- the reference's own
+    worker count (CFR:280).  Runs BEFORE the GPU is initialised so that the pool can fork safely."""
+    global _CPU_SCENE
+    import multiprocessing as mp
+    ids = sc.valid_image_ids
+    nb = len(ids)
+    _CPU_SCENE = (sc, ids, np.zeros((H, W, 3), dtype=np.uint8))
+    jobs = [(int(p[0] % nb), int(p[1] % nb)) for p in pairs_np]
     n, t0 = 0, time.perf_counter()
-    checks = []
     while True:
-        f1, f2 = ids[pairs_np[n, 0] % nb], ids[pairs_np[n, 1] % nb]
-        r = O.frame_pair(sc.depth[f1], sc.depth[f2], sc.K, sc.E[f1], sc.E[f2], sc.A, (H, W), color)
-        checks.append((int(pairs_np[n, 0] % nb), int(pairs_np[n, 1] % nb), r["n_valid"], r["n_vis"]))
+        _cpu_pair(jobs[n])
         n += 1
         el = time.perf_counter() - t0
-        if (el > budget_s and n >= 8) or n >= len(pairs_np):
+        if (el > budget_s / 2 and n >= 8) or n >= len(jobs):
             break
-    return {"value": round(n / el, 3), "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+    single = n / el
+    workers = min(25, os.cpu_count() or 1)
+    pool_jobs = jobs[:max(workers * 4, int(single * workers * budget_s / 2))][:len(jobs)]
+    pool_rate = None
+    try:
+        with mp.get_context("fork").Pool(workers, initializer=_cpu_worker_init) as pool:
+            pool.map(_cpu_pair, pool_jobs[:workers])                       # warm the workers
+            t1 = time.perf_counter()
+            pool.map(_cpu_pair, pool_jobs, chunksize=max(1, len(pool_jobs) // (workers * 4)))
+            pool_rate = len(pool_jobs) / (time.perf_counter() - t1)
+    except Exception as e:                                                  # no fork / no /dev/shm: report single only
+        print(f"[bench] pool baseline skipped: {e}", file=sys.stderr)
+    return {"value": round(single, 3), "unit": "frame-pairs/s", "cores": 1, "kind": "port",
             "sample": f"{n} of the step's 640x480 pairs through oracle/np_oracle.frame_pair "
                       f"(NumPy {np.__version__}, 1 process, in-memory images) in {el:.1f} s",
-            "host_cores_available": os.cpu_count()}, checks
+            "pool": None if pool_rate is None else {
+                "value": round(pool_rate, 2), "cores": workers,
+                "sample": f"{len(pool_jobs)} pairs over multiprocessing.Pool({workers}), 1 BLAS thread each"},
+            "host_cores_available": os.cpu_count()}
 
 
 def main():
@@ -242,6 +287,10 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    sc, pairs_np = make_base_scene(args, rank)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(sc, pairs_np, args.cpu_seconds)     # before any GPU initialisation (fork-safe)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -250,7 +299,7 @@ def main():
     # MSPA_BENCH_FORCE_DIST=1 exercises the RCCL collation path with a single rank (1-GPU boxes)
     dist_ctx = shard.init_distributed(device) if (world > 1 or os.environ.get("MSPA_BENCH_FORCE_DIST")) else None
 
-    sc, ids, depth, mats, rgb, pairs, pairs_np, nb = build_inputs(args, rank, device)
+    ids, depth, mats, rgb, pairs, nb = build_inputs(args, rank, device, sc, pairs_np)
     wall, kern_ms, out = time_variant(args.variant, args.mode, depth, mats, rgb, pairs, args.steps, args.warmup,
                                       dist_ctx)
     if dist_ctx is not None:
@@ -275,10 +324,8 @@ def main():
             extra["scene"] = time_scene_kernels(device)
 
     if rank == 0:
-        cpu, traffic = None, None
+        traffic = None
         counts = out["counts"].cpu().numpy()
-        if world == 1 and not args.no_cpu_baseline:
-            cpu, checks = cpu_baseline(sc, ids, pairs_np, nb, args.cpu_seconds)
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             t = json.load(open(tfile))
