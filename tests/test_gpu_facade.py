@@ -235,3 +235,57 @@ def test_object_movement_wrapper():
     p = eng.project_point(np.array([0.1, 0.2, 2.0]), z["fx_fy_cx_cy"], H, W)
     fx, fy, cx, cy = z["fx_fy_cx_cy"]
     assert same_f64(p, [((fx * 0.1 / (2.0 + 1e-8)) + cx) / W, ((fy * 0.2 / (2.0 + 1e-8)) + cy) / H])
+
+
+def test_object_visibility(setup):
+    """compute_object_visibility.process_scene: masked popcount on the GPU == Python set intersections."""
+    ns, g, h, sid = setup
+    COV = importlib.import_module("spatial_engine.object_perception.compute_object_visibility")
+    mvi = g.json("mvi_json")
+    n = g.points.shape[0]
+    rng = np.random.default_rng(1)
+    inst = rng.integers(0, 6, n)                      # 0 = unlabelled, objects 0..4 -> mask values 1..5
+    inst[rng.random(n) < 0.3] = 0
+    np.save(os.path.join(h.instance_data_root, sid, "instance_mask.npy"), inst)
+    h.infos[sid]["num_objects"] = 6                    # object 5 has no points, object 1 is a wall
+    for o in range(6):
+        h.infos[sid][o] = {"raw_category": "wall" if o == 1 else f"thing{o}"}
+    vis_dict = {f"{sid}:image_to_points:{k}": json.dumps(v) for k, v in mvi["image_to_points"].items()}
+    missing = g.valid_image_ids[-1]
+    del vis_dict[f"{sid}:image_to_points:{missing}"]
+    s, result, warnings = COV.process_scene(sid, h, vis_dict)
+    # straightforward restatement of the reference loop (COVIS:103-150) with Python sets
+    want = {"object_to_images": {}, "image_to_objects": {}}
+    for o in range(6):
+        if o == 1:
+            continue
+        pts = set(np.where(inst == o + 1)[0].tolist())
+        if not pts:
+            continue
+        thr = max(1, int(0.05 * len(pts)))
+        for image_id in g.valid_image_ids:
+            if image_id == missing:
+                continue
+            c = len(set(mvi["image_to_points"][image_id]) & pts)
+            if c >= thr:
+                v = (c / len(pts)) * 100.0
+                want["object_to_images"].setdefault(o, []).append({"image_id": image_id, "intersection_count": c, "visibility": v})
+                want["image_to_objects"].setdefault(image_id, []).append({"object_id": o, "intersection_count": c, "visibility": v})
+    assert s == sid and result == want and len(result["object_to_images"]) >= 3
+    assert any("has no point indices" in w for w in warnings) and any("not found in visibility dict" in w for w in warnings)
+    # resident form straight from K1's bitsets
+    scene = h.scene_on_device(sid)
+    res2 = scene.object_visibility({o: np.where(inst == o + 1)[0] for o in range(5) if o != 1})
+    full = {"object_to_images": {}, "image_to_objects": {}}
+    for o in range(5):
+        if o == 1:
+            continue
+        pts = set(np.where(inst == o + 1)[0].tolist())
+        thr = max(1, int(0.05 * len(pts)))
+        for image_id in g.valid_image_ids:
+            c = len(set(mvi["image_to_points"][image_id]) & pts)
+            if c >= thr:
+                v = (c / len(pts)) * 100.0
+                full["object_to_images"].setdefault(o, []).append({"image_id": image_id, "intersection_count": c, "visibility": v})
+                full["image_to_objects"].setdefault(image_id, []).append({"object_id": o, "intersection_count": c, "visibility": v})
+    assert res2 == full
