@@ -25,15 +25,21 @@ class DistContext:
     device: torch.device
     group: object = None
     owns_process_group: bool = False
+    backend: str = "nccl"
+
+    @property
+    def collective_device(self) -> torch.device:
+        """Where collectives run: the GPU for RCCL, host memory for gloo (CPU tests, 1-GPU boxes)."""
+        return self.device if self.backend == "nccl" else torch.device("cpu")
 
     def barrier(self):
-        if self.device.type == "cuda":
+        if self.device.type == "cuda" and self.backend == "nccl":
             dist.barrier(group=self.group, device_ids=[self.device.index])
         else:
             dist.barrier(group=self.group)
 
     def max_over_ranks(self, x: float) -> float:
-        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        t = torch.tensor([x], dtype=torch.float64, device=self.collective_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
@@ -49,11 +55,11 @@ def init_distributed(device: torch.device, backend: str = None, timeout_s: int =
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kwargs = {}
-        if device.type == "cuda":
+        if device.type == "cuda" and backend == "nccl":
             kwargs["device_id"] = device
         dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
         owns = True
-    return DistContext(dist.get_rank(), dist.get_world_size(), device, None, owns)
+    return DistContext(dist.get_rank(), dist.get_world_size(), device, None, owns, dist.get_backend())
 
 
 def partition(n_items: int, world: int, rank: int) -> Tuple[int, int]:
@@ -99,6 +105,8 @@ def collate_records(local: torch.Tensor, ctx: DistContext) -> torch.Tensor:
     Two collectives: counts (one int64 per rank), then the records padded to the largest count.
     Returns the concatenation in rank order, identical on every rank."""
     assert local.dim() == 2
+    if local.device != ctx.collective_device:
+        local = local.to(ctx.collective_device)
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     counts = [torch.zeros_like(n_local) for _ in range(ctx.world)]
     dist.all_gather(counts, n_local, group=ctx.group)

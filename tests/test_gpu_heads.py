@@ -161,3 +161,63 @@ def test_object_movement_head():
                 gv, wv = g.pop("gt_value"), w.pop("gt_value")
                 assert same_f64(gv, wv) or close_f64(gv, wv, rtol=1e-12, scale=1e-9)
             assert g == w
+
+
+# ------------------------------------------------------------------------------------------
+# end-to-end pipeline, and its invariance to sharding (2 ranks on one GPU, gloo for the collation)
+# ------------------------------------------------------------------------------------------
+def _pipeline_scenes():
+    return [synth.make_scene(7100 + k, n_points=4000, n_frames=8 + 2 * k, color_hw=(96, 128), depth_hw=(96, 128),
+                             invalid_pose_frac=0.1, with_color=False) for k in range(3)]
+
+
+def _pipeline_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "multi-spatialmllm_amd"), root):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch as th
+    from mspa import pipeline, shard as S
+    th.cuda.set_device(0)
+    ctx = S.init_distributed(th.device("cuda", 0), backend="gloo")
+    pipeline.run(_pipeline_scenes(), out_dir, ctx, th.device("cuda", 0), seed=3, n_camera=24, n_correspondence=24,
+                 depth_images_per_scene=3)
+    ctx.barrier()
+    ctx.close()
+
+
+def test_pipeline_end_to_end_and_sharding_invariance(tmp_path):
+    import json
+    import socket
+    import torch.multiprocessing as mp
+    from mspa import pipeline
+    single = str(tmp_path / "single")
+    counts = pipeline.run(_pipeline_scenes(), single, None, DEV, seed=3, n_camera=24, n_correspondence=24,
+                          depth_images_per_scene=3)
+    assert set(counts) == {"camera_movement_total_distance", "camera_movement_displacement_vector",
+                           "visual_correspondence_coor_2_coor", "depth_estimation_coor"}
+    assert counts["depth_estimation_coor"] == 9 and counts["camera_movement_total_distance"] > 0
+    for name in counts:
+        recs = [json.loads(ln) for ln in open(f"{single}/{name}.jsonl")]
+        assert len(recs) == counts[name]
+        for r in recs:      # InternVL multi-image chat schema
+            assert {"id", "image", "conversations", "height_list", "width_list", "question_type", "gt_value"} <= set(r)
+            assert r["conversations"][0]["from"] == "human" and r["conversations"][1]["from"] == "gpt"
+            assert len(r["image"]) == len(r["height_list"]) == len(r["width_list"])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    sharded = str(tmp_path / "sharded")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, sharded)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for name in counts:
+        assert open(f"{single}/{name}.jsonl").read() == open(f"{sharded}/{name}.jsonl").read(), name
