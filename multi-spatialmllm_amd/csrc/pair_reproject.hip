@@ -738,6 +738,71 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
         unsigned long long risky_rows = 0;           // wave-uniform: rows with at least one guarded lane
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's depth-1 samples have landed in LDS
 
+        // ---- tile-level culling -------------------------------------------------------------------
+        // The tile's pixels with depths in [dlo, dhi] span a frustum {d*(mx, my, 1)}, the convex hull of 8
+        // corner points; the composed map is affine in (mx*d, my*d, d) and "in view" (z > 0, 0 <= x < W*z,
+        // 0 <= y < H*z in homogeneous image coordinates) is an intersection of half-spaces.  If all 8
+        // projected corners violate ONE of those half-spaces by a margin (>= 1e-4 px, 7 orders above the
+        // rounding differences between evaluation orders), no pixel of the tile can land in frame 2:
+        // the wave writes "nothing visible" for 48 x 64 pixels without projecting any of them.
+        bool culled = false;
+        if (!WANT_XYZ && !O::template has<O_VALID_U8>(a.valid_u8) && !O::template has<O_RGBA>(a.rgba) &&
+            !O::template has<O_VIS_U8>(a.vis_u8)) {
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            const us2 *wds = reinterpret_cast<const us2 *>(&lds_d1[wave][0]);
+            us2 mn = {0xFFFF, 0xFFFF}, mxv = {0, 0};
+            const us2 one = {1, 1};
+#pragma unroll
+            for (int k = 0; k < kTightRows / 2; ++k) {
+                const us2 x = wds[c.lane + 64 * k];
+                mn = __builtin_elementwise_min(mn, (us2)(x - one));      // 0 (invalid) wraps to 0xFFFF
+                mxv = __builtin_elementwise_max(mxv, x);
+            }
+            int lo = min((int)mn.x, (int)mn.y), hi = max((int)mxv.x, (int)mxv.y);
+            for (int off = 32; off > 0; off >>= 1) {
+                lo = min(lo, __shfl_xor(lo, off));
+                hi = max(hi, __shfl_xor(hi, off));
+            }
+            if (hi == 0) {
+                culled = true;                                            // no valid depth sample at all
+            } else {
+                const int k = c.lane & 7;
+                const double cx = (double)(stripe * 64u + ((k & 1) ? 63u : 0u));
+                const double cy = (double)(row0 + ((k & 2) ? (uint32_t)(kTightRows - 1) : 0u));
+                const double cd = (double)((k & 4) ? hi : lo + 1);
+                const double hx = __builtin_fma(__builtin_fma(M[0][1], cy, __builtin_fma(M[0][0], cx, M[0][2])), cd, M[0][3]);
+                const double hy = __builtin_fma(__builtin_fma(M[1][1], cy, __builtin_fma(M[1][0], cx, M[1][2])), cd, M[1][3]);
+                const double hz = __builtin_fma(__builtin_fma(M[2][1], cy, __builtin_fma(M[2][0], cx, M[2][2])), cd, M[2][3]);
+                const double kMargin = 1e-3;                              // homogeneous units (pixel * metre)
+                const bool all_behind = __ballot(hz <= -1e-6) == ~0ull;
+                const bool all_left = __ballot(hx < -kMargin) == ~0ull;
+                const bool all_right = __ballot(hx - (double)a.W * hz > kMargin) == ~0ull;
+                const bool all_above = __ballot(hy < -kMargin) == ~0ull;
+                const bool all_below = __ballot(hy - (double)a.H * hz > kMargin) == ~0ull;
+                culled = all_behind | all_left | all_right | all_above | all_below;
+            }
+            if (culled) {
+                us2 nz = {0, 0};
+#pragma unroll
+                for (int k = 0; k < kTightRows / 2; ++k) nz += __builtin_elementwise_min(wds[c.lane + 64 * k], one);
+                int cnt = (int)nz.x + (int)nz.y;
+                for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+                n_valid = cnt;
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 none = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll 4
+                for (int r0 = 0; r0 < kTightRows; r0 += kRowGroup) {
+                    const uint32_t rowg = row0 + (uint32_t)r0;
+                    if (O::template has<O_VIS_BITS>(a.vis_bits) && c.lane < kRowGroup)
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rs_bits, bits_voff,
+                                                              (int)((rowg * wpr + stripe) * 8u), 0);
+                    if (O::template has<O_PIX>(a.pix_i16))
+                        __builtin_amdgcn_raw_buffer_store_b128(none, rs_pix, pix_voff, (int)(rowg * Wb * 4u), 0);
+                }
+            }
+        }
+
+        if (!culled)
 #pragma unroll 1
         for (int r0 = 0; r0 < kTightRows; r0 += kRowGroup) {
             uint32_t d16[kRowGroup];
