@@ -60,6 +60,8 @@ def parse_args():
                     help="fast: MSPA_PAIR_FAST (bit-exact integers via guarded composed matrices); exact: the "
                          "reference's own operation order")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--pair-offsets", default="1,2,3", help="frame-index distances the pairs are drawn from "
+                    "(neighbouring views of the camera walk; larger = less of frame 1 lands in frame 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scene-legs", action="store_true", help="skip the K1/K2 informational legs")
     ap.add_argument("--also", default="corr:exact,dense:fast,dense:exact,minimal:fast",
@@ -77,7 +79,8 @@ def make_base_scene(args, rank):
     rng = np.random.default_rng(77 + rank)
     rep = np.arange(args.pairs) % reps
     b1 = rng.integers(0, nb, args.pairs)
-    b2 = (b1 + rng.integers(1, min(4, nb), args.pairs)) % nb
+    offs = np.array([int(v) for v in args.pair_offsets.split(",")])
+    b2 = (b1 + offs[rng.integers(0, len(offs), args.pairs)]) % nb
     pairs_np = np.stack([rep * nb + b1, rep * nb + b2], axis=1).astype(np.int32)
     return sc, pairs_np
 
@@ -341,7 +344,7 @@ def main():
             "config": {"workload": "visual_correspondence unproject+reproject+occlusion kernel (K3) on "
                                    f"{args.pairs} 640x480 frame pairs per GPU per step (BASELINE.json configs[1])",
                        "variant": args.variant, "mode": args.mode, "outputs": list(spec["outputs"]),
-                       "pairs_per_step_per_gpu": args.pairs, "distinct_frames_per_gpu": int(depth.shape[0]),
+                       "pairs_per_step_per_gpu": args.pairs, "pair_offsets": args.pair_offsets, "distinct_frames_per_gpu": int(depth.shape[0]),
                        "image": "640x480 depth u16 (+rgb u8x3 for dense)", "parallelism": f"dp{world}",
                        "collation": "RCCL all_gather of per-pair records per step, overlapped with the next step" if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
