@@ -81,7 +81,9 @@ def make_base_scene(args, rank):
     b1 = rng.integers(0, nb, args.pairs)
     offs = np.array([int(v) for v in args.pair_offsets.split(",")])
     b2 = (b1 + offs[rng.integers(0, len(offs), args.pairs)]) % nb
-    pairs_np = np.stack([rep * nb + b1, rep * nb + b2], axis=1).astype(np.int32)
+    # offset 0 = the same pose seen in the next replica (independent depth noise): every pixel lands in view
+    rep2 = np.where(b2 == b1, (rep + 1) % reps, rep)
+    pairs_np = np.stack([rep * nb + b1, rep2 * nb + b2], axis=1).astype(np.int32)
     return sc, pairs_np
 
 
