@@ -62,6 +62,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--pair-offsets", default="1,2,3", help="frame-index distances the pairs are drawn from "
                     "(neighbouring views of the camera walk; larger = less of frame 1 lands in frame 2)")
+    ap.add_argument("--walk-step", type=float, default=0.15, help="camera random-walk step (m) of the synthetic scene")
+    ap.add_argument("--target-jitter", type=float, default=0.8, help="look-at jitter (m) of the synthetic scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scene-legs", action="store_true", help="skip the K1/K2 informational legs")
     ap.add_argument("--also", default="corr:exact,dense:fast,dense:exact,minimal:fast",
@@ -73,7 +75,8 @@ def make_base_scene(args, rank):
     """Host-only part of the inputs: the seeded synthetic scene and the step's pair list."""
     from mspa import synth
     sc = synth.make_scene(1000 + rank, n_points=64, n_frames=args.base_frames, color_hw=(H, W),
-                          depth_hw=(H, W), invalid_pose_frac=0.0, with_color=False)
+                          depth_hw=(H, W), invalid_pose_frac=0.0, with_color=False, walk_step=args.walk_step,
+                          target_jitter=args.target_jitter)
     nb = len(sc.valid_image_ids)
     reps = max(1, args.frames // nb)
     rng = np.random.default_rng(77 + rank)

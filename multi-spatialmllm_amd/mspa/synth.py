@@ -148,7 +148,8 @@ def render_depth(E_aligned, Kd, depth_hw, boxes):
 def make_scene(seed: int, n_points: int = 131072, n_frames: int = 64,
                color_hw: Tuple[int, int] = (480, 640), depth_hw: Tuple[int, int] = (480, 640),
                invalid_pose_frac: float = 0.02, zero_frac: float = 0.07, noise_mm: float = 5.0,
-               frame_step: int = 5, with_color: bool = True, scene_id: Optional[str] = None) -> SynthScene:
+               frame_step: int = 5, with_color: bool = True, scene_id: Optional[str] = None,
+               walk_step: float = 0.15, target_jitter: float = 0.8) -> SynthScene:
     rng = np.random.default_rng(np.random.PCG64(seed))
     boxes = _make_boxes(rng)
     K = intrinsics_for(color_hw)
@@ -175,13 +176,13 @@ def make_scene(seed: int, n_points: int = 131072, n_frames: int = 64,
     bad = set(rng.choice(np.arange(1, n_frames), size=n_bad, replace=False).tolist()) if n_bad else set()
     for f in range(n_frames):
         image_id = f"{f * frame_step:05d}"
-        eye = np.clip(eye + rng.normal(0, 0.15, 3) * [1, 1, 0.2], [0.6, 0.6, 1.2], [5.4, 5.4, 1.9])
+        eye = np.clip(eye + rng.normal(0, walk_step, 3) * [1, 1, 0.2], [0.6, 0.6, 1.2], [5.4, 5.4, 1.9])
         for _ in range(8):   # keep the camera out of the boxes
             inside = [(eye > b[0] - 0.1).all() and (eye < b[1] + 0.1).all() for b in boxes]
             if not any(inside):
                 break
             eye = np.array([rng.uniform(0.6, 5.4), rng.uniform(0.6, 5.4), 1.9])
-        target = ROOM / 2 + rng.normal(0, 0.8, 3) * [1, 1, 0.4]
+        target = ROOM / 2 + rng.normal(0, target_jitter, 3) * [1, 1, 0.4]
         E_al = _look_at(eye, target)
         E_f = _roundtrip_f(A_inv @ E_al)
         E_al = A @ E_f
