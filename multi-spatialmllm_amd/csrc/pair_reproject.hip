@@ -1,23 +1,24 @@
 // K3: frame-pair back-projection -> reprojection -> depth-buffer visibility (see include/mspa.h).
 //
-// Mapping.  A workgroup of 256 threads (4 waves) owns a strip of kIters*256 consecutive pixels of
-// ONE pair; lanes take consecutive pixels, so every depth/colour read and every output write is a
-// contiguous run per wave.  Blocks of one pair are numbered so that they land on one XCD (the
+// Common to all three kernels.  Blocks of one pair are numbered so that they land on one XCD (the
 // hardware dispatches block b to XCD b % 8): the frame-2 depth image the pair gathers from (600 KB)
 // then stays in that XCD's 4 MB L2.  Camera matrices are read through wave-uniform addresses, i.e.
 // as scalar loads into SGPRs -- the one operand v_fma_f64 takes for free -- while the per-pixel
-// chain lives in VGPRs.  No MFMA: this is point geometry, bound by HBM and the FP64 VALU.
+// chain lives in VGPRs.  No MFMA: this is point geometry, bound by HBM and VALU issue.
 //
-// Two kernels behind one entry point:
+// Three kernels behind one entry point:
 //   * pair_exact_kernel -- the reference's own operation order (five sequential 3x4 products, IEEE
-//     division).  Float64 outputs are bit-identical to the C oracle.  ~100 FP64 VALU ops / pixel,
-//     so it is FP64-issue bound, not HBM bound.
-//   * pair_fast_kernel (MSPA_PAIR_FAST) -- one composed 3x4 product + reciprocal (~35 ops/pixel).
-//     Every lane whose integer decisions (half-to-even rounding of the pixel index, the image
-//     bounds, the strict depth comparison) sit within a guard band of a decision boundary is
-//     re-evaluated with the exact chain, so masks, pixel indices and counters stay bit-exact; the
-//     guard (1e-6 px / 1e-9 m) is ~5 orders of magnitude wider than the worst rounding
-//     difference between the two evaluation orders ("Fast path").
+//     division); a workgroup owns a strip of 4096 consecutive pixels, lanes take consecutive pixels.
+//     Float64 outputs are bit-identical to the C oracle.  ~100 FP64 VALU ops / pixel: issue bound.
+//   * pair_fast_kernel (MSPA_PAIR_FAST, any image shape) -- one composed 3x4 product + reciprocal;
+//     lane <-> image column, a wave walks down a 64 x 16 tile.  Every lane whose integer decisions
+//     (half-to-even rounding of the pixel index, the image bounds, the strict depth comparison) sit
+//     within a guard band of a decision boundary is re-evaluated with the exact chain, so masks, pixel
+//     indices and counters stay bit-exact; the guard (1e-6 px / 1e-9 m) is ~5 orders of magnitude wider
+//     than the worst rounding difference between the two evaluation orders.
+//   * pair_fast_tight_kernel (MSPA_PAIR_FAST, whole-tile images such as 640x480) -- the benchmarked
+//     one: same arithmetic, plus LDS-DMA depth tiles, tile- and group-level culling, buffer-resource
+//     addressing and 16-byte stores (see the comment above it).
 #include "mspa_common.h"
 
 namespace mspa {
