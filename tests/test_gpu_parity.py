@@ -464,3 +464,76 @@ def test_track_geometry_golden():
         p1 = (round(uvn[f1, p, 0] * 1000), round(uvn[f1, p, 1] * 1000))       # OM_C:364-365
         p2 = (round(uvn[f2, p, 0] * 1000), round(uvn[f2, p, 1] * 1000))
         assert p1 == tuple(ref["p1"]) and p2 == tuple(ref["p2"])
+
+
+# ------------------------------------------------------------------------------------------
+# fast == exact on adversarially varied geometry (culling, early-out, guard, cold loop)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("hw", [(96, 128), (48, 64), (61, 83)], ids=["tight96x128", "tight48x64", "ragged61x83"])
+def test_fast_equals_exact_random_poses(hw):
+    """300 random camera pairs per shape -- looking away, nearly coincident, grazing, very close, with
+    pure translations that produce exact half-pixel ties -- must give bit-identical integer outputs from
+    the fast kernels (tile culling, group early-out, guard band, cold loop) and the exact kernel."""
+    H, W = hw
+    rng = np.random.default_rng(H * 1000 + W)
+    n_frames = 40
+    K = np.eye(4)
+    K[0, 0] = K[1, 1] = 64.0 if H == 48 else float(rng.uniform(0.6, 1.4) * W)
+    K[0, 2], K[1, 2] = W / 2.0, H / 2.0
+    A = np.eye(4)
+    A[:3, 3] = [0.5, -0.25, 0.125]
+    E_list, depth = [], []
+    for f in range(n_frames):
+        kind = f % 5
+        if kind == 0:                                   # generic look-at
+            eye, tgt = rng.uniform(-2, 2, 3), rng.uniform(-1, 1, 3) + [0, 0, 4]
+        elif kind == 1:                                 # looking the other way: everything behind / outside
+            eye, tgt = rng.uniform(-1, 1, 3), rng.uniform(-1, 1, 3) - [0, 0, 4]
+        elif kind == 2:                                 # nearly coincident with frame 0
+            eye, tgt = np.array([0.0, 0.0, 0.0]) + rng.normal(0, 1e-3, 3), np.array([0.0, 0.0, 4.0])
+        elif kind == 3:                                 # pure dyadic translation of frame 0: exact ties
+            eye, tgt = np.array([1 / 64.0, -1 / 32.0, 0.0]), np.array([1 / 64.0, -1 / 32.0, 4.0])
+        else:                                           # sideways / grazing
+            eye, tgt = rng.uniform(-3, 3, 3), rng.uniform(-3, 3, 3)
+        if f == 0:
+            eye, tgt = np.zeros(3), np.array([0.0, 0.0, 4.0])
+        E = synth._look_at(np.asarray(eye, float), np.asarray(tgt, float))
+        if kind != 3 and f != 0:
+            E = synth._roundtrip_f(E)
+        E_list.append(np.linalg.inv(A) @ E)
+        base = rng.choice([1000, 2000, 4000]) if kind in (0, 3) or f == 0 else int(rng.integers(300, 6000))
+        d = base + (rng.integers(-40, 41, (H, W)) if kind != 3 and f != 0 else 0) + \
+            (np.add.outer(np.arange(H), np.arange(W)) // 7 * int(rng.integers(0, 30)) if kind == 4 else 0)
+        d = np.clip(d, 1, 65535).astype(np.uint16)
+        d[rng.random((H, W)) < 0.05] = 0
+        if f % 7 == 6:
+            d[:] = 0                                    # a frame without any valid depth
+        depth.append(d)
+    pairs_np = rng.integers(0, n_frames, (300, 2)).astype(np.int32)
+    pairs_np[:n_frames, 0] = 0                          # frame 0 against every frame, and back
+    pairs_np[:n_frames, 1] = np.arange(n_frames)
+    pairs_np[n_frames:2 * n_frames, 0] = np.arange(n_frames)
+    pairs_np[n_frames:2 * n_frames, 1] = 0
+    dep = engine.depth_to_device(np.stack(depth), DEV)
+    mats = torch.from_numpy(engine.frame_matrices(K, A, E_list)).to(DEV)
+    pairs = torch.from_numpy(pairs_np).to(DEV)
+    outs = ("vis_bits", "pix_i16", "counts")
+    ex = engine.alloc_pair_outputs(len(pairs_np), hw, outs, DEV)
+    fa = engine.alloc_pair_outputs(len(pairs_np), hw, outs, DEV)
+    engine.pair_reproject(dep, mats, pairs, hw, ex)
+    engine.pair_reproject(dep, mats, pairs, hw, fa, flags=_lib.PAIR_FAST)
+    mn = engine.alloc_pair_outputs(len(pairs_np), hw, ("vis_bits", "counts"), DEV)
+    engine.pair_reproject(dep, mats, pairs, hw, mn, flags=_lib.PAIR_FAST)
+    torch.cuda.synchronize()
+    for k in outs:
+        bad = (ex[k] != fa[k]).reshape(len(pairs_np), -1).any(dim=1).nonzero().flatten().tolist()
+        assert not bad, f"{k}: fast != exact for pairs {[(int(pairs_np[b, 0]), int(pairs_np[b, 1])) for b in bad[:8]]}"
+    assert torch.equal(mn["vis_bits"], ex["vis_bits"]) and torch.equal(mn["counts"], ex["counts"])
+    counts = ex["counts"].cpu().numpy()
+    assert (counts[:, 1] > 0).sum() > 20 and (counts[:, 1] == 0).sum() > 20      # both regimes exercised
+    # anchor the exact kernel itself on a few pairs
+    for p in (1, n_frames + 3, 150, 299):
+        a, b = pairs_np[p]
+        ref = C.frame_pair(depth[a], depth[b], K, E_list[a], E_list[b], A, hw)
+        assert tuple(counts[p]) == (ref["n_valid"], ref["n_vis"])
+        assert np.array_equal(unpack_bits(ex["vis_bits"][p].cpu().numpy(), H * W), ref["vis"])
