@@ -477,6 +477,17 @@ def test_fast_equals_exact_random_poses(hw):
     H, W = hw
     rng = np.random.default_rng(H * 1000 + W)
     n_frames = 40
+
+    def look_at(eye, tgt):
+        fwd = tgt - eye
+        fwd = fwd / np.linalg.norm(fwd)
+        helper = np.array([0.0, 1.0, 0.0]) if abs(fwd[1]) < 0.9 else np.array([1.0, 0.0, 0.0])
+        right = np.cross(helper, fwd)
+        right /= np.linalg.norm(right)
+        E = np.eye(4)
+        E[:3, 0], E[:3, 1], E[:3, 2], E[:3, 3] = right, np.cross(fwd, right), fwd, eye
+        return E
+
     K = np.eye(4)
     K[0, 0] = K[1, 1] = 64.0 if H == 48 else float(rng.uniform(0.6, 1.4) * W)
     K[0, 2], K[1, 2] = W / 2.0, H / 2.0
@@ -497,13 +508,16 @@ def test_fast_equals_exact_random_poses(hw):
             eye, tgt = rng.uniform(-3, 3, 3), rng.uniform(-3, 3, 3)
         if f == 0:
             eye, tgt = np.zeros(3), np.array([0.0, 0.0, 4.0])
-        E = synth._look_at(np.asarray(eye, float), np.asarray(tgt, float))
+        E = look_at(np.asarray(eye, float), np.asarray(tgt, float))
         if kind != 3 and f != 0:
             E = synth._roundtrip_f(E)
         E_list.append(np.linalg.inv(A) @ E)
         base = rng.choice([1000, 2000, 4000]) if kind in (0, 3) or f == 0 else int(rng.integers(300, 6000))
-        d = base + (rng.integers(-40, 41, (H, W)) if kind != 3 and f != 0 else 0) + \
-            (np.add.outer(np.arange(H), np.arange(W)) // 7 * int(rng.integers(0, 30)) if kind == 4 else 0)
+        d = np.full((H, W), base, dtype=np.int64)
+        if kind != 3 and f != 0:
+            d = d + rng.integers(-40, 41, (H, W))
+        if kind == 4:
+            d = d + np.add.outer(np.arange(H), np.arange(W)) // 7 * int(rng.integers(0, 30))
         d = np.clip(d, 1, 65535).astype(np.uint16)
         d[rng.random((H, W)) < 0.05] = 0
         if f % 7 == 6:
