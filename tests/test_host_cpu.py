@@ -36,6 +36,32 @@ def test_error_reporting_without_gpu_calls():
         _lib.check(rc)
 
 
+def test_missing_library_fails_loudly():
+    """No libmspa.so -> ImportError naming the build command; never a silent CPU path."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from mspa import _lib\n"
+            "try:\n    _lib.load()\nexcept ImportError as e:\n    print('IMPORTERROR', 'no CPU fallback' in str(e)); sys.exit(0)\n"
+            "print('LOADED'); sys.exit(1)\n") % os.path.join(ROOT, "multi-spatialmllm_amd")
+    env = dict(os.environ, MSPA_LIB="/nonexistent/libmspa.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "IMPORTERROR True" in out.stdout, out.stdout + out.stderr
+
+
+def test_size_limits_are_rejected():
+    lib = _lib.load()
+    dummy = ctypes.c_void_p(64)       # never dereferenced: validation comes first
+    # width beyond int16 pixel indices; H*W*W >= 2^32
+    for (dh, dw, H, W) in ((480, 640, 480, 40000), (480, 640, 2000, 2000), (1, 640, 480, 640)):
+        rc = lib.mspa_pair_reproject(dummy, None, dummy, 1, dummy, 1, dh, dw, H, W, *([None] * 10), 0, None)
+        assert rc == _lib.MSPA_EINVAL, (dh, dw, H, W)
+    rc = lib.mspa_vertex_visibility(dummy, 10, 3, 1, dummy, 1, dummy, 480, 640, 480, 70000, *([None] * 5), None)
+    assert rc == _lib.MSPA_EINVAL
+    rc = lib.mspa_pair_overlap(dummy, 2, 1 << 26, dummy, 1, dummy, None, None, None)
+    assert rc == _lib.MSPA_EINVAL and b"too long" in lib.mspa_last_error_string()
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_engine_refuses_to_run_without_gpu():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
