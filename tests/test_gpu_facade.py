@@ -289,3 +289,41 @@ def test_object_visibility(setup):
                 full["object_to_images"].setdefault(o, []).append({"image_id": image_id, "intersection_count": c, "visibility": v})
                 full["image_to_objects"].setdefault(image_id, []).append({"object_id": o, "intersection_count": c, "visibility": v})
     assert res2 == full
+
+
+def test_run_split_scripts(setup, tmp_path):
+    """The two scene-precompute scripts end to end through their run_split entry points."""
+    import pickle
+    ns, g, h, sid = setup
+    info_path = str(tmp_path / "infos.pkl")
+    with open(info_path, "wb") as f:
+        pickle.dump(h.infos, f)
+    IH = ns.IH
+    orig_init = IH.SceneInfoHandler.__init__
+
+    def patched(self, info_path_, *a, **k):     # the scripts construct the handler with default roots
+        orig_init(self, info_path_, posed_images_root=h.posed_images_root, instance_data_root=h.instance_data_root)
+    IH.SceneInfoHandler.__init__ = patched
+    try:
+        vis = ns.MVI.run_split(info_path, str(tmp_path / "out" / "vis.pkl"), str(tmp_path / "w.txt"))
+        ref = g.json("mvi_json")
+        assert vis[sid]["image_to_points"] == ref["image_to_points"]
+        with open(str(tmp_path / "out" / "vis.pkl"), "rb") as f:
+            assert pickle.load(f)[sid]["image_to_points"] == ref["image_to_points"]
+        vh = IH.VisibilityInfoHandler(str(tmp_path / "out" / "vis.pkl"))
+        k0 = next(iter(ref["image_to_points"]))
+        assert vh.get_image_to_points_info(sid, k0) == ref["image_to_points"][k0]
+        try:
+            import pyarrow  # noqa: F401
+        except ImportError:
+            return
+        import pandas as pd
+        table = ns.CFR.run_split(info_path, str(tmp_path / "out" / "pairs.parquet"), str(tmp_path / "w.txt"))
+        df = pd.read_parquet(str(tmp_path / "out" / "pairs.parquet"))
+        keys = [tuple(str(x) for x in k) for k in g["cfr_pairs"]]
+        assert list(zip(df["image_id1"], df["image_id2"])) == keys and len(table[sid]) == len(keys)
+        assert same_f64(df["overlap"].to_numpy(), g["cfr_values"][:, 0])
+        nz = pd.read_parquet(str(tmp_path / "out" / "pairs_nonzero.parquet"))
+        assert len(nz) == int((g["cfr_values"][:, 0] != 0).sum())
+    finally:
+        IH.SceneInfoHandler.__init__ = orig_init
