@@ -61,7 +61,8 @@ typedef void *mspa_stream_t;        /* hipStream_t */
                                        lane near a decision boundary: masks, pixel indices and counters
                                        stay bit-exact, float32 points agree to ~1e-12 relative.  Needs
                                        slots 5/6 filled and K's third row == 0 0 1 0 (pinhole); ignored
-                                       when any float64 output is requested. */
+                                       (the exact kernel runs) when any float64 output is requested or
+                                       when out_vis_bits is requested with W % 64 != 0. */
 
 int mspa_version(void);
 const char *mspa_last_error_string(void);

@@ -1045,7 +1045,11 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
     }
     const bool ident = (dh == H && dw == W);
     // float64 outputs are defined as the reference's own operation order: they force the exact kernel
-    const bool fast = (flags & MSPA_PAIR_FAST) && !out_xyz_f64 && !out_uv_f64 && !out_depth_f64;
+    // ... and so does a bitset output whose words straddle the 64-column stripes (W % 64 != 0, e.g. ScanNet's
+    // 1296-wide colour grid): the stripe-mapped fast kernel would need two atomicOr per wave-row there and
+    // measures slower than the exact kernel's word-aligned linear mapping (7.7 vs 6.7 ms per 1 000 pairs).
+    const bool fast = (flags & MSPA_PAIR_FAST) && !out_xyz_f64 && !out_uv_f64 && !out_depth_f64 &&
+                      !(out_vis_bits && (W % 64 != 0));
     uint32_t set = 0;
     set |= out_vis_bits ? O_VIS_BITS : 0; set |= out_vis_u8 ? O_VIS_U8 : 0; set |= out_valid_u8 ? O_VALID_U8 : 0;
     set |= out_pix_i16 ? O_PIX : 0; set |= out_xyz_f32 ? O_XYZ32 : 0; set |= out_rgba ? O_RGBA : 0;
