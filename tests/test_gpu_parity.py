@@ -543,6 +543,17 @@ def test_fast_equals_exact_random_poses(hw):
         bad = (ex[k] != fa[k]).reshape(len(pairs_np), -1).any(dim=1).nonzero().flatten().tolist()
         assert not bad, f"{k}: fast != exact for pairs {[(int(pairs_np[b, 0]), int(pairs_np[b, 1])) for b in bad[:8]]}"
     assert torch.equal(mn["vis_bits"], ex["vis_bits"]) and torch.equal(mn["counts"], ex["counts"])
+    # byte-mask output set: keeps the stripe-mapped general fast kernel covered on ragged shapes, where a
+    # bitset request is routed to the exact kernel (include/mspa.h)
+    outs_b = ("vis_u8", "valid_u8", "pix_i16", "counts")
+    exb = engine.alloc_pair_outputs(len(pairs_np), hw, outs_b, DEV)
+    fab = engine.alloc_pair_outputs(len(pairs_np), hw, outs_b, DEV)
+    engine.pair_reproject(dep, mats, pairs, hw, exb)
+    engine.pair_reproject(dep, mats, pairs, hw, fab, flags=_lib.PAIR_FAST)
+    torch.cuda.synchronize()
+    for k in outs_b:
+        assert torch.equal(exb[k], fab[k]), f"{k}: general fast kernel != exact kernel"
+    assert torch.equal(exb["counts"], ex["counts"])
     counts = ex["counts"].cpu().numpy()
     assert (counts[:, 1] > 0).sum() > 20 and (counts[:, 1] == 0).sum() > 20      # both regimes exercised
     # anchor the exact kernel itself on a few pairs
