@@ -1054,7 +1054,10 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
     set |= out_vis_bits ? O_VIS_BITS : 0; set |= out_vis_u8 ? O_VIS_U8 : 0; set |= out_valid_u8 ? O_VALID_U8 : 0;
     set |= out_pix_i16 ? O_PIX : 0; set |= out_xyz_f32 ? O_XYZ32 : 0; set |= out_rgba ? O_RGBA : 0;
     set |= out_counts ? O_COUNTS : 0;
-    const bool tight24 = fast && ident && (W % 64 == 0) && (H % kTightRows == 0) && (P * 4 < (1ull << 31)) &&
+    // the tight kernel's LDS-DMA moves depth in 4-byte units and its 16-byte stores need aligned outputs
+    const bool aligned = (((uintptr_t)depth & 3u) == 0) && (((uintptr_t)out_pix_i16 & 15u) == 0) &&
+                         (((uintptr_t)out_vis_bits & 7u) == 0);
+    const bool tight24 = fast && ident && aligned && (W % 64 == 0) && (H % kTightRows == 0) && (P * 4 < (1ull << 31)) &&
                          (set == kSetCorr || set == kSetDense || set == kSetMinimal);
     if (fast) {
         const int tile_rows = tight24 ? kTightRows : kTileRows;
