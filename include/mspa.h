@@ -192,6 +192,15 @@ int mspa_track_displacement(const double *world, const double *w2c, const double
                             double cam_threshold, double *out, uint8_t *out_flags, mspa_stream_t stream);
 
 /*
+ * K7 -- the accumulation inside rigid_body_segmentation (OM_C:49-92): cumulative_loss[i, j] = sum over
+ * frames t >= 1 of |d_t(i,j) - d_{t-1}(i,j)| where that change exceeds smoothing_factor, d_t the Euclidean
+ * distance between track points i and j at frame t.  The linkage / fcluster step stays with SciPy on the
+ * host.   tracks_xyz [T, P, 3] f64 -> out_loss [P, P] f64 (symmetric, zero diagonal)
+ */
+int mspa_track_rigidity_loss(const double *tracks_xyz, int32_t T, int32_t P, double smoothing_factor,
+                             double *out_loss, mspa_stream_t stream);
+
+/*
  * K6a -- correspondence extraction on K1's bitsets: for every selection (image1, image2, j) the j-th
  * vertex (ascending index) visible in both images, i.e. element j of np.intersect1d(points1, points2)
  * (visual correspondence, VC_C:303-313); with image1 == image2 it is element j of that image's

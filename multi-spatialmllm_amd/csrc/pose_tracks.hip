@@ -96,9 +96,48 @@ __global__ __launch_bounds__(256) void track_disp_kernel(const double *__restric
     flags[2 * k + 1] = (cd < thr_cam) ? 0 : 1;     // OM_C:347-350
 }
 
+// K7: accumulated pairwise-distance change of the tracks (rigid_body_segmentation, OM_C:49-92): for every
+// point pair (i, j): sum over t >= 1 of |d_t - d_{t-1}| where it exceeds the smoothing threshold, d_t the
+// Euclidean distance of the two points at frame t (scipy pdist: sqrt((dx*dx + dy*dy) + dz*dz)).  One lane
+// per pair walks the frames in order, so the float64 sum has the reference's order.
+__global__ __launch_bounds__(256) void rigidity_loss_kernel(const double *__restrict__ tracks, int T, int P,
+                                                            double smoothing, double *__restrict__ loss) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= (int64_t)P * P) return;
+    const int i = (int)(k / P), j = (int)(k % P);
+    double acc = 0.0;
+    if (i != j) {
+        double prev = 0.0;
+        for (int t = 0; t < T; ++t) {
+            const double *a = tracks + ((int64_t)t * P + i) * 3, *b = tracks + ((int64_t)t * P + j) * 3;
+            const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+            const double d = __builtin_sqrt((dx * dx + dy * dy) + dz * dz);
+            if (t > 0) {
+                const double ch = __builtin_fabs(d - prev);
+                acc += (ch > smoothing) ? ch : 0.0;        // OM_C:46-47
+            }
+            prev = d;
+        }
+    }
+    loss[k] = acc;
+}
+
 }  // namespace mspa
 
 using namespace mspa;
+
+extern "C" int mspa_track_rigidity_loss(const double *tracks_xyz, int32_t T, int32_t P, double smoothing_factor,
+                                        double *out_loss, mspa_stream_t stream) {
+    if (T < 0 || P < 0) return fail(MSPA_EINVAL, "mspa_track_rigidity_loss: bad size");
+    if (P == 0) return MSPA_OK;
+    if (!tracks_xyz || !out_loss) return fail(MSPA_EINVAL, "mspa_track_rigidity_loss: null pointer");
+    const int64_t blocks = ((int64_t)P * P + 255) / 256;
+    if (blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_track_rigidity_loss: too many points");
+    hipLaunchKernelGGL(rigidity_loss_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, tracks_xyz, T, P,
+                       smoothing_factor, out_loss);
+    return check_hip(hipGetLastError(), "rigidity_loss_kernel launch");
+}
+
 
 extern "C" int mspa_pair_pose(const double *E_aligned, const double *Einv_aligned, const double *yaw,
                               const double *pitch, int32_t n_frames, const int32_t *pairs, int64_t n_pairs,

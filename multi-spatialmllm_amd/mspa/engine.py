@@ -307,3 +307,14 @@ def project_samples(xyz: torch.Tensor, cam_mats: torch.Tensor, depth: torch.Tens
                                         _ptr(depth), DH, DW, H, W, _ptr(samples.contiguous()), n, _ptr(uv), _ptr(d),
                                         _ptr(vis), _stream_ptr()))
     return uv, d, vis
+
+
+def track_rigidity_loss(tracks_xyz: torch.Tensor, smoothing_factor: float = 0.01) -> torch.Tensor:
+    """Enqueue K7: [T,P,3] f64 tracks -> [P,P] f64 accumulated thresholded distance change (OM_C:66-78)."""
+    _require_gpu()
+    lib = _lib.load()
+    assert tracks_xyz.dtype == torch.float64 and tracks_xyz.dim() == 3 and tracks_xyz.is_contiguous()
+    T, P, _ = tracks_xyz.shape
+    out = torch.empty((P, P), dtype=torch.float64, device=tracks_xyz.device)
+    _lib.check(lib.mspa_track_rigidity_loss(_ptr(tracks_xyz), T, P, float(smoothing_factor), _ptr(out), _stream_ptr()))
+    return out

@@ -10,6 +10,22 @@ from mspa import engine, heads
 from mspa import templates as T
 
 
+def rigid_body_segmentation(points, threshold=0.1, smoothing_factor=0.01):
+    """Groups of track indices that move rigidly together (reference: :49-92): the T x P^2 distance-change
+    accumulation runs on the GPU (K7), average linkage + fcluster stay with SciPy."""
+    from scipy.cluster.hierarchy import fcluster, linkage
+    from scipy.spatial.distance import squareform
+    pts = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float64)).cuda()
+    loss = engine.track_rigidity_loss(pts, smoothing_factor).cpu().numpy()
+    links = linkage(squareform(loss), method="average")
+    labels = fcluster(links, threshold, criterion="distance")
+    return [np.where(labels == i)[0].tolist() for i in range(1, max(labels) + 1)]
+
+
+def filter_large_groups(groups, min_size=5):
+    return [g for g in groups if len(g) > min_size]
+
+
 class TwoFrameVideoQAEngine:
     def __init__(self, question_type, sub_dataset):
         self.question_type = question_type

@@ -327,3 +327,24 @@ def test_run_split_scripts(setup, tmp_path):
         assert len(nz) == int((g["cfr_values"][:, 0] != 0).sum())
     finally:
         IH.SceneInfoHandler.__init__ = orig_init
+
+
+def test_rigid_body_segmentation():
+    """K7 + SciPy linkage == the reference's groups (tests/golden/tracks.npz) and its loss matrix."""
+    facade()
+    OM = importlib.import_module("spatial_engine.object_movement.single_object_movement_engine_coord")
+    from golden_util import GOLDEN_DIR
+    from scipy.spatial.distance import pdist, squareform
+    import torch
+    from mspa import engine
+    z = np.load(os.path.join(GOLDEN_DIR, "tracks.npz"))
+    pts = z["tracks_XYZ"]
+    groups = OM.rigid_body_segmentation(pts)
+    assert groups == json.loads(str(z["groups_json"]))
+    assert OM.filter_large_groups([[1] * 6, [2] * 5]) == [[1] * 6]
+    loss = engine.track_rigidity_loss(torch.from_numpy(np.ascontiguousarray(pts)).cuda()).cpu().numpy()
+    ref = np.zeros_like(loss)
+    for t in range(1, pts.shape[0]):                       # the reference's accumulation, restated with SciPy
+        ch = np.abs(squareform(pdist(pts[t])) - squareform(pdist(pts[t - 1])))
+        ref += np.where(ch > 0.01, ch, 0)
+    assert np.allclose(loss, ref, rtol=1e-12, atol=1e-15) and np.array_equal(loss, loss.T) and (np.diag(loss) == 0).all()
