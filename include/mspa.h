@@ -201,6 +201,21 @@ int mspa_track_rigidity_loss(const double *tracks_xyz, int32_t T, int32_t P, dou
                              double *out_loss, mspa_stream_t stream);
 
 /*
+ * K8 -- per (object, image) extent of the object's visible vertices: what compute_coverage
+ * (object_perception/single_object_coverage_finder.py:56-65) takes off `image mask & object mask`, for all
+ * three axes at once.  The coverage of a union of images is max-of-max minus min-of-min of these, so the
+ * minimal-combination search (COV:76-220) runs on them without ever forming a union mask.
+ *   vis_bits [n_images, n_words] u64 (K1's bitsets, or rows packed from the visibility parquet),
+ *   xyz [n_vertices, 3] f64 (axis-aligned scene points), objects as CSR: obj_offsets [n_objects+1] i32 into
+ *   obj_vertices (vertex ids, each < n_vertices)
+ *   -> out_lo / out_hi [n_objects, n_images, 3] f64 (+inf / -inf where the image sees none of the object),
+ *      out_count [n_objects, n_images] i32 (= intersection_count of compute_object_visibility.py:119-121)
+ */
+int mspa_object_extents(const uint64_t *vis_bits, int32_t n_images, int64_t n_words, const double *xyz,
+                        int64_t n_vertices, const int32_t *obj_offsets, const int32_t *obj_vertices, int32_t n_objects,
+                        double *out_lo, double *out_hi, int32_t *out_count, mspa_stream_t stream);
+
+/*
  * K6a -- correspondence extraction on K1's bitsets: for every selection (image1, image2, j) the j-th
  * vertex (ascending index) visible in both images, i.e. element j of np.intersect1d(points1, points2)
  * (visual correspondence, VC_C:303-313); with image1 == image2 it is element j of that image's

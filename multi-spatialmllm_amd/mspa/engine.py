@@ -318,3 +318,22 @@ def track_rigidity_loss(tracks_xyz: torch.Tensor, smoothing_factor: float = 0.01
     out = torch.empty((P, P), dtype=torch.float64, device=tracks_xyz.device)
     _lib.check(lib.mspa_track_rigidity_loss(_ptr(tracks_xyz), T, P, float(smoothing_factor), _ptr(out), _stream_ptr()))
     return out
+
+
+def object_extents(vis_bits: torch.Tensor, xyz: torch.Tensor, obj_offsets: torch.Tensor, obj_vertices: torch.Tensor):
+    """Enqueue K8: per (object, image) min / max xyz of the object's visible vertices and their count.
+    vis_bits [F, n_words] int64, xyz [V,3] f64, objects as CSR (int32).  Returns (lo [O,F,3], hi [O,F,3], count [O,F])."""
+    _require_gpu()
+    lib = _lib.load()
+    assert vis_bits.dtype == torch.int64 and vis_bits.dim() == 2 and vis_bits.is_contiguous()
+    assert xyz.dtype == torch.float64 and xyz.dim() == 2 and xyz.shape[1] == 3 and xyz.is_contiguous()
+    assert obj_offsets.dtype == torch.int32 and obj_vertices.dtype == torch.int32
+    F, n_words = vis_bits.shape
+    O = obj_offsets.numel() - 1
+    dev = vis_bits.device
+    lo = torch.empty((O, F, 3), dtype=torch.float64, device=dev)
+    hi = torch.empty((O, F, 3), dtype=torch.float64, device=dev)
+    count = torch.empty((O, F), dtype=torch.int32, device=dev)
+    _lib.check(lib.mspa_object_extents(_ptr(vis_bits), F, n_words, _ptr(xyz), xyz.shape[0], _ptr(obj_offsets),
+                                       _ptr(obj_vertices), O, _ptr(lo), _ptr(hi), _ptr(count), _stream_ptr()))
+    return lo, hi, count

@@ -380,3 +380,49 @@ def object_movement_records(scene_id: str, tracks_xyz, extrinsics_w2c, fx_fy_cx_
         if r is not None:
             records.append(r)
     return records
+
+
+# --------------------------------------------------------------------------------------------
+# object perception (OPE = object_perception/single_object_perception_engine.py)
+# --------------------------------------------------------------------------------------------
+def object_perception_records(dim_info: Dict[str, Dict], dimension_name: str, value_m, category, image_hw,
+                              max_k: int = 6, templates: T.TemplateSet = T.OBJECT_PERCEPTION,
+                              rng=_random) -> Dict[int, List[dict]]:
+    """{k: records} from a coverage table {scene: {object: {k: [image combinations]}}} (OPE:126-213).
+
+    ``value_m(scene_id, object_id)`` is the ground-truth size in metres, ``category(scene_id, object_id)``
+    the raw category, ``image_hw`` (H, W) or a callable scene_id -> (H, W).  Draw order per record: shuffle of the combination, task line, question, answer."""
+    by_k: Dict[int, List[dict]] = {k: [] for k in range(1, max_k + 1)}
+    for scene_id, objects in dim_info.items():
+        H, W = image_hw(scene_id) if callable(image_hw) else image_hw
+        for object_id, k_table in objects.items():
+            val_mm = int(round(value_m(scene_id, object_id) * 1000))
+            cat = category(scene_id, object_id)
+            for k_key, combos in k_table.items():
+                try:
+                    k = int(k_key)
+                except (TypeError, ValueError):
+                    continue
+                if k < 1 or k > max_k:
+                    continue
+                for combo_idx, combo in enumerate(combos):
+                    if not combo:
+                        continue
+                    combo = list(combo)
+                    rng.shuffle(combo)
+                    prefix = "\n".join(f"Image-{i}: <image>" for i in range(1, len(combo) + 1))
+                    task_line = rng.choice(templates.task_description)
+                    question = rng.choice(templates.questions["default"]).format(dimension=dimension_name, object_category=cat)
+                    answer = rng.choice(templates.answers["default"]).format(dimension=dimension_name, value_mm=val_mm,
+                                                                             object_category=cat)
+                    by_k[k].append({
+                        "id": f"{scene_id}_{object_id}_{k}_{combo_idx}",
+                        "image": [f"{scene_id}/{img}.jpg" for img in combo],
+                        "conversations": [{"from": "human", "value": f"{prefix}\n{task_line}\n{question}"},
+                                          {"from": "gpt", "value": answer}],
+                        "height_list": [H] * len(combo),
+                        "width_list": [W] * len(combo),
+                        "question_type": f"object_perception_{dimension_name}_estimation",
+                        "gt_value": val_mm,
+                    })
+    return by_k

@@ -26,7 +26,10 @@ class TemplateSet:
 
     @staticmethod
     def from_module(mod, question_types: Sequence[str] = ()) -> "TemplateSet":
-        task = list(getattr(mod, "TASK_DESCRIPTION"))
+        # object_perception's script names its list ASK_DESCRIPTION (OPE:25) although it reads TASK_DESCRIPTION (OPE:190)
+        task = list(getattr(mod, "TASK_DESCRIPTION", None) or getattr(mod, "ASK_DESCRIPTION"))
+        if isinstance(getattr(mod, "QUESTION_TEMPLATES", None), (list, tuple)):
+            return TemplateSet(task, {"default": list(mod.QUESTION_TEMPLATES)}, {"default": list(mod.ANSWER_TEMPLATES)})
         if hasattr(mod, "QUESTION_TEMPLATES"):
             return TemplateSet(task, {k: list(v) for k, v in mod.QUESTION_TEMPLATES.items()},
                                {k: list(v) for k, v in mod.ANSWER_TEMPLATES.items()})
@@ -106,3 +109,11 @@ OBJECT_MOVEMENT = TemplateSet(
         "tapvid3d_displacement_vector": ["`[ {x_value} , {y_value} , {z_value} ]` mm.",
                                          "Its displacement is `[ {x_value} , {y_value} , {z_value} ]` mm."],
     })
+
+OBJECT_PERCEPTION = TemplateSet(
+    task_description=["The scene is static. Use every image together to answer a question about an object's size.",
+                      "All images show the same unchanged scene; combine them to measure the object."],
+    questions={"default": ["What is the {dimension} in millimetres of the {object_category} that these images show?",
+                           "Measure the {dimension} (mm) of the {object_category} seen across these images."]},
+    answers={"default": ["Its {dimension} is about `{value_mm}` mm.",
+                         "The {object_category} has a {dimension} of roughly `{value_mm}` mm."]})

@@ -192,13 +192,116 @@ def golden_tracks(ns):
     print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB; kept {sum(kept)}/{len(kept)}")
 
 
+def golden_coverage(ns, only=None):
+    """Object coverage search (COV) + object visibility (COVIS) + perception records (OPE) of the reference on a
+    70-frame scene whose eight furniture boxes are the objects; run once on float64 and once on float32 points."""
+    import pandas  # noqa: F401  (COVIS/COV import it)
+    RH.import_object_perception(ns)
+    sc = synth.make_scene(4242, n_points=6000, n_frames=70, color_hw=(48, 64), depth_hw=(48, 64),
+                          invalid_pose_frac=0.05, with_color=False, walk_step=0.6, target_jitter=1.6)
+    xyz = sc.points[:, :3]
+    inst = np.zeros(len(xyz), dtype=np.int64)
+    bboxes, cats = [], []
+    for o, (lo, hi) in enumerate(sc.boxes):
+        on = ((xyz >= lo - 1e-9) & (xyz <= hi + 1e-9)).all(axis=1) & (inst == 0)
+        inst[on] = o + 1
+        p = xyz[on]
+        c, d = (p.max(0) + p.min(0)) / 2, p.max(0) - p.min(0)
+        bboxes.append(np.concatenate([c, d, [o]]))
+        cats.append("wall" if o == 6 else f"cabinet{o}")
+    out = {"points": sc.points, "instance_mask": inst, "bboxes": np.stack(bboxes), "categories": np.array(cats),
+           "image_ids": np.array(sc.image_ids), "color_hw": np.array(sc.color_hw)}
+    for tag, dtype in (("f64", np.float64), ("f32", np.float32)):
+        sc_t = synth.SynthScene(sc.scene_id, sc.K, sc.A, sc.E, sc.points.astype(dtype), sc.depth, sc.color,
+                                sc.color_hw, sc.depth_hw, sc.boxes)
+        h = RH.make_handler(ns, [sc_t])
+        sid = sc.scene_id
+        np.save(os.path.join(h.instance_data_root, sid, "instance_mask.npy"), inst)
+        h.infos[sid]["num_objects"] = len(bboxes)
+        for o in range(len(bboxes)):
+            h.infos[sid][o] = {"raw_category": cats[o], "aligned_bbox": bboxes[o].astype(dtype), "unaligned_bbox": bboxes[o]}
+        _, vis = ns.MVI.process_scene(sid, h, os.path.join("/tmp", f"mspa_golden_warn_cov_{tag}.txt"))
+        vis_dict = {f"{sid}:image_to_points:{k}": json.dumps(v) for k, v in vis["image_to_points"].items()}
+        _, objvis, _ = ns.COVIS.process_scene(sid, h, vis_dict)
+        random.seed(0)
+        _, cov = ns.COV.process_scene_for_coverage(sid, h, vis_dict, {sid: objvis})
+        if tag == "f64":
+            valid = h.get_all_extrinsic_valid_image_ids(sid)
+            bits = np.zeros((len(valid), (len(xyz) + 63) // 64 * 64), dtype=bool)
+            for r, img in enumerate(valid):
+                bits[r, vis["image_to_points"][img]] = True
+            out["valid_image_ids"] = np.array(valid)
+            out["vis_bits"] = np.packbits(bits, axis=1, bitorder="little").view(np.int64)
+            out["object_visibility_json"] = json.dumps(objvis)
+        out[f"coverage_{tag}_json"] = json.dumps({str(o): {dim: {str(k): [list(c) for c in combos] for k, combos in t.items()}
+                                                           for dim, t in res.items()} for o, res in cov.items()})
+        if tag == "f64":
+            # perception records of the reference from this table (its script needs two repairs to run at all:
+            # TASK_DESCRIPTION is the list it defines as ASK_DESCRIPTION, and the handler gets image_height/width)
+            import pickle
+            import tempfile
+            ns.OPE.TASK_DESCRIPTION = ns.OPE.ASK_DESCRIPTION
+            h.image_height, h.image_width = sc.color_hw
+            tmp = tempfile.mkdtemp(prefix="mspa_ope_")
+            table = {sid: {o: res["height"] for o, res in cov.items()}}
+            with open(os.path.join(tmp, "height.pkl"), "wb") as f:
+                pickle.dump(table, f)
+            random.seed(1)
+            ns.OPE.build_lwh_qa_samples(h, os.path.join(tmp, "height.pkl"), "height", "val", tmp, max_k=6, max_samples=40)
+            recs = {}
+            for fname in sorted(os.listdir(tmp)):
+                if fname.endswith(".jsonl"):
+                    recs[fname] = [json.loads(line) for line in open(os.path.join(tmp, fname))]
+            out["ope_records_json"] = json.dumps(recs)
+    # direct cases for the search itself: images that each see an interval of a 1-D object, so that several
+    # are needed, both random caps (25 first-layer images, 5000 nodes per level) trigger and levels reach 5
+    cases = []
+    rng = np.random.default_rng(77)
+    for c, (n_img, frac, dtype) in enumerate([(12, 0.6, np.float64), (34, 0.45, np.float64), (40, 0.3, np.float32),
+                                              (30, 0.22, np.float64), (26, 0.5, np.float32), (3, 0.2, np.float64)]):
+        n_pts = 300
+        pts = np.zeros((n_pts, 3), dtype=dtype)
+        axis = c % 3
+        pts[:, axis] = rng.uniform(-1.0, 2.0, n_pts).astype(dtype)
+        obj = np.sort(rng.choice(n_pts, size=220, replace=False))
+        coords = pts[obj, axis]
+        target = float(coords.max() - coords.min()) * (1.0 if c % 2 == 0 else 0.97)
+        lists = {}
+        imgs = [f"{5 * k:05d}" for k in range(n_img)]
+        for k, img in enumerate(imgs):
+            a = rng.uniform(coords.min() - 0.2, coords.max() - frac * 3.0 + 0.2)
+            seen = (pts[:, axis] >= a) & (pts[:, axis] <= a + frac * 3.0) & (rng.random(n_pts) < 0.9)
+            if k == 1:
+                seen[:] = False                                           # an image that sees nothing
+            lists[f"s:image_to_points:{img}"] = json.dumps(np.where(seen)[0].tolist())
+        visible = list(imgs)
+        if c == 1:
+            del lists[f"s:image_to_points:{imgs[4]}"]                      # missing from the index (COV:106-108)
+        random.seed(100 + c)
+        want = ns.COV.find_minimal_combinations("s", pts, obj, visible, lists, axis, target, 0.1)
+        cases.append({"points": pts.tolist(), "dtype": np.dtype(dtype).name, "object": obj.tolist(), "axis": axis,
+                      "target": target, "images": visible, "lists": lists, "seed": 100 + c,
+                      "want": {str(k): [list(x) for x in v] for k, v in want.items()}})
+        print("bfs case", c, {k: len(v) for k, v in want.items()})
+    out["bfs_cases_json"] = json.dumps(cases)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "coverage.npz"), meta=_meta(), **out)
+    cov64 = json.loads(out["coverage_f64_json"])
+    print("images per object:", {o: len(v) for o, v in json.loads(out["object_visibility_json"])["object_to_images"].items()})
+    print("coverage.npz: objects", list(cov64), "solutions per k (height):",
+          {o: {k: len(v) for k, v in r["height"].items()} for o, r in cov64.items()},
+          "f32 == f64:", out["coverage_f32_json"] == out["coverage_f64_json"])
+
+
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     ns = RH.import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "coverage":
+        return golden_coverage(ns)
     golden_scene(ns, "scene_ident", 2001, (48, 64), (48, 64), n_points=700, n_frames=6, with_color=True)
     golden_scene(ns, "scene_scaled", 2002, (73, 98), (48, 64), n_points=700, n_frames=6, with_color=False)
     golden_ties(ns)
     golden_tracks(ns)
+    golden_coverage(ns)
 
 
 if __name__ == "__main__":

@@ -158,6 +158,16 @@ def _import_reference_modules():
     return ns
 
 
+def import_object_perception(ns):
+    """Add the object_perception scripts to the namespace (their imports reseed ``random``: COV seeds 0,
+    OPE seeds 1 -- callers reseed before every use)."""
+    ns.COVIS = importlib.import_module("spatial_engine.object_perception.compute_object_visibility")
+    ns.COV = importlib.import_module("spatial_engine.object_perception.single_object_coverage_finder")
+    ns.OPE = importlib.import_module("spatial_engine.object_perception.single_object_perception_engine")
+    assert ns.COV.__file__.startswith(REFERENCE_ROOT), ns.COV.__file__
+    return ns
+
+
 def make_handler(ns, scenes, root=None):
     """Build a reference ``SceneInfoHandler`` over synthetic scenes (mspa.synth.SynthScene)."""
     root = root or tempfile.mkdtemp(prefix="mspa_ref_")
