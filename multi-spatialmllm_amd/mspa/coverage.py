@@ -113,16 +113,22 @@ class SceneExtents:
         return [self.lo[o, c, axis] for c in cols], [self.hi[o, c, axis] for c in cols]
 
 
-def scene_extents(image_bits, image_ids: Sequence[str], scene_pts: np.ndarray,
-                  object_point_indices: Dict[int, np.ndarray]) -> SceneExtents:
+def scene_extents(image_bits, image_ids: Sequence[str], scene_pts, object_point_indices: Dict[int, np.ndarray],
+                  dtype=None) -> SceneExtents:
     """One K8 launch for every (object, image) of a scene.  ``image_bits`` [F, n_words] int64 on the GPU
-    (K1's bitsets or ``scene.pack_index_lists`` of the parquet lists); ``scene_pts`` [V, >=3] float32/64."""
+    (K1's bitsets or ``scene.pack_index_lists`` of the parquet lists); ``scene_pts`` [V, >=3] float32/64 on the
+    host, or the resident [V,3] float64 device tensor (then ``dtype`` names the dtype the points had on disk)."""
     import torch
     from . import engine
     dev = image_bits.device
-    pts = np.asarray(scene_pts)[:, :3]
-    dtype = pts.dtype if pts.dtype in (np.float32, np.float64) else np.dtype(np.float64)
-    xyz = torch.from_numpy(np.ascontiguousarray(pts, dtype=np.float64)).to(dev)     # float32 -> float64 is exact
+    if isinstance(scene_pts, torch.Tensor):
+        xyz = scene_pts
+        dtype = np.dtype(dtype or np.float64)
+        pts = xyz
+    else:
+        pts = np.asarray(scene_pts)[:, :3]
+        dtype = np.dtype(dtype) if dtype is not None else (pts.dtype if pts.dtype in (np.float32, np.float64) else np.dtype(np.float64))
+        xyz = torch.from_numpy(np.ascontiguousarray(pts, dtype=np.float64)).to(dev)     # float32 -> float64 is exact
     objs = list(object_point_indices.items())
     offsets = np.zeros(len(objs) + 1, dtype=np.int64)
     for k, (_, idx) in enumerate(objs):

@@ -51,7 +51,8 @@ def pair_table_rows(scene_idx: int, scene) -> np.ndarray:
 
 def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None, device="cuda", seed: int = 0,
         n_camera: int = 64, n_correspondence: int = 64, depth_images_per_scene: int = 4,
-        overlap_range=(6, 35), question_types: Sequence[str] = ("total_distance", "displacement_vector")) -> Dict[str, int]:
+        overlap_range=(6, 35), question_types: Sequence[str] = ("total_distance", "displacement_vector"),
+        object_perception: bool = True) -> Dict[str, int]:
     """Run the ScanNet-side heads over ``scenes`` (objects with K, A, E, depth, points, color_hw, scene_id).
     Returns {jsonl name: record count} on rank 0 (empty dict elsewhere)."""
     import pandas as pd
@@ -124,6 +125,31 @@ def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None,
         recs.extend(heads.depth_estimation_records(resident[s], scenes[s].scene_id, scenes[s].color_hw,
                                                    depth_images_per_scene, T.DEPTH_ESTIMATION, rng))
     outputs["depth_estimation_coor"] = recs
+
+    # ---- object perception: visibility + coverage + records, per scene (COVIS / COV / OPE) ----------
+    if object_perception:
+        by_name: Dict[str, List[dict]] = {}
+        for s in mine:
+            if not hasattr(scenes[s], "objects"):
+                continue
+            idx, bbox, cat = scenes[s].objects()
+            rng = random.Random(f"{seed}:op:{s}")
+            cov, _ = resident[s].object_coverage(idx, bbox, rng=rng)
+            for d, dim in enumerate(("height", "length", "width")):
+                table = {scenes[s].scene_id: {o: res[dim] for o, res in cov.items()}}
+                size = {"height": lambda o: bbox[o][5], "length": lambda o: max(bbox[o][3], bbox[o][4]),
+                        "width": lambda o: min(bbox[o][3], bbox[o][4])}[dim]
+                by_k = heads.object_perception_records(table, dim, lambda _s, o: size(o), lambda _s, o: cat[o],
+                                                       scenes[s].color_hw, 6, T.OBJECT_PERCEPTION, rng)
+                for k, recs in by_k.items():
+                    if recs:
+                        by_name.setdefault(f"object_perception_{dim}_k{k}", []).extend(recs)
+        if ctx is not None:                       # every rank must enter the same collations: agree on the names
+            names: List[Optional[list]] = [None] * world
+            dist.all_gather_object(names, sorted(by_name), group=ctx.group)
+            for n in sorted({x for part in names for x in part}):
+                by_name.setdefault(n, [])
+        outputs.update(by_name)
 
     # ---- collation of the finished records + JSONL --------------------------------------------------
     counts: Dict[str, int] = {}

@@ -129,6 +129,29 @@ class SceneOnDevice:
         bits = self._visibility()["bits"]
         return object_visibility_from_bits(bits, self.ids, self.xyz.shape[0], object_point_indices, min_fraction)
 
+    def object_coverage(self, object_point_indices: Dict[int, np.ndarray], bboxes: Dict[int, Sequence[float]],
+                        tolerance: float = 0.1, min_fraction: float = 0.05, rng=None, points_dtype=np.float64):
+        """COVIS.process_scene + COV.process_scene_for_coverage for the resident scene: object visibility
+        (masked popcount, K2) and per-(object, image) extents (K8) straight from K1's bitsets, then the
+        minimal-combination search per object and axis.  ``bboxes[o]`` = (cx, cy, cz, dx, dy, dz) of the
+        axis-aligned box.  Returns ({obj: {"height"|"length"|"width": {k: [combinations]}}}, visibility)."""
+        import random as _random
+        from . import coverage
+        rng = rng or _random
+        visibility = self.object_visibility(object_point_indices, min_fraction)
+        per_object = visibility["object_to_images"]
+        out = {}
+        if not per_object:
+            return out, visibility
+        objects = {o: np.asarray(object_point_indices[o]) for o in per_object}
+        ext = coverage.scene_extents(self._visibility()["bits"], self.ids, self.xyz, objects, dtype=points_dtype)
+        for o, entries in per_object.items():
+            b = bboxes[o]
+            width_axis = 0 if b[3] < b[4] else 1                         # IH:224-230
+            out[o] = coverage.object_coverage(ext, o, [e["image_id"] for e in entries], b[5], max(b[3], b[4]),
+                                              min(b[3], b[4]), width_axis, tolerance, rng)
+        return out, visibility
+
     # ---- K3 ---------------------------------------------------------------------------------
     def pair_reproject(self, pairs_ids: Sequence[Tuple[str, str]], outputs: Sequence[str], fast: bool = True):
         pairs = torch.tensor([[self.index[a], self.index[b]] for a, b in pairs_ids], dtype=torch.int32,

@@ -41,6 +41,23 @@ class SynthScene:
     def valid_image_ids(self) -> List[str]:
         return [k for k, e in self.E.items() if np.all(np.isfinite(e))]
 
+    def objects(self):
+        """The furniture boxes as labelled objects: ({obj: vertex indices}, {obj: aligned bbox (cx,cy,cz,dx,dy,dz)},
+        {obj: category}); bbox dimensions are the extents of the object's own vertices, as ScanNet's export takes them."""
+        xyz = self.points[:, :3]
+        taken = np.zeros(len(xyz), dtype=bool)
+        idx, bbox, cat = {}, {}, {}
+        for o, (lo, hi) in enumerate(self.boxes):
+            on = ((xyz >= lo - 1e-9) & (xyz <= hi + 1e-9)).all(axis=1) & ~taken
+            taken |= on
+            if not on.any():
+                continue
+            p = xyz[on]
+            idx[o] = np.where(on)[0]
+            bbox[o] = np.concatenate([(p.max(0) + p.min(0)) / 2, p.max(0) - p.min(0)])
+            cat[o] = f"cabinet{o}"
+        return idx, bbox, cat
+
     def info_dict(self) -> dict:
         """Scene record in the reference's scene-info layout (info_handler.py:7-30)."""
         images_info = {k: {"extrinsic_matrix": e} for k, e in self.E.items()}

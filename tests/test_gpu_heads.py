@@ -197,8 +197,11 @@ def test_pipeline_end_to_end_and_sharding_invariance(tmp_path):
     single = str(tmp_path / "single")
     counts = pipeline.run(_pipeline_scenes(), single, None, DEV, seed=3, n_camera=24, n_correspondence=24,
                           depth_images_per_scene=3)
-    assert set(counts) == {"camera_movement_total_distance", "camera_movement_displacement_vector",
-                           "visual_correspondence_coor_2_coor", "depth_estimation_coor"}
+    base = {"camera_movement_total_distance", "camera_movement_displacement_vector",
+            "visual_correspondence_coor_2_coor", "depth_estimation_coor"}
+    perception = set(counts) - base
+    assert base <= set(counts) and perception and all(n.startswith("object_perception_") for n in perception)
+    assert any(n.startswith("object_perception_height_k1") for n in perception)
     assert counts["depth_estimation_coor"] == 9 and counts["camera_movement_total_distance"] > 0
     for name in counts:
         recs = [json.loads(ln) for ln in open(f"{single}/{name}.jsonl")]
@@ -221,3 +224,48 @@ def test_pipeline_end_to_end_and_sharding_invariance(tmp_path):
         assert p.exitcode == 0
     for name in counts:
         assert open(f"{single}/{name}.jsonl").read() == open(f"{sharded}/{name}.jsonl").read(), name
+
+
+def test_scene_object_coverage_matches_index_route():
+    """Resident route (K1 bitsets -> K2 popcount + K8 extents -> search) == the script route that goes through
+    the visibility index lists (what the reference's three object_perception scripts read from disk)."""
+    import importlib
+    import json
+    import random
+    from mspa.scene import SceneOnDevice
+    sc = synth.make_scene(7300, n_points=5000, n_frames=30, color_hw=(96, 128), depth_hw=(96, 128),
+                          invalid_pose_frac=0.05, with_color=False, walk_step=0.5, target_jitter=1.5)
+    scene = SceneOnDevice(sc.K, sc.A, sc.E, sc.depth, sc.color_hw, sc.points, DEV)
+    idx, bbox, cat = sc.objects()
+    assert len(idx) >= 4
+    cov, vis = scene.object_coverage(idx, bbox, rng=random.Random(5))
+    assert cov and any(res["height"] for res in cov.values())
+    COV = importlib.import_module("spatial_engine.object_perception.single_object_coverage_finder")
+    index = scene.visibility_index()["image_to_points"]
+    sid = sc.scene_id
+    vis_dict = {f"{sid}:image_to_points:{k}": json.dumps(v) for k, v in index.items()}
+
+    class H:
+        def get_scene_points_align(self, s):
+            return sc.points
+
+        def get_object_point_index(self, s, o):
+            return idx[o]
+
+        def get_object_height(self, s, o):
+            return bbox[o][5]
+
+        def get_object_length(self, s, o):
+            return max(bbox[o][3], bbox[o][4])
+
+        def get_object_width(self, s, o):
+            return min(bbox[o][3], bbox[o][4])
+
+        def get_object_width_axis_aligned(self, s, o):
+            return 0 if bbox[o][3] < bbox[o][4] else 1
+
+    state = random.getstate()
+    random.seed(5)
+    _, res = COV.process_scene_for_coverage(sid, H(), vis_dict, {sid: vis})
+    random.setstate(state)
+    assert res == cov
