@@ -211,6 +211,26 @@ def time_scene_kernels(device, n_points=131072, n_frames=320, reps=5):
             t2 += ev[1].elapsed_time(ev[2])
             t3 += ev[2].elapsed_time(ev[3])
     t1, t2, t3 = t1 / reps, t2 / reps, t3 / reps
+    # K8 (object extents for the coverage search) on the same bitsets: the scene's furniture as objects, and
+    # K7 (rigid-body distance-change accumulation) on a TAPVid-sized track block
+    idx, _, _ = sc.objects()
+    offsets = np.zeros(len(idx) + 1, dtype=np.int32)
+    offsets[1:] = np.cumsum([len(v) for v in idx.values()])
+    off_t = torch.from_numpy(offsets).to(device)
+    verts_t = torch.from_numpy(np.concatenate(list(idx.values())).astype(np.int32)).to(device)
+    tracks = torch.randn((300, 256, 3), dtype=torch.float64, device=device)
+    t8 = t7 = 0.0
+    for r in range(reps + 1):
+        ev[0].record()
+        engine.object_extents(vis["bits"], xyz, off_t, verts_t)
+        ev[1].record()
+        engine.track_rigidity_loss(tracks)
+        ev[2].record()
+        torch.cuda.synchronize()
+        if r:
+            t8 += ev[0].elapsed_time(ev[1])
+            t7 += ev[1].elapsed_time(ev[2])
+    t8, t7 = t8 / reps, t7 / reps
     b1 = F * (24 * n_points + 2 * H * W + n_points // 8)
     b2 = pairs.shape[0] * (2 * n_points // 8 + 8)
     return {"K1_vertex_visibility": {"images": F, "vertices": n_points, "kernel_ms": round(t1, 4),
@@ -221,6 +241,10 @@ def time_scene_kernels(device, n_points=131072, n_frames=320, reps=5):
                                 "pairs_per_s": round(pairs.shape[0] / (t2 * 1e-3), 1),
                                 "streaming_GBs": round(b2 / (t2 * 1e-3) / 1e9, 1)},
             "K4_pair_pose": {"pairs": int(pairs.shape[0]), "kernel_ms": round(t3, 4)},
+            "K8_object_extents": {"objects": len(idx), "object_vertices": int(offsets[-1]), "images": F,
+                                  "kernel_ms": round(t8, 4),
+                                  "bit_tests_per_s": round(float(offsets[-1]) * F / (t8 * 1e-3), 1)},
+            "K7_track_rigidity": {"frames": 300, "points": 256, "kernel_ms": round(t7, 4)},
             "scene_total": {"frames": F, "vertices": n_points, "ms": round(t1 + t2 + t3, 4),
                             "note": "CFR.process_scene for one ScanNet-sized scene (every-5th-frame average)"}}
 

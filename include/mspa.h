@@ -207,13 +207,14 @@ int mspa_track_rigidity_loss(const double *tracks_xyz, int32_t T, int32_t P, dou
  * minimal-combination search (COV:76-220) runs on them without ever forming a union mask.
  *   vis_bits [n_images, n_words] u64 (K1's bitsets, or rows packed from the visibility parquet),
  *   xyz [n_vertices, 3] f64 (axis-aligned scene points), objects as CSR: obj_offsets [n_objects+1] i32 into
- *   obj_vertices (vertex ids, each < n_vertices)
+ *   obj_vertices [n_list_entries] (vertex ids, each < n_vertices; n_list_entries = obj_offsets[n_objects])
  *   -> out_lo / out_hi [n_objects, n_images, 3] f64 (+inf / -inf where the image sees none of the object),
  *      out_count [n_objects, n_images] i32 (= intersection_count of compute_object_visibility.py:119-121)
  */
 int mspa_object_extents(const uint64_t *vis_bits, int32_t n_images, int64_t n_words, const double *xyz,
-                        int64_t n_vertices, const int32_t *obj_offsets, const int32_t *obj_vertices, int32_t n_objects,
-                        double *out_lo, double *out_hi, int32_t *out_count, mspa_stream_t stream);
+                        int64_t n_vertices, const int32_t *obj_offsets, const int32_t *obj_vertices,
+                        int64_t n_list_entries, int32_t n_objects, double *out_lo, double *out_hi, int32_t *out_count,
+                        mspa_stream_t stream);
 
 /*
  * K6a -- correspondence extraction on K1's bitsets: for every selection (image1, image2, j) the j-th

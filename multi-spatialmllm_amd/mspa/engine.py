@@ -335,5 +335,6 @@ def object_extents(vis_bits: torch.Tensor, xyz: torch.Tensor, obj_offsets: torch
     hi = torch.empty((O, F, 3), dtype=torch.float64, device=dev)
     count = torch.empty((O, F), dtype=torch.int32, device=dev)
     _lib.check(lib.mspa_object_extents(_ptr(vis_bits), F, n_words, _ptr(xyz), xyz.shape[0], _ptr(obj_offsets),
-                                       _ptr(obj_vertices), O, _ptr(lo), _ptr(hi), _ptr(count), _stream_ptr()))
+                                       _ptr(obj_vertices), obj_vertices.numel(), O, _ptr(lo), _ptr(hi), _ptr(count),
+                                       _stream_ptr()))
     return lo, hi, count
