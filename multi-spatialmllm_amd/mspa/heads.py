@@ -279,31 +279,171 @@ def depth_estimation_record(scene_id: str, image_id: str, vertex: int, uv_row, d
     }
 
 
-def depth_estimation_records(scene, scene_id: str, image_hw, max_samples: int = -1,
-                             templates: T.TemplateSet = T.DEPTH_ESTIMATION, rng=_random) -> List[dict]:
-    import torch
-    from . import engine
-    vis = scene._visibility()
-    counts = vis["count"].cpu().numpy()
-    n_visible = {k: int(c) for k, c in zip(scene.ids, counts)}
-    draws = depth_estimation_draws(scene.ids, n_visible, max_samples, templates, rng)
-    sel = [[scene.index[d["image_id"]], scene.index[d["image_id"]], j] for d in draws for j in d["positions"]]
-    if not sel:
-        return []
-    dev = scene.device
-    sel_t = torch.tensor(sel, dtype=torch.int32, device=dev)
-    vert = engine.select_common_point(vis["bits"], sel_t)
-    samples = torch.stack([vert, sel_t[:, 0]], 1).contiguous()
-    uv, d, ok = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw, samples)
-    uv, d, ok, vert = uv.cpu().numpy(), d.cpu().numpy(), ok.cpu().numpy().astype(bool), vert.cpu().numpy()
+def depth_estimation_records_fn(scene_id: str, image_ids: Sequence[str], n_visible, numeric_fn, image_hw,
+                                max_samples: int = -1, templates: T.TemplateSet = T.DEPTH_ESTIMATION, rng=_random,
+                                max_n_points_per_image: int = 1, on_skip=None) -> List[dict]:
+    """DE_C.generate_qa_training_single_scene with the numerics behind ``numeric_fn`` (see
+    ``depth_comparison_records``); ``n_visible`` is only indexed for the images that get sampled."""
+    draws = depth_estimation_draws(image_ids, n_visible, max_samples, templates, rng, max_n_points_per_image)
+    numerics = numeric_fn([(d["image_id"], j) for d in draws for j in d["positions"]])
     records, s = [], 0
     for dr in draws:
         for pick in dr["picks"]:
-            if ok[s]:
-                records.append(depth_estimation_record(scene_id, dr["image_id"], int(vert[s]), uv[s], float(d[s]), pick,
-                                                       image_hw, templates))
+            vertex, uv_row, depth_m = numerics[s]
             s += 1
+            if uv_row is None:
+                if on_skip is not None:
+                    on_skip(scene_id, dr["image_id"], [int(vertex)])
+                continue
+            records.append(depth_estimation_record(scene_id, dr["image_id"], int(vertex), uv_row, float(depth_m), pick,
+                                                   image_hw, templates))
     return records
+
+
+def depth_estimation_records(scene, scene_id: str, image_hw, max_samples: int = -1,
+                             templates: T.TemplateSet = T.DEPTH_ESTIMATION, rng=_random) -> List[dict]:
+    counts = scene._visibility()["count"].cpu().numpy()
+    n_visible = {k: int(c) for k, c in zip(scene.ids, counts)}
+    return depth_estimation_records_fn(scene_id, scene.ids, n_visible, gpu_point_numerics(scene), image_hw, max_samples,
+                                       templates, rng)
+
+
+# --------------------------------------------------------------------------------------------
+# depth comparison by coordinate (DC_C = depth_perception/depth_comparison_coor_engine.py:231-343)
+# --------------------------------------------------------------------------------------------
+def _depth_comparison_images(image_ids: Sequence[str], max_samples: int, rng) -> List[str]:
+    """DC_C:237-246: with replacement when more samples than images are asked for."""
+    ids = list(image_ids)
+    if max_samples > 0:
+        if max_samples > len(ids):
+            return rng.choices(ids, k=max_samples)
+        return rng.sample(ids, max_samples)
+    return rng.sample(ids, len(ids))
+
+
+def depth_comparison_records(scene_id: str, image_ids: Sequence[str], n_visible: Dict[str, int], numeric_fn, image_hw,
+                             max_samples: int = -1, templates: T.TemplateSet = None, rng=_random,
+                             max_n_points_per_image: int = 1, on_skip=None) -> List[dict]:
+    """Records of DC_C.generate_qa_training_single_scene.
+
+    ``numeric_fn([(image_id, position), ...]) -> [(vertex, uv_row | None, depth_m), ...]`` resolves the
+    position-th visible vertex of an image and projects it (K6a + K6b for the whole batch on the GPU).
+    Upstream skips a pair whose two points round to the same depth *before* drawing its templates, so the
+    position of later draws in the ``random`` stream depends on the numerics.  The loop below therefore
+    speculates: it draws for all remaining pairs as if none were skipped, evaluates them in one batch,
+    accepts everything up to the first skipped pair, rewinds the generator to just after that pair's vertex
+    draw and goes on from there.  Skips are rare (equal millimetre depths), so this is one batch in practice.
+    """
+    templates = templates or T.DEPTH_COMPARISON
+    H, W = image_hw
+    sampled = _depth_comparison_images(image_ids, max_samples, rng)
+    slots = [(img, r) for img in sampled for r in range(max_n_points_per_image)]
+    records: List[dict] = []
+    start = 0
+    while start < len(slots):
+        base_state = rng.getstate()
+        plan = []
+        for img, _ in slots[start:]:
+            state = rng.getstate()
+            pos = sample_indices(int(n_visible[img]), 2, rng)                 # random.sample(visible_points, 2)
+            after_pick = rng.getstate()
+            letters = ["A", "B"]
+            rng.shuffle(letters)
+            order = sample_indices(2, 2, rng)                                 # random.sample(points_info, 2)
+            closer_q = rng.choice([True, False])
+            kind = "closer" if closer_q else "farther"
+            qi = rng.choice(range(len(templates.questions[kind])))
+            ai = rng.choice(range(len(templates.answers[kind])))
+            ti = rng.choice(range(len(templates.task_description)))
+            plan.append({"image_id": img, "pos": pos, "after_pick": after_pick, "letters": letters, "order": order,
+                         "closer_q": closer_q, "kind": kind, "picks": (qi, ai, ti), "state": state})
+        numerics = numeric_fn([(p["image_id"], j) for p in plan for j in p["pos"]])
+        skipped_at = None
+        for n, p in enumerate(plan):
+            info, verts = [], []
+            for i in range(2):
+                vertex, uv_row, depth_m = numerics[2 * n + i]
+                verts.append(int(vertex))
+                if uv_row is None:                                            # DC_C:260-266
+                    continue
+                info.append({"x": round((uv_row[0] / W) * 1000), "y": round((uv_row[1] / H) * 1000),
+                             "depth": round(depth_m * 1000), "coords": (int(uv_row[0]), int(uv_row[1])),
+                             "letter": chr(65 + i)})
+            if len(info) != 2 or info[0]["depth"] == info[1]["depth"]:        # DC_C:279-284
+                if on_skip is not None:
+                    on_skip(scene_id, p["image_id"], verts)
+                skipped_at = n
+                break
+            shuffled = [info[k] for k in p["order"]]
+            for i, pi in enumerate(shuffled):
+                pi["letter"] = p["letters"][i]
+            p1, p2 = shuffled
+            closer = p1 if p1["depth"] <= p2["depth"] else p2
+            farther = p2 if p1["depth"] <= p2["depth"] else p1
+            correct = closer if p["closer_q"] else farther
+            qi, ai, ti = p["picks"]
+            question = templates.questions[p["kind"]][qi].format(x1=p1["x"], y1=p1["y"], x2=p2["x"], y2=p2["y"])
+            answer = templates.answers[p["kind"]][ai].format(correct_x=correct["x"], correct_y=correct["y"])
+            records.append({
+                "id": f"{scene_id}_{p['image_id']}_p{verts[0]}_p{verts[1]}",
+                "image": [f"{scene_id}/{p['image_id']}.jpg"],
+                "conversations": [{"from": "human", "value": f"{templates.task_description[ti]}\n{question}"},
+                                  {"from": "gpt", "value": answer}],
+                "height_list": [H],
+                "width_list": [W],
+                "question_type": "depth_comparison_coordinate",
+                "gt_value": [correct["x"], correct["y"]],
+                "points_info": shuffled,
+                "is_closer_question": p["closer_q"],
+            })
+        if skipped_at is None:
+            break
+        rng.setstate(plan[skipped_at]["after_pick"])       # the skipped pair consumed its vertex draw only
+        start += skipped_at + 1
+    return records
+
+
+def gpu_point_numerics(scene):
+    """numeric_fn for the depth heads: position-th visible vertex of an image (K6a) and its projection (K6b)."""
+    import torch
+    from . import engine
+
+    def fn(samples):
+        if not samples:
+            return []
+        vis = scene._visibility()
+        sel = torch.tensor([[scene.index[i], scene.index[i], j] for i, j in samples], dtype=torch.int32, device=scene.device)
+        vert = engine.select_common_point(vis["bits"], sel)
+        uv, d, ok = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw,
+                                           torch.stack([vert, sel[:, 0]], 1).contiguous())
+        uv, d, ok, vert = uv.cpu().numpy(), d.cpu().numpy(), ok.cpu().numpy().astype(bool), vert.cpu().numpy()
+        return [(int(vert[s]), uv[s] if ok[s] else None, float(d[s])) for s in range(len(samples))]
+    return fn
+
+
+def list_point_numerics(scene, visible_points):
+    """numeric_fn over the on-disk visibility index: ``visible_points(image_id)`` is the image's vertex list as the
+    reference reads it (VisibilityInfoHandler.get_image_to_points_info); projection + visibility check on the GPU (K6b)."""
+    import torch
+    from . import engine
+
+    def fn(samples):
+        if not samples:
+            return []
+        vert = [int(visible_points(i)[j]) for i, j in samples]
+        smp = torch.tensor([[v, scene.index[i]] for v, (i, _) in zip(vert, samples)], dtype=torch.int32, device=scene.device)
+        uv, d, ok = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw, smp)
+        uv, d, ok = uv.cpu().numpy(), d.cpu().numpy(), ok.cpu().numpy().astype(bool)
+        return [(vert[s], uv[s] if ok[s] else None, float(d[s])) for s in range(len(samples))]
+    return fn
+
+
+def depth_comparison_records_gpu(scene, scene_id: str, image_hw, max_samples: int = -1, templates: T.TemplateSet = None,
+                                 rng=_random, on_skip=None) -> List[dict]:
+    counts = scene._visibility()["count"].cpu().numpy()
+    n_visible = {k: int(c) for k, c in zip(scene.ids, counts)}
+    return depth_comparison_records(scene_id, scene.ids, n_visible, gpu_point_numerics(scene), image_hw, max_samples,
+                                    templates, rng, on_skip=on_skip)
 
 
 # --------------------------------------------------------------------------------------------

@@ -125,6 +125,12 @@ def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None,
         recs.extend(heads.depth_estimation_records(resident[s], scenes[s].scene_id, scenes[s].color_hw,
                                                    depth_images_per_scene, T.DEPTH_ESTIMATION, rng))
     outputs["depth_estimation_coor"] = recs
+    recs = []
+    for s in mine:
+        rng = random.Random(f"{seed}:depthcmp:{s}")
+        recs.extend(heads.depth_comparison_records_gpu(resident[s], scenes[s].scene_id, scenes[s].color_hw,
+                                                       depth_images_per_scene, T.DEPTH_COMPARISON, rng))
+    outputs["depth_comparison_coor"] = recs
 
     # ---- object perception: visibility + coverage + records, per scene (COVIS / COV / OPE) ----------
     if object_perception:

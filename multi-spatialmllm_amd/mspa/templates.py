@@ -90,6 +90,18 @@ DEPTH_ESTIMATION = TemplateSet(
                            "How far from the camera, in millimetres, is the point [ {x1} , {y1} ]?"]},
     answers={"default": ["`{depth}` mm.", "The point [ {x1} , {y1} ] is `{depth}` mm away."]})
 
+DEPTH_COMPARISON = TemplateSet(
+    task_description=["<image>\nTwo points of the image are given by their coordinates; compare their distance to the "
+                      "camera. " + _COORD_NOTE,
+                      "<image>\nDecide which of two image points lies nearer to or farther from the camera. " + _COORD_NOTE],
+    questions={"closer": ["Which of [ {x1} , {y1} ] and [ {x2} , {y2} ] is closer to the camera?",
+                          "Of the points [ {x1} , {y1} ] and [ {x2} , {y2} ], which one is nearer?"],
+               "farther": ["Which of [ {x1} , {y1} ] and [ {x2} , {y2} ] is farther from the camera?",
+                           "Of the points [ {x1} , {y1} ] and [ {x2} , {y2} ], which one is more distant?"]},
+    answers={"closer": ["`[ {correct_x} , {correct_y} ]` is closer.", "The nearer point is `[ {correct_x} , {correct_y} ]`."],
+             "farther": ["`[ {correct_x} , {correct_y} ]` is farther.",
+                         "The more distant point is `[ {correct_x} , {correct_y} ]`."]})
+
 OBJECT_MOVEMENT_TYPES = ("tapvid3d_total_distance", "tapvid3d_displacement_vector")
 
 OBJECT_MOVEMENT = TemplateSet(

@@ -154,6 +154,7 @@ def _import_reference_modules():
     ns.VC_C = importlib.import_module(
         "spatial_engine.visual_correspondence.visual_correspondence_qa_engine_coor_2_coor")
     ns.DE_C = importlib.import_module("spatial_engine.depth_perception.depth_estimation_coor_engine")
+    ns.DC_C = importlib.import_module("spatial_engine.depth_perception.depth_comparison_coor_engine")
     assert ns.IH.__file__.startswith(REFERENCE_ROOT), ns.IH.__file__
     return ns
 

@@ -130,6 +130,80 @@ def test_depth_estimation_head(world):
     assert got == want and len(got) == 5
 
 
+def _oracle_numeric_fn(sc, vis):
+    def fn(samples):
+        out = []
+        for image_id, j in samples:
+            v = vis["image_to_points"][image_id][j]
+            uv, d = O.point_2d_in_image(sc.points[v], sc.K, sc.A @ sc.E[image_id], sc.depth[image_id], sc.color_hw)
+            out.append((v, uv[0], float(d[0])))
+        return out
+    return fn
+
+
+def test_depth_comparison_head(world):
+    sc, scene, rows, vis = world
+    ids = O.valid_image_ids(sc.E)
+    n_visible = {k: len(vis["image_to_points"][k]) for k in ids}
+    random.seed(21)
+    got = heads.depth_comparison_records_gpu(scene, sc.scene_id, sc.color_hw, max_samples=40)
+    end_state = random.getstate()
+    random.seed(21)
+    want = heads.depth_comparison_records(sc.scene_id, ids, n_visible, _oracle_numeric_fn(sc, vis), sc.color_hw, 40)
+    assert got == want and len(got) >= 38 and random.getstate() == end_state
+    r = got[0]
+    assert r["question_type"] == "depth_comparison_coordinate" and len(r["points_info"]) == 2
+    assert {p["letter"] for p in r["points_info"]} == {"A", "B"}
+
+
+def test_depth_facade_engines(world, tmp_path):
+    """spatial_engine.depth_perception.* engines: scene handler + visibility index in, JSONL out."""
+    import importlib
+    import json
+    import pickle
+    sc, scene, rows, vis = world
+    IH = importlib.import_module("spatial_engine.utils.scannet_utils.handler.info_handler")
+    IMG = importlib.import_module("spatial_engine.utils.scannet_utils.handler._images")
+    DE = importlib.import_module("spatial_engine.depth_perception.depth_estimation_coor_engine")
+    DC = importlib.import_module("spatial_engine.depth_perception.depth_comparison_coor_engine")
+    posed, inst = str(tmp_path / "posed_images"), str(tmp_path / "inst")
+    import os
+    os.makedirs(os.path.join(inst, sc.scene_id))
+    np.save(os.path.join(inst, sc.scene_id, "aligned_points.npy"), sc.points)
+    H, W = sc.color_hw
+    for i in sc.image_ids:
+        IMG.register(os.path.join(posed, sc.scene_id, f"{i}.jpg"), np.zeros((H, W, 3), np.uint8))
+        IMG.register(os.path.join(posed, sc.scene_id, f"{i}.png"), sc.depth[i])
+    info_path, vis_path = str(tmp_path / "infos.pkl"), str(tmp_path / "vis.pkl")
+    with open(info_path, "wb") as f:
+        pickle.dump({sc.scene_id: sc.info_dict()}, f)
+    with open(vis_path, "wb") as f:
+        pickle.dump({sc.scene_id: vis}, f)
+    ids = O.valid_image_ids(sc.E)
+    n_visible = {k: len(vis["image_to_points"][k]) for k in ids}
+    for mod, cls, name in ((DE, "DepthEstimationCoorQAEngine", "depth_estimation_coor"),
+                           (DC, "DepthComparisonCoorQAEngine", "depth_comparison_coor")):
+        eng = getattr(mod, cls)(info_path, all_max_samples=12, visibility_info_path=vis_path, warning_file=str(tmp_path / "w.txt"))
+        eng.scene_info.posed_images_root, eng.scene_info.instance_data_root = posed, inst
+        random.seed(31)
+        eng.generate_qa_training_data(str(tmp_path / "train"))
+        recs = [json.loads(line) for line in open(tmp_path / "train" / f"{name}.jsonl")]
+        # the same thing from oracle numerics: one scene, max_samples = 12 // 1 + 1 = 13 images (with replacement for DC)
+        random.seed(31)
+        if name == "depth_estimation_coor":
+            want = heads.depth_estimation_records_fn(sc.scene_id, ids, n_visible, _oracle_numeric_fn(sc, vis), sc.color_hw, 13)
+        else:
+            want = heads.depth_comparison_records(sc.scene_id, ids, n_visible, _oracle_numeric_fn(sc, vis), sc.color_hw, 13)
+        if len(want) > 12:
+            want = random.sample(want, 12)
+        random.shuffle(want)
+        assert recs == json.loads(json.dumps(want)) and len(recs) >= 5
+        random.seed(32)
+        eng.generate_qa_eval_data(str(tmp_path / "val"))
+        ev = [json.loads(line) for line in open(tmp_path / "val" / f"{name}.jsonl")]
+        assert ev and all("text" in r for r in ev)
+
+
 def test_object_movement_head():
     tr = synth.make_tracks(21, T=18, P=30)
     world = O.tracks_cam_to_world(tr.tracks_XYZ, tr.extrinsics_w2c)
@@ -198,7 +272,7 @@ def test_pipeline_end_to_end_and_sharding_invariance(tmp_path):
     counts = pipeline.run(_pipeline_scenes(), single, None, DEV, seed=3, n_camera=24, n_correspondence=24,
                           depth_images_per_scene=3)
     base = {"camera_movement_total_distance", "camera_movement_displacement_vector",
-            "visual_correspondence_coor_2_coor", "depth_estimation_coor"}
+            "visual_correspondence_coor_2_coor", "depth_estimation_coor", "depth_comparison_coor"}
     perception = set(counts) - base
     assert base <= set(counts) and perception and all(n.startswith("object_perception_") for n in perception)
     assert any(n.startswith("object_perception_height_k1") for n in perception)

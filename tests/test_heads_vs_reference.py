@@ -115,6 +115,50 @@ def test_depth_estimation_records(ref, world, tmp_path):
     assert got == want and len(got) == 4
 
 
+@pytest.mark.parametrize("quantum", [0.0, 0.5])
+def test_depth_comparison_records(ref, world, tmp_path, quantum):
+    """DC_C.generate_qa_training_single_scene; with ``quantum`` both sides round depths to 0.5 m so that many pairs
+    tie and are skipped mid-stream -- the rewind of the speculative draw loop is what is under test."""
+    sc, h, rows, vis = world
+    vis_path = os.path.join(h._mspa_root, "vis.pkl")
+    RH.register_pickle(vis_path, {sc.scene_id: vis})
+    eng = ref.DC_C.DepthComparisonCoorQAEngine(h._mspa_info_path, visibility_info_path=vis_path,
+                                               warning_file=str(tmp_path / "w.txt"))
+    eng.scene_info.posed_images_root = h.posed_images_root
+    eng.scene_info.instance_data_root = h.instance_data_root
+    eng.max_samples = 60                       # more than the scene has images: drawn with replacement (DC_C:239-241)
+    if quantum:
+        plain = eng.scene_info.get_point_2d_coordinates_in_image
+
+        def quantised(*a, **k):
+            uv, d = plain(*a, **k)
+            return uv, np.round(d / quantum) * quantum
+        eng.scene_info.get_point_2d_coordinates_in_image = quantised
+    tpl = T.TemplateSet(list(eng.task_description),
+                        {"closer": list(eng.templates["closer_questions"]), "farther": list(eng.templates["farther_questions"])},
+                        {"closer": list(eng.templates["closer_answers"]), "farther": list(eng.templates["farther_answers"])})
+    random.seed(13)
+    want = eng.generate_qa_training_single_scene(sc.scene_id)
+    state_ref = random.getstate()
+    ids = O.valid_image_ids(sc.E)
+    n_visible = {k: len(vis["image_to_points"][k]) for k in ids}
+
+    def numeric_fn(samples):
+        out = []
+        for image_id, j in samples:
+            v = vis["image_to_points"][image_id][j]
+            uv, d = O.point_2d_in_image(sc.points[v], sc.K, sc.A @ sc.E[image_id], sc.depth[image_id], sc.color_hw)
+            d = float(d[0]) if not quantum else float(np.round(d[0] / quantum) * quantum)
+            out.append((v, uv[0], d))
+        return out
+    skipped = []
+    random.seed(13)
+    got = heads.depth_comparison_records(sc.scene_id, ids, n_visible, numeric_fn, sc.color_hw, 60, tpl,
+                                         on_skip=lambda *a: skipped.append(a))
+    assert got == want and random.getstate() == state_ref
+    assert len(got) + len(skipped) == 60 and (len(skipped) >= 2 if quantum else True)
+
+
 def test_object_movement_records(ref):
     tr = synth.make_tracks(21, T=18, P=30)
     H, W = tr.image_hw
