@@ -6,7 +6,7 @@ reprojection -> depth-buffer visibility) over one batch of synthetic 640x480 RGB
 are already resident in HBM.  Workload = BASELINE.json configs[1]: visual_correspondence on 1k
 640x480 pairs, one MI355X.  With --gpus N (launched by torch.distributed.run, one rank per GPU)
 every rank processes its own batch of the same size (weak scaling, pairs shard embarrassingly) and
-the per-pair records are collated with one RCCL all_gather per step.
+the per-pair records of the whole job are collated with one RCCL all_gather inside the timed region.
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement) with two extra objects:
   roofline      algorithmic HBM bytes of the K3 launch / its HIP-event-measured duration vs 8 TB/s
@@ -126,53 +126,51 @@ def time_variant(variant, mode, depth, mats, rgb, pairs, steps, warmup, dist_ctx
     from mspa import _lib
     spec = VARIANTS[variant]
     flags = _lib.PAIR_FAST if mode == "fast" else 0
-    # two output sets: with N > 1 the collation of step k (RCCL all_gather of the per-pair records, enqueued
-    # asynchronously) overlaps the kernel of step k+1, which writes the other set
-    n_buf = 2 if dist_ctx is not None else 1
-    outs = [engine.alloc_pair_outputs(pairs.shape[0], (H, W), spec["outputs"], depth.device) for _ in range(n_buf)]
-    gathered = [None] * n_buf
-    works = [None] * n_buf
+    # With N > 1 every step's per-pair records land in one job-level table [steps, pairs, 2] (the kernel writes its
+    # slice directly) which is collated ONCE, inside the timed region, with a single RCCL all_gather -- the
+    # pipeline's exchange step is per job (mspa/pipeline.py), not per launch.  (Collating after every launch was
+    # measured at +13 % per step: the RCCL kernel competes with K3 for CUs and HBM.)
+    n = pairs.shape[0]
+    out = engine.alloc_pair_outputs(n, (H, W), spec["outputs"], depth.device)
+    job_counts = torch.zeros((max(steps, warmup, 1), n, 2), dtype=torch.int32, device=depth.device) \
+        if dist_ctx is not None else None
     rgb_in = rgb if spec["rgb"] else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    state = {"n": 0}
 
-    def step(k=None):
-        b = state["n"] % n_buf
-        state["n"] += 1
-        if works[b] is not None:
-            works[b].wait()                       # stream-level: the records of two steps ago are collated
-        if k is not None:
+    def step(k, timed):
+        if job_counts is not None:
+            out["counts"] = job_counts[k]
+        if timed:
             ev[k][0].record()
-        engine.pair_reproject(depth, mats, pairs, (H, W), outs[b], rgb=rgb_in, flags=flags)
-        if k is not None:
+        engine.pair_reproject(depth, mats, pairs, (H, W), out, rgb=rgb_in, flags=flags)
+        if timed:
             ev[k][1].record()
-        if dist_ctx is not None:
-            gathered[b], works[b] = shard.collate_records_async(outs[b]["counts"], dist_ctx, gathered[b])
 
-    def drain():
-        for w in works:
-            if w is not None:
-                w.wait()
+    def collate(n_steps):
+        if dist_ctx is None:
+            return None
+        table, work = shard.collate_records_async(job_counts[:n_steps].reshape(n_steps * n, 2), dist_ctx)
+        work.wait()                              # orders the stream after the collective; the host does not block
+        return table
 
-    for _ in range(warmup):
-        step()
-    drain()
+    for k in range(warmup):
+        step(k, False)
+    collate(max(warmup, 1))                      # also warms the communicator up
     if dist_ctx is not None:
         dist_ctx.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(steps):
-        step(k)
-    drain()
+        step(k, True)
+    table = collate(steps)
     torch.cuda.synchronize()
     if dist_ctx is not None:
         dist_ctx.barrier()
     wall = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    if dist_ctx is not None and dist_ctx.rank == 0:      # the collated table really holds every rank's records
-        g = gathered[(state["n"] - 1) % n_buf]
-        assert g.shape[0] == dist_ctx.world * pairs.shape[0] and int(g[:, 0].min()) > 0
-    return wall, kern_ms, outs[(state["n"] - 1) % n_buf]
+    if table is not None and dist_ctx.rank == 0:         # the collated table really holds every rank's records
+        assert table.shape[0] == dist_ctx.world * steps * n and int(table[:, 0].min()) > 0
+    return wall, kern_ms, out
 
 
 def time_scene_kernels(device, n_points=131072, n_frames=320, reps=5):
@@ -375,7 +373,7 @@ def main():
                        "variant": args.variant, "mode": args.mode, "outputs": list(spec["outputs"]),
                        "pairs_per_step_per_gpu": args.pairs, "pair_offsets": args.pair_offsets, "distinct_frames_per_gpu": int(depth.shape[0]),
                        "image": "640x480 depth u16 (+rgb u8x3 for dense)", "parallelism": f"dp{world}",
-                       "collation": "RCCL all_gather of per-pair records per step, overlapped with the next step" if world > 1 else "none (1 GPU)"},
+                       "collation": "one RCCL all_gather of the job's per-pair records inside the timed region" if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "mspa::pair_fast_tight_kernel" if args.mode == "fast" else "mspa::pair_exact_kernel",
