@@ -234,6 +234,17 @@ __device__ __forceinline__ bool decode_block(const PairArgs &a, int64_t &pair, u
     return pair < a.n_pairs;
 }
 
+// 16-byte buffer store + guard.  Observed on gfx950 (a variant of the tight kernel that issued this store at the end
+// of a basic block whose successor began with a VALU write to the first data VGPR): lanes 12..15 of every 16 stored
+// the NEW value of that VGPR -- the store was still reading its data.  LLVM's hazard recognizer inserts the wait
+// state for > 64-bit stores only when soffset is an immediate; with an SGPR soffset it assumes none is needed.
+// One s_nop after the store keeps any following VALU write clear of the data registers.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buffer_store_b128_guarded(u32x4_t q, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(q, rs, voff, soff, 0);
+    asm volatile("s_nop 1");
+}
+
 // depth sample of frame 1 under colour pixel (mx, my): OPS:272-294
 template <bool IDENT>
 __device__ __forceinline__ uint32_t sample_depth1(const PairArgs &a, const uint16_t *__restrict__ depth1, uint32_t ic,
@@ -798,7 +809,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                         __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rs_bits, bits_voff,
                                                               (int)((rowg * wpr + stripe) * 8u), 0);
                     if (O::template has<O_PIX>(a.pix_i16))
-                        __builtin_amdgcn_raw_buffer_store_b128(none, rs_pix, pix_voff, (int)(rowg * Wb * 4u), 0);
+                        buffer_store_b128_guarded(none, rs_pix, pix_voff, (int)(rowg * Wb * 4u));
                 }
             }
         }
@@ -855,7 +866,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                 if (O::template has<O_PIX>(a.pix_i16)) {
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                     const u32x4 none = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-                    __builtin_amdgcn_raw_buffer_store_b128(none, rs_pix, pix_voff, (int)(rowg * Wb * 4u), 0);
+                    buffer_store_b128_guarded(none, rs_pix, pix_voff, (int)(rowg * Wb * 4u));
                 }
 #pragma unroll
                 for (int j = 0; j < kRowGroup; ++j) {
@@ -954,7 +965,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                 if (O::template has<O_PIX>(a.pix_i16)) {
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                     const u32x4 q = *reinterpret_cast<const u32x4 *>(&lds_px[wave][c.lane * 4]);
-                    __builtin_amdgcn_raw_buffer_store_b128(q, rs_pix, pix_voff, (int)(rowg * Wb * 4u), 0);
+                    buffer_store_b128_guarded(q, rs_pix, pix_voff, (int)(rowg * Wb * 4u));
                 }
             }
         }
