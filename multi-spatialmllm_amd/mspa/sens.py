@@ -1,0 +1,185 @@
+"""ScanNet ``.sens`` streams -> posed RGB-D frames, without the detour over PNG / JPEG / text files.
+
+Reference: spatial_engine/utils/scannet_utils/extract_posed_images.py (SENS).  Upstream unpacks every frame of a
+scene into ``posed_images/<scene>/{idx}.jpg|.png|.txt`` (SENS:59-157), a second script keeps every 5th of
+those and parses the pose text back into the scene-info pickle (update_info_file_with_images.py:30-68, UPD),
+and the task scripts re-read the PNGs frame by frame.  Here one pass over the file yields the depth frames as
+one uint16 block ready for ``engine.depth_to_device`` and the scene-info entries the handler expects --
+including the ``%f`` text round trip the poses and intrinsics go through upstream (six decimals; that rounding
+is part of the reference's numbers, SENS:138-142 + UPD:32-35,50-53).
+
+File layout (version 4, little endian; SENS:68-104, 31-48):
+    u32 version | u64 strlen | sensor name | 4 x float32[16] (intrinsic_color, extrinsic_color, intrinsic_depth,
+    extrinsic_depth) | i32 colour compression | i32 depth compression | u32 colour W, H | u32 depth W, H |
+    f32 depth_shift | u64 n_frames | n_frames x { float32[16] camera_to_world | u64 t_colour | u64 t_depth |
+    u64 colour bytes | u64 depth bytes | colour payload | depth payload }
+"""
+from __future__ import annotations
+
+import dataclasses
+import io
+import os
+import struct
+import zlib
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+VERSION = 4
+COLOR_COMPRESSION = {-1: "unknown", 0: "raw", 1: "png", 2: "jpeg"}
+DEPTH_COMPRESSION = {-1: "unknown", 0: "raw_ushort", 1: "zlib_ushort", 2: "occi_ushort"}
+_FRAME_HEAD = struct.Struct("<16f4Q")
+
+
+@dataclasses.dataclass
+class SensScene:
+    sensor_name: bytes
+    intrinsic_color: np.ndarray        # [4,4] float32
+    extrinsic_color: np.ndarray
+    intrinsic_depth: np.ndarray
+    extrinsic_depth: np.ndarray
+    color_compression: str
+    depth_compression: str
+    color_hw: tuple
+    depth_hw: tuple
+    depth_shift: float
+    n_frames_total: int
+    frame_index: List[int]             # indices into the stream of the frames kept (0, skip, 2*skip, ...)
+    camera_to_world: np.ndarray        # [F,4,4] float32
+    timestamps: np.ndarray             # [F,2] uint64 (colour, depth)
+    depth: np.ndarray                  # [F,DH,DW] uint16
+    color_jpeg: Optional[List[bytes]]  # undecoded payloads (None if not requested)
+
+    @staticmethod
+    def index_to_str(index: int) -> str:
+        return str(index).zfill(5)     # SENS:133-135
+
+
+def read_sens(path: str, frame_skip: int = 1, want_color: bool = False) -> SensScene:
+    """Parse a .sens file keeping every ``frame_skip``-th frame (SENS:106-116).  Skipped frames are seeked over,
+    depth payloads are inflated straight into one [F, DH, DW] uint16 array."""
+    with open(path, "rb") as f:
+        (version,) = struct.unpack("<I", f.read(4))
+        if version != VERSION:
+            raise AssertionError(f"unsupported .sens version {version}")          # SENS:71
+        (strlen,) = struct.unpack("<Q", f.read(8))
+        name = f.read(strlen)
+        mats = [np.frombuffer(f.read(64), dtype="<f4").reshape(4, 4).copy() for _ in range(4)]
+        c_comp, d_comp = struct.unpack("<ii", f.read(8))
+        cw, ch, dw, dh = struct.unpack("<IIII", f.read(16))
+        (shift,) = struct.unpack("<f", f.read(4))
+        (n_frames,) = struct.unpack("<Q", f.read(8))
+        color_compression, depth_compression = COLOR_COMPRESSION[c_comp], DEPTH_COMPRESSION[d_comp]
+        keep = list(range(0, n_frames, frame_skip))
+        keep_set = set(keep)
+        poses = np.empty((len(keep), 4, 4), dtype=np.float32)
+        stamps = np.empty((len(keep), 2), dtype=np.uint64)
+        depth = np.empty((len(keep), dh, dw), dtype=np.uint16)
+        jpeg: Optional[List[bytes]] = [] if want_color else None
+        k = 0
+        for i in range(n_frames):
+            head = f.read(_FRAME_HEAD.size)
+            if len(head) != _FRAME_HEAD.size:
+                raise ValueError(f"{path}: truncated at frame {i}")
+            vals = _FRAME_HEAD.unpack(head)
+            c_bytes, d_bytes = vals[18], vals[19]
+            if i not in keep_set:
+                f.seek(c_bytes + d_bytes, os.SEEK_CUR)
+                continue
+            poses[k] = np.asarray(vals[:16], dtype=np.float32).reshape(4, 4)
+            stamps[k] = (vals[16], vals[17])
+            if want_color:
+                jpeg.append(f.read(c_bytes))
+            else:
+                f.seek(c_bytes, os.SEEK_CUR)
+            payload = f.read(d_bytes)
+            if depth_compression == "zlib_ushort":
+                raw = zlib.decompress(payload)
+            elif depth_compression == "raw_ushort":
+                raw = payload
+            else:
+                raise AssertionError(f"depth compression {depth_compression} not supported")   # SENS:51
+            depth[k] = np.frombuffer(raw, dtype="<u2").reshape(dh, dw)
+            k += 1
+    return SensScene(name, mats[0], mats[1], mats[2], mats[3], color_compression, depth_compression, (ch, cw), (dh, dw),
+                     float(shift), int(n_frames), keep, poses, stamps, depth, jpeg)
+
+
+def text_roundtrip(matrix: np.ndarray) -> np.ndarray:
+    """What a float32 matrix becomes after ``np.savetxt(fmt="%f")`` (SENS:138-142) and ``float(token)`` (UPD:32-35):
+    float64 values rounded to six decimals; +-inf survive as +-inf."""
+    m = np.asarray(matrix)
+    return np.array([[float("%f" % v) for v in row] for row in m], dtype=np.float64)
+
+
+def matrix_text(matrix: np.ndarray) -> str:
+    """The text upstream writes for a pose / intrinsic matrix (one ``%f`` row per line, SENS:138-142)."""
+    buf = io.StringIO()
+    for line in np.asarray(matrix):
+        np.savetxt(buf, line[np.newaxis], fmt="%f")
+    return buf.getvalue()
+
+
+def scene_info_entries(scene_id: str, sens: SensScene, image_frame_skip: int = 5) -> dict:
+    """num_posed_images / images_info / intrinsic_matrix of one scene as UPD:20-68 builds them from the exported
+    folder: frames are named by their position among the exported ones, every ``image_frame_skip``-th is kept."""
+    images = {}
+    for k in range(0, len(sens.frame_index), image_frame_skip):
+        image_id = SensScene.index_to_str(k)
+        images[image_id] = {"image_path": f"posed_images/{scene_id}/{image_id}.jpg",
+                            "depth_image_path": f"posed_images/{scene_id}/{image_id}.png",
+                            "extrinsic_matrix": text_roundtrip(sens.camera_to_world[k])}
+    return {"num_posed_images": len(images), "images_info": images,
+            "intrinsic_matrix": text_roundtrip(sens.intrinsic_color)}
+
+
+def depth_frames(sens: SensScene, image_frame_skip: int = 5) -> Dict[str, np.ndarray]:
+    """{image_id: uint16 depth frame} for the frames ``scene_info_entries`` keeps (views, no copies)."""
+    return {SensScene.index_to_str(k): sens.depth[k] for k in range(0, len(sens.frame_index), image_frame_skip)}
+
+
+def export_posed_images(sens: SensScene, output_path: str, with_depth_png: bool = True):
+    """The folder extract_posed_images.process_scene leaves behind (SENS:161-178): intrinsic.txt, {idx}.txt,
+    {idx}.png (16-bit) and -- when the colour payloads were read -- {idx}.jpg.  The JPEG payload is written as
+    stored in the stream instead of being decoded and re-encoded."""
+    os.makedirs(output_path, exist_ok=True)
+    with open(os.path.join(output_path, "intrinsic.txt"), "w") as f:
+        f.write(matrix_text(sens.intrinsic_color))
+    for k in range(len(sens.frame_index)):
+        stem = os.path.join(output_path, SensScene.index_to_str(k))
+        with open(stem + ".txt", "w") as f:
+            f.write(matrix_text(sens.camera_to_world[k]))
+        if sens.color_jpeg is not None:
+            with open(stem + ".jpg", "wb") as f:
+                f.write(sens.color_jpeg[k])
+        if with_depth_png:
+            from PIL import Image
+            Image.fromarray(sens.depth[k]).save(stem + ".png")
+
+
+def write_sens(path: str, intrinsic_color: np.ndarray, camera_to_world: Sequence[np.ndarray], depth: Sequence[np.ndarray],
+               color_hw=(968, 1296), color_payloads: Optional[Sequence[bytes]] = None, sensor_name: bytes = b"synthetic",
+               depth_shift: float = 1000.0, depth_compression: int = 1):
+    """Write a version-4 stream (for tests and synthetic scenes); the inverse of ``read_sens``."""
+    depth = [np.ascontiguousarray(d, dtype="<u2") for d in depth]
+    dh, dw = depth[0].shape
+    eye = np.eye(4, dtype="<f4")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", VERSION))
+        f.write(struct.pack("<Q", len(sensor_name)))
+        f.write(sensor_name)
+        f.write(np.asarray(intrinsic_color, dtype="<f4").tobytes())
+        f.write(eye.tobytes())
+        f.write(np.asarray(intrinsic_color, dtype="<f4").tobytes())
+        f.write(eye.tobytes())
+        f.write(struct.pack("<ii", 2, depth_compression))
+        f.write(struct.pack("<IIII", color_hw[1], color_hw[0], dw, dh))
+        f.write(struct.pack("<f", depth_shift))
+        f.write(struct.pack("<Q", len(depth)))
+        for k, d in enumerate(depth):
+            colour = color_payloads[k] if color_payloads is not None else b""
+            payload = zlib.compress(d.tobytes()) if depth_compression == 1 else d.tobytes()
+            f.write(np.asarray(camera_to_world[k], dtype="<f4").tobytes())
+            f.write(struct.pack("<QQQQ", 1000 * k, 1000 * k + 1, len(colour), len(payload)))
+            f.write(colour)
+            f.write(payload)

@@ -292,16 +292,63 @@ def golden_coverage(ns, only=None):
           "f32 == f64:", out["coverage_f32_json"] == out["coverage_f64_json"])
 
 
+def golden_sens(ns):
+    """A synthetic .sens stream parsed by the reference's SensorData: poses, intrinsics, depth frames, the text it
+    exports and what update_info_file_with_images.py parses back from that text."""
+    import tempfile
+    import warnings
+    from mspa import sens as S
+    RH.import_sens(ns)
+    sc = synth.make_scene(5151, n_points=64, n_frames=11, color_hw=(48, 64), depth_hw=(24, 32), invalid_pose_frac=0.2,
+                          with_color=False)
+    ids = sc.image_ids
+    poses = [sc.E[i].astype(np.float32) * np.float32(1.0000001) for i in ids]      # not representable in 6 decimals
+    K = sc.K.astype(np.float32)
+    tmp = tempfile.mkdtemp(prefix="mspa_sens_")
+    path = os.path.join(tmp, "scene5151_00.sens")
+    payloads = [bytes([k, 255 - k, 7]) * (5 + k) for k in range(len(ids))]
+    S.write_sens(path, K, poses, [sc.depth[i] for i in ids], color_hw=sc.color_hw, color_payloads=payloads)
+    out = {"sens_bytes": np.frombuffer(open(path, "rb").read(), dtype=np.uint8)}
+    for skip in (1, 2):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            data = ns.SENS.SensorData(path, skip)
+            folder = os.path.join(tmp, f"posed_{skip}")
+            data.export_intrinsics(folder)
+            data.export_poses(folder)
+            RH.STORE.written.clear()
+            data.export_depth_images(folder)
+        out[f"skip{skip}_c2w"] = np.stack([f.camera_to_world for f in data.frames])
+        out[f"skip{skip}_depth"] = np.stack([RH.STORE.written[os.path.join(folder, data.index_to_str(k) + ".png")]
+                                             for k in range(len(data.frames))])
+        out[f"skip{skip}_color"] = np.array([f.color_data for f in data.frames], dtype=object).astype("S")
+        texts = {name: open(os.path.join(folder, name)).read() for name in sorted(os.listdir(folder))}
+        out[f"skip{skip}_text_json"] = json.dumps(texts)
+        # update_info_file_with_images.py:30-35,48-53 -- the parse of those files, every 5th exported frame
+        parse = lambda t: np.array([list(map(float, line.split())) for line in t.splitlines()])   # noqa: E731
+        out[f"skip{skip}_info_K"] = parse(texts["intrinsic.txt"])
+        kept = [k for k in range(len(data.frames)) if k % 5 == 0]
+        out[f"skip{skip}_info_E"] = np.stack([parse(texts[data.index_to_str(k) + ".txt"]) for k in kept])
+        out[f"skip{skip}_header"] = np.array([data.color_width, data.color_height, data.depth_width, data.depth_height,
+                                              len(data.frames)])
+        assert data.depth_compression_type == "zlib_ushort" and data.color_compression_type == "jpeg"
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "sens.npz"), meta=_meta(), **out)
+    print("sens.npz:", {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     ns = RH.import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "coverage":
         return golden_coverage(ns)
+    if len(sys.argv) > 1 and sys.argv[1] == "sens":
+        return golden_sens(ns)
     golden_scene(ns, "scene_ident", 2001, (48, 64), (48, 64), n_points=700, n_frames=6, with_color=True)
     golden_scene(ns, "scene_scaled", 2002, (73, 98), (48, 64), n_points=700, n_frames=6, with_color=False)
     golden_ties(ns)
     golden_tracks(ns)
     golden_coverage(ns)
+    golden_sens(ns)
 
 
 if __name__ == "__main__":

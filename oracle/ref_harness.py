@@ -115,6 +115,15 @@ def _install_stubs():
     sys.modules["mmengine.utils"] = utils
     sys.modules["mmengine.utils.dl_utils"] = dl_utils
     sys.modules["open3d"] = types.ModuleType("open3d")
+    mmengine.exists = os.path.exists
+    # imageio is only touched by extract_posed_images.py: payloads pass through, written arrays are captured
+    imageio = types.ModuleType("imageio")
+    v2 = types.ModuleType("imageio.v2")
+    v2.imread = lambda data, *a, **k: np.frombuffer(data, dtype=np.uint8)
+    v2.imwrite = lambda path, arr, *a, **k: STORE.written.__setitem__(path, np.array(arr))
+    imageio.v2 = v2
+    sys.modules["imageio"] = imageio
+    sys.modules["imageio.v2"] = v2
 
 
 def import_reference():
@@ -156,6 +165,13 @@ def _import_reference_modules():
     ns.DE_C = importlib.import_module("spatial_engine.depth_perception.depth_estimation_coor_engine")
     ns.DC_C = importlib.import_module("spatial_engine.depth_perception.depth_comparison_coor_engine")
     assert ns.IH.__file__.startswith(REFERENCE_ROOT), ns.IH.__file__
+    return ns
+
+
+def import_sens(ns):
+    """extract_posed_images.py (the .sens reader) under the imageio stub."""
+    ns.SENS = importlib.import_module("spatial_engine.utils.scannet_utils.extract_posed_images")
+    assert ns.SENS.__file__.startswith(REFERENCE_ROOT), ns.SENS.__file__
     return ns
 
 

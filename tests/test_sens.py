@@ -1,0 +1,112 @@
+"""mspa.sens (.sens reader, scene-info entries, export) against what the reference's SensorData and
+update_info_file_with_images.py made of the same synthetic stream (tests/golden/sens.npz, oracle/gen_golden.py)."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN_DIR
+from mspa import sens as S
+
+
+@pytest.fixture(scope="module")
+def gold(tmp_path_factory):
+    z = np.load(os.path.join(GOLDEN_DIR, "sens.npz"), allow_pickle=False)
+    path = str(tmp_path_factory.mktemp("sens") / "scene5151_00.sens")
+    with open(path, "wb") as f:
+        f.write(z["sens_bytes"].tobytes())
+    return z, path
+
+
+@pytest.mark.parametrize("skip", [1, 2])
+def test_reader_matches_reference(gold, skip, tmp_path):
+    z, path = gold
+    sc = S.read_sens(path, frame_skip=skip, want_color=True)
+    cw, ch, dw, dh, n = (int(v) for v in z[f"skip{skip}_header"])
+    assert sc.color_hw == (ch, cw) and sc.depth_hw == (dh, dw) and len(sc.frame_index) == n
+    assert sc.frame_index == list(range(0, sc.n_frames_total, skip))
+    assert sc.depth_compression == "zlib_ushort" and sc.color_compression == "jpeg" and sc.sensor_name == b"synthetic"
+    assert sc.camera_to_world.dtype == np.float32
+    assert np.array_equal(sc.camera_to_world, z[f"skip{skip}_c2w"], equal_nan=True)       # -inf poses included
+    assert skip != 1 or np.isinf(sc.camera_to_world).any()
+    assert sc.depth.dtype == np.uint16 and np.array_equal(sc.depth, z[f"skip{skip}_depth"])
+    assert [bytes(c) for c in sc.color_jpeg] == [bytes(c) for c in z[f"skip{skip}_color"]]
+    # the exported folder: same text, byte for byte; the JPEG payload passes through untouched
+    out = str(tmp_path / "posed")
+    try:
+        import PIL  # noqa: F401
+        S.export_posed_images(sc, out)
+    except ImportError:
+        S.export_posed_images(sc, out, with_depth_png=False)
+    texts = json.loads(str(z[f"skip{skip}_text_json"]))
+    for name, text in texts.items():
+        assert open(os.path.join(out, name)).read() == text, name
+    assert open(os.path.join(out, "00001.jpg"), "rb").read() == sc.color_jpeg[1]
+    try:
+        from PIL import Image
+        assert np.array_equal(np.asarray(Image.open(os.path.join(out, "00002.png"))), sc.depth[2])
+    except ImportError:
+        pass
+    # scene-info entries == the parse of that text (six-decimal float64), every 5th exported frame
+    info = S.scene_info_entries("scene5151_00", sc, image_frame_skip=5)
+    assert info["intrinsic_matrix"].dtype == np.float64
+    assert np.array_equal(info["intrinsic_matrix"], z[f"skip{skip}_info_K"])
+    E = np.stack([v["extrinsic_matrix"] for v in info["images_info"].values()])
+    assert np.array_equal(E, z[f"skip{skip}_info_E"]) and info["num_posed_images"] == len(E)
+    assert list(info["images_info"]) == [f"{k:05d}" for k in range(0, n, 5)]
+    first = info["images_info"]["00000"]
+    assert first["image_path"] == "posed_images/scene5151_00/00000.jpg"
+    assert first["depth_image_path"] == "posed_images/scene5151_00/00000.png"
+    frames = S.depth_frames(sc, 5)
+    assert list(frames) == list(info["images_info"]) and np.array_equal(frames["00005"], sc.depth[5])
+
+
+def test_text_roundtrip_values():
+    m = np.array([[1.0000001, -0.1234565, np.inf, -np.inf], [0.0, -0.0, 1e-7, 123456.789]], dtype=np.float32)
+    r = S.text_roundtrip(m)
+    assert r.dtype == np.float64
+    want = [[float("%f" % v) for v in row] for row in m]
+    assert r.tolist() == want and r[0, 2] == np.inf and r[0, 3] == -np.inf
+    assert S.matrix_text(np.eye(2, dtype=np.float32)) == "1.000000 0.000000\n0.000000 1.000000\n"
+
+
+def test_write_read_roundtrip_and_errors(tmp_path):
+    rng = np.random.default_rng(3)
+    depth = [rng.integers(0, 65536, (6, 8), dtype=np.uint16) for _ in range(5)]
+    poses = [rng.normal(size=(4, 4)).astype(np.float32) for _ in range(5)]
+    K = np.eye(4, dtype=np.float32)
+    for comp in (1, 0):                                      # zlib_ushort, raw_ushort
+        path = str(tmp_path / f"s{comp}.sens")
+        S.write_sens(path, K, poses, depth, color_hw=(12, 16), depth_compression=comp)
+        sc = S.read_sens(path, frame_skip=2)
+        assert sc.color_jpeg is None and sc.frame_index == [0, 2, 4]
+        assert np.array_equal(sc.depth, np.stack(depth)[::2]) and np.array_equal(sc.camera_to_world, np.stack(poses)[::2])
+        assert sc.timestamps[1].tolist() == [2000, 2001]
+    raw = open(path, "rb").read()
+    bad = str(tmp_path / "bad.sens")
+    with open(bad, "wb") as f:
+        f.write(struct.pack("<I", 3) + raw[4:])
+    with pytest.raises(AssertionError):
+        S.read_sens(bad)
+    with open(bad, "wb") as f:
+        f.write(raw[:len(raw) - 40])
+    with pytest.raises((ValueError, Exception)):
+        S.read_sens(bad)
+
+
+@pytest.mark.gpu
+def test_sens_to_resident_scene(gold):
+    """.sens -> scene-info entries + depth block -> SceneOnDevice -> pair table, no image files in between."""
+    from mspa.scene import SceneOnDevice
+    z, path = gold
+    sc = S.read_sens(path, frame_skip=1)
+    info = S.scene_info_entries("scene5151_00", sc, image_frame_skip=2)
+    frames = S.depth_frames(sc, 2)
+    E = {k: v["extrinsic_matrix"] for k, v in info["images_info"].items()}
+    pts = np.random.default_rng(0).uniform(0, 6, (500, 3))
+    scene = SceneOnDevice(info["intrinsic_matrix"], np.eye(4), E, frames, sc.color_hw, pts, "cuda")
+    assert scene.ids == [k for k, e in E.items() if np.isfinite(e).all()] and len(scene.ids) >= 3
+    table = scene.frames_relations()
+    assert len(table) == len(scene.ids) * (len(scene.ids) - 1) // 2
