@@ -192,6 +192,18 @@ int mspa_track_displacement(const double *world, const double *w2c, const double
                             double cam_threshold, double *out, uint8_t *out_flags, mspa_stream_t stream);
 
 /*
+ * K5c -- pair mining of the object-movement head (OM_C:484-498): for each selected track point, the distance
+ * between its world positions in every two of the frames it is visible in,
+ * np.linalg.norm(points2 - points1, axis=1) over frame_pairs = [(i, j) for i < j] in that order.
+ *   world [T, P, 3] f64 (K5a);  points [n_selected] i32;  frames = the points' visible-frame lists, concatenated,
+ *   frame_offsets [n_selected+1] i32 into it;  n_frames_max = longest list;
+ *   out_offsets [n_selected+1] i64 with out_offsets[s+1]-out_offsets[s] = n_s (n_s - 1) / 2  ->  out f64
+ */
+int mspa_track_pair_distances(const double *world, int32_t T, int32_t P, const int32_t *points,
+                              const int32_t *frame_offsets, const int32_t *frames, int32_t n_selected,
+                              int32_t n_frames_max, const int64_t *out_offsets, double *out, mspa_stream_t stream);
+
+/*
  * K7 -- the accumulation inside rigid_body_segmentation (OM_C:49-92): cumulative_loss[i, j] = sum over
  * frames t >= 1 of |d_t(i,j) - d_{t-1}(i,j)| where that change exceeds smoothing_factor, d_t the Euclidean
  * distance between track points i and j at frame t.  The linkage / fcluster step stays with SciPy on the

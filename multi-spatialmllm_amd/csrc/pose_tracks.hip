@@ -96,6 +96,30 @@ __global__ __launch_bounds__(256) void track_disp_kernel(const double *__restric
     flags[2 * k + 1] = (cd < thr_cam) ? 0 : 1;     // OM_C:347-350
 }
 
+// K5c: pair mining of the object-movement head (OM_C:484-498): for a selected track point and the frames it is
+// visible in, the world-space distance between every two of those frames, in the reference's order (i < j,
+// row-major).  np.linalg.norm(points2 - points1, axis=1): sqrt((dx*dx + dy*dy) + dz*dz).
+// grid = (ceil(n_max / 16), ceil(n_max / 16), selected points), 16 x 16 threads = a tile of the (i, j) square.
+__global__ __launch_bounds__(256) void track_pair_distances_kernel(const double *__restrict__ world, int P,
+                                                                   const int32_t *__restrict__ points,
+                                                                   const int32_t *__restrict__ frame_offsets,
+                                                                   const int32_t *__restrict__ frames,
+                                                                   const int64_t *__restrict__ out_offsets,
+                                                                   double *__restrict__ out) {
+    const int s = blockIdx.z;
+    const int beg = frame_offsets[s];
+    const int n = frame_offsets[s + 1] - beg;
+    const int i = blockIdx.y * 16 + (threadIdx.x >> 4);
+    const int j = blockIdx.x * 16 + (threadIdx.x & 15);
+    if (i >= n || j >= n || j <= i) return;
+    const int p = points[s];
+    const double *a = world + ((int64_t)frames[beg + i] * P + p) * 3;
+    const double *b = world + ((int64_t)frames[beg + j] * P + p) * 3;
+    const double dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
+    const int64_t k = out_offsets[s] + (int64_t)i * n - (int64_t)i * (i + 1) / 2 + (j - i - 1);
+    out[k] = __builtin_sqrt((dx * dx + dy * dy) + dz * dz);
+}
+
 // K7: accumulated pairwise-distance change of the tracks (rigid_body_segmentation, OM_C:49-92): for every
 // point pair (i, j): sum over t >= 1 of |d_t - d_{t-1}| where it exceeds the smoothing threshold, d_t the
 // Euclidean distance of the two points at frame t (scipy pdist: sqrt((dx*dx + dy*dy) + dz*dz)).  One lane
@@ -125,6 +149,21 @@ __global__ __launch_bounds__(256) void rigidity_loss_kernel(const double *__rest
 }  // namespace mspa
 
 using namespace mspa;
+
+extern "C" int mspa_track_pair_distances(const double *world, int32_t T, int32_t P, const int32_t *points,
+                                         const int32_t *frame_offsets, const int32_t *frames, int32_t n_selected,
+                                         int32_t n_frames_max, const int64_t *out_offsets, double *out,
+                                         mspa_stream_t stream) {
+    if (T < 0 || P < 0 || n_selected < 0 || n_frames_max < 0) return fail(MSPA_EINVAL, "mspa_track_pair_distances: bad size");
+    if (n_selected == 0 || n_frames_max < 2) return MSPA_OK;
+    if (!world || !points || !frame_offsets || !frames || !out_offsets || !out)
+        return fail(MSPA_EINVAL, "mspa_track_pair_distances: null pointer");
+    if (n_selected > 65535) return fail(MSPA_EINVAL, "mspa_track_pair_distances: too many selected points for one launch");
+    const uint32_t tiles = ((uint32_t)n_frames_max + 15u) / 16u;
+    hipLaunchKernelGGL(track_pair_distances_kernel, dim3(tiles, tiles, (uint32_t)n_selected), dim3(256), 0,
+                       (hipStream_t)stream, world, P, points, frame_offsets, frames, out_offsets, out);
+    return check_hip(hipGetLastError(), "track_pair_distances_kernel launch");
+}
 
 extern "C" int mspa_track_rigidity_loss(const double *tracks_xyz, int32_t T, int32_t P, double smoothing_factor,
                                         double *out_loss, mspa_stream_t stream) {

@@ -48,6 +48,8 @@ _SIGNATURES = {
                                      c_void_p]),
     "mspa_object_extents": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mspa_track_pair_distances": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                          c_void_p, c_void_p, c_void_p]),
     "mspa_track_rigidity_loss": (c_int, [c_void_p, c_int32, c_int32, c_double, c_void_p, c_void_p]),
     "mspa_track_displacement": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64,
                                         c_double, c_double, c_void_p, c_void_p, c_void_p]),

@@ -338,3 +338,35 @@ def object_extents(vis_bits: torch.Tensor, xyz: torch.Tensor, obj_offsets: torch
                                        _ptr(obj_vertices), obj_vertices.numel(), O, _ptr(lo), _ptr(hi), _ptr(count),
                                        _stream_ptr()))
     return lo, hi, count
+
+
+def track_pair_distances(world: torch.Tensor, points: Sequence[int], visible_frames: Sequence[np.ndarray]):
+    """Enqueue K5c: for each selected point, the distances between its world positions in every two of its visible
+    frames (i < j, row-major).  Returns a list of float64 NumPy arrays, one per point (n(n-1)/2 entries)."""
+    _require_gpu()
+    lib = _lib.load()
+    assert world.dtype == torch.float64 and world.dim() == 3 and world.is_contiguous()
+    T, P, _ = world.shape
+    S = len(points)
+    if S == 0:
+        return []
+    lens = np.array([len(v) for v in visible_frames], dtype=np.int64)
+    f_off = np.zeros(S + 1, dtype=np.int64)
+    f_off[1:] = np.cumsum(lens)
+    o_off = np.zeros(S + 1, dtype=np.int64)
+    o_off[1:] = np.cumsum(lens * (lens - 1) // 2)
+    dev = world.device
+    frames = np.concatenate([np.asarray(v, dtype=np.int32) for v in visible_frames]) if f_off[-1] else np.zeros(0, np.int32)
+    if frames.size and (frames.min() < 0 or frames.max() >= T):
+        raise ValueError("frame index outside the track")
+    pts = np.asarray(points, dtype=np.int32)
+    if pts.min() < 0 or pts.max() >= P:
+        raise ValueError("point index outside the track")
+    out = torch.empty((int(o_off[-1]),), dtype=torch.float64, device=dev)
+    if o_off[-1]:
+        _lib.check(lib.mspa_track_pair_distances(
+            _ptr(world), T, P, _ptr(torch.from_numpy(pts).to(dev)), _ptr(torch.from_numpy(f_off.astype(np.int32)).to(dev)),
+            _ptr(torch.from_numpy(frames).to(dev)), S, int(lens.max()), _ptr(torch.from_numpy(o_off).to(dev)), _ptr(out),
+            _stream_ptr()))
+    host = out.cpu().numpy()
+    return [host[o_off[s]:o_off[s + 1]] for s in range(S)]

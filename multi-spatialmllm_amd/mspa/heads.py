@@ -566,3 +566,57 @@ def object_perception_records(dim_info: Dict[str, Dict], dimension_name: str, va
                         "gt_value": val_mm,
                     })
     return by_k
+
+
+def object_movement_mine_pairs(visibility: np.ndarray, groups: Sequence[Sequence[int]], distance_fn,
+                               npoints_per_group: int = 5, npairs_per_bin=1e8, augment: bool = True,
+                               augment_ratio: float = 1.0, rng=_random, object_not_moving_threshold: float = 0.01,
+                               future_frame_windows: float = 1e8) -> List[dict]:
+    """Frame-pair mining of OM_C.generate_qa_training_single_scene (OM_C:465-567): per rigid group a few points,
+    per point one static pair plus distance-binned moving pairs, then the swap augmentation.
+
+    ``distance_fn(points, visible_frame_lists) -> [float64 array per point]`` gives, for each point, the world-space
+    distance between every two of its visible frames (i < j, row-major) -- K5c on the GPU, one launch per group.
+    Draw order, stable sort, bin edges and the carried-over ``npairs_per_bin`` follow upstream; so does its frame
+    window test, which compares the *distance* and the first frame index (OM_C:505-507) and therefore never fires
+    with the default window.
+    """
+    sample_pairs: List[dict] = []
+    for group in groups:
+        rng.shuffle(group)                                                   # in place, as upstream (OM_C:468)
+        selected = list(group[:npoints_per_group])
+        vis_frames = [np.where(visibility[:, p])[0] for p in selected]
+        todo = [k for k, v in enumerate(vis_frames) if len(v) >= 2]
+        dists = dict(zip(todo, distance_fn([selected[k] for k in todo], [vis_frames[k] for k in todo]))) if todo else {}
+        for k, point_idx in enumerate(selected):
+            if k not in dists:
+                continue
+            frames = vis_frames[k]
+            ii, jj = np.triu_indices(len(frames), 1)                         # (i, j), i < j, row-major (OM_C:482-483)
+            d = np.asarray(dists[k], dtype=np.float64)
+            f1, f2 = frames[ii], frames[jj]
+            keep = ~(f1 > d + future_frame_windows)                          # OM_C:505-507 (sic)
+            static = np.where(keep & (d < object_not_moving_threshold))[0]
+            moving = np.where(keep & ~(d < object_not_moving_threshold))[0]
+            chosen: List[int] = []
+            if len(static):
+                chosen.append(int(static[rng.choice(range(len(static)))]))
+            if len(moving):
+                moving = moving[np.argsort(d[moving], kind="stable")]        # list.sort is stable
+                dm = d[moving]
+                edges = np.histogram_bin_edges(dm.tolist(), bins=10)
+                which = np.minimum(np.digitize(dm, edges) - 1, 9)
+                bins = [moving[which == b] for b in range(10)]
+                npairs_per_bin = max(min(len(bins[4]), npairs_per_bin), 1)   # carried over to later points (OM_C:535-537)
+                for members in bins:
+                    if len(members) > npairs_per_bin:
+                        members = members[sample_indices(len(members), int(npairs_per_bin), rng)]
+                    chosen.extend(int(m) for m in members)
+            for m in chosen:
+                sample_pairs.append({"point_index": point_idx, "frame1": f1[m], "frame2": f2[m]})
+    if augment:
+        n_aug = int(len(sample_pairs) * augment_ratio)
+        for m in sample_indices(len(sample_pairs), n_aug, rng):
+            s = sample_pairs[m]
+            sample_pairs.append({"point_index": s["point_index"], "frame1": s["frame2"], "frame2": s["frame1"]})
+    return sample_pairs

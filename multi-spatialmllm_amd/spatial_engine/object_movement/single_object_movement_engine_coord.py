@@ -1,6 +1,7 @@
 """Mirror of the reference's single_object_movement_engine_coord.py geometry entry points."""
 from __future__ import annotations
 
+import os
 import random
 
 import numpy as np
@@ -52,3 +53,106 @@ class TwoFrameVideoQAEngine:
         return heads.object_movement_records(scene_id, np.asarray(points_pos_cam), np.asarray(extrinsics_w2c), intrinsics,
                                              (int(image_height), int(image_width)), sample_pairs, self.question_type,
                                              self.templates, random)
+
+    # -- scene level (reference: :405-575) ---------------------------------------------------------
+    def generate_qa_training_single_scene(self, input_file, npoints_per_group=5, npairs_per_bin=1e8, img_output_dir="",
+                                          augment=True, augment_ratio=1.0):
+        """All records of one TAPVid-3D sample file: frames to ``img_output_dir/<scene>/``, rigid groups (K7 + SciPy),
+        frame-pair mining (K5c), records (K5a + K5b).  The JPEG payloads are written as stored -- upstream decodes
+        and re-encodes them -- and the image size is read from the first payload's header."""
+        scene_id = os.path.splitext(os.path.basename(input_file))[0]
+        gt = np.load(input_file, allow_pickle=True)
+        scene_img_dir = os.path.join(img_output_dir, scene_id)
+        os.makedirs(scene_img_dir, exist_ok=True)
+        payloads = gt["images_jpeg_bytes"]
+        have = [n for n in os.listdir(scene_img_dir) if n.endswith(".jpg")]
+        if len(have) != payloads.shape[0]:
+            print(f"Saving images for {scene_id}. Total images {payloads.shape[0]}.")
+            for i, frame_bytes in enumerate(payloads):
+                with open(os.path.join(scene_img_dir, f"{i:05d}.jpg"), "wb") as fh:
+                    fh.write(bytes(frame_bytes))
+        image_height, image_width = jpeg_size(bytes(payloads[0]))
+        intrinsics = gt["fx_fy_cx_cy"]
+        tracks_xyz = np.ascontiguousarray(gt["tracks_XYZ"], dtype=np.float64)
+        visibility = gt["visibility"]
+        extrinsics_w2c = gt["extrinsics_w2c"] if "extrinsics_w2c" in gt.files else None
+        n_frames = tracks_xyz.shape[0]
+        tracks_dev = torch.from_numpy(tracks_xyz).cuda()
+        if extrinsics_w2c is not None:
+            c2w = torch.from_numpy(np.linalg.inv(extrinsics_w2c).reshape(n_frames, 16)).cuda()
+            world = engine.track_to_world(tracks_dev, c2w, intrinsics, (image_height, image_width), ("world",))["world"]
+        else:
+            world = tracks_dev
+            extrinsics_w2c = np.array([np.eye(4) for _ in range(n_frames)])
+        groups = filter_large_groups(rigid_body_segmentation(tracks_xyz), min_size=5)
+        sample_pairs = heads.object_movement_mine_pairs(
+            visibility, groups, lambda pts, frames: engine.track_pair_distances(world, pts, frames), npoints_per_group,
+            npairs_per_bin, augment, augment_ratio, random, self.object_not_moving_threshold, self.future_frame_windows)
+        return self.format_training_samples(sample_pairs, intrinsics=intrinsics, scene_id=scene_id,
+                                            points_pos_world=None, points_pos_cam=tracks_xyz, image_height=image_height,
+                                            image_width=image_width, extrinsics_w2c=extrinsics_w2c)
+
+    def _all_scenes(self, scene_id_list, source_data_root, img_output_dir, npoints_per_group, npairs_per_bin, augment,
+                    augment_ratio):
+        """Upstream maps the scenes over a fork pool, so every scene starts from a copy of the parent's ``random``
+        state and the parent's own stream is untouched by them; reproduced here scene by scene on the one GPU."""
+        parent = random.getstate()
+        data = []
+        for scene_id in scene_id_list:
+            random.setstate(parent)
+            data.extend(self.generate_qa_training_single_scene(os.path.join(source_data_root, f"{scene_id}.npz"),
+                                                               npoints_per_group, npairs_per_bin, img_output_dir, augment,
+                                                               augment_ratio))
+        random.setstate(parent)
+        return data
+
+    @staticmethod
+    def _report(kind, output_file, data):
+        still = sum(1 for e in data if e["point_moving"] == 0)
+        cam_still = sum(1 for e in data if e["cam_moving"] == 0)
+        print(f"{kind} data saved to {output_file}. In total, there are {len(data)} samples.")
+        print(f"Object not moving: {still}, Object moving: {len(data) - still}")
+        print(f"Camera not moving: {cam_still}, Camera moving: {len(data) - cam_still}")
+
+    def generate_qa_training_data(self, scene_id_list, source_data_root, output_dir, output_file, img_output_dir,
+                                  npoints_per_group, npairs_per_bin, augment, augment_ratio=1.0, max_samples=-1, num_workers=20):
+        data = self._all_scenes(scene_id_list, source_data_root, img_output_dir, npoints_per_group, npairs_per_bin, augment,
+                                augment_ratio)
+        if max_samples > 0 and len(data) > max_samples:
+            data = random.sample(data, max_samples)
+        random.shuffle(data)
+        heads.write_jsonl(output_file, data)
+        self._report("Training", output_file, data)
+
+    def format_eval_sample(self, training_sample):
+        training_sample["text"] = training_sample["conversations"][0]["value"]
+        return training_sample
+
+    def generate_qa_eval_data(self, scene_id_list, source_data_root, output_dir, output_file, img_output_dir,
+                              npoints_per_group, npairs_per_bin, augment, augment_ratio=0.3, max_samples=300, num_workers=20):
+        data = self._all_scenes(scene_id_list, source_data_root, img_output_dir, npoints_per_group, npairs_per_bin, augment,
+                                augment_ratio)
+        if max_samples > 0 and len(data) > max_samples:
+            data = random.sample(data, max_samples)
+        heads.write_jsonl(output_file, [self.format_eval_sample(s) for s in data])
+        self._report("Evaluation", output_file, data)
+
+
+def jpeg_size(data: bytes):
+    """(height, width) from a JPEG stream's start-of-frame segment."""
+    i = 2
+    if data[:2] != b"\xff\xd8":
+        raise ValueError("not a JPEG stream")
+    while i + 9 < len(data):
+        if data[i] != 0xFF:
+            i += 1
+            continue
+        marker = data[i + 1]
+        if marker in (0xD8, 0x01) or 0xD0 <= marker <= 0xD7 or marker == 0xFF:
+            i += 2 if marker != 0xFF else 1
+            continue
+        length = int.from_bytes(data[i + 2:i + 4], "big")
+        if 0xC0 <= marker <= 0xCF and marker not in (0xC4, 0xC8, 0xCC):
+            return int.from_bytes(data[i + 5:i + 7], "big"), int.from_bytes(data[i + 7:i + 9], "big")
+        i += 2 + length
+    raise ValueError("no start-of-frame segment in the JPEG stream")

@@ -348,3 +348,70 @@ def test_rigid_body_segmentation():
         ch = np.abs(squareform(pdist(pts[t])) - squareform(pdist(pts[t - 1])))
         ref += np.where(ch > 0.01, ch, 0)
     assert np.allclose(loss, ref, rtol=1e-12, atol=1e-15) and np.array_equal(loss, loss.T) and (np.diag(loss) == 0).all()
+
+
+def _fake_jpeg(h, w):
+    """Smallest byte string with a JPEG start-of-frame segment carrying (h, w) -- after an APP0 segment to skip."""
+    app0 = b"\xff\xe0\x00\x10JFIF\x00\x01\x01\x00\x00\x01\x00\x01\x00\x00"
+    sof = b"\xff\xc0\x00\x11\x08" + h.to_bytes(2, "big") + w.to_bytes(2, "big") + b"\x03\x01\x11\x00\x02\x11\x01\x03\x11\x01"
+    return b"\xff\xd8" + app0 + sof + b"\xff\xd9"
+
+
+def test_object_movement_scene_level(tmp_path):
+    """npz in, records out (OM_C.generate_qa_training_single_scene): K5a world transform, K7 grouping, K5c pair mining,
+    K5b records == the host chain with NumPy distances; K5c distances are bit-identical to np.linalg.norm."""
+    facade()
+    import random
+    import torch
+    from mspa import engine, heads, synth
+    OM = importlib.import_module("spatial_engine.object_movement.single_object_movement_engine_coord")
+    tr = synth.make_tracks(33, T=150, P=64, n_groups=4)
+    H, W = tr.image_hw
+    assert OM.jpeg_size(_fake_jpeg(H, W)) == (H, W)
+    path = str(tmp_path / f"{tr.scene_id}.npz")
+    np.savez(path, images_jpeg_bytes=np.array([_fake_jpeg(H, W)] * tr.tracks_XYZ.shape[0], dtype=object),
+             tracks_XYZ=tr.tracks_XYZ, visibility=tr.visibility, fx_fy_cx_cy=tr.fx_fy_cx_cy, extrinsics_w2c=tr.extrinsics_w2c)
+    # K5c against NumPy, bit for bit
+    T_, P_ = tr.tracks_XYZ.shape[:2]
+    c2w = np.linalg.inv(tr.extrinsics_w2c)
+    world_np = np.einsum("nij,nkj->nki", c2w, np.concatenate([tr.tracks_XYZ, np.ones((T_, P_, 1))], axis=2))[..., :3]
+    world = engine.track_to_world(torch.from_numpy(np.ascontiguousarray(tr.tracks_XYZ)).cuda(),
+                                  torch.from_numpy(c2w.reshape(T_, 16)).cuda(), tr.fx_fy_cx_cy, (H, W), ("world",))["world"]
+    world_host = world.cpu().numpy()
+    pts = [3, 40, 41, 7]
+    frames = [np.where(tr.visibility[:, p])[0] for p in pts]
+    frames[3] = frames[3][:1]                                   # a point with a single visible frame: no pairs
+    got = engine.track_pair_distances(world, pts, frames)
+    for p, fr, d in zip(pts, frames, got):
+        ii, jj = np.triu_indices(len(fr), 1)
+        want = np.linalg.norm(world_host[fr[jj], p] - world_host[fr[ii], p], axis=1)
+        assert d.shape == want.shape and np.array_equal(d, want)
+    assert len(got[3]) == 0 and len(got[0]) > 100
+    with pytest.raises(ValueError):
+        engine.track_pair_distances(world, [P_], [np.array([0, 1])])
+    # the whole scene through the façade
+    eng = OM.TwoFrameVideoQAEngine("tapvid3d_displacement_vector", "adt")
+    random.seed(23)
+    recs = eng.generate_qa_training_single_scene(path, 6, 5, str(tmp_path / "img"), True, 0.5)
+    end_state = random.getstate()
+    assert sorted(os.listdir(tmp_path / "img" / tr.scene_id))[:2] == ["00000.jpg", "00001.jpg"]
+    assert open(tmp_path / "img" / tr.scene_id / "00003.jpg", "rb").read() == _fake_jpeg(H, W)
+    groups = OM.filter_large_groups(OM.rigid_body_segmentation(tr.tracks_XYZ), min_size=5)
+
+    def distance_fn(points, frs):
+        return [np.linalg.norm(world_host[fr[np.triu_indices(len(fr), 1)[1]], p] - world_host[fr[np.triu_indices(len(fr), 1)[0]], p],
+                               axis=1) for p, fr in zip(points, frs)]
+    random.seed(23)
+    pairs = heads.object_movement_mine_pairs(tr.visibility, groups, distance_fn, 6, 5, True, 0.5)
+    want = heads.object_movement_records(tr.scene_id, tr.tracks_XYZ, tr.extrinsics_w2c, tr.fx_fy_cx_cy, (H, W), pairs,
+                                         "tapvid3d_displacement_vector", eng.templates, random)
+    assert recs == want and len(recs) > 20 and random.getstate() == end_state
+    # dataset level: JSONL + eval form
+    (tmp_path / "src").mkdir()
+    os.rename(path, tmp_path / "src" / f"{tr.scene_id}.npz")
+    out = str(tmp_path / "val.jsonl")
+    random.seed(24)
+    eng.generate_qa_eval_data([tr.scene_id], str(tmp_path / "src"), str(tmp_path), out, str(tmp_path / "img"), 1, 1, False,
+                              max_samples=10)
+    lines = [json.loads(line) for line in open(out)]
+    assert 0 < len(lines) <= 10 and all("text" in r for r in lines)

@@ -205,3 +205,45 @@ def test_default_templates_have_the_reference_keys(ref):
     for qt, lst in T.CAMERA_MOVEMENT.answers.items():
         for s in lst:
             s.format(**av)
+
+
+@pytest.mark.parametrize("npoints,npairs,augment,ratio", [(15, 30, True, 0.05), (1, 1, False, 1.0), (4, 1e8, True, 1.0)])
+def test_object_movement_pair_mining(ref, tmp_path, npoints, npairs, augment, ratio):
+    """Frame-pair mining of OM_C.generate_qa_training_single_scene (groups -> points -> static + binned moving pairs ->
+    swap augmentation): same pairs in the same order, same ``random`` stream afterwards."""
+    import sys
+    tr = synth.make_tracks(33, T=150, P=64, n_groups=4)
+    H, W = tr.image_hw
+    sys.modules["cv2"].imdecode = lambda arr, flags=None: np.zeros((H, W, 3), np.uint8)
+    path = str(tmp_path / f"{tr.scene_id}.npz")
+    jpeg = np.array([b"\xff\xd8fake"] * tr.tracks_XYZ.shape[0], dtype=object)
+    np.savez(path, images_jpeg_bytes=jpeg, tracks_XYZ=tr.tracks_XYZ, visibility=tr.visibility, fx_fy_cx_cy=tr.fx_fy_cx_cy,
+             extrinsics_w2c=tr.extrinsics_w2c, queries_xyt=np.zeros((tr.tracks_XYZ.shape[1], 3)))
+    eng = ref.OM_C.TwoFrameVideoQAEngine("tapvid3d_total_distance", "adt")
+    captured = {}
+
+    def capture(sample_pairs, **kw):
+        captured["pairs"] = [dict(s) for s in sample_pairs]
+        captured["world"] = kw["points_pos_world"]
+        return []
+    eng.format_training_samples = capture
+    random.seed(17)
+    eng.generate_qa_training_single_scene(path, npoints, npairs, str(tmp_path / "img"), augment, ratio)
+    state_ref = random.getstate()
+    world = captured["world"]
+    groups = ref.OM_C.filter_large_groups(ref.OM_C.rigid_body_segmentation(tr.tracks_XYZ), min_size=5)
+    assert len(groups) >= 2
+
+    def distance_fn(points, frames):
+        out = []
+        for p, fr in zip(points, frames):
+            ii, jj = np.triu_indices(len(fr), 1)
+            out.append(np.linalg.norm(world[fr[jj], p] - world[fr[ii], p], axis=1))
+        return out
+    random.seed(17)
+    got = heads.object_movement_mine_pairs(tr.visibility, groups, distance_fn, npoints, npairs, augment, ratio)
+    want = captured["pairs"]
+    assert len(got) == len(want) and len(got) > 0
+    assert [(s["point_index"], int(s["frame1"]), int(s["frame2"])) for s in got] == \
+           [(s["point_index"], int(s["frame1"]), int(s["frame2"])) for s in want]
+    assert random.getstate() == state_ref
