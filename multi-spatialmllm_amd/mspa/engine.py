@@ -364,9 +364,12 @@ def track_pair_distances(world: torch.Tensor, points: Sequence[int], visible_fra
         raise ValueError("point index outside the track")
     out = torch.empty((int(o_off[-1]),), dtype=torch.float64, device=dev)
     if o_off[-1]:
-        _lib.check(lib.mspa_track_pair_distances(
-            _ptr(world), T, P, _ptr(torch.from_numpy(pts).to(dev)), _ptr(torch.from_numpy(f_off.astype(np.int32)).to(dev)),
-            _ptr(torch.from_numpy(frames).to(dev)), S, int(lens.max()), _ptr(torch.from_numpy(o_off).to(dev)), _ptr(out),
-            _stream_ptr()))
+        # named tensors: a temporary would be freed (and its block reused by the next upload) before the launch
+        pts_t = torch.from_numpy(pts).to(dev)
+        f_off_t = torch.from_numpy(f_off.astype(np.int32)).to(dev)
+        frames_t = torch.from_numpy(frames).to(dev)
+        o_off_t = torch.from_numpy(o_off).to(dev)
+        _lib.check(lib.mspa_track_pair_distances(_ptr(world), T, P, _ptr(pts_t), _ptr(f_off_t), _ptr(frames_t), S,
+                                                 int(lens.max()), _ptr(o_off_t), _ptr(out), _stream_ptr()))
     host = out.cpu().numpy()
     return [host[o_off[s]:o_off[s + 1]] for s in range(S)]
