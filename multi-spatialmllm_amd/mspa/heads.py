@@ -132,6 +132,40 @@ def camera_movement_records(scene, rows: Sequence[dict], question_type: str, ima
             for k, r in enumerate(rows)]
 
 
+def camera_movement_dataset(rows: Sequence, frame_pose, image_hw_of, question_type: str,
+                            templates: T.TemplateSet = T.CAMERA_MOVEMENT, rng=_random, device="cuda") -> List[dict]:
+    """The record loop of CME.build_train_dataset (CME:295-299) for rows that may span many scenes: the relative
+    poses of ALL rows come from one K4 launch over a table of the distinct frames, then the records are filled in
+    row order -- the numerics never influence a draw, so the ``random`` stream is the per-row loop's.
+
+    ``frame_pose(scene_id, image_id)`` -> axis-aligned camera-to-world 4x4; ``image_hw_of(scene_id, image_id)`` -> (H, W).
+    """
+    import torch
+    from . import engine
+    if len(rows) == 0:
+        return []
+    table: Dict[Tuple[str, str], int] = {}
+    poses = []
+    idx = np.empty((len(rows), 2), dtype=np.int32)
+    for k, r in enumerate(rows):
+        for c, key in enumerate(((r["scene_id"], r["image_id1"]), (r["scene_id"], r["image_id2"]))):
+            if key not in table:
+                E = np.asarray(frame_pose(*key), dtype=np.float64)
+                assert not np.isnan(E).any(), f"E is nan for {key[0]} {key[1]}"        # CME:160-161
+                table[key] = len(poses)
+                poses.append(E)
+            idx[k, c] = table[key]
+    E_all = np.stack(poses)
+    E_t = torch.from_numpy(E_all.reshape(-1, 16)).to(device)
+    Einv_t = torch.from_numpy(np.linalg.inv(E_all).reshape(-1, 16)).to(device)       # same LAPACK call as per frame
+    zeros = torch.zeros(len(poses), dtype=torch.float64, device=device)
+    both = torch.from_numpy(np.concatenate([idx, idx[:, ::-1]], axis=0).copy()).to(device)
+    out = engine.pair_pose(E_t, Einv_t, zeros, zeros, both).cpu().numpy()
+    n = len(rows)
+    return [camera_movement_record(r, k, question_type, out[k, 3:6], out[n + k, 3:6],
+                                   image_hw_of(r["scene_id"], r["image_id1"]), templates, rng) for k, r in enumerate(rows)]
+
+
 # --------------------------------------------------------------------------------------------
 # visual correspondence, coordinate -> coordinate (VC_C:264-394)
 # --------------------------------------------------------------------------------------------
@@ -233,6 +267,89 @@ def visual_correspondence_records(scene, rows: Sequence[dict], image_hw, start_i
             records.append(visual_correspondence_record(rows[k], start_idx + k, draws[k], uv[ss], uv[[s + m for s in ss]],
                                                         image_hw, templates))
     return records
+
+
+def visual_correspondence_dataset(rows: Sequence, get_scene, get_bits=None, templates: T.TemplateSet = T.VISUAL_CORRESPONDENCE,
+                                  rng=_random, max_points_per_pair: int = 1, on_warn=None) -> List[Optional[dict]]:
+    """The record loop of VC_C.build_train_dataset (VC_C:424-429) for rows that may span many scenes.
+
+    Pass 1 (per scene, GPU): size of the common visible set of every row (K2 on the scene's bitsets).
+    Pass 2 (host, global row order): every draw of VC_C.build_training_sample -- they depend on those sizes only.
+    Pass 3 (per scene, GPU): the drawn positions -> vertices (K6a) -> both projections + visibility re-check (K6b).
+    Returns one entry per row in row order, None where upstream returns None (no common vertex / unknown scene).
+
+    ``get_scene(scene_id)`` -> resident ``SceneOnDevice`` (or None if the scene is unknown); ``get_bits(scene_id,
+    scene)`` -> [F, n_words] bitsets in ``scene.ids`` order (default: K1 on the resident scene).
+    """
+    import torch
+    from . import engine
+    warn = on_warn or (lambda message: None)
+    by_scene: Dict[str, List[int]] = {}
+    for k, r in enumerate(rows):
+        by_scene.setdefault(r["scene_id"], []).append(k)
+    n_common = np.zeros(len(rows), dtype=np.int64)
+    known: Dict[str, bool] = {}
+    pair_idx: Dict[int, Tuple[int, int]] = {}
+    bits_of = get_bits or (lambda scene_id, scene: scene._visibility()["bits"])
+    for scene_id, ks in by_scene.items():
+        scene = get_scene(scene_id)
+        known[scene_id] = scene is not None
+        if scene is None:
+            continue
+        usable = [k for k in ks if rows[k]["image_id1"] in scene.index and rows[k]["image_id2"] in scene.index]
+        if not usable:
+            continue
+        idx = np.array([[scene.index[rows[k]["image_id1"]], scene.index[rows[k]["image_id2"]]] for k in usable], dtype=np.int32)
+        _, inter, _ = engine.pair_overlap(bits_of(scene_id, scene), torch.from_numpy(idx).to(scene.device), want_counts=True)
+        n_common[usable] = inter.cpu().numpy()
+        for k, (a, b) in zip(usable, idx):
+            pair_idx[k] = (int(a), int(b))
+    draws: List[Optional[dict]] = []
+    for k, r in enumerate(rows):                                          # global row order: the stream of the per-row loop
+        if not known[r["scene_id"]]:
+            rng.random()                                                  # the swap coin is drawn before the scene check (VC_C:280)
+            warn(f"[build_training_sample] Warning: Visibility info not found for scene {r['scene_id']}\n")
+            draws.append(None)
+            continue
+        d = visual_correspondence_draws([r], [n_common[k]], templates, rng, max_points_per_pair)[0]
+        if d is None:
+            warn(f"[build_training_sample] Warning: No common visible points for scene {r['scene_id']} "
+                 f"{r['image_id1']}, {r['image_id2']}\n")
+        draws.append(d)
+    out: List[Optional[dict]] = [None] * len(rows)
+    for scene_id, ks in by_scene.items():
+        live = [k for k in ks if draws[k] is not None]
+        if not live:
+            continue
+        scene = get_scene(scene_id)
+        dev = scene.device
+        sel, owner = [], []
+        for k in live:
+            a, b = pair_idx[k]
+            for j in draws[k]["positions"]:
+                sel.append([a, b, j])
+                owner.append(k)
+        sel_t = torch.tensor(sel, dtype=torch.int32, device=dev)
+        vert = engine.select_common_point(bits_of(scene_id, scene), sel_t)
+        first = torch.tensor([pair_idx[k][1] if draws[k]["swap"] else pair_idx[k][0] for k in owner], dtype=torch.int32, device=dev)
+        second = torch.tensor([pair_idx[k][0] if draws[k]["swap"] else pair_idx[k][1] for k in owner], dtype=torch.int32, device=dev)
+        samples = torch.cat([torch.stack([vert, first], 1), torch.stack([vert, second], 1)], 0).contiguous()
+        uv, _, ok = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw, samples)
+        uv, ok, vert_h = uv.cpu().numpy(), ok.cpu().numpy().astype(bool), vert.cpu().numpy()
+        m = len(owner)
+        slots: Dict[int, List[int]] = {}
+        for s, k in enumerate(owner):
+            slots.setdefault(k, []).append(s)
+        for k, ss in slots.items():
+            bad = [s for s in ss if not (ok[s] and ok[s + m])]
+            if bad:                                                        # VC_C:321-338: warn and drop the pair
+                s = bad[0]
+                r, swap = rows[k], draws[k]["swap"]
+                img = (r["image_id2"] if swap else r["image_id1"]) if not ok[s] else (r["image_id1"] if swap else r["image_id2"])
+                warn(f"Warning: Point {int(vert_h[s])} is not visible in image {img} in scene {scene_id}.\n")
+                continue
+            out[k] = visual_correspondence_record(rows[k], k, draws[k], uv[ss], uv[[s + m for s in ss]], scene.image_hw, templates)
+    return out
 
 
 # --------------------------------------------------------------------------------------------

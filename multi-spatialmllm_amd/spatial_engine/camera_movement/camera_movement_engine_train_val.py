@@ -2,6 +2,8 @@
 with the reference's signature on top of ``mspa.heads`` (K4 for the relative pose)."""
 from __future__ import annotations
 
+import json
+import os
 import random
 
 import numpy as np
@@ -35,3 +37,77 @@ def build_training_sample(scene_infos, row, idx: int, question_type: str):
 
 
 convert_train_sample_to_eval_sample = heads.to_eval_sample
+
+
+def _build_samples(parquet_path, scene_infos, qtype, desired_count, overlap_min, overlap_max, interval, tag):
+    import pandas as pd
+    df = pd.read_parquet(parquet_path)
+    print(f"[{tag}: {qtype}] Loaded DF with {len(df)} rows from {parquet_path}")
+    print(f"[{tag}: {qtype}] sampling {desired_count} samples in overlap=[{overlap_min}..{overlap_max}]")
+    df_sampled = sample_dataframe(df, all_overlap_samples=desired_count, non_overlap_samples=0, overlap_min=overlap_min,
+                                  overlap_max=overlap_max, interval=interval)
+    print(f"[{tag}: {qtype}] got {len(df_sampled)} sampled rows")
+    rows = [df_sampled.iloc[k] for k in range(len(df_sampled))]
+    # one K4 launch for the relative poses of every sampled row, then the records in row order
+    return heads.camera_movement_dataset(rows, scene_infos.get_extrinsic_matrix_align, scene_infos.get_image_shape, qtype,
+                                         TEMPLATE_SET, random)
+
+
+def build_train_dataset(parquet_path, output_dir, scene_infos, qtype, desired_count, overlap_min, overlap_max, interval):
+    """{qtype}_train.jsonl from the pair table (reference: :271-308)."""
+    out_samples = _build_samples(parquet_path, scene_infos, qtype, desired_count, overlap_min, overlap_max, interval, "Train")
+    random.shuffle(out_samples)
+    out_file = os.path.join(output_dir, f"{qtype}_train.jsonl")
+    print(f"[Train: {qtype}] writing {len(out_samples)} items to {out_file}")
+    heads.write_jsonl(out_file, out_samples)
+
+
+def build_val_dataset(parquet_path, output_dir, scene_infos, qtype, desired_count, overlap_min, overlap_max, interval):
+    """{qtype}_val.jsonl in the eval form (reference: :314-354)."""
+    out_samples = [convert_train_sample_to_eval_sample(s) for s in
+                   _build_samples(parquet_path, scene_infos, qtype, desired_count, overlap_min, overlap_max, interval, "Val")]
+    random.shuffle(out_samples)
+    out_file = os.path.join(output_dir, f"{qtype}_val.jsonl")
+    print(f"[Val: {qtype}] writing {len(out_samples)} items to {out_file}")
+    heads.write_jsonl(out_file, out_samples)
+
+
+DEBUG = False
+TRAIN_QUESTION_SAMPLES = {"x_movement": 1000000, "y_movement": 1000000, "z_movement": 1000000, "yaw_movement": 1000000,
+                          "pitch_movement": 1000000, "yaw_angle": 1000000, "pitch_angle": 1000000, "total_distance": 3000000,
+                          "displacement_vector": 3000000}
+VAL_QUESTION_ORDER = ("x_movement", "y_movement", "z_movement", "yaw_movement", "pitch_movement", "total_distance", "yaw_angle",
+                      "pitch_angle", "displacement_vector")
+
+
+def main():
+    """Same paths, budgets, seeds and order of question types as upstream's main (:360-444)."""
+    from spatial_engine.utils.scannet_utils.handler.info_handler import SceneInfoHandler
+    np.random.seed(0)
+    random.seed(0)
+    info_path = "data/scannet/scannet_instance_data/scenes_train_val_info_i_D5.pkl"
+    overlap_min, overlap_max, interval, version = 6, 35, 1, "v1_0"
+    train_counts = dict(TRAIN_QUESTION_SAMPLES)
+    val_counts = {k: 300 for k in VAL_QUESTION_ORDER}
+    if DEBUG:
+        train_parquet = "training_data/camera_movement/train_camera_info_D5_debug_nonzero.parquet"
+        val_parquet = "evaluation_data/camera_movement/val_camera_info_D5_debug_nonzero.parquet"
+        train_counts = {k: 100 for k in train_counts}
+        val_counts = {k: 100 for k in val_counts}
+        version += "_debug"
+    else:
+        train_parquet = "training_data/camera_movement/train_camera_info_D5.parquet"
+        val_parquet = "evaluation_data/camera_movement/val_camera_info_D5.parquet"
+    train_dir, val_dir = f"training_data/camera_movement/{version}", f"evaluation_data/camera_movement/{version}"
+    os.makedirs(train_dir, exist_ok=True)
+    os.makedirs(val_dir, exist_ok=True)
+    scene_infos = SceneInfoHandler(info_path)
+    for qtype in train_counts:
+        print(f"\n=== Processing question type: {qtype} ===")
+        build_val_dataset(val_parquet, val_dir, scene_infos, qtype, val_counts[qtype], overlap_min, overlap_max, interval)
+        build_train_dataset(train_parquet, train_dir, scene_infos, qtype, train_counts[qtype], overlap_min, overlap_max, interval)
+    print("All question types processed. Done.")
+
+
+if __name__ == "__main__":
+    main()
