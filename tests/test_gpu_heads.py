@@ -343,3 +343,80 @@ def test_scene_object_coverage_matches_index_route():
     _, res = COV.process_scene_for_coverage(sid, H(), vis_dict, {sid: vis})
     random.setstate(state)
     assert res == cov
+
+
+def test_dataset_level_builders(tmp_path):
+    """CME / VC_C build_train_dataset + build_val_dataset: one batched GPU pass over rows that span scenes == the per-row
+    loop of build_training_sample (which is pinned to the reference) under the same seed, shuffle included."""
+    import importlib
+    import json
+    import os
+    import pickle
+    pd = pytest.importorskip("pandas")
+    pytest.importorskip("pyarrow")
+    IH = importlib.import_module("spatial_engine.utils.scannet_utils.handler.info_handler")
+    IMG = importlib.import_module("spatial_engine.utils.scannet_utils.handler._images")
+    CME = importlib.import_module("spatial_engine.camera_movement.camera_movement_engine_train_val")
+    VC = importlib.import_module("spatial_engine.visual_correspondence.visual_correspondence_qa_engine_coor_2_coor")
+    scenes = [synth.make_scene(7400 + k, n_points=3000, n_frames=9 + k, color_hw=(96, 128), depth_hw=(96, 128),
+                               invalid_pose_frac=0.1, with_color=False) for k in range(2)]
+    posed, inst = str(tmp_path / "posed_images"), str(tmp_path / "inst")
+    infos, vis_all, table_rows = {}, {}, []
+    for sc in scenes:
+        os.makedirs(os.path.join(inst, sc.scene_id))
+        np.save(os.path.join(inst, sc.scene_id, "aligned_points.npy"), sc.points)
+        for i in sc.image_ids:
+            IMG.register(os.path.join(posed, sc.scene_id, f"{i}.jpg"), np.zeros(sc.color_hw + (3,), np.uint8))
+            IMG.register(os.path.join(posed, sc.scene_id, f"{i}.png"), sc.depth[i])
+        infos[sc.scene_id] = sc.info_dict()
+        resident = SceneOnDevice(sc.K, sc.A, sc.E, sc.depth, sc.color_hw, sc.points, DEV)
+        vis_all[sc.scene_id] = resident.visibility_index()
+        for (a, b), v in resident.frames_relations().items():
+            table_rows.append({"scene_id": sc.scene_id, "image_id1": a, "image_id2": b, "overlap": float(v["overlap"]),
+                               "distance": float(v["distance"]), "yaw": float(v["yaw"]), "pitch": float(v["pitch"])})
+    vis_all["scene_not_in_handler"] = {"image_to_points": {}, "point_to_images": {}}
+    info_path, vis_path, table_path = str(tmp_path / "infos.pkl"), str(tmp_path / "vis.pkl"), str(tmp_path / "pairs.parquet")
+    with open(info_path, "wb") as f:
+        pickle.dump(infos, f)
+    with open(vis_path, "wb") as f:
+        pickle.dump(vis_all, f)
+    df = pd.DataFrame(table_rows)
+    df.to_parquet(table_path)
+    h = IH.SceneInfoHandler(info_path, posed_images_root=posed, instance_data_root=inst)
+    lo, hi = 1, 60
+    assert ((df["overlap"] >= lo) & (df["overlap"] <= hi)).sum() >= 10
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+
+    # ---- camera movement ----
+    random.seed(40); np.random.seed(40)
+    CME.build_train_dataset(table_path, out, h, "displacement_vector", 30, lo, hi, 1)
+    got = [json.loads(line) for line in open(os.path.join(out, "displacement_vector_train.jsonl"))]
+    random.seed(40); np.random.seed(40)
+    sampled = CME.sample_dataframe(pd.read_parquet(table_path), all_overlap_samples=30, non_overlap_samples=0, overlap_min=lo,
+                                   overlap_max=hi, interval=1)
+    want = [CME.build_training_sample(h, sampled.iloc[k], k, "displacement_vector") for k in range(len(sampled))]
+    random.shuffle(want)
+    assert got == json.loads(json.dumps(want)) and len(got) >= 10 and len({r["image"][0].split("/")[0] for r in got}) == 2
+    random.seed(41); np.random.seed(41)
+    CME.build_val_dataset(table_path, out, h, "yaw_movement", 12, lo, hi, 1)
+    val = [json.loads(line) for line in open(os.path.join(out, "yaw_movement_val.jsonl"))]
+    assert val and all("text" in r and "conversations" not in r for r in val)
+
+    # ---- visual correspondence ----
+    warn = str(tmp_path / "warn.txt")
+    open(warn, "w").close()
+    random.seed(42); np.random.seed(42)
+    VC.build_train_dataset(table_path, out, h, 30, lo, hi, 1, vis_path, warn)
+    got = [json.loads(line) for line in open(os.path.join(out, "train_visual_correspondence_coor_2_coor.jsonl"))]
+    random.seed(42); np.random.seed(42)
+    sampled = VC.sample_dataframe(pd.read_parquet(table_path), all_overlap_samples=30, non_overlap_samples=0, overlap_min=lo,
+                                  overlap_max=hi, interval=1)
+    want = [VC.build_training_sample(h, sampled.iloc[k], k, vis_all, warn) for k in range(len(sampled))]
+    want = [w for w in want if w]
+    random.shuffle(want)
+    assert got == json.loads(json.dumps(want)) and len(got) >= 10
+    random.seed(43); np.random.seed(43)
+    VC.build_val_dataset(table_path, out, h, 8, lo, hi, 1, vis_path, warn)
+    val = [json.loads(line) for line in open(os.path.join(out, "val_visual_correspondence_coor_2_coor.jsonl"))]
+    assert val and all("text" in r for r in val)
