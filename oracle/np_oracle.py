@@ -376,3 +376,161 @@ def object_displacement(tracks_world, tracks_cam, extrinsics_w2c, fx_fy_cx_cy, i
         "point_moving": int(moving),
         "cam_moving": int(cam_moving),
     }
+
+
+# --------------------------------------------------------------------------------------
+# object perception: object visibility (COVIS), coverage search on boolean masks (COV)
+#   COVIS = object_perception/compute_object_visibility.py, COV = object_perception/single_object_coverage_finder.py
+# --------------------------------------------------------------------------------------
+def object_visibility(object_points: Dict[int, Sequence[int]], image_to_points: Dict[str, Sequence[int]],
+                      image_ids: Sequence[str]) -> dict:
+    """COVIS:103-150 with Python sets: per (object, image) intersection size against max(1, int(0.05 * n))."""
+    result = {"object_to_images": {}, "image_to_objects": {}}
+    for obj, pts in object_points.items():
+        pts = set(int(p) for p in pts)
+        if not pts:
+            continue
+        threshold = max(1, int(0.05 * len(pts)))                           # COVIS:112
+        for image_id in image_ids:
+            if image_id not in image_to_points:
+                continue
+            count = len(set(image_to_points[image_id]) & pts)              # COVIS:119-121
+            if count >= threshold:
+                vis = (count / len(pts)) * 100.0
+                result["object_to_images"].setdefault(obj, []).append(
+                    {"image_id": image_id, "intersection_count": count, "visibility": vis})
+                result["image_to_objects"].setdefault(image_id, []).append(
+                    {"object_id": obj, "intersection_count": count, "visibility": vis})
+    return result
+
+
+def compute_coverage(scene_pts, mask, axis):
+    """COV:56-65."""
+    if not mask.any():
+        return None
+    coords = scene_pts[mask][:, axis]
+    return max(coords) - min(coords)
+
+
+def coverage_minimal_combinations(scene_pts, object_points, images: Sequence[str], image_to_points, axis, target, tolerance=0.1,
+                                  max_images=5, rng=None):
+    """COV:76-220 on boolean masks over all scene vertices, as upstream carries them: level-by-level search with the
+    superset pruning, the cumulative-union early prune, the 25-image cap and the 5000-node cap."""
+    import random as _random
+    rng = rng or _random
+    n_pts = len(scene_pts)
+    obj_mask = np.zeros(n_pts, dtype=bool)
+    obj_mask[np.asarray(object_points, dtype=np.int64)] = True                # COV:99-100
+    masks = {}
+    for img in images:                                                       # COV:103-112
+        if img not in image_to_points:
+            continue
+        m = np.zeros(n_pts, dtype=bool)
+        m[np.asarray(image_to_points[img], dtype=np.int64)] = True
+        masks[img] = np.logical_and(m, obj_mask)
+    valid = list(masks)
+    if len(valid) > 25:                                                      # COV:118-119
+        valid = rng.sample(valid, 25)
+    n = len(valid)
+
+    def covers(mask):                                                        # COV:67-73, 144-146
+        cov = compute_coverage(scene_pts, mask, axis)
+        return cov is not None and abs(cov - target) <= tolerance * target
+
+    tail = [None] * n                                                        # COV:122-127
+    for i in range(n - 1, -1, -1):
+        tail[i] = masks[valid[i]].copy() if i == n - 1 else np.logical_or(masks[valid[i]], tail[i + 1])
+    found = []
+    level = []
+    for i, img in enumerate(valid):                                          # COV:151-155
+        members = np.zeros(n, dtype=bool)
+        members[i] = True
+        level.append(([img], masks[img], i, members))
+    first_layer, solutions, k = [], {}, 1
+    while k <= max_images and level:                                         # COV:163
+        expand, fresh = [], []
+        for comb, union, last, members in level:
+            if any(np.array_equal(np.logical_and(m, members), m) for m in found):   # COV:132-142
+                continue
+            if covers(union):                                                # COV:174-179
+                fresh.append(members)
+                solutions.setdefault(k, []).append(tuple(comb))
+            else:
+                if last < n - 1 and not covers(np.logical_or(tail[last], union)):   # COV:181-184
+                    continue
+                expand.append((comb, union, last, members))
+                if k == 1:
+                    first_layer.append((comb, union, last, members))
+        found.extend(fresh)
+        nxt = []
+        if k < max_images:                                                   # COV:195-205
+            for comb, union, last, members in expand:
+                for c1, u1, last1, m1 in first_layer:
+                    if last1 > last:
+                        nxt.append((comb + c1, np.logical_or(union, u1), last1, np.logical_or(m1, members)))
+        if len(nxt) > 5000:                                                  # COV:207-209
+            nxt = rng.sample(nxt, 5000)
+        level = nxt
+        k += 1
+    return solutions
+
+
+# --------------------------------------------------------------------------------------
+# object movement: rigid grouping loss (OM_C:66-78), frame-pair mining (OM_C:465-567)
+# --------------------------------------------------------------------------------------
+def rigidity_loss(points: np.ndarray, smoothing_factor: float = 0.01) -> np.ndarray:
+    """Cumulative thresholded change of all pairwise distances, frame after frame (OM_C:66-78)."""
+    T, P, _ = points.shape
+    loss = np.zeros((P, P))
+
+    def dist_matrix(x):
+        d = x[:, None, :] - x[None, :, :]
+        return np.sqrt((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2])
+    prev = dist_matrix(points[0])
+    for t in range(1, T):
+        cur = dist_matrix(points[t])
+        change = np.abs(cur - prev)
+        loss += np.where(change > smoothing_factor, change, 0)                # OM_C:46-47
+        prev = cur
+    return loss
+
+
+def mine_frame_pairs(tracks_world, visibility, groups, npoints_per_group=5, npairs_per_bin=1e8, augment=True,
+                     augment_ratio=1.0, rng=None, object_not_moving_threshold=0.01, future_frame_windows=1e8):
+    """OM_C:465-567 with the reference's Python lists and loops (its frame-window test, which reads the distance where
+    a frame index is meant, included)."""
+    import random as _random
+    rng = rng or _random
+    sample_pairs = []
+    for group in groups:
+        rng.shuffle(group)
+        for point_idx in group[:npoints_per_group]:
+            frames = np.where(visibility[:, point_idx])[0]
+            if len(frames) < 2:
+                continue
+            pairs = np.array([(i, j) for i in range(len(frames)) for j in range(i + 1, len(frames))])
+            f1, f2 = frames[pairs[:, 0]], frames[pairs[:, 1]]
+            dists = np.linalg.norm(tracks_world[f2, point_idx] - tracks_world[f1, point_idx], axis=1)
+            static, moving = [], []
+            for disp in zip(dists, f1, f2):
+                if disp[1] > disp[0] + future_frame_windows:                 # OM_C:505-507 (sic)
+                    continue
+                (static if disp[0] < object_not_moving_threshold else moving).append(disp)
+            selected = []
+            if static:
+                selected.append(rng.choice(static))
+            if moving:
+                moving.sort(key=lambda x: x[0])
+                edges = np.histogram_bin_edges([d[0] for d in moving], bins=10)
+                bins = [[] for _ in range(10)]
+                for disp in moving:
+                    bins[min(np.digitize(disp[0], edges) - 1, 9)].append(disp)
+                npairs_per_bin = max(min(len(bins[4]), npairs_per_bin), 1)
+                for b in bins:
+                    selected.extend(rng.sample(b, npairs_per_bin) if len(b) > npairs_per_bin else b)
+            for _, a, b in selected:
+                sample_pairs.append({"point_index": point_idx, "frame1": a, "frame2": b})
+    if augment:
+        for s in rng.sample(sample_pairs, int(len(sample_pairs) * augment_ratio)):
+            sample_pairs.append({"point_index": s["point_index"], "frame1": s["frame2"], "frame2": s["frame1"]})
+    return sample_pairs

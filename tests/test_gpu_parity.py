@@ -562,3 +562,51 @@ def test_fast_equals_exact_random_poses(hw):
         ref = C.frame_pair(depth[a], depth[b], K, E_list[a], E_list[b], A, hw)
         assert tuple(counts[p]) == (ref["n_valid"], ref["n_vis"])
         assert np.array_equal(unpack_bits(ex["vis_bits"][p].cpu().numpy(), H * W), ref["vis"])
+
+
+# ------------------------------------------------------------------------------------------
+# K7 rigidity loss / K8 object extents against the oracle at sizes beyond the golden fixtures
+# ------------------------------------------------------------------------------------------
+def test_rigidity_loss_vs_oracle():
+    tr = synth.make_tracks(71, T=120, P=200, n_groups=6)
+    loss = engine.track_rigidity_loss(torch.from_numpy(np.ascontiguousarray(tr.tracks_XYZ)).to(DEV), 0.01).cpu().numpy()
+    want = O.rigidity_loss(tr.tracks_XYZ, 0.01)
+    assert np.array_equal(loss, want)                       # same operation order, correctly rounded sqrt
+    assert (loss > 0).any() and np.array_equal(loss, loss.T)
+    empty = engine.track_rigidity_loss(torch.zeros((5, 0, 3), dtype=torch.float64, device=DEV))
+    assert empty.shape == (0, 0)
+    one = engine.track_rigidity_loss(torch.randn((1, 7, 3), dtype=torch.float64, device=DEV)).cpu().numpy()
+    assert (one == 0).all()                                 # a single frame has no change to accumulate
+
+
+def test_object_extents_vs_oracle_large():
+    from mspa import coverage
+    from mspa.scene import pack_index_lists
+    rng = np.random.default_rng(12)
+    V, F, n_obj = 20000, 70, 12
+    pts = rng.normal(0, 2, (V, 3))
+    label = rng.integers(-1, n_obj, V)                      # -1 = unlabelled
+    objs = {o: np.where(label == o)[0] for o in range(n_obj)}
+    objs[3] = objs[3][:1]                                   # a one-vertex object
+    objs[5] = rng.permutation(objs[5])                      # vertex list in arbitrary order
+    lists = [np.where(rng.random(V) < rng.uniform(0.0, 0.3))[0] for _ in range(F)]
+    lists[4] = np.zeros(0, dtype=np.int64)                  # an image that sees nothing
+    ids = [f"{k:05d}" for k in range(F)]
+    bits = torch.from_numpy(pack_index_lists(lists, V)).to(DEV)
+    ext = coverage.scene_extents(bits, ids, pts, objs)
+    seen = np.zeros((F, V), dtype=bool)
+    for f, l in enumerate(lists):
+        seen[f, l] = True
+    for o, idx in objs.items():
+        k = ext.object_index[o]
+        m = np.zeros(V, dtype=bool)
+        m[idx] = True
+        for f in range(F):
+            both = seen[f] & m
+            assert ext.count[k, f] == both.sum()
+            for axis in range(3):
+                cov = O.compute_coverage(pts, both, axis)
+                if cov is None:
+                    assert ext.lo[k, f, axis] == np.inf and ext.hi[k, f, axis] == -np.inf
+                else:
+                    assert ext.hi[k, f, axis] - ext.lo[k, f, axis] == cov

@@ -247,3 +247,8 @@ def test_object_movement_pair_mining(ref, tmp_path, npoints, npairs, augment, ra
     assert [(s["point_index"], int(s["frame1"]), int(s["frame2"])) for s in got] == \
            [(s["point_index"], int(s["frame1"]), int(s["frame2"])) for s in want]
     assert random.getstate() == state_ref
+    # the oracle's list-and-loop restatement gives the same pairs
+    orc = O.mine_frame_pairs(world, tr.visibility, [list(g) for g in ref.OM_C.filter_large_groups(
+        ref.OM_C.rigid_body_segmentation(tr.tracks_XYZ), min_size=5)], npoints, npairs, augment, ratio, random.Random(17))
+    assert [(s["point_index"], int(s["frame1"]), int(s["frame2"])) for s in orc] == \
+           [(s["point_index"], int(s["frame1"]), int(s["frame2"])) for s in want]
