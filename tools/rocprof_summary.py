@@ -52,7 +52,7 @@ def main():
               f"MI355X_MICROARCH.md HBM section) = {g('FETCH_SIZE')*2048/1e6:.1f} MB read per dispatch")
     if g("WRITE_SIZE") is not None:
         print(f"- WRITE_SIZE (KiB as reported) = {g('WRITE_SIZE'):.0f}  -> x1024 = {g('WRITE_SIZE')*1024/1e6:.1f} MB written "
-              f"per dispatch (uncalibrated on gfx950)")
+              f"per dispatch (x1.000 on fill / copy kernels of known size: profiles/r01_counter_calibration.md)")
     if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None:
         print(f"- L2 hit rate = {g('TCC_HIT_sum')/(g('TCC_HIT_sum')+g('TCC_MISS_sum')):.3f}")
 

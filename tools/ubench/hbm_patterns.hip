@@ -1,0 +1,78 @@
+// Calibration of rocprofv3's FETCH_SIZE for the load shapes the K3 kernel uses: each kernel reads a known number of
+// bytes once (buffers are larger than L2 + Infinity Cache and touched in a streaming order).  Run under
+// `rocprofv3 --kernel-trace --pmc FETCH_SIZE` (tools/calibrate.sh) and compare reported KiB with the bytes below.
+//   read_b128   16 B per lane, coalesced   (1 KiB per wave instruction)
+//   read_b32     4 B per lane, coalesced   (256 B per wave instruction)
+//   read_lds_b32 4 B per lane through LDS-DMA (global_load_lds), the depth-1 tile path of K3
+//   gather_b16   2 B per lane, lanes spread over a 600 KB window (the depth-2 gather of K3): counts 64-B sectors
+// Build: hipcc --offload-arch=gfx950 -O2 -o hbm_patterns hbm_patterns.hip
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+
+constexpr size_t kBytes = 1ull << 30;
+
+__global__ void read_b128(const uint4 *__restrict__ p, size_t n, uint32_t *out) {
+    uint32_t acc = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = p[i];
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+__global__ void read_b32(const uint32_t *__restrict__ p, size_t n, uint32_t *out) {
+    uint32_t acc = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += p[i];
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+__global__ void read_lds_b32(const uint32_t *__restrict__ p, size_t n, uint32_t *out) {
+    __shared__ uint32_t lds[4][64 * 8];
+    typedef __attribute__((address_space(1))) const void gvoid_t;
+    typedef __attribute__((address_space(3))) void lvoid_t;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t acc = 0;
+    const size_t waves = (size_t)gridDim.x * 4, w = blockIdx.x * 4 + wave;
+    for (size_t base = w * 512; base + 512 <= n; base += waves * 512) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            __builtin_amdgcn_global_load_lds((gvoid_t *)(p + base + k * 64 + lane), (lvoid_t *)&lds[wave][k * 64], 4, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += lds[wave][k * 64 + lane];
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+__global__ void gather_b16(const uint16_t *__restrict__ p, size_t n_windows, uint32_t *out) {
+    // every wave instruction: 64 lanes at pseudo-random 2-byte positions inside one 614400-byte window (a 640x480
+    // depth frame), 4800 instructions per window = 307200 gathers (one per pixel, as K3 issues them)
+    uint32_t acc = 0;
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6, waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t job = wave; job < n_windows * 4800; job += waves) {
+        const size_t win = job / 4800, k = job % 4800;
+        const uint32_t h = (uint32_t)(k * 64 + lane) * 2654435761u;
+        acc += p[win * 307200 + (h % 307200u)];
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+int main() {
+    void *buf;
+    uint32_t *out;
+    hipMalloc(&buf, kBytes);
+    hipMalloc(&out, 4);
+    hipMemset(buf, 1, kBytes);
+    for (int rep = 0; rep < 2; ++rep) {
+        read_b128<<<4096, 256>>>((const uint4 *)buf, kBytes / 16, out);
+        read_b32<<<4096, 256>>>((const uint32_t *)buf, kBytes / 4, out);
+        read_lds_b32<<<4096, 256>>>((const uint32_t *)buf, kBytes / 4, out);
+        gather_b16<<<4096, 256>>>((const uint16_t *)buf, kBytes / 614400, out);
+    }
+    hipDeviceSynchronize();
+    printf("bytes per kernel: read_* %zu; gather_b16 touches %zu windows x 614400 B, issues %zu 2-byte loads\n", kBytes,
+           kBytes / 614400, kBytes / 614400 * 307200);
+    return 0;
+}
