@@ -356,7 +356,7 @@ def visual_correspondence_dataset(rows: Sequence, get_scene, get_bits=None, temp
 # depth estimation by coordinate (DE_C:175-254)
 # --------------------------------------------------------------------------------------------
 def depth_estimation_draws(image_ids: Sequence[str], n_visible: Dict[str, int], max_samples: int,
-                           templates: T.TemplateSet, rng=_random, max_n_points_per_image: int = 1):
+                           templates: T.TemplateSet, rng=_random, max_n_points_per_image: int = 1, dot: bool = False):
     """Random decisions of DE_C.generate_qa_training_single_scene: which images, which visible-vertex
     positions, which templates (question, answer, task description -- in that order, DE_C:224-230)."""
     n_images = min(max_samples, len(image_ids)) if max_samples > 0 else len(image_ids)
@@ -368,29 +368,36 @@ def depth_estimation_draws(image_ids: Sequence[str], n_visible: Dict[str, int], 
             pos = rng.choices(range(n), k=max_n_points_per_image)
         else:
             pos = sample_indices(n, max_n_points_per_image, rng)
-        picks = [(rng.choice(range(len(templates.questions["default"]))),
-                  rng.choice(range(len(templates.answers["default"]))),
-                  rng.choice(range(len(templates.task_description)))) for _ in pos]
-        draws.append({"image_id": image_id, "positions": pos, "picks": picks})
+        picks, colors = [], []
+        for _ in pos:
+            if dot:                                                           # DE_D:219-222: the disc colour comes first
+                from .annotate import generate_distinct_colors
+                colors.append(generate_distinct_colors(1, rng)[0])
+            picks.append((rng.choice(range(len(templates.questions["default"]))),
+                          rng.choice(range(len(templates.answers["default"]))),
+                          rng.choice(range(len(templates.task_description)))))
+        draws.append({"image_id": image_id, "positions": pos, "picks": picks, "colors": colors})
     return draws
 
 
 def depth_estimation_record(scene_id: str, image_id: str, vertex: int, uv_row, depth_m: float, pick, image_hw,
-                            templates: T.TemplateSet = T.DEPTH_ESTIMATION) -> dict:
+                            templates: T.TemplateSet = T.DEPTH_ESTIMATION, dot: bool = False) -> dict:
     H, W = image_hw
     x, y = normalised(uv_row, image_hw)
     depth = round(depth_m * 1000)                                         # DE_C:218
     qi, ai, ti = pick
-    question = templates.questions["default"][qi].format(x1=x, y1=y)
+    question = templates.questions["default"][qi]
+    if not dot:                                                           # the dot question names no coordinates (DE_D:232)
+        question = question.format(x1=x, y1=y)
     answer = templates.answers["default"][ai].format(x1=x, y1=y, depth=depth)
     return {
         "id": f"{scene_id}_{image_id}_point{vertex}",
-        "image": [f"{scene_id}/{image_id}.jpg"],
+        "image": [f"{scene_id}/{image_id}_p{vertex}_annotated.jpg" if dot else f"{scene_id}/{image_id}.jpg"],
         "conversations": [{"from": "human", "value": f"{templates.task_description[ti]}\n{question}"},
                           {"from": "gpt", "value": answer}],
         "height_list": [H],
         "width_list": [W],
-        "question_type": "depth_estimation_coor",
+        "question_type": "depth_estimation_dot" if dot else "depth_estimation_coor",
         "gt_value": depth,
         "ori_coordinates": [int(uv_row[0]), int(uv_row[1])],
     }
@@ -398,22 +405,26 @@ def depth_estimation_record(scene_id: str, image_id: str, vertex: int, uv_row, d
 
 def depth_estimation_records_fn(scene_id: str, image_ids: Sequence[str], n_visible, numeric_fn, image_hw,
                                 max_samples: int = -1, templates: T.TemplateSet = T.DEPTH_ESTIMATION, rng=_random,
-                                max_n_points_per_image: int = 1, on_skip=None) -> List[dict]:
-    """DE_C.generate_qa_training_single_scene with the numerics behind ``numeric_fn`` (see
-    ``depth_comparison_records``); ``n_visible`` is only indexed for the images that get sampled."""
-    draws = depth_estimation_draws(image_ids, n_visible, max_samples, templates, rng, max_n_points_per_image)
+                                max_n_points_per_image: int = 1, on_skip=None, dot: bool = False,
+                                on_mark=None) -> List[dict]:
+    """DE_C / DE_D.generate_qa_training_single_scene with the numerics behind ``numeric_fn`` (see
+    ``depth_comparison_records``); ``n_visible`` is only indexed for the images that get sampled.  In ``dot`` mode
+    ``on_mark(scene_id, image_id, vertex, (px, py), colour)`` receives the disc to draw for every record."""
+    draws = depth_estimation_draws(image_ids, n_visible, max_samples, templates, rng, max_n_points_per_image, dot)
     numerics = numeric_fn([(d["image_id"], j) for d in draws for j in d["positions"]])
     records, s = [], 0
     for dr in draws:
-        for pick in dr["picks"]:
+        for n, pick in enumerate(dr["picks"]):
             vertex, uv_row, depth_m = numerics[s]
             s += 1
             if uv_row is None:
                 if on_skip is not None:
                     on_skip(scene_id, dr["image_id"], [int(vertex)])
                 continue
+            if dot and on_mark is not None:
+                on_mark(scene_id, dr["image_id"], int(vertex), (int(uv_row[0]), int(uv_row[1])), dr["colors"][n])
             records.append(depth_estimation_record(scene_id, dr["image_id"], int(vertex), uv_row, float(depth_m), pick,
-                                                   image_hw, templates))
+                                                   image_hw, templates, dot))
     return records
 
 
@@ -440,8 +451,9 @@ def _depth_comparison_images(image_ids: Sequence[str], max_samples: int, rng) ->
 
 def depth_comparison_records(scene_id: str, image_ids: Sequence[str], n_visible: Dict[str, int], numeric_fn, image_hw,
                              max_samples: int = -1, templates: T.TemplateSet = None, rng=_random,
-                             max_n_points_per_image: int = 1, on_skip=None) -> List[dict]:
-    """Records of DC_C.generate_qa_training_single_scene.
+                             max_n_points_per_image: int = 1, on_skip=None, dot: bool = False, on_mark=None) -> List[dict]:
+    """Records of DC_C.generate_qa_training_single_scene (``dot``: of DC_D's, depth_comparison_dot_engine.py:240-375 --
+    lettered discs instead of coordinates; ``on_mark(scene_id, image_id, vertices, points_info, colours)`` gets them).
 
     ``numeric_fn([(image_id, position), ...]) -> [(vertex, uv_row | None, depth_m), ...]`` resolves the
     position-th visible vertex of an image and projects it (K6a + K6b for the whole batch on the GPU).
@@ -457,8 +469,8 @@ def depth_comparison_records(scene_id: str, image_ids: Sequence[str], n_visible:
     slots = [(img, r) for img in sampled for r in range(max_n_points_per_image)]
     records: List[dict] = []
     start = 0
+    retries_left = 10 if dot else 0          # DC_D re-draws a tied pair up to 10 more times (DC_D:263-309); DC_C gives up at once
     while start < len(slots):
-        base_state = rng.getstate()
         plan = []
         for img, _ in slots[start:]:
             state = rng.getstate()
@@ -472,8 +484,9 @@ def depth_comparison_records(scene_id: str, image_ids: Sequence[str], n_visible:
             qi = rng.choice(range(len(templates.questions[kind])))
             ai = rng.choice(range(len(templates.answers[kind])))
             ti = rng.choice(range(len(templates.task_description)))
+            colors = [(rng.randint(0, 255), rng.randint(0, 255), rng.randint(0, 255)) for _ in range(2)] if dot else []  # DC_D:335-336
             plan.append({"image_id": img, "pos": pos, "after_pick": after_pick, "letters": letters, "order": order,
-                         "closer_q": closer_q, "kind": kind, "picks": (qi, ai, ti), "state": state})
+                         "closer_q": closer_q, "kind": kind, "picks": (qi, ai, ti), "state": state, "colors": colors})
         numerics = numeric_fn([(p["image_id"], j) for p in plan for j in p["pos"]])
         skipped_at = None
         for n, p in enumerate(plan):
@@ -499,24 +512,38 @@ def depth_comparison_records(scene_id: str, image_ids: Sequence[str], n_visible:
             farther = p2 if p1["depth"] <= p2["depth"] else p1
             correct = closer if p["closer_q"] else farther
             qi, ai, ti = p["picks"]
-            question = templates.questions[p["kind"]][qi].format(x1=p1["x"], y1=p1["y"], x2=p2["x"], y2=p2["y"])
-            answer = templates.answers[p["kind"]][ai].format(correct_x=correct["x"], correct_y=correct["y"])
+            if dot:
+                question = templates.questions[p["kind"]][qi]
+                answer = templates.answers[p["kind"]][ai].format(correct_label=correct["letter"])
+                if on_mark is not None:
+                    on_mark(scene_id, p["image_id"], verts, shuffled, p["colors"])
+            else:
+                question = templates.questions[p["kind"]][qi].format(x1=p1["x"], y1=p1["y"], x2=p2["x"], y2=p2["y"])
+                answer = templates.answers[p["kind"]][ai].format(correct_x=correct["x"], correct_y=correct["y"])
             records.append({
                 "id": f"{scene_id}_{p['image_id']}_p{verts[0]}_p{verts[1]}",
-                "image": [f"{scene_id}/{p['image_id']}.jpg"],
+                "image": [f"{scene_id}/{p['image_id']}_p{verts[0]}_p{verts[1]}_annotated.jpg" if dot
+                          else f"{scene_id}/{p['image_id']}.jpg"],
                 "conversations": [{"from": "human", "value": f"{templates.task_description[ti]}\n{question}"},
                                   {"from": "gpt", "value": answer}],
                 "height_list": [H],
                 "width_list": [W],
-                "question_type": "depth_comparison_coordinate",
-                "gt_value": [correct["x"], correct["y"]],
+                "question_type": "depth_comparison_annotated" if dot else "depth_comparison_coordinate",
+                "gt_value": correct["letter"] if dot else [correct["x"], correct["y"]],
                 "points_info": shuffled,
                 "is_closer_question": p["closer_q"],
             })
         if skipped_at is None:
             break
         rng.setstate(plan[skipped_at]["after_pick"])       # the skipped pair consumed its vertex draw only
-        start += skipped_at + 1
+        if skipped_at > 0:
+            retries_left = 10 if dot else 0                # a different slot than the one that was being retried
+        start += skipped_at
+        if retries_left > 0:
+            retries_left -= 1                              # same slot again, with a fresh pair
+        else:
+            start += 1                                     # give up on this slot
+            retries_left = 10 if dot else 0
     return records
 
 

@@ -102,6 +102,20 @@ DEPTH_COMPARISON = TemplateSet(
              "farther": ["`[ {correct_x} , {correct_y} ]` is farther.",
                          "The more distant point is `[ {correct_x} , {correct_y} ]`."]})
 
+DEPTH_ESTIMATION_DOT = TemplateSet(
+    task_description=["<image>\nOne point of the image is marked with a coloured dot; report its distance from the camera.",
+                      "<image>\nEstimate the depth at the marked dot."],
+    questions={"default": ["What is the depth (in mm) at the marked point?", "How far from the camera, in millimetres, is the dot?"]},
+    answers={"default": ["`{depth}` mm.", "The marked point is `{depth}` mm away."]})
+
+DEPTH_COMPARISON_DOT = TemplateSet(
+    task_description=["<image>\nTwo points are marked with lettered dots; compare their distance to the camera.",
+                      "<image>\nDecide which lettered dot lies nearer to or farther from the camera."],
+    questions={"closer": ["Which marked point is closer to the camera?", "Which lettered dot is nearer to the viewer?"],
+               "farther": ["Which marked point is farther from the camera?", "Which lettered dot is more distant?"]},
+    answers={"closer": ["Point `{correct_label}` is closer.", "`{correct_label}` is the nearer point."],
+             "farther": ["Point `{correct_label}` is farther.", "`{correct_label}` is the more distant point."]})
+
 OBJECT_MOVEMENT_TYPES = ("tapvid3d_total_distance", "tapvid3d_displacement_vector")
 
 OBJECT_MOVEMENT = TemplateSet(

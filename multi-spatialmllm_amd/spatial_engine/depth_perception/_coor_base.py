@@ -35,6 +35,7 @@ class DepthCoorEngineBase:
         self.visibility_info = VisibilityInfoHandler(visibility_info_path)
         self.max_samples = -1
         self.templates = self.TEMPLATE_SET
+        self.annotator = None          # dot variants: mspa.annotate.PillowAnnotator() unless the caller sets another one
 
     # -- helpers ------------------------------------------------------------------------------
     def _warn(self, message):
@@ -53,6 +54,15 @@ class DepthCoorEngineBase:
         scene = self.scene_info.scene_on_device(scene_id)
         return (self.scene_info.get_all_extrinsic_valid_image_ids(scene_id), _LazyCounts(visible_points),
                 heads.list_point_numerics(scene, visible_points), self.scene_info.get_image_shape(scene_id))
+
+    def _annotated_path(self, scene_id, name):
+        return os.path.join(self.image_output_dir, scene_id, name)
+
+    def _annotator(self):
+        if self.annotator is None:
+            from mspa.annotate import PillowAnnotator
+            self.annotator = PillowAnnotator()
+        return self.annotator
 
     def generate_qa_training_single_scene(self, scene_id):
         raise NotImplementedError

@@ -164,6 +164,11 @@ def _import_reference_modules():
         "spatial_engine.visual_correspondence.visual_correspondence_qa_engine_coor_2_coor")
     ns.DE_C = importlib.import_module("spatial_engine.depth_perception.depth_estimation_coor_engine")
     ns.DC_C = importlib.import_module("spatial_engine.depth_perception.depth_comparison_coor_engine")
+    ns.DE_D = importlib.import_module("spatial_engine.depth_perception.depth_estimation_dot_engine")
+    ns.DC_D = importlib.import_module("spatial_engine.depth_perception.depth_comparison_dot_engine")
+    ns.VC_D = importlib.import_module(
+        "spatial_engine.visual_correspondence.visual_correspondence_qa_engine_dot_2_multichoice")
+    ns.OM_D = importlib.import_module("spatial_engine.object_movement.single_object_movement_engine_dot")
     assert ns.IH.__file__.startswith(REFERENCE_ROOT), ns.IH.__file__
     return ns
 

@@ -159,6 +159,78 @@ def test_depth_comparison_records(ref, world, tmp_path, quantum):
     assert len(got) + len(skipped) == 60 and (len(skipped) >= 2 if quantum else True)
 
 
+def _oracle_numeric_fn(sc, vis, quantum=0.0):
+    def fn(samples):
+        out = []
+        for image_id, j in samples:
+            v = vis["image_to_points"][image_id][j]
+            uv, d = O.point_2d_in_image(sc.points[v], sc.K, sc.A @ sc.E[image_id], sc.depth[image_id], sc.color_hw)
+            d = float(d[0]) if not quantum else float(np.round(d[0] / quantum) * quantum)
+            out.append((v, uv[0], d))
+        return out
+    return fn
+
+
+def test_depth_estimation_dot_records(ref, world, tmp_path):
+    """DE_D: the coordinate head plus a disc colour drawn before the templates; annotated image names."""
+    sc, h, rows, vis = world
+    vis_path = os.path.join(h._mspa_root, "vis.pkl")
+    RH.register_pickle(vis_path, {sc.scene_id: vis})
+    eng = ref.DE_D.DepthEstimationDotQAEngine(h._mspa_info_path, visibility_info_path=vis_path, image_output_dir=str(tmp_path / "img"),
+                                              warning_file=str(tmp_path / "w.txt"))
+    eng.scene_info.posed_images_root = h.posed_images_root
+    eng.scene_info.instance_data_root = h.instance_data_root
+    eng.max_samples = 5
+    tpl = T.TemplateSet(list(eng.task_description), {"default": list(eng.templates["questions"])},
+                        {"default": list(eng.templates["answers"])})
+    random.seed(19)
+    want = eng.generate_qa_training_single_scene(sc.scene_id)
+    state_ref = random.getstate()
+    ids = O.valid_image_ids(sc.E)
+    n_visible = {k: len(vis["image_to_points"][k]) for k in ids}
+    marks = []
+    random.seed(19)
+    got = heads.depth_estimation_records_fn(sc.scene_id, ids, n_visible, _oracle_numeric_fn(sc, vis), sc.color_hw, 5, tpl,
+                                            dot=True, on_mark=lambda *a: marks.append(a))
+    assert got == want and len(got) == 5 and random.getstate() == state_ref
+    assert len(marks) == 5 and all(len(m[4]) == 3 for m in marks)
+    assert got[0]["image"][0].endswith("_annotated.jpg") and got[0]["question_type"] == "depth_estimation_dot"
+
+
+@pytest.mark.parametrize("quantum", [0.0, 0.5])
+def test_depth_comparison_dot_records(ref, world, tmp_path, quantum):
+    sc, h, rows, vis = world
+    vis_path = os.path.join(h._mspa_root, "vis.pkl")
+    RH.register_pickle(vis_path, {sc.scene_id: vis})
+    eng = ref.DC_D.DepthComparisonDotQAEngine(h._mspa_info_path, visibility_info_path=vis_path, image_output_dir=str(tmp_path / "img"),
+                                              warning_file=str(tmp_path / "w.txt"))
+    eng.scene_info.posed_images_root = h.posed_images_root
+    eng.scene_info.instance_data_root = h.instance_data_root
+    eng.max_samples = 50
+    if quantum:
+        plain = eng.scene_info.get_point_2d_coordinates_in_image
+
+        def quantised(*a, **k):
+            uv, d = plain(*a, **k)
+            return uv, np.round(d / quantum) * quantum
+        eng.scene_info.get_point_2d_coordinates_in_image = quantised
+    tpl = T.TemplateSet(list(eng.task_description),
+                        {"closer": list(eng.templates["closer_questions"]), "farther": list(eng.templates["farther_questions"])},
+                        {"closer": list(eng.templates["closer_answers"]), "farther": list(eng.templates["farther_answers"])})
+    random.seed(29)
+    want = eng.generate_qa_training_single_scene(sc.scene_id)
+    state_ref = random.getstate()
+    ids = O.valid_image_ids(sc.E)
+    n_visible = {k: len(vis["image_to_points"][k]) for k in ids}
+    marks, skipped = [], []
+    random.seed(29)
+    got = heads.depth_comparison_records(sc.scene_id, ids, n_visible, _oracle_numeric_fn(sc, vis, quantum), sc.color_hw, 50, tpl,
+                                         on_skip=lambda *a: skipped.append(a), dot=True, on_mark=lambda *a: marks.append(a))
+    assert got == want and random.getstate() == state_ref
+    assert len(got) == 50 and len(marks) == 50 and (len(skipped) >= 2 if quantum else True)   # tied pairs are re-drawn (DC_D:263-309)
+    assert got[0]["gt_value"] in ("A", "B") and got[0]["question_type"] == "depth_comparison_annotated"
+
+
 def test_object_movement_records(ref):
     tr = synth.make_tracks(21, T=18, P=30)
     H, W = tr.image_hw
