@@ -17,6 +17,7 @@ depth_estimation_coor_engine.py (DE_C), object_movement/single_object_movement_e
 from __future__ import annotations
 
 import json
+import os
 import random as _random
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
@@ -352,6 +353,190 @@ def visual_correspondence_dataset(rows: Sequence, get_scene, get_bits=None, temp
     return out
 
 
+def _vc_dot_row_draws(n_common: int, known: bool, image_hw, templates: T.TemplateSet, rng, correct_point=None):
+    """All draws of VC_D.build_training_sample for one row (VC_D:290-386), in order.  ``correct_point`` None = assume that
+    no random distractor lands exactly on the correct pixel (checked afterwards); given = apply upstream's rejection."""
+    from .annotate import generate_distinct_colors
+    swap = rng.random() < 0.5                                              # VC_D:290
+    if not known or n_common == 0:
+        return {"swap": swap, "dead": True}
+    pos = sample_indices(int(n_common), 1, rng)[0]                          # VC_D:326-327 (max_points_per_pair == 1)
+    color1 = (rng.randint(0, 255), rng.randint(0, 255), rng.randint(0, 255))   # VC_D:356
+    H, W = image_hw
+    wrong = []
+    while len(wrong) < 3:                                                  # VC_D:362-367
+        p = (rng.randint(0, W - 10), rng.randint(0, H - 10))
+        if correct_point is None or p != correct_point:
+            wrong.append(p)
+    order = [0, 1, 2, 3]                                                   # 0 = the correct point
+    rng.shuffle(order)                                                     # VC_D:371
+    labels = ["A", "B", "C", "D"]
+    rng.shuffle(labels)                                                    # VC_D:374
+    colors = generate_distinct_colors(4, rng)                              # VC_D:379
+    ti = rng.choice(range(len(templates.task_description)))
+    qi = rng.choice(range(len(templates.questions["default"])))
+    ai = rng.choice(range(len(templates.answers["default"])))
+    return {"swap": swap, "dead": False, "pos": pos, "color1": color1, "wrong": wrong, "order": order, "labels": labels,
+            "colors": colors, "picks": (ti, qi, ai)}
+
+
+class GpuCorrespondenceBackend:
+    """Numerics of the correspondence heads for rows that span scenes: sizes of the common visible sets (K2), the
+    drawn positions -> vertices (K6a) and their projections into both images (K6b), one batch per scene."""
+
+    def __init__(self, get_scene, get_bits=None):
+        self.get_scene = get_scene
+        self.bits_of = get_bits or (lambda scene_id, scene: scene._visibility()["bits"])
+
+    def image_hw(self, scene_id):
+        scene = self.get_scene(scene_id)
+        return None if scene is None else scene.image_hw
+
+    def common_counts(self, scene_id, pairs: Sequence[Tuple[str, str]]) -> Optional[List[int]]:
+        """len(intersect1d(points(image1), points(image2))) per pair; None if the scene is unknown."""
+        import torch
+        from . import engine
+        scene = self.get_scene(scene_id)
+        if scene is None:
+            return None
+        out = [0] * len(pairs)
+        usable = [n for n, (a, b) in enumerate(pairs) if a in scene.index and b in scene.index]
+        if usable:
+            idx = np.array([[scene.index[pairs[n][0]], scene.index[pairs[n][1]]] for n in usable], dtype=np.int32)
+            _, inter, _ = engine.pair_overlap(self.bits_of(scene_id, scene), torch.from_numpy(idx).to(scene.device), want_counts=True)
+            for n, c in zip(usable, inter.cpu().numpy()):
+                out[n] = int(c)
+        return out
+
+    def project(self, scene_id, jobs: Sequence[Tuple[str, str, int]]):
+        """jobs: (first image, second image, position in their sorted common set) -> [(vertex, uv1, uv2, ok1, ok2)]."""
+        import torch
+        from . import engine
+        scene = self.get_scene(scene_id)
+        dev = scene.device
+        a = [scene.index[j[0]] for j in jobs]
+        b = [scene.index[j[1]] for j in jobs]
+        sel = torch.tensor([[x, y, j[2]] for x, y, j in zip(a, b, jobs)], dtype=torch.int32, device=dev)
+        vert = engine.select_common_point(self.bits_of(scene_id, scene), sel)
+        first = torch.tensor(a, dtype=torch.int32, device=dev)
+        second = torch.tensor(b, dtype=torch.int32, device=dev)
+        samples = torch.cat([torch.stack([vert, first], 1), torch.stack([vert, second], 1)], 0).contiguous()
+        uv, _, ok = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw, samples)
+        uv, ok, vert_h = uv.cpu().numpy(), ok.cpu().numpy().astype(bool), vert.cpu().numpy()
+        m = len(jobs)
+        return [(int(vert_h[s]), uv[s], uv[s + m], bool(ok[s]), bool(ok[s + m])) for s in range(m)]
+
+
+def visual_correspondence_dot_dataset(rows: Sequence, backend, templates: T.TemplateSet = None, rng=_random, on_warn=None,
+                                      on_mark=None) -> List[Optional[dict]]:
+    """Record loop of the multiple-choice correspondence head (visual_correspondence_qa_engine_dot_2_multichoice.py
+    :279-433, VC_D) for rows that may span scenes.  ``backend``: ``GpuCorrespondenceBackend`` (or anything with its
+    three methods).
+
+    Pass 1 (per scene): sizes of the common visible sets.  Pass 2 (host, global row order): every draw.  Pass 3 (per
+    scene): drawn positions -> vertices -> projections.  Upstream rejects a random distractor that coincides with the
+    correct pixel (VC_D:366) -- a draw that depends on the projection.  The draws are made assuming no such coincidence
+    and checked afterwards; at the first row where one did occur the generator is taken back to that row (replayed from
+    a checkpoint kept every 1024 rows), the row is redrawn with the rejection applied, and the passes resume behind it.
+    ``on_mark(row_index, scene_id, first_image, second_image, vertex, p1_pixel, colour1, labelled_points, colours)``.
+    """
+    templates = templates or T.VISUAL_CORRESPONDENCE_DOT
+    warn = on_warn or (lambda message: None)
+    by_scene: Dict[str, List[int]] = {}
+    for k, r in enumerate(rows):
+        by_scene.setdefault(r["scene_id"], []).append(k)
+    n = len(rows)
+    n_common = [0] * n
+    known = [False] * n
+    hw: Dict[str, Tuple[int, int]] = {}
+    for scene_id, ks in by_scene.items():                                  # pass 1
+        counts = backend.common_counts(scene_id, [(rows[k]["image_id1"], rows[k]["image_id2"]) for k in ks])
+        if counts is None:
+            continue
+        hw[scene_id] = backend.image_hw(scene_id)
+        for k, c in zip(ks, counts):
+            known[k], n_common[k] = True, c
+
+    out: List[Optional[dict]] = [None] * n
+    start = 0
+    forced: Dict[int, Tuple[int, int]] = {}                                # row -> correct pixel where the rejection applies
+    STRIDE = 1024
+
+    def draw(k):
+        return _vc_dot_row_draws(n_common[k], known[k], hw.get(rows[k]["scene_id"], (0, 0)), templates, rng, forced.get(k))
+
+    while start < n:
+        draws: Dict[int, dict] = {}
+        checkpoints: Dict[int, tuple] = {}
+        for k in range(start, n):                                          # pass 2
+            if (k - start) % STRIDE == 0:
+                checkpoints[k] = rng.getstate()
+            draws[k] = draw(k)
+        proj: Dict[int, tuple] = {}
+        for scene_id, ks in by_scene.items():                              # pass 3
+            live = [k for k in ks if k >= start and not draws[k]["dead"]]
+            if not live:
+                continue
+            jobs = []
+            for k in live:
+                r, d = rows[k], draws[k]
+                i1, i2 = (r["image_id2"], r["image_id1"]) if d["swap"] else (r["image_id1"], r["image_id2"])
+                jobs.append((i1, i2, d["pos"]))
+            for k, res in zip(live, backend.project(scene_id, jobs)):
+                proj[k] = res
+        clash = None
+        for k in range(start, n):                                          # records, until a distractor hits the correct pixel
+            r, d = rows[k], draws[k]
+            image1, image2 = (r["image_id2"], r["image_id1"]) if d["swap"] else (r["image_id1"], r["image_id2"])
+            if d["dead"]:
+                if not known[k]:
+                    warn(f"[build_training_sample] Warning: Visibility info not found for scene {r['scene_id']}\n")
+                else:
+                    warn(f"[build_training_sample] Warning: No common visible points for scene {r['scene_id']} {image1}, {image2}\n")
+                continue
+            vertex, uv1, uv2, ok1, ok2 = proj[k]
+            if not (ok1 and ok2):
+                # upstream returns before any further draw (VC_D:339-351) while the draws above went on; unreachable when
+                # the visibility index and the depth test agree
+                raise RuntimeError(f"vertex {vertex} of the common set failed the visibility re-check in scene {r['scene_id']}")
+            correct = (int(uv2[0]), int(uv2[1]))
+            if k not in forced and correct in d["wrong"]:
+                clash = (k, correct)
+                break
+            H, W = hw[r["scene_id"]]
+            points = [correct] + d["wrong"]
+            labeled = dict(zip(d["labels"], [points[j] for j in d["order"]]))
+            correct_label = [lab for lab, p in labeled.items() if p == correct][0]
+            ti, qi, ai = d["picks"]
+            p1_pixel = (int(uv1[0]), int(uv1[1]))
+            if on_mark is not None:
+                on_mark(k, r["scene_id"], image1, image2, vertex, p1_pixel, d["color1"], labeled,
+                        {lab: d["colors"][j] for j, lab in enumerate(d["labels"])})
+            out[k] = {
+                "id": f"{k}_p{vertex}",
+                "image": [os.path.join(r["scene_id"], f"{k}_point{vertex}_{image1}_{image2}_img1.jpg"),
+                          os.path.join(r["scene_id"], f"{k}_point{vertex}_{image1}_{image2}_img2.jpg")],
+                "conversations": [{"from": "human", "value": f"{templates.task_description[ti]}\n{templates.questions['default'][qi]}"},
+                                  {"from": "gpt", "value": templates.answers["default"][ai].format(correct_label=correct_label)}],
+                "height_list": [H] * 2,
+                "width_list": [W] * 2,
+                "question_type": "visual_correspondence_multiple_choice",
+                "gt_value": correct_label,
+                "p1_list": [p1_pixel[0], p1_pixel[1]],
+                "p2_list": [correct] + d["wrong"],
+            }
+        if clash is None:
+            break
+        k, correct = clash                                                 # take the generator back to the start of row k
+        base = max(c for c in checkpoints if c <= k)
+        rng.setstate(checkpoints[base])
+        for j in range(base, k):
+            draw(j)
+        forced[k] = correct
+        start = k
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # depth estimation by coordinate (DE_C:175-254)
 # --------------------------------------------------------------------------------------------
@@ -594,9 +779,14 @@ def depth_comparison_records_gpu(scene, scene_id: str, image_hw, max_samples: in
 # object movement on TAPVid-3D tracks (OM_C:317-404)
 # --------------------------------------------------------------------------------------------
 def object_movement_record(scene_id: str, frame1: int, frame2: int, point_index: int, question_type: str,
-                           numeric: dict, image_hw, templates: T.TemplateSet = T.OBJECT_MOVEMENT, rng=_random) -> Optional[dict]:
+                           numeric: dict, image_hw, templates: T.TemplateSet = T.OBJECT_MOVEMENT, rng=_random,
+                           dot: bool = False, needs_annotation=None, on_mark=None) -> Optional[dict]:
     """numeric: distance, vector (camera-1 axes, metres), point_moving, cam_moving, p1n/p2n (normalised
-    projections or None) -- K5's outputs for this (frame1, frame2, point)."""
+    projections or None) -- K5's outputs for this (frame1, frame2, point).
+
+    ``dot`` (single_object_movement_engine_dot.py:341-436, OM_D): the first frame carries a disc on the point; its colour
+    is drawn after the templates and only when the annotated file is still to be made (``needs_annotation(name)``,
+    OM_D:409-413), ``on_mark(frame1, frame2, point, pixel, colour_or_None)`` receives the job."""
     if numeric["p1n"] is None or numeric["p2n"] is None:                  # OM_C:360-362
         return None
     H, W = image_hw
@@ -611,14 +801,25 @@ def object_movement_record(scene_id: str, frame1: int, frame2: int, point_index:
     if not numeric["point_moving"]:
         answer_text = "The point did not move. " + answer_text
     images = [f"{scene_id}/{frame:05d}.jpg" for frame in [frame1, frame2]]
+    if dot:
+        from .annotate import generate_distinct_colors
+        name = f"{frame1:05d}_{point_index}_annotated.jpg"
+        color = None
+        if needs_annotation is None or needs_annotation(name):
+            color = generate_distinct_colors(1, rng)[0]
+        if on_mark is not None:
+            on_mark(frame1, frame2, point_index, (int(numeric["p1n"][0] * W), int(numeric["p1n"][1] * H)), color)
+        images = [f"{scene_id}/{name}", f"{scene_id}/{frame2:05d}.jpg"]
     return {
-        "id": f"{scene_id}_{frame1}_{frame2}_{point_index}",
+        "id": f"{scene_id}_{frame1}_{frame2}_{point_index}" + ("_ann" if dot else ""),
         "image": images,
         "conversations": [{"from": "human", "value": f"{task_description}\n{question}"},
                           {"from": "gpt", "value": answer_text}],
         "height_list": [H] * 2,
         "width_list": [W] * 2,
-        "gt_value": int(numeric["distance"] * 1000) if "total_distance" in question_type else list(vec),
+        # OM_D:429 tests ``== "total_distance"`` against the "tapvid3d_..." names, so its dot records always carry the vector
+        "gt_value": (int(numeric["distance"] * 1000) if (question_type == "total_distance" if dot else "total_distance" in question_type)
+                     else list(vec)),
         "question_type": question_type,
         "point_moving": int(numeric["point_moving"]),
         "cam_moving": int(numeric["cam_moving"]),
@@ -628,7 +829,8 @@ def object_movement_record(scene_id: str, frame1: int, frame2: int, point_index:
 
 
 def object_movement_numeric(tracks_xyz: np.ndarray, extrinsics_w2c: np.ndarray, fx_fy_cx_cy, image_hw,
-                            triples: np.ndarray, device="cuda") -> List[dict]:
+                            triples: np.ndarray, device="cuda", obj_threshold: float = 0.01,
+                            cam_threshold: float = 0.01) -> List[dict]:
     """GPU stage: K5a + K5b for a list of (frame1, frame2, point) triples."""
     import torch
     from . import engine
@@ -639,7 +841,7 @@ def object_movement_numeric(tracks_xyz: np.ndarray, extrinsics_w2c: np.ndarray, 
     w2c = torch.from_numpy(w2c_np.reshape(T_, 16)).to(device)
     res = engine.track_to_world(tr, c2w, fx_fy_cx_cy, image_hw)
     trip = torch.from_numpy(np.ascontiguousarray(triples, dtype=np.int32)).to(device)
-    disp, flags = engine.track_displacement(res["world"], w2c, c2w, trip)
+    disp, flags = engine.track_displacement(res["world"], w2c, c2w, trip, obj_threshold, cam_threshold)
     uvn, ok = res["uvn"].cpu().numpy(), res["ok"].cpu().numpy().astype(bool)
     disp, flags = disp.cpu().numpy(), flags.cpu().numpy()
     out = []
@@ -653,14 +855,17 @@ def object_movement_numeric(tracks_xyz: np.ndarray, extrinsics_w2c: np.ndarray, 
 
 def object_movement_records(scene_id: str, tracks_xyz, extrinsics_w2c, fx_fy_cx_cy, image_hw, sample_pairs: Sequence[dict],
                             question_type: str, templates: T.TemplateSet = T.OBJECT_MOVEMENT, rng=_random,
-                            device="cuda") -> List[dict]:
-    """format_training_samples (OM_C:317-404) for already chosen {frame1, frame2, point_index} samples."""
+                            device="cuda", dot: bool = False, needs_annotation=None, on_mark=None,
+                            obj_threshold: float = 0.01, cam_threshold: float = 0.01) -> List[dict]:
+    """format_training_samples (OM_C:317-404; OM_D:341-436 with ``dot``) for already chosen {frame1, frame2, point_index}
+    samples."""
     triples = np.array([[s["frame1"], s["frame2"], s["point_index"]] for s in sample_pairs], dtype=np.int32).reshape(-1, 3)
-    numeric = object_movement_numeric(tracks_xyz, extrinsics_w2c, fx_fy_cx_cy, image_hw, triples, device)
+    numeric = object_movement_numeric(tracks_xyz, extrinsics_w2c, fx_fy_cx_cy, image_hw, triples, device, obj_threshold,
+                                      cam_threshold)
     records = []
     for s, num in zip(sample_pairs, numeric):
         r = object_movement_record(scene_id, int(s["frame1"]), int(s["frame2"]), int(s["point_index"]), question_type, num,
-                                   image_hw, templates, rng)
+                                   image_hw, templates, rng, dot, needs_annotation, on_mark)
         if r is not None:
             records.append(r)
     return records

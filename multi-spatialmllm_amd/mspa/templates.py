@@ -102,6 +102,27 @@ DEPTH_COMPARISON = TemplateSet(
              "farther": ["`[ {correct_x} , {correct_y} ]` is farther.",
                          "The more distant point is `[ {correct_x} , {correct_y} ]`."]})
 
+VISUAL_CORRESPONDENCE_DOT = TemplateSet(
+    task_description=[_TWO_IMG + "A point is marked with a dot in Image-1; Image-2 shows four lettered candidates. Pick the one "
+                                 "that is the same scene point.",
+                      _TWO_IMG + "Match the marked point of the first image with one of the lettered dots in the second."],
+    questions={"default": ["Which lettered dot in Image-2 corresponds to the dot in Image-1?",
+                           "Choose the letter of the point in the second image that matches the marked point."]},
+    answers={"default": ["`{correct_label}`", "The matching point is `{correct_label}`."]})
+
+OBJECT_MOVEMENT_DOT = TemplateSet(
+    task_description=[_TWO_IMG + "A point is marked with a dot in Image-1; objects and the camera may have moved before Image-2. "
+                                 "Describe the motion of the marked point relative to the first image.",
+                      _TWO_IMG + "Track the dotted point of the first frame into the second frame."],
+    questions={"tapvid3d_total_distance": ["How far (in mm) did the marked point move?",
+                                           "Give the travelled distance in mm of the dotted point."],
+               "tapvid3d_displacement_vector": ["With X right, Y down, Z forward in the first view, what is the displacement (mm) "
+                                                "of the marked point?",
+                                                "Report the [ x , y , z ] displacement in mm of the dotted point."]},
+    answers={"tapvid3d_total_distance": ["It moved `{total_distance}` mm.", "The distance is `{total_distance}` mm."],
+             "tapvid3d_displacement_vector": ["`[ {x_value} , {y_value} , {z_value} ]` mm.",
+                                              "Its displacement is `[ {x_value} , {y_value} , {z_value} ]` mm."]})
+
 DEPTH_ESTIMATION_DOT = TemplateSet(
     task_description=["<image>\nOne point of the image is marked with a coloured dot; report its distance from the camera.",
                       "<image>\nEstimate the depth at the marked dot."],

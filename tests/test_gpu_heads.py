@@ -420,3 +420,193 @@ def test_dataset_level_builders(tmp_path):
     VC.build_val_dataset(table_path, out, h, 8, lo, hi, 1, vis_path, warn)
     val = [json.loads(line) for line in open(os.path.join(out, "val_visual_correspondence_coor_2_coor.jsonl"))]
     assert val and all("text" in r for r in val)
+
+
+# ------------------------------------------------------------------------------------------
+# "dot" variants: records from the GPU numerics == records from oracle numerics; annotation jobs; real JPEGs via Pillow
+# ------------------------------------------------------------------------------------------
+def _write_scene_files(tmp_path, scenes, with_real_jpeg):
+    import importlib
+    import os
+    import pickle
+    IMG = importlib.import_module("spatial_engine.utils.scannet_utils.handler._images")
+    posed, inst = str(tmp_path / "posed_images"), str(tmp_path / "inst")
+    infos = {}
+    for sc in scenes:
+        os.makedirs(os.path.join(inst, sc.scene_id), exist_ok=True)
+        os.makedirs(os.path.join(posed, sc.scene_id), exist_ok=True)
+        np.save(os.path.join(inst, sc.scene_id, "aligned_points.npy"), sc.points)
+        for i in sc.image_ids:
+            jpg = os.path.join(posed, sc.scene_id, f"{i}.jpg")
+            IMG.register(jpg, np.zeros(sc.color_hw + (3,), np.uint8))
+            IMG.register(os.path.join(posed, sc.scene_id, f"{i}.png"), sc.depth[i])
+            if with_real_jpeg:
+                from PIL import Image
+                Image.fromarray(np.full(sc.color_hw + (3,), 90, np.uint8)).save(jpg)
+        infos[sc.scene_id] = sc.info_dict()
+    info_path = str(tmp_path / "infos.pkl")
+    with open(info_path, "wb") as f:
+        pickle.dump(infos, f)
+    return info_path, posed, inst
+
+
+def test_depth_dot_engines(world, tmp_path):
+    import importlib
+    import json
+    import os
+    import pickle
+    from mspa.annotate import RecordingAnnotator
+    sc, scene, rows, vis = world
+    try:
+        import PIL  # noqa: F401
+        real = True
+    except ImportError:
+        real = False
+    info_path, posed, inst = _write_scene_files(tmp_path, [sc], real)
+    vis_path = str(tmp_path / "vis.pkl")
+    with open(vis_path, "wb") as f:
+        pickle.dump({sc.scene_id: vis}, f)
+    DE = importlib.import_module("spatial_engine.depth_perception.depth_estimation_dot_engine")
+    DC = importlib.import_module("spatial_engine.depth_perception.depth_comparison_dot_engine")
+    ids = O.valid_image_ids(sc.E)
+    n_visible = {k: len(vis["image_to_points"][k]) for k in ids}
+    for mod, cls, name in ((DE, "DepthEstimationDotQAEngine", "depth_estimation_dot"), (DC, "DepthComparisonDotQAEngine", "depth_comparison_dot")):
+        img_dir = str(tmp_path / f"img_{name}")
+        eng = getattr(mod, cls)(info_path, all_max_samples=6, image_output_dir=img_dir, visibility_info_path=vis_path,
+                                warning_file=str(tmp_path / "w.txt"))
+        eng.scene_info.posed_images_root, eng.scene_info.instance_data_root = posed, inst
+        rec = RecordingAnnotator()
+        eng.annotator = rec
+        random.seed(51)
+        eng.generate_qa_training_data(str(tmp_path / f"train_{name}"))
+        got = [json.loads(line) for line in open(tmp_path / f"train_{name}" / f"{name}.jsonl")]
+        random.seed(51)
+        if name == "depth_estimation_dot":
+            want = heads.depth_estimation_records_fn(sc.scene_id, ids, n_visible, _oracle_numeric_fn(sc, vis), sc.color_hw, 7,
+                                                     T.DEPTH_ESTIMATION_DOT, dot=True)
+        else:
+            want = heads.depth_comparison_records(sc.scene_id, ids, n_visible, _oracle_numeric_fn(sc, vis), sc.color_hw, 7,
+                                                  T.DEPTH_COMPARISON_DOT, dot=True)
+        if len(want) > 6:
+            want = random.sample(want, 6)
+        random.shuffle(want)
+        assert got == json.loads(json.dumps(want)) and len(got) >= 5
+        assert len(rec.jobs) >= len(got) and all(j[0] == "annotate" and j[2].endswith("_annotated.jpg") for j in rec.jobs)
+        marks = rec.jobs[0][3]
+        assert len(marks) == (1 if name == "depth_estimation_dot" else 2) and marks[0][2] == 10
+        if real:                                           # the real thing once: a JPEG with the disc in it
+            from PIL import Image
+            eng.annotator = None
+            random.seed(52)
+            recs = eng.generate_qa_training_single_scene(sc.scene_id)
+            path = os.path.join(img_dir, recs[0]["image"][0])
+            im = np.asarray(Image.open(path))
+            assert im.shape[:2] == sc.color_hw and (np.abs(im.astype(int) - 90).max() > 20)
+
+
+def test_correspondence_dot_facade(tmp_path):
+    import importlib
+    import json
+    import os
+    import pickle
+    pd = pytest.importorskip("pandas")
+    pytest.importorskip("pyarrow")
+    from mspa.annotate import RecordingAnnotator
+    IH = importlib.import_module("spatial_engine.utils.scannet_utils.handler.info_handler")
+    VD = importlib.import_module("spatial_engine.visual_correspondence.visual_correspondence_qa_engine_dot_2_multichoice")
+    scenes = [synth.make_scene(7500 + k, n_points=3000, n_frames=9, color_hw=(96, 128), depth_hw=(96, 128),
+                               invalid_pose_frac=0.1, with_color=False) for k in range(2)]
+    info_path, posed, inst = _write_scene_files(tmp_path, scenes, False)
+    vis_all, table_rows = {}, []
+    for sc in scenes:
+        resident = SceneOnDevice(sc.K, sc.A, sc.E, sc.depth, sc.color_hw, sc.points, DEV)
+        vis_all[sc.scene_id] = resident.visibility_index()
+        for (a, b), v in resident.frames_relations().items():
+            table_rows.append({"scene_id": sc.scene_id, "image_id1": a, "image_id2": b, "overlap": float(v["overlap"]),
+                               "distance": float(v["distance"]), "yaw": float(v["yaw"]), "pitch": float(v["pitch"])})
+    vis_path, table_path = str(tmp_path / "vis.pkl"), str(tmp_path / "pairs.parquet")
+    with open(vis_path, "wb") as f:
+        pickle.dump(vis_all, f)
+    pd.DataFrame(table_rows).to_parquet(table_path)
+    h = IH.SceneInfoHandler(info_path, posed_images_root=posed, instance_data_root=inst)
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    warn = str(tmp_path / "w.txt")
+    open(warn, "w").close()
+    rec = RecordingAnnotator()
+    VD.ANNOTATOR = rec
+    random.seed(61); np.random.seed(61)
+    VD.build_train_dataset(table_path, out, h, 24, 1, 60, 1, vis_path, warn)
+    got = [json.loads(line) for line in open(os.path.join(out, "train_visual_correspondence_dot_2_multichoice.jsonl"))]
+    # the same from oracle numerics
+    by_id = {sc.scene_id: sc for sc in scenes}
+
+    class Backend:
+        def image_hw(self, s):
+            return by_id[s].color_hw
+
+        def common_counts(self, s, pairs):
+            i2p = vis_all[s]["image_to_points"]
+            return [len(np.intersect1d(i2p.get(a, []), i2p.get(b, []))) for a, b in pairs]
+
+        def project(self, s, jobs):
+            sc, i2p, res = by_id[s], vis_all[s]["image_to_points"], []
+            for a, b, pos in jobs:
+                v = int(np.intersect1d(i2p[a], i2p[b])[pos])
+                uv1, _ = O.point_2d_in_image(sc.points[v], sc.K, sc.A @ sc.E[a], sc.depth[a], sc.color_hw)
+                uv2, _ = O.point_2d_in_image(sc.points[v], sc.K, sc.A @ sc.E[b], sc.depth[b], sc.color_hw)
+                res.append((v, uv1[0], uv2[0], True, True))
+            return res
+    random.seed(61); np.random.seed(61)
+    sampled = VD.sample_dataframe(pd.read_parquet(table_path), all_overlap_samples=24, non_overlap_samples=0, overlap_min=1,
+                                  overlap_max=60, interval=1)
+    want = [w for w in heads.visual_correspondence_dot_dataset([sampled.iloc[k] for k in range(len(sampled))], Backend(),
+                                                               T.VISUAL_CORRESPONDENCE_DOT) if w]
+    random.shuffle(want)
+    assert got == json.loads(json.dumps(want)) and len(got) >= 8
+    assert len(rec.jobs) == 2 * len(got) and len(rec.jobs[1][3]) == 4 and {m[4] for m in rec.jobs[1][3]} == {"A", "B", "C", "D"}
+    r = got[0]
+    assert r["gt_value"] in "ABCD" and len(r["p2_list"]) == 4 and r["question_type"] == "visual_correspondence_multiple_choice"
+    # single-row entry point keeps the caller's index in the names
+    random.seed(62)
+    one = VD.build_training_sample(h, sampled.iloc[0], 37, vis_all, warn, image_output_dir=str(tmp_path / "dbg"))
+    assert one is None or (one["id"].startswith("37_p") and one["image"][0].split(os.sep)[-1].startswith("37_point"))
+
+
+def test_object_movement_dot_facade(tmp_path):
+    import importlib
+    import os
+    from mspa.annotate import RecordingAnnotator
+    OMD = importlib.import_module("spatial_engine.object_movement.single_object_movement_engine_dot")
+    tr = synth.make_tracks(33, T=150, P=64, n_groups=4)
+    H, W = tr.image_hw
+    sof = b"\xff\xd8\xff\xc0\x00\x11\x08" + H.to_bytes(2, "big") + W.to_bytes(2, "big") + b"\x03\x01\x11\x00\x02\x11\x01\x03\x11\x01\xff\xd9"
+    (tmp_path / "src").mkdir()
+    path = str(tmp_path / "src" / f"{tr.scene_id}.npz")
+    np.savez(path, images_jpeg_bytes=np.array([sof] * tr.tracks_XYZ.shape[0], dtype=object), tracks_XYZ=tr.tracks_XYZ,
+             visibility=tr.visibility, fx_fy_cx_cy=tr.fx_fy_cx_cy, extrinsics_w2c=tr.extrinsics_w2c)
+    eng = OMD.TwoFrameVideoQAEngineDot("tapvid3d_total_distance", "adt")
+
+    class Touching(RecordingAnnotator):                     # the existence test of later samples needs the files to appear
+        def annotate(self, src, dst, marks):
+            super().annotate(src, dst, marks)
+            os.makedirs(os.path.dirname(dst), exist_ok=True)
+            open(dst, "wb").close()
+
+        def copy(self, src, dst):
+            super().copy(src, dst)
+            os.makedirs(os.path.dirname(dst), exist_ok=True)
+            open(dst, "wb").close()
+    eng.annotator = Touching()
+    random.seed(71)
+    recs = eng.generate_qa_training_single_scene(path, str(tmp_path / "base"), 6, 5, str(tmp_path / "img"), True, 0.5)
+    assert len(recs) > 20 and all(r["id"].endswith("_ann") and r["image"][0].endswith("_annotated.jpg") for r in recs)
+    assert all(isinstance(r["gt_value"], list) for r in recs)          # upstream's == "total_distance" never matches (OM_D:429)
+    n_ann = sum(j[0] == "annotate" for j in eng.annotator.jobs)
+    assert n_ann == len({r["image"][0] for r in recs}) and n_ann <= len(recs)
+    assert all(j[3][0][2] == W // 100 for j in eng.annotator.jobs if j[0] == "annotate")
+    out = str(tmp_path / "val.jsonl")
+    random.seed(72)
+    eng.generate_qa_eval_data([tr.scene_id], str(tmp_path / "src"), str(tmp_path / "base"), str(tmp_path), out, str(tmp_path / "img2"),
+                              1, 1, False, max_samples=5)
+    assert os.path.exists(out.replace(".jsonl", "_orig.jsonl")) and 0 < sum(1 for _ in open(out)) <= 5

@@ -267,6 +267,173 @@ def test_object_movement_records(ref):
             assert g == w
 
 
+def test_object_movement_dot_records(ref, tmp_path):
+    """OM_D.format_training_samples: the colour of the disc is drawn after the templates and only for annotated frames
+    that do not exist yet, so repeated (frame1, point) samples shorten the stream."""
+    tr = synth.make_tracks(21, T=18, P=30)
+    H, W = tr.image_hw
+    world = O.tracks_cam_to_world(tr.tracks_XYZ, tr.extrinsics_w2c)
+    rng = np.random.default_rng(2)
+    pairs = [{"frame1": int(a), "frame2": int(b), "point_index": int(p)}
+             for a, b, p in zip(rng.integers(0, 18, 40), rng.integers(0, 18, 40), rng.integers(0, 30, 40))]
+    pairs += [dict(pairs[3]), dict(pairs[7], frame2=1)]                  # repeats of an annotated (frame1, point)
+    base = tmp_path / "base" / tr.scene_id
+    base.mkdir(parents=True)
+    for f in range(18):
+        (base / f"{f:05d}.jpg").write_bytes(b"jpeg")
+        RH.STORE.images[str(base / f"{f:05d}.jpg")] = np.zeros((H, W, 3), np.uint8)
+    import cv2
+    real_imwrite = cv2.imwrite
+    cv2.imwrite = lambda path, img: open(path, "wb").write(b"x") or True   # the existence test needs real files
+    try:
+        for qt in T.OBJECT_MOVEMENT_TYPES:
+            eng = ref.OM_D.TwoFrameVideoQAEngineDot(qt, "adt")
+            eng.image_width, eng.image_height = W, H                      # upstream reads self.image_width without setting it
+            tpl = T.TemplateSet.from_module(ref.OM_D)
+            out_dir = tmp_path / f"out_{qt}"
+            random.seed(5)
+            want = eng.format_training_samples(pairs, tr.fx_fy_cx_cy, tr.scene_id, world, tr.tracks_XYZ, H, W,
+                                               tr.extrinsics_w2c, str(tmp_path / "base"), str(out_dir))
+            state_ref = random.getstate()
+            done, marks = set(), []
+            random.seed(5)
+            got = []
+            for s in pairs:
+                o = O.object_displacement(world, tr.tracks_XYZ, tr.extrinsics_w2c, tr.fx_fy_cx_cy, tr.image_hw,
+                                          s["frame1"], s["frame2"], s["point_index"])
+                p1n = O.project_point(tr.tracks_XYZ[s["frame1"], s["point_index"]], tr.fx_fy_cx_cy, H, W)
+                p2n = O.project_point(tr.tracks_XYZ[s["frame2"], s["point_index"]], tr.fx_fy_cx_cy, H, W)
+                if o is None:
+                    num = {"p1n": p1n, "p2n": p2n}
+                else:
+                    dist = np.linalg.norm(world[s["frame2"], s["point_index"]] - world[s["frame1"], s["point_index"]])
+                    num = {"distance": float(dist) if o["point_moving"] else 0, "vector": o["gt_vector"],
+                           "point_moving": bool(o["point_moving"]), "cam_moving": bool(o["cam_moving"]), "p1n": p1n, "p2n": p2n}
+
+                def needs(name):
+                    fresh = name not in done
+                    done.add(name)
+                    return fresh
+                r = heads.object_movement_record(tr.scene_id, s["frame1"], s["frame2"], s["point_index"], qt, num, tr.image_hw, tpl,
+                                                 dot=True, needs_annotation=needs, on_mark=lambda *a: marks.append(a))
+                if r is not None:
+                    got.append(r)
+            assert got == want and len(got) > 10 and random.getstate() == state_ref
+            assert sum(m[4] is None for m in marks) >= 1 and got[0]["id"].endswith("_ann")
+    finally:
+        cv2.imwrite = real_imwrite
+
+
+class _OracleCorrespondenceBackend:
+    """The three numerics of heads.GpuCorrespondenceBackend from the oracle (CPU)."""
+
+    def __init__(self, sc, vis):
+        self.sc, self.vis = sc, vis
+
+    def image_hw(self, scene_id):
+        return self.sc.color_hw if scene_id == self.sc.scene_id else None
+
+    def common_counts(self, scene_id, pairs):
+        if scene_id != self.sc.scene_id:
+            return None
+        i2p = self.vis["image_to_points"]
+        return [len(np.intersect1d(i2p.get(a, []), i2p.get(b, []))) for a, b in pairs]
+
+    def project(self, scene_id, jobs):
+        sc, i2p, out = self.sc, self.vis["image_to_points"], []
+        for a, b, pos in jobs:
+            v = int(np.intersect1d(i2p[a], i2p[b])[pos])
+            uv1, _ = O.point_2d_in_image(sc.points[v], sc.K, sc.A @ sc.E[a], sc.depth[a], sc.color_hw)
+            uv2, _ = O.point_2d_in_image(sc.points[v], sc.K, sc.A @ sc.E[b], sc.depth[b], sc.color_hw)
+            out.append((v, uv1[0], uv2[0], True, True))
+        return out
+
+
+def test_visual_correspondence_dot_records(ref, world, tmp_path):
+    """VC_D.build_training_sample row after row == the batched dataset function (same draws, same records, same stream at
+    the end), including a row whose random distractor is forced onto the correct pixel."""
+    sc, h, rows, vis = world
+    H, W = sc.color_hw
+    h.image_width, h.image_height = W, H                    # upstream reads these handler attributes without defining them
+    ref.VC_D.USE_PICKLE = True
+    tpl = T.TemplateSet.from_module(ref.VC_D, ["default"])
+    vis_dict = {sc.scene_id: vis}
+    warn = str(tmp_path / "w.txt")
+    all_rows = rows + [dict(rows[0], scene_id="scene_unknown_00")] + rows[:5]
+    img_dir = str(tmp_path / "images")
+    random.seed(31)
+    want = [ref.VC_D.build_training_sample(h, row, n, vis_dict, warn, image_output_dir=img_dir) for n, row in enumerate(all_rows)]
+    state_ref = random.getstate()
+    marks = []
+    random.seed(31)
+    got = heads.visual_correspondence_dot_dataset(all_rows, _OracleCorrespondenceBackend(sc, vis), tpl,
+                                                  on_mark=lambda *a: marks.append(a))
+    assert len(got) == len(want) and sum(g is not None for g in got) >= 4
+    for g, w in zip(got, want):
+        assert g == w
+    assert random.getstate() == state_ref and len(marks) == sum(g is not None for g in got)
+
+    # force a clash: a generator whose first distractor of row 2 is the correct pixel of that row
+    class Rigged(random.Random):
+        """Overrides two randint results at one position of the stream -- and again whenever the generator is back at that
+        very position, as it is when the draws are replayed from a checkpoint."""
+        armed = None
+
+        def __init__(self, seed):
+            super().__init__(seed)
+            self.fixed = {}
+
+        def randint(self, a, b):
+            key = hash(self.getstate())
+            v = super().randint(a, b)
+            if key in self.fixed:
+                return self.fixed[key]
+            if self.armed and a == 0 and b in (W - 10, H - 10):
+                self.fixed[key] = self.armed.pop(0)
+                return self.fixed[key]
+            return v
+    # the rigged runs use seed 77: take the correct pixel of the target row from an unrigged run with that seed (the draws
+    # in front of the distractors -- swap, vertex, disc colour -- are the same with and without the rig)
+    dry = heads.visual_correspondence_dot_dataset(all_rows, _OracleCorrespondenceBackend(sc, vis), tpl, random.Random(77))
+    live = [n for n, g in enumerate(dry) if g is not None and g["p2_list"][0][0] <= W - 10 and g["p2_list"][0][1] <= H - 10][1]
+    cx, cy = dry[live]["p2_list"][0]
+    forced_rows = []
+    plain_draws = heads._vc_dot_row_draws
+
+    def spy(n_common, known, image_hw, templates, rng, correct_point=None):
+        if correct_point is not None:
+            forced_rows.append(correct_point)
+        return plain_draws(n_common, known, image_hw, templates, rng, correct_point)
+    heads._vc_dot_row_draws = spy
+    if True:
+        def run(fn):
+            rng = Rigged(77)
+            state = {"row": -1}
+            orig = rng.random
+
+            def coin():                                      # the swap coin opens every row: arm the rig at row `live`
+                state["row"] += 1
+                if state["row"] == live:
+                    rng.armed = [cx, cy]
+                return orig()
+            rng.random = coin
+            return fn(rng), rng.getstate()
+        real = ref.VC_D.random
+        try:
+            def ref_run(rng):
+                ref.VC_D.random = rng
+                ref.DE_D.random = rng                        # generate_distinct_colors lives in VC_D itself; harmless
+                return [ref.VC_D.build_training_sample(h, row, n, vis_dict, warn, image_output_dir=img_dir)
+                        for n, row in enumerate(all_rows)]
+            want2, s_ref = run(ref_run)
+        finally:
+            ref.VC_D.random = real
+        got2, s_got = run(lambda rng: heads.visual_correspondence_dot_dataset(all_rows, _OracleCorrespondenceBackend(sc, vis), tpl, rng))
+        heads._vc_dot_row_draws = plain_draws
+        assert got2 == want2 and got2[live]["p2_list"][0] not in got2[live]["p2_list"][1:]
+        assert forced_rows and forced_rows[0] == (cx, cy)          # the rejection path really ran
+
+
 def test_default_templates_have_the_reference_keys(ref):
     tpl = T.TemplateSet.from_module(ref.CME)
     assert set(T.CAMERA_MOVEMENT.questions) == set(tpl.questions) and set(T.CAMERA_MOVEMENT.answers) == set(tpl.answers)
