@@ -914,7 +914,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                            !(qz[j] > kGuardZ);
             }
             // ---- stage 3: depth test, outputs -------------------------------------------------------
-            unsigned long long vm[kRowGroup];
+            unsigned long long vm[kRowGroup], rbm[kRowGroup];
 #pragma unroll
             for (int j = 0; j < kRowGroup; ++j) {
                 const int g = r0 + j;
@@ -923,16 +923,9 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                 const bool vis = inview[j] & (qz[j] < dv);
                 const bool rk = inview[j] & (risky[j] | !(__builtin_fabs(qz[j] - dv) > kGuardZ));
                 vm[j] = __ballot(vis);
-                const unsigned long long rb = __ballot(rk);
+                rbm[j] = __ballot(rk);
                 n_vis += __popcll(vm[j]);
                 n_valid += __popcll(__ballot(valid[j]));
-                if (rb) {                                            // wave-uniform, rare
-                    if (c.lane == 0) {
-                        lds_rb[wave][g] = rb;
-                        lds_vm[wave][g] = vm[j];
-                    }
-                    risky_rows |= 1ull << g;
-                }
                 if (O::template has<O_PIX>(a.pix_i16)) lds_px[wave][j * 64 + c.lane] = (uint32_t)(inview[j] ? pix[j] : -1);
                 const uint32_t i = row * Wb + col;
                 const int64_t o = c.obase + (int64_t)i;
@@ -953,6 +946,17 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                     }
                     a.rgba[o] = colr | (valid[j] ? 0xFF000000u : 0u);
                 }
+            }
+            if (rbm[0] | rbm[1] | rbm[2] | rbm[3]) {                 // wave-uniform, rare: one branch per group, not per row
+#pragma unroll
+                for (int j = 0; j < kRowGroup; ++j)
+                    if (rbm[j]) {
+                        if (c.lane == 0) {
+                            lds_rb[wave][r0 + j] = rbm[j];
+                            lds_vm[wave][r0 + j] = vm[j];
+                        }
+                        risky_rows |= 1ull << (r0 + j);
+                    }
             }
             {
                 const uint32_t rowg = row0 + (uint32_t)r0;
