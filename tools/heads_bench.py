@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""End-to-end throughput of the task heads on one MI355X (records per second, record stage in Python included).
+
+Synthetic ScanNet-sized scenes (640x480 depth, 131072 vertices, 64 posed frames each) and a TAPVid-sized track block
+(300 frames x 256 points).  The reference's own wall-clock comments are quoted beside each row;
+they were taken on unknown CPU hardware with images read from disk, so they are context, not a like-for-like baseline.
+
+    python tools/heads_bench.py [--scenes 4] [--frames 64] > gpurun_out/heads.md
+"""
+import argparse
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "multi-spatialmllm_amd"), ROOT]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scenes", type=int, default=4)
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--points", type=int, default=131072)
+    args = ap.parse_args()
+    import torch
+    from mspa import heads, synth
+    from mspa import templates as T
+    from mspa.scene import SceneOnDevice
+    dev = "cuda"
+    rows_out = []
+
+    def timed(label, fn, unit, ref):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rows_out.append((label, n, dt, n / dt, unit, ref))
+
+    t0 = time.perf_counter()
+    scenes = [synth.make_scene(9000 + k, n_points=args.points, n_frames=args.frames, color_hw=(480, 640), depth_hw=(480, 640),
+                               invalid_pose_frac=0.0, with_color=False) for k in range(args.scenes)]
+    host_s = time.perf_counter() - t0
+    resident = {}
+
+    def upload():
+        for sc in scenes:
+            resident[sc.scene_id] = SceneOnDevice(sc.K, sc.A, sc.E, sc.depth, sc.color_hw, sc.points, dev)
+        return sum(len(s.ids) for s in resident.values())
+    timed("upload: depth frames + vertices + camera tables", upload, "frames", "-")
+
+    table = []
+
+    def pair_tables():
+        n = 0
+        for sc in scenes:
+            rel = resident[sc.scene_id].frames_relations()
+            for (a, b), v in rel.items():
+                table.append({"scene_id": sc.scene_id, "image_id1": a, "image_id2": b, "overlap": float(v["overlap"]),
+                              "distance": float(v["distance"]), "yaw": float(v["yaw"]), "pitch": float(v["pitch"])})
+            n += len(rel)
+        return n
+    timed("calculate_frames_relations.process_scene (K1+K2+K4, dict build included)", pair_tables, "pairs",
+          "106.8 M pairs published, wall-clock not stated (Pool(25))")
+
+    def vis_index():
+        n = 0
+        for sc in scenes[:1]:
+            idx = resident[sc.scene_id].visibility_index()
+            n += len(idx["image_to_points"])
+        return n
+    timed("make_visibility_info.process_scene (K1 + index lists on the host), 1 scene", vis_index, "images",
+          "val split 47 min, train 3 h (Pool(25))")
+
+    rng = random.Random(0)
+    by_id = {sc.scene_id: sc for sc in scenes}
+    usable = [r for r in table if r["overlap"] >= 1.0]        # the reference samples overlap bins 6..35 %
+    cme_rows = [rng.choice(usable) for _ in range(100000)]
+
+    def cme():
+        recs = heads.camera_movement_dataset(cme_rows, lambda s, i: by_id[s].A @ by_id[s].E[i], lambda s, i: (480, 640),
+                                             "displacement_vector", T.CAMERA_MOVEMENT, random.Random(1))
+        return len(recs)
+    timed("camera_movement build_train_dataset record loop (one K4 launch + record stage)", cme, "records",
+          "~4 min per 1 M (1 process) = 4.2 k/s")
+
+    vc_rows = [rng.choice(usable) for _ in range(20000)]
+    backend = heads.GpuCorrespondenceBackend(lambda s: resident.get(s))
+
+    def vc():
+        recs = heads.visual_correspondence_dataset(vc_rows, lambda s: resident.get(s), None, T.VISUAL_CORRESPONDENCE, random.Random(2))
+        return sum(r is not None for r in recs)
+    timed("visual_correspondence coor_2_coor record loop (K2 / K6a / K6b per scene + record stage)", vc, "records",
+          "4 h per 1 M (1 process) = 69/s")
+
+    def vcd():
+        recs = heads.visual_correspondence_dot_dataset(vc_rows, backend, T.VISUAL_CORRESPONDENCE_DOT, random.Random(3))
+        return sum(r is not None for r in recs)
+    timed("visual_correspondence dot_2_multichoice record loop (no image drawing)", vcd, "records",
+          "7 h per 500 K (1 process, with image writes) = 20/s")
+
+    def depth_est():
+        n = 0
+        for rep in range(20):
+            for sc in scenes:
+                n += len(heads.depth_estimation_records(resident[sc.scene_id], sc.scene_id, (480, 640), -1, T.DEPTH_ESTIMATION,
+                                                        random.Random(rep)))
+        return n
+    timed("depth_estimation_coor per-scene loop (K6a / K6b + record stage)", depth_est, "records", "331,295 in 51 min = 108/s")
+
+    def depth_cmp():
+        n = 0
+        for rep in range(20):
+            for sc in scenes:
+                n += len(heads.depth_comparison_records_gpu(resident[sc.scene_id], sc.scene_id, (480, 640), -1, T.DEPTH_COMPARISON,
+                                                            random.Random(rep)))
+        return n
+    timed("depth_comparison_coor per-scene loop", depth_cmp, "records", "337,523 in 1.5 h = 62/s")
+
+    def objects():
+        n = 0
+        for sc in scenes:
+            idx, bbox, cat = sc.objects()
+            cov, _ = resident[sc.scene_id].object_coverage(idx, bbox, rng=random.Random(4))
+            n += sum(len(v) for res in cov.values() for dim in res.values() for v in dim.values())
+        return n
+    timed("object visibility + coverage search (K2 masked popcount, K8, host search), all scenes", objects, "combinations", "-")
+
+    tr = synth.make_tracks(5, T=300, P=256, n_groups=8)
+
+    def om():
+        import torch as th
+        from mspa import engine
+        from scipy.cluster.hierarchy import fcluster, linkage
+        from scipy.spatial.distance import squareform
+        tracks = th.from_numpy(np.ascontiguousarray(tr.tracks_XYZ)).to(dev)
+        loss = engine.track_rigidity_loss(tracks).cpu().numpy()
+        labels = fcluster(linkage(squareform(loss, checks=False), method="average"), 0.1, criterion="distance")
+        groups = [g for g in (np.where(labels == i)[0].tolist() for i in range(1, max(labels) + 1)) if len(g) > 5]
+        c2w = th.from_numpy(np.linalg.inv(tr.extrinsics_w2c).reshape(-1, 16)).to(dev)
+        world = engine.track_to_world(tracks, c2w, tr.fx_fy_cx_cy, tr.image_hw, ("world",))["world"]
+        pairs = heads.object_movement_mine_pairs(tr.visibility, groups, lambda p, f: engine.track_pair_distances(world, p, f),
+                                                 15, 30, True, 0.05, random.Random(5))
+        recs = heads.object_movement_records(tr.scene_id, tr.tracks_XYZ, tr.extrinsics_w2c, tr.fx_fy_cx_cy, tr.image_hw, pairs,
+                                             "tapvid3d_displacement_vector", T.OBJECT_MOVEMENT, random.Random(6))
+        return len(recs)
+    timed("object_movement scene: K7 grouping + SciPy linkage + K5c mining + K5a/K5b records (300 x 256 track block)", om,
+          "records", "-")
+
+    print(f"# Task-head throughput on one MI355X (tools/heads_bench.py; {args.scenes} scenes x {args.frames} frames x {args.points} vertices)\n")
+    print(f"Host-side synthetic scene generation took {host_s:.1f} s (not part of any row).\n")
+    print("| stage | items | seconds | items/s | unit | reference's own comment |")
+    print("|---|---|---|---|---|---|")
+    for label, n, dt, rate, unit, ref in rows_out:
+        print(f"| {label} | {n} | {dt:.3f} | {rate:,.0f} | {unit} | {ref} |")
+
+
+if __name__ == "__main__":
+    main()
