@@ -52,22 +52,29 @@ class SceneOnDevice:
         return self._vis
 
     # ---- CFR.process_scene ------------------------------------------------------------------
-    def frames_relations(self) -> Dict[Tuple[str, str], Dict[str, float]]:
-        """{(id1, id2): {overlap, distance, yaw, pitch}} for all i < j in key order (CFR:176-189)."""
+    def frames_relations_arrays(self) -> Dict[str, np.ndarray]:
+        """The pair table in columns: frame indices i < j (key order of CFR:176-178) and overlap / distance / yaw / pitch."""
         vis = self._visibility()
         F = len(self.ids)
         pairs = engine.all_pairs(F, self.device)
         overlap = engine.pair_overlap(vis["bits"], pairs)
         yaw, pitch = engine.extract_yaw_pitch_host(self.E_aligned)
-        E_t = torch.from_numpy(np.stack(self.E_aligned).reshape(F, 16)).to(self.device)
+        E_t = torch.from_numpy(np.stack(self.E_aligned).reshape(F, 16)).to(self.device) if F else \
+            torch.zeros((0, 16), dtype=torch.float64, device=self.device)
         Einv_t = self.cam_mats[:, 0, :].contiguous()
         pose = engine.pair_pose(E_t, Einv_t, torch.from_numpy(yaw).to(self.device),
                                 torch.from_numpy(pitch).to(self.device), pairs)
         overlap, pose, pairs = overlap.cpu().numpy(), pose.cpu().numpy(), pairs.cpu().numpy()
+        return {"i": pairs[:, 0], "j": pairs[:, 1], "overlap": overlap, "distance": pose[:, 0], "yaw": pose[:, 1],
+                "pitch": pose[:, 2]}
+
+    def frames_relations(self) -> Dict[Tuple[str, str], Dict[str, float]]:
+        """{(id1, id2): {overlap, distance, yaw, pitch}} for all i < j in key order (CFR:176-189)."""
+        t = self.frames_relations_arrays()
         table = {}
-        for n, (i, j) in enumerate(pairs):
-            table[(self.ids[i], self.ids[j])] = {"overlap": np.float64(overlap[n]), "distance": np.float64(pose[n, 0]),
-                                                 "yaw": np.float64(pose[n, 1]), "pitch": np.float64(pose[n, 2])}
+        for n, (i, j) in enumerate(zip(t["i"], t["j"])):
+            table[(self.ids[i], self.ids[j])] = {"overlap": np.float64(t["overlap"][n]), "distance": np.float64(t["distance"][n]),
+                                                 "yaw": np.float64(t["yaw"][n]), "pitch": np.float64(t["pitch"][n])}
         return table
 
     def empty_frames(self) -> List[str]:

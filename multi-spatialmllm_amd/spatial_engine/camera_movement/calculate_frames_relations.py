@@ -84,13 +84,58 @@ def process_scene(scene_id, scene_infos, warning_file):
     return scene_id, table
 
 
+class PairTable:
+    """One scene's pair table in columns (what ``run_split`` keeps instead of a dict with an entry per pair)."""
+
+    def __init__(self, scene_id, ids, arrays):
+        self.scene_id, self.ids, self.arrays = scene_id, ids, arrays
+
+    def __len__(self):
+        return len(self.arrays["overlap"])
+
+    def to_arrow(self, nonzero_only=False):
+        import pyarrow as pa
+        a = self.arrays
+        keep = (a["overlap"] != 0.0) if nonzero_only else np.ones(len(self), dtype=bool)      # NaN != 0.0 stays (reference: :67)
+        ids = np.asarray(self.ids, dtype=object)
+        n = int(keep.sum())
+        return pa.table({
+            "scene_id": pa.array([self.scene_id] * n, type=pa.string()),
+            "image_id1": pa.array(ids[a["i"][keep]], type=pa.string()) if n else pa.array([], type=pa.string()),
+            "image_id2": pa.array(ids[a["j"][keep]], type=pa.string()) if n else pa.array([], type=pa.string()),
+            "overlap": pa.array(a["overlap"][keep], type=pa.float64()),
+            "distance": pa.array(a["distance"][keep], type=pa.float64()),
+            "yaw": pa.array(a["yaw"][keep], type=pa.float64()),
+            "pitch": pa.array(a["pitch"][keep], type=pa.float64()),
+        })
+
+
+def process_scene_columns(scene_id, scene_infos, warning_file) -> PairTable:
+    """``process_scene`` without a Python object per pair: the same numbers as columns, the same warning lines."""
+    print(f"Start processing {scene_id}.")
+    scene = scene_infos.scene_on_device(scene_id)
+    for image_id in scene.empty_frames():
+        with open(warning_file, "a") as f:
+            f.write(f"{scene_id}: {image_id} has no in bound points\n")
+    arrays = scene.frames_relations_arrays()
+    vals = np.stack([arrays[k] for k in ("overlap", "distance", "yaw", "pitch")], axis=1)
+    for n in np.where(~np.isfinite(vals).all(axis=1))[0]:
+        key = (scene.ids[arrays["i"][n]], scene.ids[arrays["j"][n]])
+        with open(warning_file, "a") as f:
+            f.write(f"{scene_id}: {key} has something wrong {[np.float64(v) for v in vals[n]]}. \n")
+    print(f"Finished scene {scene_id}.")
+    return PairTable(scene_id, list(scene.ids), arrays)
+
+
 def run_split(scene_info_path, output_parquet, warning_file, num_workers=15, save_interval=20):
-    """Pair tables of every scene of a split -> ``output_parquet`` (+ ``*_nonzero.parquet``), with the
-    reference's periodic partial saves (reference: :200-253).  ``num_workers`` is accepted and ignored:
-    scenes run back to back on the GPU (one ScanNet-sized scene takes ~0.25 ms of kernel time)."""
+    """Pair tables of every scene of a split -> ``output_parquet`` (+ ``*_nonzero.parquet``) (reference: :200-253).
+    ``num_workers`` is accepted and ignored: scenes run back to back on the GPU (a ScanNet-sized scene takes ~0.25 ms of
+    kernel time).  The tables stay columnar from the kernels to the parquet row groups -- ScanNet's 106.8 M pairs as a
+    dict with one entry per pair would not fit in memory -- and both files are streamed, one row group per scene, instead
+    of being rewritten every ``save_interval`` scenes.  Returns {scene_id: PairTable}."""
+    import pyarrow.parquet as pq
     from spatial_engine.utils.scannet_utils.handler.info_handler import SceneInfoHandler
     scene_infos = SceneInfoHandler(scene_info_path)
-    overlap_info = {}
     all_scene_ids = scene_infos.get_all_scene_ids()
     print(f"[run_split] Found {len(all_scene_ids)} scenes in {scene_info_path}.")
     if DEBUG and len(all_scene_ids) > 1:
@@ -100,16 +145,44 @@ def run_split(scene_info_path, output_parquet, warning_file, num_workers=15, sav
     out_dir = os.path.dirname(output_parquet)
     if out_dir:
         os.makedirs(out_dir, exist_ok=True)
-    for count, scene_id in enumerate(all_scene_ids):
-        _, overlap_info[scene_id] = process_scene(scene_id, scene_infos, warning_file)
-        if (count + 1) % save_interval == 0:
-            save_overlap_info(overlap_info, output_parquet)
-            save_overlap_info_nonzero(overlap_info, nonzero_parquet)
-            print(f"[run_split] Saved partial results for {count + 1} scenes to {output_parquet}")
-    save_overlap_info(overlap_info, output_parquet)
-    save_overlap_info_nonzero(overlap_info, nonzero_parquet)
-    total = sum(len(v) for v in overlap_info.values())
-    nonzero = sum(1 for scene in overlap_info.values() for pair in scene.values() if pair["overlap"] != 0.0)
+    tables, writers, total, nonzero = {}, [None, None], 0, 0
+    try:
+        for count, scene_id in enumerate(all_scene_ids):
+            t = process_scene_columns(scene_id, scene_infos, warning_file)
+            tables[scene_id] = t
+            for w, (path, nz) in enumerate(((output_parquet, False), (nonzero_parquet, True))):
+                arrow = t.to_arrow(nz)
+                if writers[w] is None:
+                    writers[w] = pq.ParquetWriter(path, arrow.schema)
+                writers[w].write_table(arrow)
+                if nz:
+                    nonzero += arrow.num_rows
+                else:
+                    total += arrow.num_rows
+            if (count + 1) % save_interval == 0:
+                print(f"[run_split] {count + 1} scenes written to {output_parquet}")
+    finally:
+        for w in writers:
+            if w is not None:
+                w.close()
     print(f"[run_split] Total number of records: {total}")
     print(f"[run_split] Total number of nonzero records: {nonzero}")
-    return overlap_info
+    return tables
+
+
+def main():
+    """Same paths as upstream's main (:255-289): train and val pair tables + their warning files."""
+    train_dir, val_dir = "training_data/camera_movement", "evaluation_data/camera_movement"
+    os.makedirs(train_dir, exist_ok=True)
+    os.makedirs(val_dir, exist_ok=True)
+    suffix = "_debug" if DEBUG else ""
+    print(f"[main] DEBUG mode: {DEBUG}")
+    for split, info, out_dir in (("train", "data/scannet/scannet_instance_data/scenes_train_info_i_D5.pkl", train_dir),
+                                 ("val", "data/scannet/scannet_instance_data/scenes_val_info_i_D5.pkl", val_dir)):
+        out = os.path.join(out_dir, f"{split}_camera_info_D5{suffix}.parquet")
+        print(f"[main] Processing {split} split -> {out}")
+        run_split(info, out, os.path.join(out_dir, f"{split}_warning_D5{suffix}.txt"), num_workers=25, save_interval=20)
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,13 @@ def main():
             idx = resident[sc.scene_id].visibility_index()
             n += len(idx["image_to_points"])
         return n
+    def pair_tables_columns():
+        n = 0
+        for sc in scenes:
+            n += len(resident[sc.scene_id].frames_relations_arrays()["overlap"])
+        return n
+    timed("the same as columns (frames_relations_arrays: what run_split streams to parquet)", pair_tables_columns, "pairs", "-")
+
     timed("make_visibility_info.process_scene (K1 + index lists on the host), 1 scene", vis_index, "images",
           "val split 47 min, train 3 h (Pool(25))")
 
