@@ -11,7 +11,7 @@ cap COV:118-119 and the 5000-node cap COV:207-209), so with the same seed it ret
 from __future__ import annotations
 
 import random as _random
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
 

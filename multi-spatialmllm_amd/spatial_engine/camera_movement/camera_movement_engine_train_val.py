@@ -2,7 +2,6 @@
 with the reference's signature on top of ``mspa.heads`` (K4 for the relative pose)."""
 from __future__ import annotations
 
-import json
 import os
 import random
 

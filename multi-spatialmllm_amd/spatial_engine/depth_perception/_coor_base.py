@@ -2,7 +2,6 @@
 depth_comparison_coor_engine.py share their constructor, scene sampling and writers line for line)."""
 from __future__ import annotations
 
-import json
 import os
 import random
 

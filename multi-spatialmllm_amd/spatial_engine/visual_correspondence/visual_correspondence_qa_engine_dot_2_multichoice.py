@@ -3,7 +3,6 @@ lettered candidates in Image-2, answer = the letter.  Numerics batched per scene
 through ``mspa.annotate``."""
 from __future__ import annotations
 
-import json
 import os
 import random
 

@@ -3,7 +3,6 @@
 Every comparison is bit-for-bit: both sides run the same NumPy/BLAS in the same process, so the
 restatement must reproduce the reference's float64 results exactly, not approximately.
 """
-import os
 import random
 
 import numpy as np
