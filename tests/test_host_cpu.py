@@ -62,6 +62,25 @@ def test_size_limits_are_rejected():
     assert rc == _lib.MSPA_EINVAL and b"too long" in lib.mspa_last_error_string()
 
 
+def test_new_entry_points_validate_before_launching():
+    """K5c / K7 / K8: bad sizes and null pointers come back as MSPA_EINVAL, empty inputs as MSPA_OK -- no HIP call either way."""
+    lib = _lib.load()
+    dummy = ctypes.c_void_p(64)
+    assert lib.mspa_track_rigidity_loss(dummy, -1, 4, 0.01, dummy, None) == _lib.MSPA_EINVAL
+    assert lib.mspa_track_rigidity_loss(None, 3, 4, 0.01, dummy, None) == _lib.MSPA_EINVAL
+    assert lib.mspa_track_rigidity_loss(None, 3, 0, 0.01, None, None) == _lib.MSPA_OK            # no points: nothing to do
+    assert lib.mspa_track_rigidity_loss(dummy, 3, 1 << 20, 0.01, dummy, None) == _lib.MSPA_EINVAL   # P*P/256 blocks > 2^31
+    assert lib.mspa_object_extents(dummy, 4, 1, dummy, 100, dummy, dummy, 5, 2, dummy, dummy, dummy, None) == _lib.MSPA_EINVAL
+    assert b"shorter than the vertex count" in lib.mspa_last_error_string()
+    assert lib.mspa_object_extents(None, 4, 2, dummy, 100, dummy, dummy, 5, 2, dummy, dummy, dummy, None) == _lib.MSPA_EINVAL
+    assert lib.mspa_object_extents(None, 0, 2, None, 100, None, None, 0, 2, None, None, None, None) == _lib.MSPA_OK
+    assert lib.mspa_object_extents(dummy, 65536 * 64, 2, dummy, 100, dummy, dummy, 5, 2, dummy, dummy, dummy, None) == _lib.MSPA_EINVAL
+    assert lib.mspa_track_pair_distances(dummy, 3, 4, dummy, dummy, dummy, -1, 3, dummy, dummy, None) == _lib.MSPA_EINVAL
+    assert lib.mspa_track_pair_distances(None, 3, 4, dummy, dummy, dummy, 2, 3, dummy, dummy, None) == _lib.MSPA_EINVAL
+    assert lib.mspa_track_pair_distances(None, 3, 4, None, None, None, 0, 0, None, None, None) == _lib.MSPA_OK
+    assert lib.mspa_track_pair_distances(dummy, 3, 4, dummy, dummy, dummy, 70000, 3, dummy, dummy, None) == _lib.MSPA_EINVAL
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_engine_refuses_to_run_without_gpu():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
