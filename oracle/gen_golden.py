@@ -122,6 +122,61 @@ def golden_scene(ns, name, seed, color_hw, depth_hw, n_points, n_frames, with_co
     print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def stable_color_image(hw):
+    """A colour image that needs no random generator (so that tests can rebuild it anywhere, bit for bit)."""
+    H, W = hw
+    return ((np.arange(H * W * 3, dtype=np.uint64) * np.uint64(2654435761)) >> np.uint64(7)).astype(np.uint8).reshape(H, W, 3)
+
+
+def sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def golden_scannet_shape(ns):
+    """The reference at ScanNet's own shapes (colour 1296x968 over depth 640x480): vertex projections and
+    masks as arrays, the full-frame back-projection and one composite pair as SHA-256 of the float64 bytes."""
+    color_hw, depth_hw = (968, 1296), (480, 640)
+    sc = synth.make_scene(6006, n_points=4096, n_frames=3, color_hw=color_hw, depth_hw=depth_hw, invalid_pose_frac=0.34,
+                          with_color=False)
+    ids = sc.image_ids
+    bad = [i for i in ids if not np.isfinite(sc.E[i]).all()]
+    assert len(bad) == 1
+    sc.depth[bad[0]] = np.zeros(depth_hw, dtype=np.uint16)          # never read (the frame is dropped); compresses to nothing
+    h = RH.make_handler(ns, [sc])
+    sid = sc.scene_id
+    g = scene_arrays(sc)
+    valid = h.get_all_extrinsic_valid_image_ids(sid)
+    g["valid_image_ids"] = np.array(valid)
+    pts = h.get_scene_points_align(sid)[:, :3]
+    uv, dep, vis = [], [], []
+    for image_id in valid:
+        u, d = h.project_3d_point_to_image(sid, image_id, pts)
+        uv.append(u)
+        dep.append(d)
+        vis.append(h.check_point_visibility(sid, image_id, u, d))
+    g["ref_uv"], g["ref_depth"], g["ref_vis"] = np.stack(uv), np.stack(dep), np.stack(vis)
+    color = stable_color_image(color_hw)
+    f0, f1 = valid[0], valid[1]
+    a7 = ns.OPS.project_mask_to_3d(sc.depth[f0], sc.K, sc.E[f0], None, sc.A, color)       # colour grid: 1,254,528 pixels
+    g["a7_rows"] = np.array(a7.shape[0])
+    g["a7_sha_xyz"], g["a7_sha_rgb"], g["a7_sha_all"] = np.array(sha(a7[:, :3])), np.array(sha(a7[:, 3:])), np.array(sha(a7))
+    g["a7_head"] = a7[:64].copy()
+    u, d = h.project_3d_point_to_image(sid, f1, a7[:, :3])
+    v = h.check_point_visibility(sid, f1, u, d)
+    g["pair_ids"] = np.array([[f0, f1]])
+    g["pair_n_vis"] = np.array(int(v.sum()))
+    g["pair_sha_vis"], g["pair_sha_uv"], g["pair_sha_depth"] = np.array(sha(v)), np.array(sha(u)), np.array(sha(d))
+    _, table = ns.CFR.process_scene(sid, h, "/tmp/mspa_golden_warn_scannet_shape.txt")
+    keys = list(table.keys())
+    g["cfr_pairs"] = np.array(keys)
+    g["cfr_values"] = np.array([[table[k][f] for f in ("overlap", "distance", "yaw", "pitch")] for k in keys])
+    g["meta"] = np.array(_meta())
+    path = os.path.join(GOLDEN_DIR, "scannet_shape.npz")
+    np.savez_compressed(path, **g)
+    print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB; a7 rows {a7.shape[0]}, pair visible {int(v.sum())}")
+
+
 def golden_ties(ns):
     """Engineered rounding ties and depth equalities, every operation exact in float64."""
     H, W = 48, 64
@@ -343,12 +398,15 @@ def main():
         return golden_coverage(ns)
     if len(sys.argv) > 1 and sys.argv[1] == "sens":
         return golden_sens(ns)
+    if len(sys.argv) > 1 and sys.argv[1] == "scannet_shape":
+        return golden_scannet_shape(ns)
     golden_scene(ns, "scene_ident", 2001, (48, 64), (48, 64), n_points=700, n_frames=6, with_color=True)
     golden_scene(ns, "scene_scaled", 2002, (73, 98), (48, 64), n_points=700, n_frames=6, with_color=False)
     golden_ties(ns)
     golden_tracks(ns)
     golden_coverage(ns)
     golden_sens(ns)
+    golden_scannet_shape(ns)
 
 
 if __name__ == "__main__":
