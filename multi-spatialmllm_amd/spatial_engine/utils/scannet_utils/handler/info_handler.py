@@ -30,23 +30,40 @@ def _load_any(path):
 
 
 def _dev(a, dtype=np.float64):
+    """NumPy / list input -> device tensor; a torch tensor stays a tensor (moved to the GPU / float64 if need be)."""
+    if isinstance(a, torch.Tensor):
+        return a.to(device="cuda", dtype=torch.float64 if dtype == np.float64 else None).contiguous()
     return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dtype))).cuda()
+
+
+def _like(result: torch.Tensor, *inputs, as_bool=False):
+    """Results go back the way the inputs came: torch tensors in -> device tensors out (callers can stay on the GPU),
+    NumPy in -> NumPy out (the reference's return types)."""
+    if as_bool:
+        result = result.to(torch.bool)
+    if any(isinstance(x, torch.Tensor) for x in inputs):
+        return result
+    return result.cpu().numpy()
 
 
 def project_points(points, K, E):
     """[N,4] homogeneous world points, 4x4 K, 4x4 camera->world E -> ([N,2] un-rounded pixel
     coordinates, [N] signed camera depth), float64 (reference: info_handler.py:46-72).
     The homogeneous coordinate must be 1 (it is at every call site of the reference)."""
-    points = np.asarray(points, dtype=np.float64)
+    given = points
+    if not isinstance(points, torch.Tensor):
+        points = np.asarray(points, dtype=np.float64)
     if points.ndim != 2 or points.shape[1] != 4:
         raise ValueError("points must be [N, 4] homogeneous coordinates")
-    if not np.all(points[:, 3] == 1.0):
+    if not bool((points[:, 3] == 1.0).all()):
         raise ValueError("libmspa projects affine points: the homogeneous coordinate must be exactly 1")
+    K = K.cpu().numpy() if isinstance(K, torch.Tensor) else K
+    E = E.cpu().numpy() if isinstance(E, torch.Tensor) else E
     cam = torch.from_numpy(engine.camera_matrices(np.asarray(K, np.float64), [np.asarray(E, np.float64)])).cuda()
     xyz = _dev(points[:, :3])
     dummy = torch.zeros((1, 2, 2), dtype=torch.int16, device="cuda")
     out = engine.vertex_visibility(xyz, cam, dummy, (2, 2), ("uv", "depth"))
-    return out["uv"][0].cpu().numpy(), out["depth"][0].cpu().numpy()
+    return _like(out["uv"][0], given), _like(out["depth"][0], given)
 
 
 class SceneInfoHandler:
@@ -204,13 +221,17 @@ class SceneInfoHandler:
         """[N,3] or (3,) world points -> ([N,2] pixel coordinates, [N] depth)  (IH:313-335)."""
         K = self.get_intrinsic_matrix(scene_id, image_id)
         E = self.get_extrinsic_matrix_align(scene_id, image_id) if align else self.get_extrinsic_matrix(scene_id, image_id)
+        if isinstance(points_3d, torch.Tensor):
+            pts = points_3d.to(device="cuda", dtype=torch.float64)
+            pts = pts[None, :] if pts.ndim == 1 else pts
+            return project_points(torch.cat([pts[:, :3], torch.ones((pts.shape[0], 1), dtype=torch.float64, device="cuda")], 1), K, E)
         pts = np.asarray(points_3d, dtype=np.float64)
         pts = pts[None, :] if pts.ndim == 1 else pts
         return project_points(np.hstack([pts[:, :3], np.ones((pts.shape[0], 1))]), K, E)
 
     def check_point_in_image_boundary(self, scene_id, points_2d):
         out = engine.check_visibility(_dev(points_2d), None, None, self.get_image_shape(scene_id), ("in_bounds",))
-        return out["in_bounds"].cpu().numpy().astype(bool)
+        return _like(out["in_bounds"], points_2d, as_bool=True)
 
     def _depth_dev(self, scene_id, image_id):
         return engine.depth_to_device(self.get_depth_image(scene_id, image_id), "cuda")
@@ -218,12 +239,12 @@ class SceneInfoHandler:
     def check_point_visibility_by_depth(self, scene_id, image_id, points_2d, points_depth):
         out = engine.check_visibility(_dev(points_2d), _dev(points_depth), self._depth_dev(scene_id, image_id),
                                       self.get_image_shape(scene_id, image_id), ("by_depth",))
-        return out["by_depth"].cpu().numpy().astype(bool)
+        return _like(out["by_depth"], points_2d, points_depth, as_bool=True)
 
     def check_point_visibility(self, scene_id, image_id, points_2d, points_depth):
         out = engine.check_visibility(_dev(points_2d), _dev(points_depth), self._depth_dev(scene_id, image_id),
                                       self.get_image_shape(scene_id), ("visible",))
-        return out["visible"].cpu().numpy().astype(bool)
+        return _like(out["visible"], points_2d, points_depth, as_bool=True)
 
     def get_point_2d_coordinates_in_image(self, scene_id, image_id, point_id, align=True, check_visible=False,
                                           return_depth=False):

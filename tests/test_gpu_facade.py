@@ -237,6 +237,29 @@ def test_object_movement_wrapper():
     assert same_f64(p, [((fx * 0.1 / (2.0 + 1e-8)) + cx) / W, ((fy * 0.2 / (2.0 + 1e-8)) + cy) / H])
 
 
+def test_torch_tensors_stay_on_the_device(setup):
+    """the same entry points accept torch ROCm tensors and then return device tensors with the same values."""
+    import torch
+    ns, g, h, sid = setup
+    image_id = g.valid_image_ids[0]
+    pts = h.get_scene_points_align(sid)[:, :3]
+    uv_np, d_np = h.project_3d_point_to_image(sid, image_id, pts)
+    uv_t, d_t = h.project_3d_point_to_image(sid, image_id, torch.from_numpy(pts).cuda())
+    assert isinstance(uv_t, torch.Tensor) and uv_t.is_cuda and d_t.is_cuda and uv_t.dtype == torch.float64
+    assert np.array_equal(uv_t.cpu().numpy(), uv_np, equal_nan=True) and np.array_equal(d_t.cpu().numpy(), d_np, equal_nan=True)
+    vis_np = h.check_point_visibility(sid, image_id, uv_np, d_np)
+    vis_t = h.check_point_visibility(sid, image_id, uv_t, d_t)
+    assert vis_t.dtype == torch.bool and vis_t.is_cuda and np.array_equal(vis_t.cpu().numpy(), vis_np)
+    assert np.array_equal(h.check_point_in_image_boundary(sid, uv_t).cpu().numpy(), h.check_point_in_image_boundary(sid, uv_np))
+    assert np.array_equal(h.check_point_visibility_by_depth(sid, image_id, uv_t, d_t).cpu().numpy(),
+                          h.check_point_visibility_by_depth(sid, image_id, uv_np, d_np))
+    hom = torch.cat([torch.from_numpy(pts).cuda(), torch.ones((len(pts), 1), dtype=torch.float64, device="cuda")], 1)
+    uv2, _ = ns.IH.project_points(hom, g.K, h.get_extrinsic_matrix_align(sid, image_id))
+    assert uv2.is_cuda and np.array_equal(uv2.cpu().numpy(), uv_np, equal_nan=True)
+    with pytest.raises(ValueError):
+        ns.IH.project_points(hom * 2.0, g.K, g.E[image_id])
+
+
 def test_object_visibility(setup):
     """compute_object_visibility.process_scene: masked popcount on the GPU == Python set intersections."""
     ns, g, h, sid = setup
