@@ -38,7 +38,8 @@ VARIANTS = {
     "corr": {"outputs": ("vis_bits", "pix_i16", "counts"), "rgb": False,
              "bytes_per_px": 2 + 2 + 1 / 8 + 4},
     "dense": {"outputs": ("vis_u8", "pix_i16", "xyz_f32", "rgba", "counts"), "rgb": True,
-              "bytes_per_px": 2 + 2 + 3 + 1 + 4 + 12 + 4},
+              "bytes_per_px": 2 + 2 + 3 + 1 + 4 + 12},    # SURVEY.md 8d canonical dense = 7,372,800 B/pair; the rgba output
+                                                             # (4 B/px) this variant also writes is NOT counted
     "minimal": {"outputs": ("vis_bits", "counts"), "rgb": False, "bytes_per_px": 2 + 2 + 1 / 8},
 }
 
