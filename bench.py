@@ -174,6 +174,28 @@ def time_variant(variant, mode, depth, mats, rgb, pairs, steps, warmup, dist_ctx
     return wall, kern_ms, out
 
 
+def measured_hbm_ceilings(device):
+    """What this GPU's memory system delivers to plain torch kernels (GB/s): write-only fill and read+write copy of 2 GiB.
+    The copy figure is the practical ceiling for a kernel that, like K3, both reads and writes HBM."""
+    import torch
+    n = (1 << 31) // 4
+    x = torch.empty(n, dtype=torch.int32, device=device)
+    y = torch.empty_like(x)
+    out = {}
+    for name, fn, nbytes in (("fill_write_only", lambda: x.fill_(3), 4 * n), ("copy_read_write", lambda: y.copy_(x), 8 * n)):
+        for _ in range(2):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        out[name] = round(nbytes * 10 / (a.elapsed_time(b) * 1e-3) / 1e9, 1)
+    del x, y
+    return out
+
+
 def time_scene_kernels(device, n_points=131072, n_frames=320, reps=5):
     """K1 (vertex visibility) + K2 (all-pairs overlap) + K4 (pair pose) on one synthetic scene:
     the per-scene work of CFR.process_scene.  Informational legs with their own byte formulas
@@ -363,6 +385,7 @@ def main():
             if t.get("variant") == args.variant and t.get("pairs") == args.pairs and t.get("mode") == args.mode:
                 traffic = t.get("hbm_bytes_per_launch")
         info = _lib.device_info(local_rank)
+        ceilings = measured_hbm_ceilings(device) if not args.no_scene_legs else None
         line = {
             "metric": "frame-pairs/sec MultiSPA geometry pipe (640x480 RGB-D)",
             "value": round(value, 1), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
@@ -378,7 +401,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "mspa::pair_fast_tight_kernel" if args.mode == "fast" else "mspa::pair_exact_kernel",
-                         "kernel_ms": round(kern_ms, 4), "bytes_per_pair": int(spec["bytes_per_px"] * P)},
+                         "kernel_ms": round(kern_ms, 4), "bytes_per_pair": int(spec["bytes_per_px"] * P),
+                         "measured_ceilings_GBs": ceilings,
+                         "traffic_GBs": round(traffic / (kern_ms * 1e-3) / 1e9, 1) if traffic else None},
             "cpu_baseline": cpu,
             "variants": extra,
             "device": info,
