@@ -59,7 +59,55 @@ __global__ void gather_b16(const uint16_t *__restrict__ p, size_t n_windows, uin
     if (acc == 0x12345678u) out[0] = acc;
 }
 
-int main() {
+__global__ void copy_b128(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// K3's mix: read 2 bytes per pixel, write 4 bytes per pixel (+ the 1/8 byte bitset is ignored): 16-byte loads, 2 x 16-byte stores
+__global__ void read1_write2(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 v = src[i];
+        dst[2 * i] = v;
+        dst[2 * i + 1] = make_uint4(v.y, v.x, v.w, v.z);
+    }
+}
+
+template <typename F>
+static void timed(const char *name, double bytes, F launch) {
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    launch();
+    hipEventRecord(a);
+    for (int k = 0; k < 10; ++k) launch();
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    printf("| %s | %.2f GB | %.3f ms | %.2f TB/s |\n", name, bytes / 1e9, ms / 10, bytes * 10 / (ms * 1e-3) / 1e12);
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1) {                      // `hbm_patterns time`: hand-written streaming kernels, timed with HIP events
+        void *s, *d;
+        uint32_t *o;
+        hipMalloc(&s, kBytes);
+        hipMalloc(&d, 2 * kBytes);
+        hipMalloc(&o, 4);
+        hipMemset(s, 1, kBytes);
+        hipMemset(d, 2, 2 * kBytes);
+        printf("| kernel (16 B per lane, grid-stride) | bytes moved | time | rate |\n|---|---|---|---|\n");
+        for (int blocks : {2048, 8192, 32768}) {
+            char name[64];
+            snprintf(name, sizeof name, "read only, %d blocks", blocks);
+            timed(name, (double)kBytes, [&] { read_b128<<<blocks, 256>>>((const uint4 *)s, kBytes / 16, o); });
+            snprintf(name, sizeof name, "copy 1:1, %d blocks", blocks);
+            timed(name, 2.0 * kBytes, [&] { copy_b128<<<blocks, 256>>>((const uint4 *)s, (uint4 *)d, kBytes / 16); });
+            snprintf(name, sizeof name, "read 1 : write 2, %d blocks", blocks);
+            timed(name, 3.0 * kBytes, [&] { read1_write2<<<blocks, 256>>>((const uint4 *)s, (uint4 *)d, kBytes / 16); });
+        }
+        return 0;
+    }
     void *buf;
     uint32_t *out;
     hipMalloc(&buf, kBytes);
