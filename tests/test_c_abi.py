@@ -1,0 +1,39 @@
+"""include/mspa.h is a plain C header and libmspa.so a plain C-ABI library: a C99 program compiled with gcc links against it,
+reads the version and gets MSPA_EINVAL + a message for a bad call (no GPU needed -- validation precedes any HIP call)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "multi-spatialmllm_amd")
+
+PROGRAM = r"""
+#include <stdio.h>
+#include <string.h>
+#include "mspa.h"
+int main(void) {
+    if (mspa_version() < 100) return 2;
+    if (mspa_pair_overlap(NULL, 1, 1, NULL, 0, NULL, NULL, NULL, NULL) != MSPA_EINVAL) return 3;
+    if (!strstr(mspa_last_error_string(), "null pointer")) return 4;
+    if (mspa_track_rigidity_loss(NULL, 3, 0, 0.01, NULL, NULL) != MSPA_OK) return 5;      /* empty input: nothing to do */
+    if (mspa_object_extents(NULL, 0, 2, NULL, 100, NULL, NULL, 0, 2, NULL, NULL, NULL, NULL) != MSPA_OK) return 6;
+    printf("ok %d\n", mspa_version());
+    return 0;
+}
+"""
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="no C compiler")
+def test_header_is_c99_and_library_links_from_c(tmp_path):
+    if not os.path.exists(os.path.join(LIBDIR, "libmspa.so")):
+        pytest.skip("libmspa.so not built")
+    src = tmp_path / "cabi.c"
+    src.write_text(PROGRAM)
+    exe = str(tmp_path / "cabi")
+    build = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                            str(src), "-o", exe, "-L", LIBDIR, "-lmspa", f"-Wl,-rpath,{LIBDIR}"], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and run.stdout.startswith("ok "), (run.returncode, run.stdout, run.stderr)
