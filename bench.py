@@ -364,7 +364,7 @@ def main():
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
 
     extra = {}
-    if rank == 0:
+    if rank == 0 and world == 1:      # informational single-GPU legs; with N > 1 every rank leaves together after the timed job
         for leg in [v for v in _legs(args.also) if v != f"{args.variant}:{args.mode}"]:
             v, m = leg.split(":")
             w2, k2, _ = time_variant(v, m, depth, mats, rgb, pairs, max(3, args.steps // 4), 1, None)
@@ -385,7 +385,7 @@ def main():
             if t.get("variant") == args.variant and t.get("pairs") == args.pairs and t.get("mode") == args.mode:
                 traffic = t.get("hbm_bytes_per_launch")
         info = _lib.device_info(local_rank)
-        ceilings = measured_hbm_ceilings(device) if not args.no_scene_legs else None
+        ceilings = measured_hbm_ceilings(device) if (world == 1 and not args.no_scene_legs) else None
         line = {
             "metric": "frame-pairs/sec MultiSPA geometry pipe (640x480 RGB-D)",
             "value": round(value, 1), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
@@ -411,6 +411,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if dist_ctx is not None:
+        dist_ctx.barrier()          # leave together: no rank tears the communicator down under another one's feet
         dist_ctx.close()
 
 
