@@ -349,10 +349,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     _lib.load()
+    ids, depth, mats, rgb, pairs, nb = build_inputs(args, rank, device, sc, pairs_np)
     # MSPA_BENCH_FORCE_DIST=1 exercises the RCCL collation path with a single rank (1-GPU boxes)
     dist_ctx = shard.init_distributed(device) if (world > 1 or os.environ.get("MSPA_BENCH_FORCE_DIST")) else None
-
-    ids, depth, mats, rgb, pairs, nb = build_inputs(args, rank, device, sc, pairs_np)
     wall, kern_ms, out = time_variant(args.variant, args.mode, depth, mats, rgb, pairs, args.steps, args.warmup,
                                       dist_ctx)
     if dist_ctx is not None:
