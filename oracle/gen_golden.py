@@ -177,6 +177,40 @@ def golden_scannet_shape(ns):
     print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB; a7 rows {a7.shape[0]}, pair visible {int(v.sum())}")
 
 
+def golden_cme256(ns):
+    """G6 of SURVEY.md 8c: CME.build_training_sample answer_values for 256 pairs of a 24-frame walk -- both swap branches,
+    yaw differences pushed beyond +-180 (wrap), a static pair, mirrored pairs."""
+    sc = synth.make_scene(8118, n_points=64, n_frames=24, color_hw=(48, 64), depth_hw=(48, 64), invalid_pose_frac=0.0,
+                          with_color=False, walk_step=0.4, target_jitter=1.5)
+    h = RH.make_handler(ns, [sc])
+    sid, ids = sc.scene_id, sc.image_ids
+    rng = np.random.default_rng(3)
+    pairs = [(int(a), int(b)) for a, b in zip(rng.integers(0, 24, 256), rng.integers(0, 24, 256))]
+    pairs[0] = (5, 5)                                                     # no motion at all
+    pairs[1], pairs[2] = (3, 17), (17, 3)
+    yaw_pitch = {}
+    for i in ids:
+        yaw_pitch[i] = ns.CFR.extract_yaw_pitch(h.get_extrinsic_matrix_align(sid, i))
+    rows, answers, swaps = [], [], []
+    for n, (a, b) in enumerate(pairs):
+        ia, ib = ids[a], ids[b]
+        ta = h.get_extrinsic_matrix_align(sid, ia)[:3, 3]
+        tb = h.get_extrinsic_matrix_align(sid, ib)[:3, 3]
+        yaw = yaw_pitch[ib][0] - yaw_pitch[ia][0] + (290.0 if n % 7 == 0 else 0.0) - (310.0 if n % 11 == 0 else 0.0)
+        row = {"scene_id": sid, "image_id1": ia, "image_id2": ib, "overlap": 20.0, "distance": float(np.linalg.norm(tb - ta)),
+               "yaw": float(yaw), "pitch": float(yaw_pitch[ib][1] - yaw_pitch[ia][1])}
+        random.seed(4000 + n)
+        swaps.append(random.random() < 0.5)
+        random.seed(4000 + n)
+        sample = ns.CME.build_training_sample(h, row, n, "displacement_vector")
+        rows.append([a, b, row["yaw"], row["pitch"], row["distance"]])
+        answers.append(json.dumps(sample["answer_values"]))
+    out = {"A": sc.A, "E": np.stack([sc.E[i] for i in ids]), "rows": np.array(rows), "swap": np.array(swaps),
+           "answers_json": np.array(answers), "meta": np.array(_meta())}
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "cme256.npz"), **out)
+    print("cme256.npz: swaps", int(np.sum(swaps)), "of", len(swaps), "wrapped rows", int(np.sum(np.abs(np.array(rows)[:, 2]) > 180)))
+
+
 def golden_ties(ns):
     """Engineered rounding ties and depth equalities, every operation exact in float64."""
     H, W = 48, 64
@@ -400,6 +434,8 @@ def main():
         return golden_sens(ns)
     if len(sys.argv) > 1 and sys.argv[1] == "scannet_shape":
         return golden_scannet_shape(ns)
+    if len(sys.argv) > 1 and sys.argv[1] == "cme256":
+        return golden_cme256(ns)
     golden_scene(ns, "scene_ident", 2001, (48, 64), (48, 64), n_points=700, n_frames=6, with_color=True)
     golden_scene(ns, "scene_scaled", 2002, (73, 98), (48, 64), n_points=700, n_frames=6, with_color=False)
     golden_ties(ns)
@@ -407,6 +443,7 @@ def main():
     golden_coverage(ns)
     golden_sens(ns)
     golden_scannet_shape(ns)
+    golden_cme256(ns)
 
 
 if __name__ == "__main__":

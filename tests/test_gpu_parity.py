@@ -610,3 +610,29 @@ def test_object_extents_vs_oracle_large():
                     assert ext.lo[k, f, axis] == np.inf and ext.hi[k, f, axis] == -np.inf
                 else:
                     assert ext.hi[k, f, axis] - ext.lo[k, f, axis] == cov
+
+
+def test_pair_pose_256_pairs_golden():
+    """K4 + the answer fields of the camera-movement head against the reference's 256 answer_values (cme256.npz)."""
+    import os
+    from golden_util import GOLDEN_DIR
+    from mspa import heads
+    z = np.load(os.path.join(GOLDEN_DIR, "cme256.npz"))
+    Ea = [z["A"] @ e for e in z["E"]]
+    E_t = torch.from_numpy(np.stack(Ea).reshape(-1, 16)).to(DEV)
+    Einv_t = torch.from_numpy(np.linalg.inv(np.stack(Ea)).reshape(-1, 16)).to(DEV)
+    zeros = torch.zeros(len(Ea), dtype=torch.float64, device=DEV)
+    idx = z["rows"][:, :2].astype(np.int32)
+    both = torch.from_numpy(np.concatenate([idx, idx[:, ::-1]], axis=0).copy()).to(DEV)
+    out = engine.pair_pose(E_t, Einv_t, zeros, zeros, both).cpu().numpy()
+    n = len(idx)
+    assert f64_ok(out[:n, 0], z["rows"][:, 4])                       # the pair-table distance of every row
+    for k, ((a, b, yaw, pitch, dist), swap, ans) in enumerate(zip(z["rows"], z["swap"], z["answers_json"])):
+        ref = json.loads(str(ans))
+        yaw_angle, pitch_angle = (-yaw, -pitch) if swap else (yaw, pitch)
+        if abs(yaw_angle) > 180:
+            yaw_angle = yaw_angle - 360 if yaw_angle > 0 else yaw_angle + 360
+        got = heads.camera_movement_answer_values(out[n + k, 3:6] if swap else out[k, 3:6], yaw_angle, pitch_angle)
+        dv_ref, dv_got = ref.pop("displacement_vector"), got.pop("displacement_vector")
+        assert got == ref, k
+        assert f64_ok(dv_got, dv_ref)

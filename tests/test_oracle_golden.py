@@ -153,3 +153,19 @@ def test_tracks():
     d, f1, f2 = O.point_pair_distances(world, z["visibility"], 3)
     vf = np.where(z["visibility"][:, 3])[0]
     assert len(d) == len(vf) * (len(vf) - 1) // 2
+
+
+def test_relative_pose_256_pairs():
+    """the reference's CME answer_values for 256 pairs (both swap branches, wrapped yaw differences)."""
+    import os
+    from golden_util import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, "cme256.npz"))
+    E = [O.aligned_extrinsic(z["A"], e) for e in z["E"]]
+    wrapped = 0
+    for (a, b, yaw, pitch, dist), swap, ans in zip(z["rows"], z["swap"], z["answers_json"]):
+        ref = json.loads(str(ans))
+        got = O.relative_pose_answer_values(E[int(a)], E[int(b)], yaw, pitch, bool(swap))
+        dv_ref, dv_got = ref.pop("displacement_vector"), got.pop("displacement_vector")
+        assert got == ref and f64_ok(dv_got, dv_ref)
+        wrapped += abs(yaw) > 180
+    assert wrapped >= 20 and 60 < int(z["swap"].sum()) < 200
