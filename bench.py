@@ -60,6 +60,9 @@ def parse_args():
     ap.add_argument("--mode", choices=("fast", "exact"), default="fast",
                     help="fast: MSPA_PAIR_FAST (bit-exact integers via guarded composed matrices); exact: the "
                          "reference's own operation order")
+    ap.add_argument("--stream", choices=("auto", "on", "off"), default="auto",
+                    help="MSPA_PAIR_STREAM hint (frame 1 read non-temporally); auto = on when the step's pairs touch each resident "
+                         "frame at most ~1.5 times, as they do with the default 2040 frames / 1000 pairs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--pair-offsets", default="1,2,3", help="frame-index distances the pairs are drawn from "
                     "(neighbouring views of the camera walk; larger = less of frame 1 lands in frame 2)")
@@ -119,14 +122,20 @@ def build_inputs(args, rank, device, sc, pairs_np):
     return ids, depth, mats, rgb, pairs, nb
 
 
-def time_variant(variant, mode, depth, mats, rgb, pairs, steps, warmup, dist_ctx):
+def stream_hint(args, n_frames):
+    if args.stream != "auto":
+        return args.stream == "on"
+    return 2 * args.pairs <= 1.5 * n_frames
+
+
+def time_variant(variant, mode, depth, mats, rgb, pairs, steps, warmup, dist_ctx, stream=False):
     """Returns (wall seconds for `steps` steps, mean kernel ms from HIP events, outputs)."""
     import torch
     from mspa import engine, shard
 
     from mspa import _lib
     spec = VARIANTS[variant]
-    flags = _lib.PAIR_FAST if mode == "fast" else 0
+    flags = (_lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0)) if mode == "fast" else 0
     # With N > 1 every step's per-pair records land in one job-level table [steps, pairs, 2] (the kernel writes its
     # slice directly) which is collated ONCE, inside the timed region, with a single RCCL all_gather -- the
     # pipeline's exchange step is per job (mspa/pipeline.py), not per launch.  (Collating after every launch was
@@ -352,8 +361,9 @@ def main():
     ids, depth, mats, rgb, pairs, nb = build_inputs(args, rank, device, sc, pairs_np)
     # MSPA_BENCH_FORCE_DIST=1 exercises the RCCL collation path with a single rank (1-GPU boxes)
     dist_ctx = shard.init_distributed(device) if (world > 1 or os.environ.get("MSPA_BENCH_FORCE_DIST")) else None
+    stream = stream_hint(args, int(depth.shape[0]))
     wall, kern_ms, out = time_variant(args.variant, args.mode, depth, mats, rgb, pairs, args.steps, args.warmup,
-                                      dist_ctx)
+                                      dist_ctx, stream)
     if dist_ctx is not None:
         wall = dist_ctx.max_over_ranks(wall)
     pairs_per_step = args.pairs * world
@@ -366,7 +376,7 @@ def main():
     if rank == 0 and world == 1:      # informational single-GPU legs; with N > 1 every rank leaves together after the timed job
         for leg in [v for v in _legs(args.also) if v != f"{args.variant}:{args.mode}"]:
             v, m = leg.split(":")
-            w2, k2, _ = time_variant(v, m, depth, mats, rgb, pairs, max(3, args.steps // 4), 1, None)
+            w2, k2, _ = time_variant(v, m, depth, mats, rgb, pairs, max(3, args.steps // 4), 1, None, stream)
             b2 = VARIANTS[v]["bytes_per_px"] * P * args.pairs
             extra[leg] = {"pairs_per_s_1gpu": round(args.pairs / (k2 * 1e-3), 1), "kernel_ms": round(k2, 4),
                         "achieved_GBs": round(b2 / (k2 * 1e-3) / 1e9, 1),
@@ -394,6 +404,7 @@ def main():
             "config": {"workload": "visual_correspondence unproject+reproject+occlusion kernel (K3) on "
                                    f"{args.pairs} 640x480 frame pairs per GPU per step (BASELINE.json configs[1])",
                        "variant": args.variant, "mode": args.mode, "outputs": list(spec["outputs"]),
+                       "stream_hint": bool(stream and args.mode == "fast"),
                        "pairs_per_step_per_gpu": args.pairs, "pair_offsets": args.pair_offsets, "distinct_frames_per_gpu": int(depth.shape[0]),
                        "image": "640x480 depth u16 (+rgb u8x3 for dense)", "parallelism": f"dp{world}",
                        "collation": "one RCCL all_gather of the job's per-pair records inside the timed region" if world > 1 else "none (1 GPU)"},

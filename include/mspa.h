@@ -63,6 +63,10 @@ typedef void *mspa_stream_t;        /* hipStream_t */
                                        slots 5/6 filled and K's third row == 0 0 1 0 (pinhole); ignored
                                        (the exact kernel runs) when any float64 output is requested or
                                        when out_vis_bits is requested with W % 64 != 0. */
+#define MSPA_PAIR_STREAM 2u         /* caller's hint: the frames of this launch are (mostly) not revisited by other pairs of
+                                       the same launch -- frame 1 is read with the non-temporal hint so that it does not
+                                       displace frame-2 lines that ARE revisited (gathers).  Results are identical with or
+                                       without it; measured +3 % with distinct frames, -10 % when 48 frames serve 1000 pairs */
 
 int mspa_version(void);
 const char *mspa_last_error_string(void);

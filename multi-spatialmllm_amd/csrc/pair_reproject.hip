@@ -239,9 +239,11 @@ __device__ __forceinline__ bool decode_block(const PairArgs &a, int64_t &pair, u
 // the NEW value of that VGPR -- the store was still reading its data.  LLVM's hazard recognizer inserts the wait
 // state for > 64-bit stores only when soffset is an immediate; with an SGPR soffset it assumes none is needed.
 // One s_nop after the store keeps any following VALU write clear of the data registers.
+// The store carries the non-temporal hint (aux 2 = nt): the outputs are full 128-byte lines that this launch never reads
+// back; measured -2.5..-3 % on the headline kernel, with distinct as well as with heavily re-used input frames.
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void buffer_store_b128_guarded(u32x4_t q, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(q, rs, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(q, rs, voff, soff, 2);
     asm volatile("s_nop 1");
 }
 
@@ -646,7 +648,7 @@ __device__ __forceinline__ int med3_0(int x, int hi) {   // clamp(x, 0, hi), hi 
     return r;
 }
 
-template <uint32_t SET>
+template <uint32_t SET, bool STREAM>
 __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
                                                                    const uint8_t *__restrict__ rgb,
                                                                    const double *__restrict__ mats,
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
 #pragma unroll
         for (int k = 0; k < kTightRows / 2; ++k)
             __builtin_amdgcn_global_load_lds((gvoid_t *)(src + (int64_t)(2 * k) * a.W),
-                                             (lvoid_t *)&lds_d1[wave][k * 128], 4, 0, 0);
+                                             (lvoid_t *)&lds_d1[wave][k * 128], 4, 0, STREAM ? 2 : 0);   // aux 2 = nt
     }
 
     const double *__restrict__ U = m1 + MSPA_MAT_UNPROJ * 16;
@@ -1039,7 +1041,7 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
     const uint64_t P = (uint64_t)H * (uint64_t)W;
     if (P * (uint64_t)W >= (1ull << 32)) return fail(MSPA_EINVAL, "mspa_pair_reproject: H*W*W must be < 2^32");
     if (out_rgba && !rgb) return fail(MSPA_EINVAL, "mspa_pair_reproject: out_rgba needs rgb");
-    if (flags & ~MSPA_PAIR_FAST) return fail(MSPA_EINVAL, "mspa_pair_reproject: unknown flag");
+    if (flags & ~(MSPA_PAIR_FAST | MSPA_PAIR_STREAM)) return fail(MSPA_EINVAL, "mspa_pair_reproject: unknown flag");
     if (n_pairs == 0) return MSPA_OK;
     hipStream_t s = (hipStream_t)stream;
 
@@ -1098,7 +1100,12 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
         else hipLaunchKernelGGL(pair_exact_kernel<false>, grid, block, 0, s, depth, rgb, frame_mats, pairs, a);
     } else if (tight24) {
 #define MSPA_LAUNCH_TIGHT(SET_) \
-    hipLaunchKernelGGL((pair_fast_tight_kernel<SET_>), grid, block, 0, s, depth, rgb, frame_mats, pairs, a)
+    do { \
+        if (flags & MSPA_PAIR_STREAM) \
+            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, true>), grid, block, 0, s, depth, rgb, frame_mats, pairs, a); \
+        else \
+            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, false>), grid, block, 0, s, depth, rgb, frame_mats, pairs, a); \
+    } while (0)
         if (set == kSetCorr) MSPA_LAUNCH_TIGHT(kSetCorr);
         else if (set == kSetDense) MSPA_LAUNCH_TIGHT(kSetDense);
         else MSPA_LAUNCH_TIGHT(kSetMinimal);

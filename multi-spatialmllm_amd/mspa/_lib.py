@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("MSPA_LIB", os.path.join(_PKG_ROOT, "libmspa.so"))
 MSPA_OK, MSPA_EINVAL, MSPA_EHIP, MSPA_EUNSUPPORTED = 0, -1, -2, -3
 MAT_KINV, MAT_E, MAT_A, MAT_EINV_ALIGNED, MAT_K, MAT_UNPROJ, MAT_REPROJ, FRAME_MATS = 0, 1, 2, 3, 4, 5, 6, 7
 PAIR_FAST = 1
+PAIR_STREAM = 2
 
 
 class MspaError(RuntimeError):

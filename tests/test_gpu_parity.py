@@ -353,6 +353,12 @@ def test_full_size_properties():
     torch.cuda.synchronize()
     for k in outf:
         assert torch.equal(out[k], outf[k]), f"fast path differs from exact kernel in {k}"
+    # the streaming hint changes cache policy only
+    outs = engine.alloc_pair_outputs(n_pairs, sc.color_hw, ("vis_bits", "pix_i16", "counts"), DEV)
+    engine.pair_reproject(depth, mats, pairs, sc.color_hw, outs, flags=_lib.PAIR_FAST | _lib.PAIR_STREAM)
+    torch.cuda.synchronize()
+    for k in outs:
+        assert torch.equal(out[k], outs[k]), f"MSPA_PAIR_STREAM changed {k}"
     # shard the same batch in two launches: results must not depend on batching / block mapping
     out2 = engine.alloc_pair_outputs(n_pairs, sc.color_hw, ("vis_bits", "counts"), DEV)
     h = 373

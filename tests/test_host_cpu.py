@@ -32,6 +32,9 @@ def test_error_reporting_without_gpu_calls():
     assert rc == _lib.MSPA_EINVAL and b"null pointer" in lib.mspa_last_error_string()
     rc = lib.mspa_pair_reproject(None, None, None, 1, None, 0, 480, 640, 480, 640, *([None] * 10), 0, None)
     assert rc == _lib.MSPA_EINVAL
+    dummy = ctypes.c_void_p(64)
+    rc = lib.mspa_pair_reproject(dummy, None, dummy, 1, dummy, 1, 480, 640, 480, 640, *([None] * 10), 4, None)   # unknown flag bit
+    assert rc == _lib.MSPA_EINVAL and b"unknown flag" in lib.mspa_last_error_string()
     with pytest.raises(_lib.MspaError):
         _lib.check(rc)
 

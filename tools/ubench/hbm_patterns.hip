@@ -67,8 +67,27 @@ __global__ void copy_b128(const uint4 *__restrict__ src, uint4 *__restrict__ dst
 __global__ void read1_write2(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint4 v = src[i];
-        dst[2 * i] = v;
-        dst[2 * i + 1] = make_uint4(v.y, v.x, v.w, v.z);
+        dst[i] = v;                                               // two fully coalesced output streams
+        dst[n + i] = make_uint4(v.y, v.x, v.w, v.z);
+    }
+}
+
+__global__ void copy_b128_nt(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 *s = (const u4 *)src;
+    u4 *d = (u4 *)dst;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(&s[i]), &d[i]);
+}
+
+__global__ void read1_write2_nt(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 *s = (const u4 *)src;
+    u4 *d = (u4 *)dst;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const u4 v = __builtin_nontemporal_load(&s[i]);
+        __builtin_nontemporal_store(v, &d[i]);                    // two fully coalesced output streams
+        __builtin_nontemporal_store(v.yxwz, &d[n + i]);
     }
 }
 
@@ -105,6 +124,10 @@ int main(int argc, char **argv) {
             timed(name, 2.0 * kBytes, [&] { copy_b128<<<blocks, 256>>>((const uint4 *)s, (uint4 *)d, kBytes / 16); });
             snprintf(name, sizeof name, "read 1 : write 2, %d blocks", blocks);
             timed(name, 3.0 * kBytes, [&] { read1_write2<<<blocks, 256>>>((const uint4 *)s, (uint4 *)d, kBytes / 16); });
+            snprintf(name, sizeof name, "copy 1:1 nontemporal, %d blocks", blocks);
+            timed(name, 2.0 * kBytes, [&] { copy_b128_nt<<<blocks, 256>>>((const uint4 *)s, (uint4 *)d, kBytes / 16); });
+            snprintf(name, sizeof name, "read 1 : write 2, nontemporal stores, %d blocks", blocks);
+            timed(name, 3.0 * kBytes, [&] { read1_write2_nt<<<blocks, 256>>>((const uint4 *)s, (uint4 *)d, kBytes / 16); });
         }
         return 0;
     }
