@@ -880,9 +880,9 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                     if (O::template has<O_XYZ32>(a.xyz_f32)) {
                         float *q = a.xyz_f32 + 3 * o;
                         const float fn = __builtin_nanf("");
-                        q[0] = valid[j] ? fx[j] : fn;
-                        q[1] = valid[j] ? fy[j] : fn;
-                        q[2] = valid[j] ? fz[j] : fn;
+                        __builtin_nontemporal_store(valid[j] ? fx[j] : fn, q + 0);
+                        __builtin_nontemporal_store(valid[j] ? fy[j] : fn, q + 1);
+                        __builtin_nontemporal_store(valid[j] ? fz[j] : fn, q + 2);
                     }
                     if (O::template has<O_RGBA>(a.rgba)) {
                         uint32_t colr = 0;
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                             const uint8_t *s = c.rgb1 + 3 * (int64_t)i;
                             colr = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
                         }
-                        a.rgba[o] = colr | (valid[j] ? 0xFF000000u : 0u);
+                        __builtin_nontemporal_store(colr | (valid[j] ? 0xFF000000u : 0u), a.rgba + o);
                     }
                 }
                 continue;
@@ -936,9 +936,9 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                 if (O::template has<O_XYZ32>(a.xyz_f32)) {
                     float *q = a.xyz_f32 + 3 * o;
                     const float fn = __builtin_nanf("");
-                    q[0] = valid[j] ? fx[j] : fn;
-                    q[1] = valid[j] ? fy[j] : fn;
-                    q[2] = valid[j] ? fz[j] : fn;
+                    __builtin_nontemporal_store(valid[j] ? fx[j] : fn, q + 0);
+                    __builtin_nontemporal_store(valid[j] ? fy[j] : fn, q + 1);
+                    __builtin_nontemporal_store(valid[j] ? fz[j] : fn, q + 2);
                 }
                 if (O::template has<O_RGBA>(a.rgba)) {
                     uint32_t colr = 0;
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                         const uint8_t *s = c.rgb1 + 3 * (int64_t)i;
                         colr = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
                     }
-                    a.rgba[o] = colr | (valid[j] ? 0xFF000000u : 0u);
+                    __builtin_nontemporal_store(colr | (valid[j] ? 0xFF000000u : 0u), a.rgba + o);
                 }
             }
             if (rbm[0] | rbm[1] | rbm[2] | rbm[3]) {                 // wave-uniform, rare: one branch per group, not per row
