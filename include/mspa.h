@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MSPA_VERSION 100            /* 0.1.0 */
+#define MSPA_VERSION 110            /* 0.1.10: + mspa_track_pair_distances, mspa_track_rigidity_loss, mspa_object_extents, MSPA_PAIR_STREAM */
 
 #define MSPA_OK 0
 #define MSPA_EINVAL (-1)            /* bad argument (null pointer, size out of range, ...) */
