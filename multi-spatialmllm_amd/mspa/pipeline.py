@@ -10,8 +10,9 @@ collations:
      exactly what a single process would pick;
   2. the finished QA records are gathered to rank 0 (``all_gather_object`` over RCCL), shuffled with the
      head's seed and written as JSONL.
-This is BASELINE.json configs[4] in miniature (the five task families end to end); the ScanNet readers
-(.sens / PLY decode) stay out of scope, scenes come in as arrays (``mspa.synth`` or the façade handler).
+This is BASELINE.json configs[4] in miniature: camera movement, visual correspondence, depth estimation / comparison and
+object perception from the posed RGB-D scenes, object movement from TAPVid-style track blocks (``tracks=``).  Scenes and
+tracks come in as arrays (``mspa.synth``, ``mspa.sens`` or the façade handler).
 
     python -m mspa.pipeline --scenes 4 --frames 12 --out /tmp/mspa_out            # 1 GPU
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m mspa.pipeline ...
@@ -52,7 +53,7 @@ def pair_table_rows(scene_idx: int, scene) -> np.ndarray:
 def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None, device="cuda", seed: int = 0,
         n_camera: int = 64, n_correspondence: int = 64, depth_images_per_scene: int = 4,
         overlap_range=(6, 35), question_types: Sequence[str] = ("total_distance", "displacement_vector"),
-        object_perception: bool = True) -> Dict[str, int]:
+        object_perception: bool = True, tracks: Sequence = ()) -> Dict[str, int]:
     """Run the ScanNet-side heads over ``scenes`` (objects with K, A, E, depth, points, color_hw, scene_id).
     Returns {jsonl name: record count} on rank 0 (empty dict elsewhere)."""
     import pandas as pd
@@ -157,6 +158,30 @@ def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None,
                 by_name.setdefault(n, [])
         outputs.update(by_name)
 
+    # ---- object movement on TAPVid-style track blocks (OM_C): blocks sharded like scenes -----------------------
+    if tracks:
+        from scipy.cluster.hierarchy import fcluster, linkage
+        from scipy.spatial.distance import squareform
+        from . import engine
+        mine_tr = shard.lpt_assign([float(t.tracks_XYZ.shape[0]) * t.tracks_XYZ.shape[1] ** 2 for t in tracks], world)[rank]
+        for qt in T.OBJECT_MOVEMENT_TYPES:
+            recs = []
+            for k in mine_tr:
+                tr = tracks[k]
+                rng = random.Random(f"{seed}:om:{qt}:{k}")
+                xyz = np.ascontiguousarray(tr.tracks_XYZ, dtype=np.float64)
+                dev_tracks = torch.from_numpy(xyz).to(device)
+                loss = engine.track_rigidity_loss(dev_tracks).cpu().numpy()                       # K7
+                labels = fcluster(linkage(squareform(loss, checks=False), method="average"), 0.1, criterion="distance")
+                groups = [g for g in (np.where(labels == i)[0].tolist() for i in range(1, max(labels) + 1)) if len(g) > 5]
+                c2w = torch.from_numpy(np.linalg.inv(tr.extrinsics_w2c).reshape(-1, 16)).to(device)
+                world_xyz = engine.track_to_world(dev_tracks, c2w, tr.fx_fy_cx_cy, tr.image_hw, ("world",))["world"]   # K5a
+                pairs_k = heads.object_movement_mine_pairs(                                       # K5c
+                    tr.visibility, groups, lambda p, f: engine.track_pair_distances(world_xyz, p, f), 5, 3, True, 0.05, rng)
+                recs.extend(heads.object_movement_records(tr.scene_id, xyz, tr.extrinsics_w2c, tr.fx_fy_cx_cy, tr.image_hw,
+                                                          pairs_k, qt, T.OBJECT_MOVEMENT, rng, device))   # K5a + K5b
+            outputs[f"object_movement_{qt}"] = recs
+
     # ---- collation of the finished records + JSONL --------------------------------------------------
     counts: Dict[str, int] = {}
     os.makedirs(out_dir, exist_ok=True)
@@ -181,6 +206,7 @@ def main():
     ap.add_argument("--scenes", type=int, default=4)
     ap.add_argument("--frames", type=int, default=12)
     ap.add_argument("--points", type=int, default=20000)
+    ap.add_argument("--tracks", type=int, default=2, help="TAPVid-style track blocks for the object-movement family")
     ap.add_argument("--out", default="mspa_out")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
@@ -195,7 +221,8 @@ def main():
     ctx = shard.init_distributed(device) if world > 1 else None
     scenes = [synth.make_scene(7000 + k, n_points=args.points, n_frames=args.frames + 3 * (k % 3),
                                color_hw=(480, 640), with_color=False) for k in range(args.scenes)]
-    counts = run(scenes, args.out, ctx, device, args.seed)
+    tracks = [synth.make_tracks(300 + k, T=120, P=96, n_groups=4) for k in range(args.tracks)]
+    counts = run(scenes, args.out, ctx, device, args.seed, tracks=tracks)
     if ctx is None or ctx.rank == 0:
         print({"out": args.out, "records": counts})
     if ctx is not None:

@@ -245,6 +245,10 @@ def _pipeline_scenes():
                              invalid_pose_frac=0.1, with_color=False) for k in range(3)]
 
 
+def _pipeline_tracks():
+    return [synth.make_tracks(400 + k, T=100, P=64, n_groups=3) for k in range(3)]
+
+
 def _pipeline_worker(rank, world, port, out_dir):
     import os
     import sys
@@ -258,7 +262,7 @@ def _pipeline_worker(rank, world, port, out_dir):
     th.cuda.set_device(0)
     ctx = S.init_distributed(th.device("cuda", 0), backend="gloo")
     pipeline.run(_pipeline_scenes(), out_dir, ctx, th.device("cuda", 0), seed=3, n_camera=24, n_correspondence=24,
-                 depth_images_per_scene=3)
+                 depth_images_per_scene=3, tracks=_pipeline_tracks())
     ctx.barrier()
     ctx.close()
 
@@ -270,13 +274,15 @@ def test_pipeline_end_to_end_and_sharding_invariance(tmp_path):
     from mspa import pipeline
     single = str(tmp_path / "single")
     counts = pipeline.run(_pipeline_scenes(), single, None, DEV, seed=3, n_camera=24, n_correspondence=24,
-                          depth_images_per_scene=3)
+                          depth_images_per_scene=3, tracks=_pipeline_tracks())
     base = {"camera_movement_total_distance", "camera_movement_displacement_vector",
-            "visual_correspondence_coor_2_coor", "depth_estimation_coor", "depth_comparison_coor"}
+            "visual_correspondence_coor_2_coor", "depth_estimation_coor", "depth_comparison_coor",
+            "object_movement_tapvid3d_total_distance", "object_movement_tapvid3d_displacement_vector"}
     perception = set(counts) - base
     assert base <= set(counts) and perception and all(n.startswith("object_perception_") for n in perception)
     assert any(n.startswith("object_perception_height_k1") for n in perception)
     assert counts["depth_estimation_coor"] == 9 and counts["camera_movement_total_distance"] > 0
+    assert counts["object_movement_tapvid3d_total_distance"] > 0
     for name in counts:
         recs = [json.loads(ln) for ln in open(f"{single}/{name}.jsonl")]
         assert len(recs) == counts[name]
