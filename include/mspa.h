@@ -61,8 +61,9 @@ typedef void *mspa_stream_t;        /* hipStream_t */
                                        lane near a decision boundary: masks, pixel indices and counters
                                        stay bit-exact, float32 points agree to ~1e-12 relative.  Needs
                                        slots 5/6 filled and K's third row == 0 0 1 0 (pinhole); ignored
-                                       (the exact kernel runs) when any float64 output is requested or
-                                       when out_vis_bits is requested with W % 64 != 0. */
+                                       (the exact kernel runs) when any float64 output is requested.  A bitset
+                                       output on a width that is not a multiple of 64 takes a linear pixel mapping
+                                       (64 consecutive pixel indices per wave) so that ballots stay whole words. */
 #define MSPA_PAIR_STREAM 2u         /* caller's hint: the frames of this launch are (mostly) not revisited by other pairs of
                                        the same launch -- frame 1 is read with the non-temporal hint so that it does not
                                        displace frame-2 lines that ARE revisited (gathers).  Results are identical with or

@@ -366,7 +366,7 @@ constexpr int kRowGroup = 4;                     // rows whose depth-2 gathers a
 //    and patches the outputs (pixel index store, bit flip by atomicXor, counter delta).
 //  * TIGHT = the image is a whole number of tiles (W % 64 == 0, H % kTileRows == 0, true for 640x480):
 //    no edge predicates, bitset words coincide with wave rows.
-template <bool IDENT, bool TIGHT, uint32_t SET, bool GENERIC>
+template <bool IDENT, bool TIGHT, uint32_t SET, bool GENERIC, bool LINEAR = false>
 __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__restrict__ depth,
                                                              const uint8_t *__restrict__ rgb,
                                                              const double *__restrict__ mats,
@@ -418,7 +418,19 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
     const bool col_ok = TIGHT ? true : (tile_ok && col < (uint32_t)a.W);
     const uint32_t colc = col_ok ? col : 0u;
     const uint32_t row0 = band * (uint32_t)kTileRows;
-    const bool words_aligned = TIGHT || (a.W & 63) == 0;
+    const bool words_aligned = TIGHT || LINEAR || (a.W & 63) == 0;
+    // LINEAR mapping (images whose width is not a multiple of 64, when a bitset is wanted): the tile is kTileRows runs
+    // of 64 CONSECUTIVE pixel indices, so that a wave's ballot is exactly one word of the bitset whatever the width;
+    // (row, column) come from a magic division per lane and the affine terms are evaluated per pixel, not advanced per row.
+    const uint32_t lin_base = tile * (uint32_t)(kTileRows * 64);
+    auto lin_pixel = [&](int g, uint32_t &i, uint32_t &row, uint32_t &colx) -> bool {
+        const uint32_t raw = lin_base + (uint32_t)g * 64u + (uint32_t)c.lane;
+        const bool ok = tile_ok && raw < (uint32_t)a.P;
+        i = ok ? raw : 0u;
+        row = __umulhi(i, a.div_magic);
+        colx = i - row * (uint32_t)a.W;
+        return ok;
+    };
 
     int n_valid = 0, n_vis = 0;          // wave totals, kept uniform (SALU popcounts of ballots)
     if (tile_ok) {
@@ -426,6 +438,12 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
         if (!IDENT) dx1 = round_clip((double)colc * a.sx, a.dw - 1);   // OPS:286-290, column part
         // depth-1 sample of (tile row g, this lane's column); rows past the image are clamped
         auto load_d1 = [&](int g) -> uint32_t {
+            if (LINEAR) {
+                uint32_t i, row, colx;
+                lin_pixel(g, i, row, colx);
+                if (IDENT) return c.depth1[i];
+                return c.depth1[round_clip((double)row * a.sy, a.dh - 1) * a.dw + round_clip((double)colx * a.sx, a.dw - 1)];
+            }
             const uint32_t row = TIGHT ? row0 + (uint32_t)g : min(row0 + (uint32_t)g, (uint32_t)a.H - 1u);
             if (IDENT) return c.depth1[row * (uint32_t)a.W + colc];
             const int dy = round_clip((double)row * a.sy, a.dh - 1);
@@ -467,7 +485,20 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 #pragma unroll
             for (int j = 0; j < kRowGroup; ++j) {
                 const int g = r0 + j;
-                const bool in_img = TIGHT ? true : (col_ok && (row0 + (uint32_t)g) < (uint32_t)a.H);
+                bool in_img = TIGHT ? true : (col_ok && (row0 + (uint32_t)g) < (uint32_t)a.H);
+                if (LINEAR) {
+                    uint32_t i, row, colx;
+                    in_img = lin_pixel(g, i, row, colx);
+                    const double mxl = (double)colx, myl = (double)row;
+                    t0 = __builtin_fma(M[0][1], myl, __builtin_fma(M[0][0], mxl, M[0][2]));
+                    t1 = __builtin_fma(M[1][1], myl, __builtin_fma(M[1][0], mxl, M[1][2]));
+                    t2 = __builtin_fma(M[2][1], myl, __builtin_fma(M[2][0], mxl, M[2][2]));
+                    if (WANT_XYZ) {
+                        s0 = __builtin_fma(Us[0][1], myl, __builtin_fma(Us[0][0], mxl, Us[0][2]));
+                        s1 = __builtin_fma(Us[1][1], myl, __builtin_fma(Us[1][0], mxl, Us[1][2]));
+                        s2 = __builtin_fma(Us[2][1], myl, __builtin_fma(Us[2][0], mxl, Us[2][2]));
+                    }
+                }
                 valid[j] = in_img & (d16[j] != 0u);                          // OPS:297
                 const double dmm = (double)d16[j];
                 // (ix, iy, iz) = M * (mx*d, my*d, d, 1) = d * (M[:, :3] * (mx, my, 1)) + M[:, 3]
@@ -522,9 +553,14 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 #pragma unroll
             for (int j = 0; j < kRowGroup; ++j) {
                 const int g = r0 + j;
-                const uint32_t row = row0 + (uint32_t)g;
-                const bool row_ok = TIGHT ? true : row < (uint32_t)a.H;       // wave-uniform
-                const bool in_img = col_ok && row_ok;
+                uint32_t row = row0 + (uint32_t)g;
+                bool row_ok = TIGHT ? true : row < (uint32_t)a.H;             // wave-uniform
+                bool in_img = col_ok && row_ok;
+                uint32_t lin_i = 0, lin_col = 0;
+                if (LINEAR) {
+                    in_img = lin_pixel(g, lin_i, row, lin_col);
+                    row_ok = tile_ok && (lin_base + (uint32_t)g * 64u) < (uint32_t)a.P;   // the run's first pixel exists
+                }
                 const double dv = (double)dv16[j] * 0.001;
                 const bool vis = test[j] & (qz[j] < dv);
                 const bool rk = valid[j] & (risky[j] | (test[j] & !(__builtin_fabs(qz[j] - dv) > kGuardZ)));
@@ -535,7 +571,8 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
                 n_valid += __popcll(__ballot(valid[j]));
                 if (!row_ok) continue;
                 if (O::template has<O_VIS_BITS>(a.vis_bits)) {
-                    const uint64_t bit0 = (uint64_t)row * (uint64_t)a.W + (uint64_t)stripe * 64u;
+                    const uint64_t bit0 = LINEAR ? (uint64_t)(lin_base + (uint32_t)g * 64u)
+                                                 : (uint64_t)row * (uint64_t)a.W + (uint64_t)stripe * 64u;
                     uint64_t *wp = a.vis_bits + pair * c.words_per_pair + (int64_t)(bit0 >> 6);
                     if (words_aligned) {
                         if (c.lane == 0) *wp = vmask;
@@ -546,7 +583,8 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
                     }
                 }
                 if (in_img) {
-                    const int64_t o = c.obase + (int64_t)(row * (uint32_t)a.W + colc);
+                    const uint32_t pix_i = LINEAR ? lin_i : row * (uint32_t)a.W + colc;
+                    const int64_t o = c.obase + (int64_t)pix_i;
                     if (O::template has<O_VIS_U8>(a.vis_u8)) a.vis_u8[o] = vis ? 1 : 0;
                     if (O::template has<O_VALID_U8>(a.valid_u8)) a.valid_u8[o] = valid[j] ? 1 : 0;
                     if (O::template has<O_PIX>(a.pix_i16))
@@ -561,7 +599,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
                     if (O::template has<O_RGBA>(a.rgba)) {
                         uint32_t colr = 0;
                         if (c.rgb1) {
-                            const uint8_t *s = c.rgb1 + 3 * (int64_t)(row * (uint32_t)a.W + colc);
+                            const uint8_t *s = c.rgb1 + 3 * (int64_t)pix_i;
                             colr = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
                         }
                         a.rgba[o] = colr | (valid[j] ? 0xFF000000u : 0u);
@@ -577,24 +615,30 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
             while (risky_rows) {
                 const int g = __builtin_ctz(risky_rows);
                 risky_rows &= risky_rows - 1u;
-                const uint32_t row = row0 + (uint32_t)g;
-                const uint32_t i = row * (uint32_t)a.W + colc;
+                uint32_t row = row0 + (uint32_t)g;
+                uint32_t i = row * (uint32_t)a.W + colc;
+                uint32_t colx = col;
+                double mxe = mxd;
+                if (LINEAR) {
+                    lin_pixel(g, i, row, colx);
+                    mxe = (double)colx;
+                }
                 uint32_t dd;
                 if (IDENT) {
                     dd = c.depth1[i];
                 } else {
                     const int dy = round_clip((double)row * a.sy, a.dh - 1);
-                    dd = c.depth1[dy * a.dw + dx1];
+                    dd = c.depth1[dy * a.dw + (LINEAR ? round_clip((double)colx * a.sx, a.dw - 1) : dx1)];
                 }
                 Pixel p;
-                exact_unproject(m1, mxd, (double)row, (double)dd * 0.001, p.ax, p.ay, p.az);
+                exact_unproject(m1, mxe, (double)row, (double)dd * 0.001, p.ax, p.ay, p.az);
                 exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
                 p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi, &p.inview);
                 const bool was = (vis_rows >> g) & 1u;
                 if (p.vis != was) {
                     delta += p.vis ? 1 : -1;
                     if (O::template has<O_VIS_BITS>(a.vis_bits)) {
-                        const uint64_t bit = (uint64_t)row * (uint64_t)a.W + (uint64_t)col;
+                        const uint64_t bit = LINEAR ? (uint64_t)i : (uint64_t)row * (uint64_t)a.W + (uint64_t)col;
                         atomicXor((unsigned long long *)(a.vis_bits + pair * c.words_per_pair + (int64_t)(bit >> 6)),
                                   1ull << (bit & 63u));
                     }
@@ -1065,8 +1109,8 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
     // ... and so does a bitset output whose words straddle the 64-column stripes (W % 64 != 0, e.g. ScanNet's
     // 1296-wide colour grid): the stripe-mapped fast kernel would need two atomicOr per wave-row there and
     // measures slower than the exact kernel's word-aligned linear mapping (7.7 vs 6.7 ms per 1 000 pairs).
-    const bool fast = (flags & MSPA_PAIR_FAST) && !out_xyz_f64 && !out_uv_f64 && !out_depth_f64 &&
-                      !(out_vis_bits && (W % 64 != 0));
+    const bool fast = (flags & MSPA_PAIR_FAST) && !out_xyz_f64 && !out_uv_f64 && !out_depth_f64;
+    const bool linear = fast && out_vis_bits && (W % 64 != 0);   // bitset on a width that is not a multiple of 64
     uint32_t set = 0;
     set |= out_vis_bits ? O_VIS_BITS : 0; set |= out_vis_u8 ? O_VIS_U8 : 0; set |= out_valid_u8 ? O_VALID_U8 : 0;
     set |= out_pix_i16 ? O_PIX : 0; set |= out_xyz_f32 ? O_XYZ32 : 0; set |= out_rgba ? O_RGBA : 0;
@@ -1079,14 +1123,10 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
     if (fast) {
         const int tile_rows = tight24 ? kTightRows : kTileRows;
         a.n_stripes = (W + 63) / 64;
-        a.n_tiles = a.n_stripes * ((H + tile_rows - 1) / tile_rows);
+        a.n_tiles = linear ? (int)((P + (int64_t)kTileRows * 64 - 1) / ((int64_t)kTileRows * 64))
+                           : a.n_stripes * ((H + tile_rows - 1) / tile_rows);
         a.stripe_magic = (uint32_t)((1ull << 32) / (uint64_t)a.n_stripes) + 1u;
         a.strips = (a.n_tiles + (kThreads / kWave) - 1) / (kThreads / kWave);
-        if (out_vis_bits && (W & 63)) {   // stripes straddle bitset words: the kernel ORs into zeros
-            int rc = check_hip(hipMemsetAsync(out_vis_bits, 0, sizeof(uint64_t) * ((P + 63) / 64) * n_pairs, s),
-                               "hipMemsetAsync(vis_bits)");
-            if (rc) return rc;
-        }
     } else {
         a.n_stripes = a.n_tiles = 0;
         a.stripe_magic = 0;
@@ -1119,6 +1159,19 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
             else if (set == kSetDense) MSPA_LAUNCH_FAST(true, true, kSetDense, false);
             else if (set == kSetMinimal) MSPA_LAUNCH_FAST(true, true, kSetMinimal, false);
             else MSPA_LAUNCH_FAST(true, true, 0u, true);
+        } else if (linear) {
+#define MSPA_LAUNCH_LINEAR(ID, SET_, GEN) \
+    hipLaunchKernelGGL((pair_fast_kernel<ID, false, SET_, GEN, true>), grid, block, 0, s, depth, rgb, frame_mats, pairs, a)
+            if (ident) {
+                if (set == kSetCorr) MSPA_LAUNCH_LINEAR(true, kSetCorr, false);
+                else if (set == kSetMinimal) MSPA_LAUNCH_LINEAR(true, kSetMinimal, false);
+                else MSPA_LAUNCH_LINEAR(true, 0u, true);
+            } else {
+                if (set == kSetCorr) MSPA_LAUNCH_LINEAR(false, kSetCorr, false);
+                else if (set == kSetMinimal) MSPA_LAUNCH_LINEAR(false, kSetMinimal, false);
+                else MSPA_LAUNCH_LINEAR(false, 0u, true);
+            }
+#undef MSPA_LAUNCH_LINEAR
         } else if (ident) {
             MSPA_LAUNCH_FAST(true, false, 0u, true);
         } else {

@@ -71,6 +71,17 @@ def test_exact_kernel_reproduces_reference_bytes(g):
     assert sha(out["depth_f64"][0].cpu().numpy()[valid]) == str(g["pair_sha_depth"])
     vis = out["vis_u8"][0].cpu().numpy().astype(bool)
     assert sha(vis[valid]) == str(g["pair_sha_vis"]) and int(vis.sum()) == int(g["pair_n_vis"]) == int(out["counts"][0, 1])
+    # the fast path at this shape (width 1296 = 20.25 x 64: linear pixel mapping, colour grid != depth grid): same integers
+    from mspa import _lib
+    ex = engine.alloc_pair_outputs(2, g.color_hw, ("vis_bits", "vis_u8", "valid_u8", "pix_i16", "counts"), "cuda")
+    fa = engine.alloc_pair_outputs(2, g.color_hw, ("vis_bits", "vis_u8", "valid_u8", "pix_i16", "counts"), "cuda")
+    both = torch.tensor([[0, 1], [1, 0]], dtype=torch.int32, device="cuda")
+    engine.pair_reproject(depth, mats, both, g.color_hw, ex, rgb=rgb)
+    engine.pair_reproject(depth, mats, both, g.color_hw, fa, rgb=rgb, flags=_lib.PAIR_FAST)
+    torch.cuda.synchronize()
+    for k in ex:
+        assert torch.equal(ex[k], fa[k]), f"fast (linear mapping) differs from exact in {k}"
+    assert int(fa["counts"][0, 1]) == int(g["pair_n_vis"])
     # the scene kernels at these shapes
     from mspa.scene import SceneOnDevice
     scene = SceneOnDevice(g.K, g.A, g.E, g.depth, g.color_hw, g.points, "cuda")

@@ -1,5 +1,7 @@
 import sys, time, numpy as np, torch
-sys.path[:0] = ["/root/repo/multi-spatialmllm_amd", "/root/repo"]
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "multi-spatialmllm_amd"), ROOT]
 from mspa import engine, synth, _lib
 dev = "cuda"
 for color_hw in [(480, 640), (968, 1296)]:
