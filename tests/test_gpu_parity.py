@@ -476,13 +476,15 @@ def test_track_geometry_golden():
 # ------------------------------------------------------------------------------------------
 # fast == exact on adversarially varied geometry (culling, early-out, guard, cold loop)
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("hw", [(96, 128), (48, 64), (61, 83)], ids=["tight96x128", "tight48x64", "ragged61x83"])
-def test_fast_equals_exact_random_poses(hw):
+@pytest.mark.parametrize("hw,dhw", [((96, 128), None), ((48, 64), None), ((61, 83), None), ((61, 83), (48, 64))],
+                         ids=["tight96x128", "tight48x64", "ragged61x83", "ragged61x83_over_depth48x64"])
+def test_fast_equals_exact_random_poses(hw, dhw):
     """300 random camera pairs per shape -- looking away, nearly coincident, grazing, very close, with
     pure translations that produce exact half-pixel ties -- must give bit-identical integer outputs from
     the fast kernels (tile culling, group early-out, guard band, cold loop) and the exact kernel."""
     H, W = hw
-    rng = np.random.default_rng(H * 1000 + W + int(os.environ.get("MSPA_STRESS_SEED", "0")))   # other seeds: one-off stress runs
+    DH, DW = dhw or hw                                   # depth grid; colour grid (H, W) is scaled onto it when they differ
+    rng = np.random.default_rng(H * 1000 + W + DH + int(os.environ.get("MSPA_STRESS_SEED", "0")))   # other seeds: one-off stress runs
     n_frames = 40
 
     def look_at(eye, tgt):
@@ -520,13 +522,13 @@ def test_fast_equals_exact_random_poses(hw):
             E = synth._roundtrip_f(E)
         E_list.append(np.linalg.inv(A) @ E)
         base = rng.choice([1000, 2000, 4000]) if kind in (0, 3) or f == 0 else int(rng.integers(300, 6000))
-        d = np.full((H, W), base, dtype=np.int64)
+        d = np.full((DH, DW), base, dtype=np.int64)
         if kind != 3 and f != 0:
-            d = d + rng.integers(-40, 41, (H, W))
+            d = d + rng.integers(-40, 41, (DH, DW))
         if kind == 4:
-            d = d + np.add.outer(np.arange(H), np.arange(W)) // 7 * int(rng.integers(0, 30))
+            d = d + np.add.outer(np.arange(DH), np.arange(DW)) // 7 * int(rng.integers(0, 30))
         d = np.clip(d, 1, 65535).astype(np.uint16)
-        d[rng.random((H, W)) < 0.05] = 0
+        d[rng.random((DH, DW)) < 0.05] = 0
         if f % 7 == 6:
             d[:] = 0                                    # a frame without any valid depth
         depth.append(d)
@@ -550,8 +552,8 @@ def test_fast_equals_exact_random_poses(hw):
         bad = (ex[k] != fa[k]).reshape(len(pairs_np), -1).any(dim=1).nonzero().flatten().tolist()
         assert not bad, f"{k}: fast != exact for pairs {[(int(pairs_np[b, 0]), int(pairs_np[b, 1])) for b in bad[:8]]}"
     assert torch.equal(mn["vis_bits"], ex["vis_bits"]) and torch.equal(mn["counts"], ex["counts"])
-    # byte-mask output set: keeps the stripe-mapped general fast kernel covered on ragged shapes, where a
-    # bitset request is routed to the exact kernel (include/mspa.h)
+    # byte-mask output set: the stripe-mapped general fast kernel on ragged shapes (a bitset request there takes the
+    # linear pixel mapping, exercised above)
     outs_b = ("vis_u8", "valid_u8", "pix_i16", "counts")
     exb = engine.alloc_pair_outputs(len(pairs_np), hw, outs_b, DEV)
     fab = engine.alloc_pair_outputs(len(pairs_np), hw, outs_b, DEV)
