@@ -17,6 +17,12 @@ from . import _lib
 _AFFINE_ROW = np.array([0.0, 0.0, 0.0, 1.0])
 
 
+def _require(condition: bool, what: str):
+    """Argument checks in front of raw device pointers: a real exception, not an ``assert`` that ``python -O`` drops."""
+    if not condition:
+        raise ValueError(f"mspa.engine: requirement not met: {what}")
+
+
 def _require_gpu():
     if not torch.cuda.is_available():
         raise RuntimeError("mspa.engine needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -30,7 +36,7 @@ def _stream_ptr() -> int:
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     if t is None:
         return None
-    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensors only"
+    _require(t.is_cuda and t.is_contiguous(), "device-resident contiguous tensors only")
     return t.data_ptr()
 
 
@@ -123,14 +129,14 @@ def pair_reproject(depth: torch.Tensor, mats: torch.Tensor, pairs: torch.Tensor,
     alloc_pair_outputs and is filled in place."""
     _require_gpu()
     lib = _lib.load()
-    assert depth.dtype in (torch.int16, torch.uint16) and depth.dim() == 3
-    assert mats.dtype == torch.float64 and mats.shape[1:] == (_lib.FRAME_MATS, 16)
-    assert pairs.dtype == torch.int32 and pairs.dim() == 2 and pairs.shape[1] == 2
+    _require(depth.dtype in (torch.int16, torch.uint16) and depth.dim() == 3, "depth.dtype in (torch.int16, torch.uint16) and depth.dim() == 3")
+    _require(mats.dtype == torch.float64 and mats.shape[1:] == (_lib.FRAME_MATS, 16), "mats.dtype == torch.float64 and mats.shape[1:] == (_lib.FRAME_MATS, 16)")
+    _require(pairs.dtype == torch.int32 and pairs.dim() == 2 and pairs.shape[1] == 2, "pairs.dtype == torch.int32 and pairs.dim() == 2 and pairs.shape[1] == 2")
     F, DH, DW = depth.shape
-    assert mats.shape[0] == F
+    _require(mats.shape[0] == F, "mats.shape[0] == F")
     H, W = image_hw
     if rgb is not None:
-        assert rgb.dtype == torch.uint8 and tuple(rgb.shape) == (F, H, W, 3)
+        _require(rgb.dtype == torch.uint8 and tuple(rgb.shape) == (F, H, W, 3), "rgb.dtype == torch.uint8 and tuple(rgb.shape) == (F, H, W, 3)")
     g = lambda k: _ptr(out.get(k))
     _lib.check(lib.mspa_pair_reproject(
         _ptr(depth), _ptr(rgb), _ptr(mats), F, _ptr(pairs), pairs.shape[0], DH, DW, H, W,
@@ -145,12 +151,12 @@ def vertex_visibility(xyz: torch.Tensor, cam_mats: torch.Tensor, depth: torch.Te
     given as xyz.t()); cam_mats [I,2,16]; depth [I,DH,DW].  Returns the requested outputs."""
     _require_gpu()
     lib = _lib.load()
-    assert xyz.dtype == torch.float64 and xyz.dim() == 2 and xyz.is_cuda
+    _require(xyz.dtype == torch.float64 and xyz.dim() == 2 and xyz.is_cuda, "xyz.dtype == torch.float64 and xyz.dim() == 2 and xyz.is_cuda")
     n = xyz.shape[0]
     ps, cs = xyz.stride(0), xyz.stride(1)
-    assert xyz.shape[1] >= 3 and ps > 0 and cs > 0
+    _require(xyz.shape[1] >= 3 and ps > 0 and cs > 0, "xyz.shape[1] >= 3 and ps > 0 and cs > 0")
     I, DH, DW = depth.shape
-    assert cam_mats.dtype == torch.float64 and tuple(cam_mats.shape) == (I, 2, 16)
+    _require(cam_mats.dtype == torch.float64 and tuple(cam_mats.shape) == (I, 2, 16), "cam_mats.dtype == torch.float64 and tuple(cam_mats.shape) == (I, 2, 16)")
     H, W = image_hw
     dev = xyz.device
     out: Dict[str, torch.Tensor] = {}
@@ -165,7 +171,7 @@ def vertex_visibility(xyz: torch.Tensor, cam_mats: torch.Tensor, depth: torch.Te
         out["depth"] = torch.empty((I, n), dtype=torch.float64, device=dev)
     if "count" in want:
         out["count"] = torch.empty((I,), dtype=torch.int32, device=dev)
-    assert cam_mats.is_contiguous() and depth.is_contiguous()
+    _require(cam_mats.is_contiguous() and depth.is_contiguous(), "cam_mats.is_contiguous() and depth.is_contiguous()")
     _lib.check(lib.mspa_vertex_visibility(
         xyz.data_ptr(), n, ps, cs, cam_mats.data_ptr(), I, depth.data_ptr(), DH, DW, H, W,
         _ptr(out.get("bits")), _ptr(out.get("mask")), _ptr(out.get("uv")), _ptr(out.get("depth")),
@@ -182,8 +188,8 @@ def pair_overlap(bits: torch.Tensor, pairs: torch.Tensor, want_counts: bool = Fa
     """Enqueue K2 on K1's bitsets.  Returns overlap [n_pairs] f64 (+ inter, union int32)."""
     _require_gpu()
     lib = _lib.load()
-    assert bits.dtype == torch.int64 and bits.dim() == 2 and bits.is_contiguous()
-    assert pairs.dtype == torch.int32 and pairs.dim() == 2 and pairs.shape[1] == 2 and pairs.is_contiguous()
+    _require(bits.dtype == torch.int64 and bits.dim() == 2 and bits.is_contiguous(), "bits.dtype == torch.int64 and bits.dim() == 2 and bits.is_contiguous()")
+    _require(pairs.dtype == torch.int32 and pairs.dim() == 2 and pairs.shape[1] == 2 and pairs.is_contiguous(), "pairs.dtype == torch.int32 and pairs.dim() == 2 and pairs.shape[1] == 2 and pairs.is_conti")
     n_pairs = pairs.shape[0]
     overlap = torch.empty((n_pairs,), dtype=torch.float64, device=bits.device)
     inter = torch.empty((n_pairs,), dtype=torch.int32, device=bits.device) if want_counts else None
@@ -212,8 +218,8 @@ def pair_pose(E_aligned: torch.Tensor, Einv_aligned: torch.Tensor, yaw: torch.Te
     lib = _lib.load()
     F = E_aligned.shape[0]
     for t in (E_aligned, Einv_aligned):
-        assert t.dtype == torch.float64 and tuple(t.shape) == (F, 16)
-    assert yaw.dtype == torch.float64 and pitch.dtype == torch.float64 and pairs.dtype == torch.int32
+        _require(t.dtype == torch.float64 and tuple(t.shape) == (F, 16), "t.dtype == torch.float64 and tuple(t.shape) == (F, 16)")
+    _require(yaw.dtype == torch.float64 and pitch.dtype == torch.float64 and pairs.dtype == torch.int32, "yaw.dtype == torch.float64 and pitch.dtype == torch.float64 and pairs.dtype == torch.int32")
     out = torch.empty((pairs.shape[0], 6), dtype=torch.float64, device=E_aligned.device)
     _lib.check(lib.mspa_pair_pose(_ptr(E_aligned), _ptr(Einv_aligned), _ptr(yaw), _ptr(pitch), F, _ptr(pairs),
                                   pairs.shape[0], _ptr(out), _stream_ptr()))
@@ -227,7 +233,7 @@ def track_to_world(tracks_xyz: torch.Tensor, c2w: Optional[torch.Tensor], fx_fy_
     lib = _lib.load()
     import ctypes
     T, P, _ = tracks_xyz.shape
-    assert tracks_xyz.dtype == torch.float64 and tracks_xyz.is_contiguous()
+    _require(tracks_xyz.dtype == torch.float64 and tracks_xyz.is_contiguous(), "tracks_xyz.dtype == torch.float64 and tracks_xyz.is_contiguous()")
     dev = tracks_xyz.device
     out = {}
     if "world" in want:
@@ -250,7 +256,7 @@ def track_displacement(world: torch.Tensor, w2c: torch.Tensor, c2w: torch.Tensor
     _require_gpu()
     lib = _lib.load()
     T, P, _ = world.shape
-    assert triples.dtype == torch.int32 and triples.dim() == 2 and triples.shape[1] == 3
+    _require(triples.dtype == torch.int32 and triples.dim() == 2 and triples.shape[1] == 3, "triples.dtype == torch.int32 and triples.dim() == 2 and triples.shape[1] == 3")
     n = triples.shape[0]
     out = torch.empty((n, 5), dtype=torch.float64, device=world.device)
     flags = torch.empty((n, 2), dtype=torch.uint8, device=world.device)
@@ -265,7 +271,7 @@ def check_visibility(uv: torch.Tensor, point_depth: Optional[torch.Tensor], dept
     _require_gpu()
     lib = _lib.load()
     n = uv.shape[0]
-    assert uv.dtype == torch.float64 and uv.dim() == 2 and uv.shape[1] == 2 and uv.is_contiguous()
+    _require(uv.dtype == torch.float64 and uv.dim() == 2 and uv.shape[1] == 2 and uv.is_contiguous(), "uv.dtype == torch.float64 and uv.dim() == 2 and uv.shape[1] == 2 and uv.is_contiguous()")
     out = {k: torch.empty((n,), dtype=torch.uint8, device=uv.device) for k in want}
     dh, dw = (depth_image.shape[-2], depth_image.shape[-1]) if depth_image is not None else (0, 0)
     H, W = image_hw
@@ -280,8 +286,8 @@ def select_common_point(bits: torch.Tensor, selections: torch.Tensor) -> torch.T
     [n] int32 vertex index: element j of np.intersect1d of the two visible lists (-1 if out of range)."""
     _require_gpu()
     lib = _lib.load()
-    assert bits.dtype == torch.int64 and bits.dim() == 2 and bits.is_contiguous()
-    assert selections.dtype == torch.int32 and selections.dim() == 2 and selections.shape[1] == 3
+    _require(bits.dtype == torch.int64 and bits.dim() == 2 and bits.is_contiguous(), "bits.dtype == torch.int64 and bits.dim() == 2 and bits.is_contiguous()")
+    _require(selections.dtype == torch.int32 and selections.dim() == 2 and selections.shape[1] == 3, "selections.dtype == torch.int32 and selections.dim() == 2 and selections.shape[1] == 3")
     out = torch.empty((selections.shape[0],), dtype=torch.int32, device=bits.device)
     _lib.check(lib.mspa_select_common_point(_ptr(bits), bits.shape[0], bits.shape[1], _ptr(selections.contiguous()),
                                             selections.shape[0], _ptr(out), _stream_ptr()))
@@ -293,10 +299,10 @@ def project_samples(xyz: torch.Tensor, cam_mats: torch.Tensor, depth: torch.Tens
     """Enqueue K6b.  samples [n, 2] int32 (vertex, image) -> (uv [n,2] f64, depth [n] f64, visible [n] u8)."""
     _require_gpu()
     lib = _lib.load()
-    assert xyz.dtype == torch.float64 and xyz.dim() == 2 and xyz.shape[1] >= 3
-    assert samples.dtype == torch.int32 and samples.dim() == 2 and samples.shape[1] == 2
+    _require(xyz.dtype == torch.float64 and xyz.dim() == 2 and xyz.shape[1] >= 3, "xyz.dtype == torch.float64 and xyz.dim() == 2 and xyz.shape[1] >= 3")
+    _require(samples.dtype == torch.int32 and samples.dim() == 2 and samples.shape[1] == 2, "samples.dtype == torch.int32 and samples.dim() == 2 and samples.shape[1] == 2")
     I, DH, DW = depth.shape
-    assert tuple(cam_mats.shape) == (I, 2, 16) and cam_mats.is_contiguous() and depth.is_contiguous()
+    _require(tuple(cam_mats.shape) == (I, 2, 16) and cam_mats.is_contiguous() and depth.is_contiguous(), "tuple(cam_mats.shape) == (I, 2, 16) and cam_mats.is_contiguous() and depth.is_contiguous()")
     n = samples.shape[0]
     dev = xyz.device
     uv = torch.empty((n, 2), dtype=torch.float64, device=dev)
@@ -313,7 +319,7 @@ def track_rigidity_loss(tracks_xyz: torch.Tensor, smoothing_factor: float = 0.01
     """Enqueue K7: [T,P,3] f64 tracks -> [P,P] f64 accumulated thresholded distance change (OM_C:66-78)."""
     _require_gpu()
     lib = _lib.load()
-    assert tracks_xyz.dtype == torch.float64 and tracks_xyz.dim() == 3 and tracks_xyz.is_contiguous()
+    _require(tracks_xyz.dtype == torch.float64 and tracks_xyz.dim() == 3 and tracks_xyz.is_contiguous(), "tracks_xyz.dtype == torch.float64 and tracks_xyz.dim() == 3 and tracks_xyz.is_contiguous()")
     T, P, _ = tracks_xyz.shape
     out = torch.empty((P, P), dtype=torch.float64, device=tracks_xyz.device)
     _lib.check(lib.mspa_track_rigidity_loss(_ptr(tracks_xyz), T, P, float(smoothing_factor), _ptr(out), _stream_ptr()))
@@ -325,9 +331,9 @@ def object_extents(vis_bits: torch.Tensor, xyz: torch.Tensor, obj_offsets: torch
     vis_bits [F, n_words] int64, xyz [V,3] f64, objects as CSR (int32).  Returns (lo [O,F,3], hi [O,F,3], count [O,F])."""
     _require_gpu()
     lib = _lib.load()
-    assert vis_bits.dtype == torch.int64 and vis_bits.dim() == 2 and vis_bits.is_contiguous()
-    assert xyz.dtype == torch.float64 and xyz.dim() == 2 and xyz.shape[1] == 3 and xyz.is_contiguous()
-    assert obj_offsets.dtype == torch.int32 and obj_vertices.dtype == torch.int32
+    _require(vis_bits.dtype == torch.int64 and vis_bits.dim() == 2 and vis_bits.is_contiguous(), "vis_bits.dtype == torch.int64 and vis_bits.dim() == 2 and vis_bits.is_contiguous()")
+    _require(xyz.dtype == torch.float64 and xyz.dim() == 2 and xyz.shape[1] == 3 and xyz.is_contiguous(), "xyz.dtype == torch.float64 and xyz.dim() == 2 and xyz.shape[1] == 3 and xyz.is_contiguous(")
+    _require(obj_offsets.dtype == torch.int32 and obj_vertices.dtype == torch.int32, "obj_offsets.dtype == torch.int32 and obj_vertices.dtype == torch.int32")
     F, n_words = vis_bits.shape
     O = obj_offsets.numel() - 1
     dev = vis_bits.device
@@ -345,7 +351,7 @@ def track_pair_distances(world: torch.Tensor, points: Sequence[int], visible_fra
     frames (i < j, row-major).  Returns a list of float64 NumPy arrays, one per point (n(n-1)/2 entries)."""
     _require_gpu()
     lib = _lib.load()
-    assert world.dtype == torch.float64 and world.dim() == 3 and world.is_contiguous()
+    _require(world.dtype == torch.float64 and world.dim() == 3 and world.is_contiguous(), "world.dtype == torch.float64 and world.dim() == 3 and world.is_contiguous()")
     T, P, _ = world.shape
     S = len(points)
     if S == 0:

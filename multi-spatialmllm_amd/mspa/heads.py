@@ -260,7 +260,8 @@ def visual_correspondence_records(scene, rows: Sequence[dict], image_hw, start_i
         uv, _, vis = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw, samples)
         uv, vis = uv.cpu().numpy(), vis.cpu().numpy().astype(bool)
         m = len(owner)
-        assert vis.all(), "a vertex taken from both visibility lists failed the visibility re-check (IH:297-300)"
+        if not vis.all():
+            raise RuntimeError("a vertex taken from both visibility lists failed the visibility re-check (IH:297-300)")
         by_row: Dict[int, List[int]] = {}
         for s, k in enumerate(owner):
             by_row.setdefault(k, []).append(s)

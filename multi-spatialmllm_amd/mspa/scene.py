@@ -43,7 +43,8 @@ class SceneOnDevice:
 
     # ---- K1 -------------------------------------------------------------------------------
     def vertex_visibility(self, want=("bits", "count")) -> Dict[str, torch.Tensor]:
-        assert self.xyz is not None, "scene uploaded without vertices"
+        if self.xyz is None:
+            raise ValueError("scene uploaded without vertices")
         return engine.vertex_visibility(self.xyz, self.cam_mats, self.depth, self.image_hw, want)
 
     def _visibility(self):

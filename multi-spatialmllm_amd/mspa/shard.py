@@ -92,7 +92,8 @@ def collate_records_async(local: torch.Tensor, ctx: DistContext, out: torch.Tens
     per-step batches): ONE all_gather, enqueued asynchronously -- no count exchange, no host
     synchronisation.  Returns (gathered [world*n, k], work); ``work.wait()`` orders the caller's stream
     after the collective (it does not block the host on RCCL)."""
-    assert local.dim() == 2 and local.is_contiguous()
+    if local.dim() != 2 or not local.is_contiguous():
+        raise ValueError("collate_records_async: a contiguous [n, k] record tensor is required")
     if out is None:
         out = torch.empty((ctx.world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
     work = dist.all_gather_into_tensor(out, local, group=ctx.group, async_op=True)
@@ -104,7 +105,8 @@ def collate_records(local: torch.Tensor, ctx: DistContext) -> torch.Tensor:
 
     Two collectives: counts (one int64 per rank), then the records padded to the largest count.
     Returns the concatenation in rank order, identical on every rank."""
-    assert local.dim() == 2
+    if local.dim() != 2:
+        raise ValueError("collate_records: a [n, k] record tensor is required")
     if local.device != ctx.collective_device:
         local = local.to(ctx.collective_device)
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
