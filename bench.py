@@ -13,6 +13,8 @@ Prints ONE JSON line on rank 0 (see the contract in the task statement) with two
   cpu_baseline  the NumPy restatement of the reference path (oracle/np_oracle.py) timed on this box
 
     python bench.py                      # N=1, 1000 pairs/step, corr variant
+    MSPA_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2
+                                         # testing aid for 1-GPU boxes: both ranks on GPU 0, collation over gloo
     python bench.py --variant dense      # + rgb in, byte mask, xyz f32, rgba out
 """
 from __future__ import annotations
@@ -355,12 +357,16 @@ def main():
         cpu = cpu_baseline(sc, pairs_np, args.cpu_seconds)     # before any GPU initialisation (fork-safe)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
+    share = bool(os.environ.get("MSPA_BENCH_SHARE_GPU"))     # testing aid: every rank on GPU 0, collation over gloo
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     _lib.load()
     ids, depth, mats, rgb, pairs, nb = build_inputs(args, rank, device, sc, pairs_np)
     # MSPA_BENCH_FORCE_DIST=1 exercises the RCCL collation path with a single rank (1-GPU boxes)
-    dist_ctx = shard.init_distributed(device) if (world > 1 or os.environ.get("MSPA_BENCH_FORCE_DIST")) else None
+    dist_ctx = (shard.init_distributed(device, backend="gloo" if share else None)
+                if (world > 1 or os.environ.get("MSPA_BENCH_FORCE_DIST")) else None)
     stream = stream_hint(args, int(depth.shape[0]))
     wall, kern_ms, out = time_variant(args.variant, args.mode, depth, mats, rgb, pairs, args.steps, args.warmup,
                                       dist_ctx, stream)

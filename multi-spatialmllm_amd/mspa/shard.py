@@ -96,6 +96,15 @@ def collate_records_async(local: torch.Tensor, ctx: DistContext, out: torch.Tens
         raise ValueError("collate_records_async: a contiguous [n, k] record tensor is required")
     if out is None:
         out = torch.empty((ctx.world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
+    if local.device != ctx.collective_device:          # gloo: collectives on host memory (CPU tests, ranks sharing one GPU)
+        parts = [torch.empty(local.shape, dtype=local.dtype) for _ in range(ctx.world)]
+        dist.all_gather(parts, local.cpu(), group=ctx.group)
+        out.copy_(torch.cat(parts, 0))
+
+        class _Done:
+            def wait(self):
+                return True
+        return out, _Done()
     work = dist.all_gather_into_tensor(out, local, group=ctx.group, async_op=True)
     return out, work
 
