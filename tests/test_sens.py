@@ -110,3 +110,54 @@ def test_sens_to_resident_scene(gold):
     assert scene.ids == [k for k, e in E.items() if np.isfinite(e).all()] and len(scene.ids) >= 3
     table = scene.frames_relations()
     assert len(table) == len(scene.ids) * (len(scene.ids) - 1) // 2
+
+
+def test_extract_posed_images_mirror(gold, tmp_path, monkeypatch):
+    """The mirrored scripts: SensorData surface, posed_images/<scene>/ layout == the reference's texts, and the scene-info
+    update from the folder == from the .sens stream == the reference's parse."""
+    import importlib
+    import pickle
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multi-spatialmllm_amd")
+    for name in [m for m in sys.modules if m == "spatial_engine" or m.startswith("spatial_engine.")]:
+        if not (getattr(sys.modules[name], "__file__", None) or "").startswith(pkg):
+            del sys.modules[name]
+    if pkg not in sys.path:
+        sys.path.insert(0, pkg)
+    EPI = importlib.import_module("spatial_engine.utils.scannet_utils.extract_posed_images")
+    UPD = importlib.import_module("spatial_engine.utils.scannet_utils.update_info_file_with_images")
+    z, path = gold
+    scans = tmp_path / "scans" / "scene5151_00"
+    scans.mkdir(parents=True)
+    (scans / "scene5151_00.sens").write_bytes(z["sens_bytes"].tobytes())
+    data = EPI.SensorData(str(scans / "scene5151_00.sens"), 1)
+    assert (data.color_width, data.color_height, data.depth_width, data.depth_height, len(data.frames)) == \
+        tuple(int(v) for v in z["skip1_header"])
+    assert data.depth_compression_type == "zlib_ushort" and np.array_equal(data.frames[3].camera_to_world, z["skip1_c2w"][3])
+    assert np.frombuffer(data.frames[2].decompress_depth("zlib_ushort"), dtype=np.uint16).reshape(24, 32).tolist() == \
+        z["skip1_depth"][2].tolist()
+    monkeypatch.chdir(tmp_path)
+    try:
+        import PIL  # noqa: F401
+    except ImportError:
+        pytest.skip("Pillow is needed for the depth PNGs")
+    EPI.process_directory("scans", 1, nproc=1)
+    texts = json.loads(str(z["skip1_text_json"]))
+    folder = tmp_path / "posed_images" / "scene5151_00"
+    for name, text in texts.items():
+        assert (folder / name).read_text() == text, name
+    assert (folder / "00004.jpg").read_bytes() == bytes(z["skip1_color"][4])
+    info_file = tmp_path / "infos.pkl"
+    with open(info_file, "wb") as f:
+        pickle.dump({"scene5151_00": {"num_objects": 0}}, f)
+    out1 = UPD.update_info_file(str(info_file), str(tmp_path / "posed_images"), 5)
+    with open(out1, "rb") as f:
+        from_folder = pickle.load(f)["scene5151_00"]
+    out2 = UPD.update_info_file(str(info_file), None, 5, sens_root=str(tmp_path / "scans"))
+    with open(out2, "rb") as f:
+        from_sens = pickle.load(f)["scene5151_00"]
+    assert out1.endswith("infos_i_D5.pkl") and from_folder["num_posed_images"] == from_sens["num_posed_images"] == 3
+    for src in (from_folder, from_sens):
+        assert np.array_equal(src["intrinsic_matrix"], z["skip1_info_K"])
+        assert np.array_equal(np.stack([v["extrinsic_matrix"] for v in src["images_info"].values()]), z["skip1_info_E"])
+        assert list(src["images_info"]) == ["00000", "00005", "00010"] and src["num_objects"] == 0
