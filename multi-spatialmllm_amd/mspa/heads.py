@@ -177,13 +177,14 @@ def normalised(uv_row, image_hw) -> Tuple[int, int]:
 
 
 def visual_correspondence_draws(rows: Sequence[dict], n_common: Sequence[int], templates: T.TemplateSet,
-                                rng=_random, max_points_per_pair: int = 1):
+                                rng=_random, max_points_per_pair: int = 1, invisible: Sequence = None):
     """Every random decision of VC_C.build_training_sample for a batch, in the reference's order, given only
     the number of common visible vertices per pair: swap coin, position(s) inside the sorted intersection,
     template picks.  Returns a list of dicts (None for pairs without common vertices, VC_C:304-309)."""
     draws = []
-    for row, n in zip(rows, n_common):
-        swap = rng.random() < 0.5                                        # VC_C:280
+    for r_idx, (row, n) in enumerate(zip(rows, n_common)):
+        hidden = (invisible[r_idx] if invisible is not None else None) or ()   # slots whose vertex failed the re-check:
+        swap = rng.random() < 0.5                                        # VC_C:280       upstream draws no template for them
         if n == 0:
             draws.append(None)
             continue
@@ -191,9 +192,10 @@ def visual_correspondence_draws(rows: Sequence[dict], n_common: Sequence[int], t
             pos = sample_indices(int(n), max_points_per_pair, rng)
         else:
             pos = [rng.choice(range(int(n))) for _ in range(max_points_per_pair)]
-        picks = [(rng.choice(range(len(templates.task_description))),
-                  rng.choice(range(len(templates.questions["default"]))),
-                  rng.choice(range(len(templates.answers["default"])))) for _ in pos]
+        picks = [None if s in hidden else (rng.choice(range(len(templates.task_description))),
+                                           rng.choice(range(len(templates.questions["default"]))),
+                                           rng.choice(range(len(templates.answers["default"]))))
+                 for s in range(len(pos))]
         draws.append({"swap": swap, "positions": pos, "picks": picks})
     return draws
 
@@ -207,7 +209,10 @@ def visual_correspondence_record(row: dict, idx: int, draw: dict, uv1: np.ndarra
         image1, image2 = image2, image1
     H, W = image_hw
     conversation, p1_list, p2_list = [], [], []
-    for k, (ti, qi, ai) in enumerate(draw["picks"]):
+    for k, pick in enumerate(draw["picks"]):
+        if pick is None:                                                   # vertex not visible after all (VC_C:327-338)
+            continue
+        ti, qi, ai = pick
         x1, y1 = normalised(uv1[k], image_hw)
         x2, y2 = normalised(uv2[k], image_hw)
         question = templates.questions["default"][qi].format(x1=x1, y1=y1, x2=x2, y2=y2)
@@ -279,89 +284,113 @@ def visual_correspondence_dataset(rows: Sequence, get_scene, get_bits=None, temp
     Pass 2 (host, global row order): every draw of VC_C.build_training_sample -- they depend on those sizes only.
     Pass 3 (per scene, GPU): the drawn positions -> vertices (K6a) -> both projections + visibility re-check (K6b).
     Returns one entry per row in row order, None where upstream returns None (no common vertex / unknown scene).
+    Upstream draws no template for a vertex that fails the re-check (VC_C:327-338; only possible when the visibility index
+    is stale): such a row is found after pass 3, the generator is rewound to it (checkpoints every 1024 rows) and the
+    passes resume with that slot marked -- as in ``visual_correspondence_dot_dataset``.
 
-    ``get_scene(scene_id)`` -> resident ``SceneOnDevice`` (or None if the scene is unknown); ``get_bits(scene_id,
-    scene)`` -> [F, n_words] bitsets in ``scene.ids`` order (default: K1 on the resident scene).
+    ``get_scene(scene_id)`` -> resident ``SceneOnDevice`` (or None if the scene is unknown) and ``get_bits(scene_id, scene)``
+    -> [F, n_words] bitsets in ``scene.ids`` order (default: K1 on the resident scene); or pass a ready backend
+    (``GpuCorrespondenceBackend``-like object) as ``get_scene``.
     """
-    import torch
-    from . import engine
+    backend = get_scene if hasattr(get_scene, "project") else GpuCorrespondenceBackend(get_scene, get_bits)
     warn = on_warn or (lambda message: None)
     by_scene: Dict[str, List[int]] = {}
     for k, r in enumerate(rows):
         by_scene.setdefault(r["scene_id"], []).append(k)
-    n_common = np.zeros(len(rows), dtype=np.int64)
-    known: Dict[str, bool] = {}
-    pair_idx: Dict[int, Tuple[int, int]] = {}
-    bits_of = get_bits or (lambda scene_id, scene: scene._visibility()["bits"])
-    for scene_id, ks in by_scene.items():
-        scene = get_scene(scene_id)
-        known[scene_id] = scene is not None
-        if scene is None:
+    n = len(rows)
+    n_common = [0] * n
+    known = [False] * n
+    hw: Dict[str, Tuple[int, int]] = {}
+    for scene_id, ks in by_scene.items():                                  # pass 1
+        counts = backend.common_counts(scene_id, [(rows[k]["image_id1"], rows[k]["image_id2"]) for k in ks])
+        if counts is None:
             continue
-        usable = [k for k in ks if rows[k]["image_id1"] in scene.index and rows[k]["image_id2"] in scene.index]
-        if not usable:
-            continue
-        idx = np.array([[scene.index[rows[k]["image_id1"]], scene.index[rows[k]["image_id2"]]] for k in usable], dtype=np.int32)
-        _, inter, _ = engine.pair_overlap(bits_of(scene_id, scene), torch.from_numpy(idx).to(scene.device), want_counts=True)
-        n_common[usable] = inter.cpu().numpy()
-        for k, (a, b) in zip(usable, idx):
-            pair_idx[k] = (int(a), int(b))
-    draws: List[Optional[dict]] = []
-    for k, r in enumerate(rows):                                          # global row order: the stream of the per-row loop
-        if not known[r["scene_id"]]:
-            rng.random()                                                  # the swap coin is drawn before the scene check (VC_C:280)
-            warn(f"[build_training_sample] Warning: Visibility info not found for scene {r['scene_id']}\n")
-            draws.append(None)
-            continue
-        d = visual_correspondence_draws([r], [n_common[k]], templates, rng, max_points_per_pair)[0]
-        if d is None:
-            warn(f"[build_training_sample] Warning: No common visible points for scene {r['scene_id']} "
-                 f"{r['image_id1']}, {r['image_id2']}\n")
-        draws.append(d)
-    out: List[Optional[dict]] = [None] * len(rows)
-    for scene_id, ks in by_scene.items():
-        live = [k for k in ks if draws[k] is not None]
-        if not live:
-            continue
-        scene = get_scene(scene_id)
-        dev = scene.device
-        sel, owner = [], []
-        for k in live:
-            a, b = pair_idx[k]
-            for j in draws[k]["positions"]:
-                sel.append([a, b, j])
-                owner.append(k)
-        sel_t = torch.tensor(sel, dtype=torch.int32, device=dev)
-        vert = engine.select_common_point(bits_of(scene_id, scene), sel_t)
-        first = torch.tensor([pair_idx[k][1] if draws[k]["swap"] else pair_idx[k][0] for k in owner], dtype=torch.int32, device=dev)
-        second = torch.tensor([pair_idx[k][0] if draws[k]["swap"] else pair_idx[k][1] for k in owner], dtype=torch.int32, device=dev)
-        samples = torch.cat([torch.stack([vert, first], 1), torch.stack([vert, second], 1)], 0).contiguous()
-        uv, _, ok = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw, samples)
-        uv, ok, vert_h = uv.cpu().numpy(), ok.cpu().numpy().astype(bool), vert.cpu().numpy()
-        m = len(owner)
-        slots: Dict[int, List[int]] = {}
-        for s, k in enumerate(owner):
-            slots.setdefault(k, []).append(s)
-        for k, ss in slots.items():
-            bad = [s for s in ss if not (ok[s] and ok[s + m])]
-            if bad:                                                        # VC_C:321-338: warn and drop the pair
-                s = bad[0]
-                r, swap = rows[k], draws[k]["swap"]
-                img = (r["image_id2"] if swap else r["image_id1"]) if not ok[s] else (r["image_id1"] if swap else r["image_id2"])
-                warn(f"Warning: Point {int(vert_h[s])} is not visible in image {img} in scene {scene_id}.\n")
+        hw[scene_id] = backend.image_hw(scene_id)
+        for k, c in zip(ks, counts):
+            known[k], n_common[k] = True, c
+
+    hidden: Dict[int, set] = {}                                            # row -> slots whose vertex failed the re-check
+    out: List[Optional[dict]] = [None] * n
+    STRIDE = 1024
+
+    def draw(k):
+        if not known[k]:
+            rng.random()                                                   # the swap coin comes before the scene check (VC_C:280)
+            return None
+        return visual_correspondence_draws([rows[k]], [n_common[k]], templates, rng, max_points_per_pair, [hidden.get(k)])[0]
+
+    start = 0
+    while start < n:
+        draws: Dict[int, Optional[dict]] = {}
+        checkpoints: Dict[int, tuple] = {}
+        for k in range(start, n):                                          # pass 2
+            if (k - start) % STRIDE == 0:
+                checkpoints[k] = rng.getstate()
+            draws[k] = draw(k)
+        proj: Dict[int, list] = {}
+        for scene_id, ks in by_scene.items():                              # pass 3
+            live = [k for k in ks if k >= start and draws[k] is not None]
+            if not live:
                 continue
-            out[k] = visual_correspondence_record(rows[k], k, draws[k], uv[ss], uv[[s + m for s in ss]], scene.image_hw, templates)
+            jobs, owner = [], []
+            for k in live:
+                r, d = rows[k], draws[k]
+                i1, i2 = (r["image_id2"], r["image_id1"]) if d["swap"] else (r["image_id1"], r["image_id2"])
+                for j in d["positions"]:
+                    jobs.append((i1, i2, j))
+                    owner.append(k)
+            for k, res in zip(owner, backend.project(scene_id, jobs)):
+                proj.setdefault(k, []).append(res)
+        redo = None
+        for k in range(start, n):                                          # records, until a row needs its draws corrected
+            r, d = rows[k], draws[k]
+            if d is None:
+                if not known[k]:
+                    warn(f"[build_training_sample] Warning: Visibility info not found for scene {r['scene_id']}\n")
+                else:
+                    warn(f"[build_training_sample] Warning: No common visible points for scene {r['scene_id']} "
+                         f"{r['image_id1']}, {r['image_id2']}\n")
+                continue
+            image1, image2 = (r["image_id2"], r["image_id1"]) if d["swap"] else (r["image_id1"], r["image_id2"])
+            bad = {s for s, (_, _, _, ok1, ok2) in enumerate(proj[k]) if not (ok1 and ok2)}
+            if bad - hidden.get(k, set()):
+                for s in sorted(bad):
+                    vertex, _, _, ok1, ok2 = proj[k][s]
+                    if not ok1:
+                        warn(f"Warning: Point {vertex} is not visible in image {image1} in scene {r['scene_id']}.\n")
+                    if not ok2:
+                        warn(f"Warning: Point {vertex} is not visible in image {image2} in scene {r['scene_id']}.\n")
+                redo = (k, bad)
+                break
+            if all(p is None for p in d["picks"]):                         # VC_C:373-378
+                warn(f"[build_training_sample] Warning: No conversation for scene {r['scene_id']} {image1}, {image2}\n")
+                continue
+            uv1 = np.stack([res[1] for res in proj[k]])
+            uv2 = np.stack([res[2] for res in proj[k]])
+            out[k] = visual_correspondence_record(r, k, d, uv1, uv2, hw[r["scene_id"]], templates)
+        if redo is None:
+            break
+        k, bad = redo                                                      # take the generator back to the start of row k
+        base = max(c for c in checkpoints if c <= k)
+        rng.setstate(checkpoints[base])
+        for j in range(base, k):
+            draw(j)
+        hidden[k] = set(bad)
+        start = k
     return out
 
 
 def _vc_dot_row_draws(n_common: int, known: bool, image_hw, templates: T.TemplateSet, rng, correct_point=None):
     """All draws of VC_D.build_training_sample for one row (VC_D:290-386), in order.  ``correct_point`` None = assume that
-    no random distractor lands exactly on the correct pixel (checked afterwards); given = apply upstream's rejection."""
+    no random distractor lands exactly on the correct pixel (checked afterwards); a pixel = apply upstream's rejection;
+    the string "invisible" = the drawn vertex failed the visibility re-check, upstream returns right after the pick."""
     from .annotate import generate_distinct_colors
     swap = rng.random() < 0.5                                              # VC_D:290
     if not known or n_common == 0:
         return {"swap": swap, "dead": True}
     pos = sample_indices(int(n_common), 1, rng)[0]                          # VC_D:326-327 (max_points_per_pair == 1)
+    if correct_point == "invisible":                                       # VC_D:339-351: no further draw for this row
+        return {"swap": swap, "dead": True, "pos": pos, "invisible": True}
     color1 = (rng.randint(0, 255), rng.randint(0, 255), rng.randint(0, 255))   # VC_D:356
     H, W = image_hw
     wrong = []
@@ -490,16 +519,23 @@ def visual_correspondence_dot_dataset(rows: Sequence, backend, templates: T.Temp
             r, d = rows[k], draws[k]
             image1, image2 = (r["image_id2"], r["image_id1"]) if d["swap"] else (r["image_id1"], r["image_id2"])
             if d["dead"]:
-                if not known[k]:
+                if d.get("invisible"):
+                    pass                                                   # warned when the failure was found
+                elif not known[k]:
                     warn(f"[build_training_sample] Warning: Visibility info not found for scene {r['scene_id']}\n")
                 else:
                     warn(f"[build_training_sample] Warning: No common visible points for scene {r['scene_id']} {image1}, {image2}\n")
                 continue
             vertex, uv1, uv2, ok1, ok2 = proj[k]
             if not (ok1 and ok2):
-                # upstream returns before any further draw (VC_D:339-351) while the draws above went on; unreachable when
-                # the visibility index and the depth test agree
-                raise RuntimeError(f"vertex {vertex} of the common set failed the visibility re-check in scene {r['scene_id']}")
+                # the index and the depth test disagree (a stale visibility file): upstream warns and returns before any
+                # further draw (VC_D:339-351) -- rewind to this row and redraw it that way
+                if not ok1:
+                    warn(f"Warning: Point {vertex} is not visible in image {image1} in scene {r['scene_id']}.\n")
+                if not ok2:
+                    warn(f"Warning: Point {vertex} is not visible in image {image2} in scene {r['scene_id']}.\n")
+                clash = (k, "invisible")
+                break
             correct = (int(uv2[0]), int(uv2[1]))
             if k not in forced and correct in d["wrong"]:
                 clash = (k, correct)

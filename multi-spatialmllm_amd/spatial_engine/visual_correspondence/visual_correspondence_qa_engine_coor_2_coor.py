@@ -31,22 +31,33 @@ def build_training_sample(scene_infos, row, idx: int, visibility_info_dict, warn
         return None
     i2p = visibility_info_dict[scene_id].get("image_to_points", {})
     common = np.intersect1d(i2p.get(row["image_id1"], []), i2p.get(row["image_id2"], []))
+    state = random.getstate()
     draw = heads.visual_correspondence_draws([row], [len(common)], TEMPLATE_SET, random, max_points_per_pair)[0]
     if draw is None:
         warn(f"[build_training_sample] Warning: No common visible points for scene {scene_id} "
              f"{row['image_id1']}, {row['image_id2']}\n")
         return None
     first, second = (row["image_id2"], row["image_id1"]) if draw["swap"] else (row["image_id1"], row["image_id2"])
-    uv1, uv2 = [], []
-    for j in draw["positions"]:
+    uv1, uv2, hidden = [], [], set()
+    for s_idx, j in enumerate(draw["positions"]):
         v = int(common[j])
         a = scene_infos.get_point_2d_coordinates_in_image(scene_id, first, v, align=True, check_visible=True)
         b = scene_infos.get_point_2d_coordinates_in_image(scene_id, second, v, align=True, check_visible=True)
-        if len(a) == 0 or len(b) == 0:
-            warn(f"Warning: Point {v} is not visible in image {first if len(a) == 0 else second} in scene {scene_id}.\n")
-            return None
+        if len(a) == 0 or len(b) == 0:                       # only with a stale index; upstream draws no template for it
+            if len(a) == 0:
+                warn(f"Warning: Point {v} is not visible in image {first} in scene {scene_id}.\n")
+            if len(b) == 0:
+                warn(f"Warning: Point {v} is not visible in image {second} in scene {scene_id}.\n")
+            hidden.add(s_idx)
+            a = b = np.zeros((1, 2))
         uv1.append(a[0])
         uv2.append(b[0])
+    if hidden:                                               # redo this row's draws without templates for those slots
+        random.setstate(state)
+        draw = heads.visual_correspondence_draws([row], [len(common)], TEMPLATE_SET, random, max_points_per_pair, [hidden])[0]
+        if all(p is None for p in draw["picks"]):
+            warn(f"[build_training_sample] Warning: No conversation for scene {scene_id} {first}, {second}\n")
+            return None
     return heads.visual_correspondence_record(row, idx, draw, np.stack(uv1), np.stack(uv2),
                                               scene_infos.get_image_shape(scene_id), TEMPLATE_SET)
 

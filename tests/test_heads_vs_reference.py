@@ -87,6 +87,47 @@ def test_visual_correspondence_records(ref, world, tmp_path):
         assert got == w
 
 
+def test_visual_correspondence_stale_index(ref, world, tmp_path):
+    """A vertex of the common set that fails the visibility re-check (stale index): upstream draws no template for it and
+    drops the row; the batched dataset function ends with the same records and the same ``random`` stream."""
+    sc, h, rows, vis = world
+    tpl = T.TemplateSet.from_module(ref.VC_C, ["default"])
+    vis_dict = {sc.scene_id: vis}
+    warn = str(tmp_path / "w.txt")
+    random.seed(7)
+    base = [ref.VC_C.build_training_sample(h, row, n, vis_dict, warn) for n, row in enumerate(rows)]
+    target = [n for n, b in enumerate(base) if b is not None][2]
+    bad_vertex = None
+    plain_get = h.get_point_2d_coordinates_in_image
+    state = {"row": -1}
+
+    def flaky(scene_id, image_id, point_id, **kw):
+        out = plain_get(scene_id, image_id, point_id, **kw)
+        if state["row"] == target and state.setdefault("img", image_id) == image_id:
+            state["vertex"] = point_id
+            return out[:0]
+        return out
+    h.get_point_2d_coordinates_in_image = flaky
+    random.seed(7)
+    want = []
+    for n, row in enumerate(rows):
+        state["row"] = n
+        want.append(ref.VC_C.build_training_sample(h, row, n, vis_dict, warn))
+    end_ref = random.getstate()
+    h.get_point_2d_coordinates_in_image = plain_get
+    assert want[target] is None and "vertex" in state
+    bad_vertex = state["vertex"]
+
+    class Flaky(_OracleCorrespondenceBackend):
+        def project(self, scene_id, jobs):
+            return [(v, a, b, o1 and v != bad_vertex, o2) for (v, a, b, o1, o2) in super().project(scene_id, jobs)]
+    warned = []
+    random.seed(7)
+    got = heads.visual_correspondence_dataset(rows, Flaky(sc, vis), None, tpl, on_warn=warned.append)
+    assert got == want and random.getstate() == end_ref
+    assert any("is not visible in image" in w for w in warned) and any("No conversation" in w for w in warned)
+
+
 def test_depth_estimation_records(ref, world, tmp_path):
     sc, h, rows, vis = world
     vis_path = os.path.join(h._mspa_root, "vis.pkl")
@@ -372,6 +413,35 @@ def test_visual_correspondence_dot_records(ref, world, tmp_path):
     for g, w in zip(got, want):
         assert g == w
     assert random.getstate() == state_ref and len(marks) == sum(g is not None for g in got)
+
+    # a vertex that fails the visibility re-check (stale index): upstream warns and returns before the colour draws
+    target = [n for n, g in enumerate(got) if g is not None][1]
+    plain_get = h.get_point_2d_coordinates_in_image
+    calls = {"row": -1}
+
+    def flaky(scene_id, image_id, point_id, **kw):
+        out = plain_get(scene_id, image_id, point_id, **kw)
+        return out[:0] if calls["row"] == target and calls.setdefault("hit", image_id) == image_id else out
+    h.get_point_2d_coordinates_in_image = flaky
+    random.seed(31)
+    want3 = []
+    for n, row in enumerate(all_rows):
+        calls["row"] = n
+        want3.append(ref.VC_D.build_training_sample(h, row, n, vis_dict, warn, image_output_dir=img_dir))
+    state3 = random.getstate()
+    h.get_point_2d_coordinates_in_image = plain_get
+    assert want3[target] is None
+
+    class Flaky(_OracleCorrespondenceBackend):
+        def project(self, scene_id, jobs):
+            res = super().project(scene_id, jobs)
+            return [(v, a, b, o1 and v != bad_vertex, o2) for (v, a, b, o1, o2) in res]
+    bad_vertex = int(got[target]["id"].split("_p")[1])
+    warned = []
+    random.seed(31)
+    got3 = heads.visual_correspondence_dot_dataset(all_rows, Flaky(sc, vis), tpl, on_warn=warned.append)
+    # (the oracle backend flags that vertex wherever it is drawn; with seed 31 it is drawn for the target row only)
+    assert got3 == want3 and random.getstate() == state3 and any("is not visible in image" in w for w in warned)
 
     # force a clash: a generator whose first distractor of row 2 is the correct pixel of that row
     class Rigged(random.Random):
