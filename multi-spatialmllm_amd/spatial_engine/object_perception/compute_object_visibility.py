@@ -51,3 +51,46 @@ def process_scene(scene_id, scene_info_handler, visibility_dict):
     image_bits = torch.from_numpy(pack_index_lists(lists, n_points)).cuda()
     result = object_visibility_from_bits(image_bits, image_ids, n_points, objects)
     return scene_id, result, warnings_list
+
+
+def load_visibility_dict(parquet_file):
+    import pandas as pd
+    df = pd.read_parquet(parquet_file)
+    return dict(zip(df["key"].tolist(), df["values"].tolist()))
+
+
+def process_split(split_name, scene_info_path, visibility_parquet_file, output_dir):
+    """All scenes of a split -> ``output_dir/object_visibility.pkl`` + ``warning.txt`` (reference: :153-195)."""
+    import os
+    import pickle
+    from spatial_engine.utils.scannet_utils.handler.info_handler import SceneInfoHandler
+    os.makedirs(output_dir, exist_ok=True)
+    output_pkl_file = os.path.join(output_dir, "object_visibility.pkl")
+    warning_file = os.path.join(output_dir, "warning.txt")
+    scene_info_handler = SceneInfoHandler(scene_info_path)
+    print(f"Loading visibility dict from {visibility_parquet_file}.")
+    visibility_dict = load_visibility_dict(visibility_parquet_file)
+    results, all_warnings = {}, []
+    for scene_id in scene_info_handler.get_all_scene_ids():
+        scene_id, scene_result, warnings = process_scene(scene_id, scene_info_handler, visibility_dict)
+        results[scene_id] = scene_result
+        all_warnings.extend(warnings)
+    with open(warning_file, "w") as wf:
+        for w in all_warnings:
+            wf.write(w + "\n")
+    with open(output_pkl_file, "wb") as f:
+        pickle.dump(results, f, protocol=pickle.HIGHEST_PROTOCOL)
+    print(f"Finished processing split '{split_name}'.")
+    print(f"Result saved to {output_pkl_file}")
+    print(f"Warnings saved to {warning_file}")
+
+
+def main():
+    """Same paths as upstream's main (:198-218)."""
+    root = "data/scannet/scannet_instance_data"
+    for split_name, out in (("val", "evaluation_data/object_perception"), ("train", "training_data/object_perception")):
+        process_split(split_name, f"{root}/scenes_{split_name}_info_i_D5.pkl", f"{root}/{split_name}_visibility_info_D5.parquet", out)
+
+
+if __name__ == "__main__":
+    main()

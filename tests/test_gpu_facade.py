@@ -296,6 +296,31 @@ def test_object_visibility(setup):
                 want["image_to_objects"].setdefault(image_id, []).append({"object_id": o, "intersection_count": c, "visibility": v})
     assert s == sid and result == want and len(result["object_to_images"]) >= 3
     assert any("has no point indices" in w for w in warnings) and any("not found in visibility dict" in w for w in warnings)
+    # split level: parquet index in, object_visibility.pkl + warning.txt out
+    try:
+        import pyarrow  # noqa: F401
+        import pandas as pd
+        import pickle
+        import tempfile
+        tmp = tempfile.mkdtemp(prefix="mspa_covis_")
+        pq_path, info_path = os.path.join(tmp, "vis.parquet"), os.path.join(tmp, "infos.pkl")
+        pd.DataFrame({"key": list(vis_dict), "values": list(vis_dict.values())}).to_parquet(pq_path)
+        with open(info_path, "wb") as f:
+            pickle.dump(h.infos, f)
+        orig_init = ns.IH.SceneInfoHandler.__init__
+
+        def patched(self, info_path_, *a, **k):
+            orig_init(self, info_path_, posed_images_root=h.posed_images_root, instance_data_root=h.instance_data_root)
+        ns.IH.SceneInfoHandler.__init__ = patched
+        try:
+            COV.process_split("val", info_path, pq_path, os.path.join(tmp, "out"))
+        finally:
+            ns.IH.SceneInfoHandler.__init__ = orig_init
+        with open(os.path.join(tmp, "out", "object_visibility.pkl"), "rb") as f:
+            assert pickle.load(f) == {sid: want}
+        assert "has no point indices" in open(os.path.join(tmp, "out", "warning.txt")).read()
+    except ImportError:
+        pass
     # resident form straight from K1's bitsets
     scene = h.scene_on_device(sid)
     res2 = scene.object_visibility({o: np.where(inst == o + 1)[0] for o in range(5) if o != 1})
