@@ -156,3 +156,42 @@ def jpeg_size(data: bytes):
             return int.from_bytes(data[i + 5:i + 7], "big"), int.from_bytes(data[i + 7:i + 9], "big")
         i += 2 + length
     raise ValueError("no start-of-frame segment in the JPEG stream")
+
+
+def main(engine_cls=None, dot=False):
+    """Same splits, budgets and file names as upstream's __main__ (coord: :660-706; dot: OM_D:700-776)."""
+    version = "v1_0"
+    engine_cls = engine_cls or TwoFrameVideoQAEngine
+    qtypes = ("tapvid3d_total_distance", "tapvid3d_displacement_vector")
+    if dot:
+        train_dir, val_dir = f"training_data_v2/object_movement_dot/{version}", f"evaluation_data_v2/object_movement_dot/{version}"
+    else:
+        train_dir, val_dir = f"training_data/object_movement_coord/{version}", f"evaluation_data/object_movement_coord/{version}"
+    base_img_dir, base_npz, meta = "data/my_tapvid3d_images", "data/tapvid3d_dataset", "data/tapvid3d_dataset/meta_data"
+
+    def ids(sub, split):
+        with open(f"{meta}/{sub}/{split}.txt") as f:
+            return [line.rstrip("\n") for line in f]
+    for split, out_root, npoints, npairs, augment in (("val", val_dir, 1, 1, False), ("train", train_dir, 15, 30, True)):
+        for q_type in qtypes:
+            for sub in ("adt", "pstudio"):
+                out_dir = f"{out_root}/{sub}"
+                os.makedirs(out_dir, exist_ok=True)
+                name = f"{sub}_{q_type}_val.jsonl" if split == "val" else f"{sub}_{q_type}_train_{npoints}points_{npairs}pairs.jsonl"
+                eng = engine_cls(question_type=q_type, sub_dataset=sub)
+                common = dict(scene_id_list=ids(sub, split), source_data_root=f"{base_npz}/{sub}", output_dir=out_dir,
+                              output_file=os.path.join(out_dir, name), npoints_per_group=npoints, npairs_per_bin=npairs,
+                              augment=augment)
+                if dot:
+                    img_dir = f"{out_dir}/{q_type}_images"
+                    common.update(base_img_dir=base_img_dir, img_output_dir=img_dir)
+                else:
+                    common.update(img_output_dir=base_img_dir)
+                if split == "val":
+                    eng.generate_qa_eval_data(max_samples=300, **common)
+                else:
+                    eng.generate_qa_training_data(augment_ratio=0.05, **common)
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,7 @@ from mspa import templates as T
 from mspa.annotate import Mark
 from spatial_engine.object_movement.single_object_movement_engine_coord import (TwoFrameVideoQAEngine, filter_large_groups,
                                                                                 jpeg_size, rigid_body_segmentation)
+from spatial_engine.object_movement.single_object_movement_engine_coord import main as _main
 
 random.seed(1)
 np.random.seed(1)
@@ -124,3 +125,7 @@ class TwoFrameVideoQAEngineDot(TwoFrameVideoQAEngine):
         heads.write_jsonl(output_file, subsampled)
         self._report("Original evaluation", output_file.replace(".jsonl", "_orig.jsonl"), data)
         self._report("Subsampled evaluation", output_file, subsampled)
+
+
+if __name__ == "__main__":
+    _main(TwoFrameVideoQAEngineDot, dot=True)

@@ -48,9 +48,10 @@ def process_scene(scene_id, scene_infos, warning_file):
     return scene_id, result
 
 
-def run_split(scene_info_path, output_file, warning_file, num_workers=8):
+def run_split(scene_info_path, output_file, warning_file, num_workers=8, keep=True):
     """Visibility index of every scene of a split -> ``output_file`` (.parquet in the readers' format, or
-    .pkl as the nested dict).  ``num_workers`` is accepted and ignored (GPU loop)."""
+    .pkl as the nested dict).  ``num_workers`` is accepted and ignored (GPU loop); ``keep=False`` drops each scene's
+    index after it has been written (parquet output), for splits that do not fit in memory."""
     from spatial_engine.utils.scannet_utils.handler.info_handler import SceneInfoHandler
     scene_infos = SceneInfoHandler(scene_info_path)
     all_scene_ids = scene_infos.get_all_scene_ids()
@@ -62,15 +63,45 @@ def run_split(scene_info_path, output_file, warning_file, num_workers=8):
         print("[run_split] DEBUG mode. Only processing first scene.")
     print(f"[run_split] Found {len(all_scene_ids)} scenes in {scene_info_path}")
     scene_visibility_dict = {}
-    for scene_id in all_scene_ids:
-        _, scene_visibility_dict[scene_id] = process_scene(scene_id, scene_infos, warning_file)
     if output_file.endswith(".pkl"):
+        for scene_id in all_scene_ids:
+            _, scene_visibility_dict[scene_id] = process_scene(scene_id, scene_infos, warning_file)
         with open(output_file, "wb") as f:
             pickle.dump(scene_visibility_dict, f)
         n = sum(len(v["image_to_points"]) + len(v["point_to_images"]) for v in scene_visibility_dict.values())
     else:
-        df = visibility_dict_to_frame(scene_visibility_dict)
-        df.to_parquet(output_file, index=False)
-        n = len(df)
+        # parquet: one row group per scene, streamed -- the train split is 13 GB of JSON strings and need not sit in memory
+        import pyarrow as pa
+        import pyarrow.parquet as pq
+        writer, n = None, 0
+        try:
+            for scene_id in all_scene_ids:
+                _, vis = process_scene(scene_id, scene_infos, warning_file)
+                if keep:
+                    scene_visibility_dict[scene_id] = vis
+                table = pa.Table.from_pandas(visibility_dict_to_frame({scene_id: vis}), preserve_index=False)
+                if writer is None:
+                    writer = pq.ParquetWriter(output_file, table.schema)
+                writer.write_table(table)
+                n += table.num_rows
+        finally:
+            if writer is not None:
+                writer.close()
     print(f"[run_split] Done. Wrote {n} entries to {output_file}")
     return scene_visibility_dict
+
+
+def main():
+    """Same paths as upstream's main (:178-214): val, then train."""
+    root = "data/scannet/scannet_instance_data"
+    suffix = "_debug" if DEBUG else ""
+    print("[main] DEBUG =", DEBUG)
+    for split in ("val", "train"):
+        out = os.path.join(root, f"{split}_visibility_info_D5{suffix}.parquet")
+        print(f"[main] Generating {split} visibility -> {out}")
+        run_split(os.path.join(root, f"scenes_{split}_info_i_D5.pkl"), out,
+                  os.path.join(root, f"make_visibility_{split}_warning{suffix}.txt"), num_workers=25)
+
+
+if __name__ == "__main__":
+    main()
