@@ -366,6 +366,14 @@ def test_run_split_scripts(setup, tmp_path):
         except ImportError:
             return
         import pandas as pd
+        # the visibility index streamed to parquet (one row group per scene), read back through the handler
+        kept = ns.MVI.run_split(info_path, str(tmp_path / "out" / "vis.parquet"), str(tmp_path / "w.txt"), keep=False)
+        assert kept == {}
+        vp = IH.VisibilityInfoHandler(str(tmp_path / "out" / "vis.parquet"))
+        for image_id, want_list in ref["image_to_points"].items():
+            assert vp.get_image_to_points_info(sid, image_id) == want_list
+        some = next(k for k, v in ref["point_to_images"].items() if v)
+        assert vp.get_point_to_images_info(sid, int(some)) == ref["point_to_images"][some]
         table = ns.CFR.run_split(info_path, str(tmp_path / "out" / "pairs.parquet"), str(tmp_path / "w.txt"))
         df = pd.read_parquet(str(tmp_path / "out" / "pairs.parquet"))
         keys = [tuple(str(x) for x in k) for k in g["cfr_pairs"]]
