@@ -23,6 +23,7 @@ struct VertexArgs {
     double *uv;
     double *depth_out;
     int32_t *count_atomic;
+    uint32_t vblocks, igroups;     // vertex blocks, image groups of kImgPerBlock (grid decode)
 };
 
 constexpr int kVThreads = 256;
@@ -32,14 +33,22 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_kernel(const doub
                                                                       const double *__restrict__ cam_mats,
                                                                       const uint16_t *__restrict__ depth,
                                                                       VertexArgs a) {
-    const int64_t i = (int64_t)blockIdx.x * kVThreads + threadIdx.x;
+    // XCD-aware decode of the 1-D grid: workgroup b runs on XCD b % 8, and each XCD has its own L2.  All vertex blocks of one
+    // image group go to the same XCD, so a group's depth frames are gathered through ONE L2 instead of eight (measured before
+    // the change: 672 MB fetched per 320-image scene against 197 MB of depth frames).
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t slot = blockIdx.x >> 3;
+    const uint32_t vblock = slot % a.vblocks;
+    const uint32_t group = (slot / a.vblocks) * 8u + xcd;
+    if (group >= a.igroups) return;
+    const int64_t i = (int64_t)vblock * kVThreads + threadIdx.x;
     const bool live = i < a.n_points;
     const int64_t ic = live ? i : a.n_points - 1;
     const int lane = threadIdx.x & 63;
     const double x = xyz[ic * a.point_stride];
     const double y = xyz[ic * a.point_stride + a.comp_stride];
     const double z = xyz[ic * a.point_stride + 2 * a.comp_stride];
-    const int img0 = blockIdx.y * kImgPerBlock;
+    const int img0 = (int)group * kImgPerBlock;
     const int img1 = min(img0 + kImgPerBlock, a.n_images);
     const int64_t dpix = (int64_t)a.dh * a.dw;
 
@@ -169,8 +178,11 @@ extern "C" int mspa_vertex_visibility(const double *xyz, int64_t n_points, int64
     a.count_atomic = count_from_bits ? nullptr : out_count;
     const int64_t bx = (n_points + kVThreads - 1) / kVThreads;
     const int64_t by = (n_images + kImgPerBlock - 1) / kImgPerBlock;
-    if (bx > 0x7fffffffLL || by > 65535) return fail(MSPA_EINVAL, "mspa_vertex_visibility: batch too large; split it");
-    hipLaunchKernelGGL(vertex_visibility_kernel, dim3((uint32_t)bx, (uint32_t)by), dim3(kVThreads), 0, s, xyz, cam_mats, depth, a);
+    const int64_t blocks = bx * ((by + 7) / 8) * 8;
+    if (bx > 0x7fffffffLL || blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_vertex_visibility: batch too large; split it");
+    a.vblocks = (uint32_t)bx;
+    a.igroups = (uint32_t)by;
+    hipLaunchKernelGGL(vertex_visibility_kernel, dim3((uint32_t)blocks), dim3(kVThreads), 0, s, xyz, cam_mats, depth, a);
     int rc = check_hip(hipGetLastError(), "vertex_visibility_kernel launch");
     if (rc || !count_from_bits) return rc;
     const int per_block = kVThreads / kWave;
