@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- frame-pairs/sec of the MultiSPA geometry pipe on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path (kernel K3, mspa_pair_reproject: back-projection ->
-reprojection -> depth-buffer visibility) over one batch of synthetic 640x480 RGB-D frame pairs that
-are already resident in HBM.  Workload = BASELINE.json configs[1]: visual_correspondence on 1k
-640x480 pairs, one MI355X.  With --gpus N (launched by torch.distributed.run, one rank per GPU)
-every rank processes its own batch of the same size (weak scaling, pairs shard embarrassingly) and
-the per-pair records of the whole job are collated with one RCCL all_gather inside the timed region.
+One "step" = one pass of the hot path (kernel K3, mspa_pair_reproject: back-projection -> reprojection ->
+depth-buffer visibility) over one batch of synthetic 640x480 RGB-D frame pairs that are already resident in HBM.
+Workload = BASELINE.json configs[1]: visual_correspondence on 1k 640x480 pairs, one MI355X.
+
+WHICH pairs is part of the contract (the fast kernels cull what cannot land in frame 2, so their cost depends on
+the overlap of the two views): the pairs are drawn from the scene's all-pairs overlap table (K1 + K2 = the
+reference's calculate_camera_overlap) with the reference's own overlap-binned sampler -- equal quotas over the
+1 %-wide bins 6..35 % (VC_C:485-505), both frame orders (VC_C:280) -- see mspa/workload.py.  `value` is that
+workload ("vc"); the same line carries a fixed three-point sweep (low / vc / high overlap) in `sweep`.
+
+    python bench.py                      # N=1, 1000 pairs/step, corr variant, vc workload
+    python bench.py --gpus 8             # re-executes itself under torch.distributed.run, one rank per GPU
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8     # what the driver does: same thing
+    python bench.py --variant dense      # + rgb in, byte mask, xyz f32, rgba out
+
+With --gpus N every rank processes its own batch of the same size (weak scaling, pairs shard embarrassingly) and
+the per-pair records of the whole job are collated with one RCCL all_gather inside the timed region.  On a box
+with fewer GPUs than ranks the ranks share the GPUs that exist and collate over gloo (reported in the line:
+"gpus_shared": true -- a launch check, not a scaling measurement).
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement) with two extra objects:
   roofline      algorithmic HBM bytes of the K3 launch / its HIP-event-measured duration vs 8 TB/s
   cpu_baseline  the NumPy restatement of the reference path (oracle/np_oracle.py) timed on this box
-
-    python bench.py                      # N=1, 1000 pairs/step, corr variant
-    MSPA_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2
-                                         # testing aid for 1-GPU boxes: both ranks on GPU 0, collation over gloo
-    python bench.py --variant dense      # + rgb in, byte mask, xyz f32, rgba out
 """
 from __future__ import annotations
 
@@ -50,6 +58,9 @@ def _legs(spec):
     return [v for v in spec.replace("'", "").replace('"', "").split(",") if v and v != "none"]
 
 
+WORKLOADS = ("vc", "low", "high")
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,46 +68,60 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=1000, help="frame pairs per step per GPU")
     ap.add_argument("--frames", type=int, default=2048, help="distinct device-resident frames per GPU")
-    ap.add_argument("--base-frames", type=int, default=24, help="frames rendered on the host per GPU")
+    ap.add_argument("--base-frames", type=int, default=64, help="frames of the synthetic scene rendered on the host per "
+                    "GPU (SURVEY.md 8d: F = 64 cameras per scene)")
+    ap.add_argument("--scene-points", type=int, default=131072, help="scene vertices the overlap table is measured on")
+    ap.add_argument("--workload", choices=WORKLOADS, default="vc",
+                    help="which pairs of the scene (mspa/workload.py): vc = the reference's overlap-binned sample 6..35 %% "
+                         "(headline), low = overlap < 6 %%, high = near-identical views")
     ap.add_argument("--variant", choices=sorted(VARIANTS), default="corr")
     ap.add_argument("--mode", choices=("fast", "exact"), default="fast",
                     help="fast: MSPA_PAIR_FAST (bit-exact integers via guarded composed matrices); exact: the "
                          "reference's own operation order")
     ap.add_argument("--stream", choices=("auto", "on", "off"), default="auto",
                     help="MSPA_PAIR_STREAM hint (frame 1 read non-temporally); auto = on when the step's pairs touch each resident "
-                         "frame at most ~1.5 times, as they do with the default 2040 frames / 1000 pairs")
+                         "frame at most ~1.5 times, as they do with the default 2048 frames / 1000 pairs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
-    ap.add_argument("--pair-offsets", default="1,2,3", help="frame-index distances the pairs are drawn from "
-                    "(neighbouring views of the camera walk; larger = less of frame 1 lands in frame 2)")
-    ap.add_argument("--walk-step", type=float, default=0.15, help="camera random-walk step (m) of the synthetic scene")
-    ap.add_argument("--target-jitter", type=float, default=0.8, help="look-at jitter (m) of the synthetic scene")
+    ap.add_argument("--walk-step", type=float, default=0.08, help="camera random-walk step (m) of the synthetic scene")
+    ap.add_argument("--target-step", type=float, default=0.25, help="look-at random-walk step (m) of the synthetic scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scene-legs", action="store_true", help="skip the K1/K2 informational legs")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the low / high overlap legs of the sweep")
     ap.add_argument("--also", default="corr:exact,dense:fast,dense:exact,minimal:fast",
                     help="comma list of extra variant:mode legs timed briefly on rank 0 ('none' = skip)")
     return ap.parse_args()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU, exactly
+    the command line the driver uses for N > 1.  The rank-0 JSON line and the exit code pass through."""
+    import socket
+    import subprocess
+    import torch
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        print(f"[bench] {args.gpus} ranks on {n_dev} GPU(s): ranks share devices, collation over gloo "
+              "(launch check only, not a scaling measurement)", file=sys.stderr)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def make_base_scene(args, rank):
-    """Host-only part of the inputs: the seeded synthetic scene and the step's pair list."""
+    """Host-only part of the inputs: the seeded synthetic scene (SURVEY.md 8d recipe; the camera follows a hand-held
+    sweep so that one scene populates every overlap bin the reference samples from)."""
     from mspa import synth
-    sc = synth.make_scene(1000 + rank, n_points=64, n_frames=args.base_frames, color_hw=(H, W),
-                          depth_hw=(H, W), invalid_pose_frac=0.0, with_color=False, walk_step=args.walk_step,
-                          target_jitter=args.target_jitter)
-    nb = len(sc.valid_image_ids)
-    reps = max(1, args.frames // nb)
-    rng = np.random.default_rng(77 + rank)
-    rep = np.arange(args.pairs) % reps
-    b1 = rng.integers(0, nb, args.pairs)
-    offs = np.array([int(v) for v in args.pair_offsets.split(",")])
-    b2 = (b1 + offs[rng.integers(0, len(offs), args.pairs)]) % nb
-    # offset 0 = the same pose seen in the next replica (independent depth noise): every pixel lands in view
-    rep2 = np.where(b2 == b1, (rep + 1) % reps, rep)
-    pairs_np = np.stack([rep * nb + b1, rep2 * nb + b2], axis=1).astype(np.int32)
-    return sc, pairs_np
+    return synth.make_scene(1000 + rank, n_points=args.scene_points, n_frames=args.base_frames, color_hw=(H, W),
+                            depth_hw=(H, W), invalid_pose_frac=0.0, with_color=False, trajectory="sweep",
+                            walk_step=args.walk_step, target_step=args.target_step)
 
 
-def build_inputs(args, rank, device, sc, pairs_np):
+def build_inputs(args, rank, device, sc):
     """Expand the host-rendered frames on the device into `frames` distinct frames."""
     import torch
     from mspa import engine
@@ -119,9 +144,31 @@ def build_inputs(args, rank, device, sc, pairs_np):
     rgb = None
     if VARIANTS[args.variant]["rgb"] or any(VARIANTS[v.split(":")[0]]["rgb"] for v in _legs(args.also)):
         rgb = torch.randint(0, 256, (n_frames, H, W, 3), generator=g, device=device, dtype=torch.uint8)
-    # pairs: two different views of the same replica, walking through all replicas (make_base_scene)
-    pairs = torch.from_numpy(pairs_np).to(device)
-    return ids, depth, mats, rgb, pairs, nb
+    return depth, mats, rgb, nb, reps
+
+
+def scene_overlap_table(sc, device):
+    """The scene's all-pairs overlap column exactly as the reference defines it (CFR:102-137: |a & b| / |a | b| * 100 over
+    the per-image vertex visibility masks), from K1 + K2 -- bit-equal to the reference (tests/test_gpu_parity.py).
+    Not timed: it only decides which pairs the step consists of."""
+    import torch
+    from mspa import engine
+    ids = sc.valid_image_ids
+    Ea = [sc.A @ sc.E[i] for i in ids]
+    cam = torch.from_numpy(engine.camera_matrices(sc.K, Ea)).to(device)
+    depth = engine.depth_to_device(np.stack([sc.depth[i] for i in ids]), device)
+    xyz = torch.from_numpy(np.ascontiguousarray(sc.points[:, :3])).to(device)
+    vis = engine.vertex_visibility(xyz, cam, depth, (H, W), ("bits",))
+    return engine.pair_overlap(vis["bits"], engine.all_pairs(len(ids), device)).cpu().numpy()
+
+
+def workload_pairs(overlap, nb, reps, n_pairs, kind, rank):
+    """Frame-index pairs of one workload: base-scene pairs from mspa/workload.py, pair p placed in replica p % reps
+    (1 000 pairs walk through 2 048 distinct frames).  Returns (pairs [n,2] int32, base pairs, description)."""
+    from mspa import workload
+    base, info = workload.select_pairs(overlap, nb, n_pairs, kind, seed=77 + rank)
+    rep = (np.arange(n_pairs) % reps).astype(np.int32)
+    return np.stack([rep * nb + base[:, 0], rep * nb + base[:, 1]], axis=1).astype(np.int32), base, info
 
 
 def stream_hint(args, n_frames):
@@ -287,30 +334,37 @@ _CPU_SCENE = None
 def _cpu_pair(job):
     """One frame pair through the NumPy restatement of the reference path (worker side)."""
     from oracle import np_oracle as O
-    sc, ids, color = _CPU_SCENE
+    depth, K, E, A, color = _CPU_SCENE
     a, b = job
-    r = O.frame_pair(sc.depth[ids[a]], sc.depth[ids[b]], sc.K, sc.E[ids[a]], sc.E[ids[b]], sc.A, (H, W), color)
+    r = O.frame_pair(depth[a], depth[b], K, E[a], E[b], A, (H, W), color)
     return r["n_vis"]
 
 
-def _cpu_worker_init():
+def _cpu_worker_init(payload_path):
+    """Pool workers are SPAWNED (fresh interpreters: the parent holds a live HIP runtime by now and must not be
+    forked); the scene reaches them as one .npz file."""
+    global _CPU_SCENE
     try:
         from threadpoolctl import threadpool_limits
         threadpool_limits(1)                 # one BLAS thread per worker, as OMP_NUM_THREADS=1 would
     except Exception:
         pass
+    z = np.load(payload_path)
+    _CPU_SCENE = (z["depth"], z["K"], z["E"], z["A"], np.zeros((H, W, 3), dtype=np.uint8))
 
 
-def cpu_baseline(sc, pairs_np, budget_s):
+def cpu_baseline(sc, base_pairs, budget_s, with_pool=True):
     """Time the NumPy restatement of the reference path (oracle/np_oracle.frame_pair) on a bounded sample
     of the step's pairs: (i) one process, (ii) multiprocessing.Pool(min(25, cores)) -- the reference's own
-    worker count (CFR:280).  Runs BEFORE the GPU is initialised so that the pool can fork safely."""
+    worker count (CFR:280).  The oracle is used here as the thing timed BESIDE the product, never inside it."""
     global _CPU_SCENE
     import multiprocessing as mp
+    import tempfile
     ids = sc.valid_image_ids
-    nb = len(ids)
-    _CPU_SCENE = (sc, ids, np.zeros((H, W, 3), dtype=np.uint8))
-    jobs = [(int(p[0] % nb), int(p[1] % nb)) for p in pairs_np]
+    depth = np.stack([sc.depth[i] for i in ids])
+    E = np.stack([sc.E[i] for i in ids])
+    _CPU_SCENE = (depth, sc.K, E, sc.A, np.zeros((H, W, 3), dtype=np.uint8))
+    jobs = [(int(p[0]), int(p[1])) for p in base_pairs]
     n, t0 = 0, time.perf_counter()
     while True:
         _cpu_pair(jobs[n])
@@ -320,16 +374,20 @@ def cpu_baseline(sc, pairs_np, budget_s):
             break
     single = n / el
     workers = min(25, os.cpu_count() or 1)
-    pool_jobs = jobs[:max(workers * 4, int(single * workers * budget_s / 2))][:len(jobs)]
-    pool_rate = None
-    try:
-        with mp.get_context("fork").Pool(workers, initializer=_cpu_worker_init) as pool:
-            pool.map(_cpu_pair, pool_jobs[:workers])                       # warm the workers
-            t1 = time.perf_counter()
-            pool.map(_cpu_pair, pool_jobs, chunksize=max(1, len(pool_jobs) // (workers * 4)))
-            pool_rate = len(pool_jobs) / (time.perf_counter() - t1)
-    except Exception as e:                                                  # no fork / no /dev/shm: report single only
-        print(f"[bench] pool baseline skipped: {e}", file=sys.stderr)
+    pool_rate, pool_jobs = None, []
+    if with_pool:
+        pool_jobs = jobs[:max(workers * 4, int(single * workers * budget_s / 2))][:len(jobs)]
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                payload = os.path.join(td, "scene.npz")
+                np.savez(payload, depth=depth, K=sc.K, E=E, A=sc.A)
+                with mp.get_context("spawn").Pool(workers, initializer=_cpu_worker_init, initargs=(payload,)) as pool:
+                    pool.map(_cpu_pair, pool_jobs[:workers])                       # warm the workers
+                    t1 = time.perf_counter()
+                    pool.map(_cpu_pair, pool_jobs, chunksize=max(1, len(pool_jobs) // (workers * 4)))
+                    pool_rate = len(pool_jobs) / (time.perf_counter() - t1)
+        except Exception as e:                                                  # no /dev/shm etc.: report single only
+            print(f"[bench] pool baseline skipped: {e}", file=sys.stderr)
     return {"value": round(single, 3), "unit": "frame-pairs/s", "cores": 1, "kind": "port",
             "sample": f"{n} of the step's 640x480 pairs through oracle/np_oracle.frame_pair "
                       f"(NumPy {np.__version__}, 1 process, in-memory images) in {el:.1f} s",
@@ -339,31 +397,44 @@ def cpu_baseline(sc, pairs_np, budget_s):
             "host_cores_available": os.cpu_count()}
 
 
+def committed_traffic(key):
+    """PMC-measured HBM bytes per launch for a named leg, from the committed profiles/traffic.json (collected with
+    tools/profile.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command).  NOT measured in
+    this run -- counters cannot be read from inside the process -- and reported as such (`traffic_source`)."""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tfile):
+        return None
+    return json.load(open(tfile)).get(key)
+
+
 def main():
     args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "0"))
+    if world == 0:
+        if args.gpus > 1:
+            self_launch(args)                       # does not return
+        world = 1
     import torch
     from mspa import _lib, engine, shard
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    sc, pairs_np = make_base_scene(args, rank)
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(sc, pairs_np, args.cpu_seconds)     # before any GPU initialisation (fork-safe)
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
-    share = bool(os.environ.get("MSPA_BENCH_SHARE_GPU"))     # testing aid: every rank on GPU 0, collation over gloo
-    if share:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    # fewer GPUs than ranks (a 1-GPU box asked for --gpus 2): ranks share devices and collate over gloo -- RCCL refuses
+    # two ranks on one device.  A launch check; the line says so.
+    share = bool(os.environ.get("MSPA_BENCH_SHARE_GPU")) or n_dev < world
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     _lib.load()
-    ids, depth, mats, rgb, pairs, nb = build_inputs(args, rank, device, sc, pairs_np)
+    sc = make_base_scene(args, rank)
+    depth, mats, rgb, nb, reps = build_inputs(args, rank, device, sc)
+    overlap = scene_overlap_table(sc, device)
+    pairs_np, base_pairs, winfo = workload_pairs(overlap, nb, reps, args.pairs, args.workload, rank)
+    pairs = torch.from_numpy(pairs_np).to(device)
     # MSPA_BENCH_FORCE_DIST=1 exercises the RCCL collation path with a single rank (1-GPU boxes)
     dist_ctx = (shard.init_distributed(device, backend="gloo" if share else None)
                 if (world > 1 or os.environ.get("MSPA_BENCH_FORCE_DIST")) else None)
@@ -378,29 +449,58 @@ def main():
     bytes_per_launch = spec["bytes_per_px"] * P * args.pairs
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
 
-    extra = {}
+    def vis_fraction(o):
+        c = o["counts"].cpu().numpy().reshape(-1, 2)
+        return round(float(c[:, 1].sum() / max(1, c[:, 0].sum())), 4)
+
+    def leg(v, m, prs, steps):
+        w2, k2, o2 = time_variant(v, m, depth, mats, rgb, prs, steps, 1, None, stream)
+        b2 = VARIANTS[v]["bytes_per_px"] * P * args.pairs
+        return {"pairs_per_s_1gpu": round(args.pairs / (k2 * 1e-3), 1), "kernel_ms": round(k2, 4),
+                "achieved_GBs": round(b2 / (k2 * 1e-3) / 1e9, 1), "frac": round(b2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "bytes_per_pair": int(VARIANTS[v]["bytes_per_px"] * P), "visible_fraction": vis_fraction(o2)}
+
+    extra, sweep = {}, {}
+    head_vis = vis_fraction(out) if rank == 0 else None
     if rank == 0 and world == 1:      # informational single-GPU legs; with N > 1 every rank leaves together after the timed job
-        for leg in [v for v in _legs(args.also) if v != f"{args.variant}:{args.mode}"]:
-            v, m = leg.split(":")
-            w2, k2, _ = time_variant(v, m, depth, mats, rgb, pairs, max(3, args.steps // 4), 1, None, stream)
-            b2 = VARIANTS[v]["bytes_per_px"] * P * args.pairs
-            extra[leg] = {"pairs_per_s_1gpu": round(args.pairs / (k2 * 1e-3), 1), "kernel_ms": round(k2, 4),
-                        "achieved_GBs": round(b2 / (k2 * 1e-3) / 1e9, 1),
-                        "frac": round(b2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "bytes_per_pair": int(VARIANTS[v]["bytes_per_px"] * P)}
-        if world == 1 and not args.no_scene_legs:
+        short = max(3, args.steps // 4)
+        if not args.no_sweep:         # the same variant on the other two points of the overlap sweep
+            for kind in WORKLOADS:
+                if kind == args.workload:
+                    sweep[kind] = {"pairs_per_s_1gpu": round(args.pairs / (kern_ms * 1e-3), 1), "kernel_ms": round(kern_ms, 4),
+                                   "achieved_GBs": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+                                   "bytes_per_pair": int(spec["bytes_per_px"] * P), "visible_fraction": head_vis,
+                                   "pairs": winfo, "headline": True}
+                    continue
+                p2, _, i2 = workload_pairs(overlap, nb, reps, args.pairs, kind, rank)
+                sweep[kind] = dict(leg(args.variant, args.mode, torch.from_numpy(p2).to(device), max(short, 5)), pairs=i2)
+        for lg in [v for v in _legs(args.also) if v != f"{args.variant}:{args.mode}"]:
+            v, m = lg.split(":")
+            extra[lg] = leg(v, m, pairs, short)
+        if not args.no_scene_legs:
             extra["scene"] = time_scene_kernels(device)
+            t1 = committed_traffic("K1_vertex_visibility")
+            if t1:
+                k1 = extra["scene"]["K1_vertex_visibility"]
+                k1["frac_note"] = ("`frac` prices SURVEY.md 8d's streaming byte count (no cache-residency credit); "
+                                   "`traffic_frac` is the PMC-measured HBM traffic / time / peak")
+                k1["traffic"] = t1["hbm_bytes_per_launch"]
+                k1["traffic_frac"] = round(t1["hbm_bytes_per_launch"] / (k1["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                k1["traffic_source"] = t1["source"]
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        # after the GPU legs (the pair list comes from K1 + K2); at N > 1 only the 1-process leg, with half the budget,
+        # while the other ranks wait at the final barrier
+        cpu = cpu_baseline(sc, base_pairs, args.cpu_seconds if world == 1 else args.cpu_seconds / 2, with_pool=(world == 1))
 
     if rank == 0:
-        traffic = None
-        counts = out["counts"].cpu().numpy()
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            t = json.load(open(tfile))
-            if t.get("variant") == args.variant and t.get("pairs") == args.pairs and t.get("mode") == args.mode:
-                traffic = t.get("hbm_bytes_per_launch")
-        info = _lib.device_info(local_rank)
+        tkey = f"{args.variant}:{args.mode}:{args.workload}"
+        t = committed_traffic(tkey) if args.pairs == 1000 else None
+        traffic = t["hbm_bytes_per_launch"] if t else None
+        info = _lib.device_info(dev_index)
         ceilings = measured_hbm_ceilings(device) if (world == 1 and not args.no_scene_legs) else None
+        tight = args.mode == "fast"
         line = {
             "metric": "frame-pairs/sec MultiSPA geometry pipe (640x480 RGB-D)",
             "value": round(value, 1), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
@@ -408,23 +508,37 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "visual_correspondence unproject+reproject+occlusion kernel (K3) on "
-                                   f"{args.pairs} 640x480 frame pairs per GPU per step (BASELINE.json configs[1])",
+                                   f"{args.pairs} 640x480 frame pairs per GPU per step (BASELINE.json configs[1]); pairs = "
+                                   f"'{args.workload}' sample of the scene's overlap table: {winfo['rule']}",
+                       "pairs": winfo, "visible_fraction": head_vis,
+                       "scene": {"frames": nb, "vertices": args.scene_points, "trajectory": "sweep",
+                                 "walk_step_m": args.walk_step, "target_step_m": args.target_step,
+                                 "recipe": "SURVEY.md 8d (6x6x3 m room, 8 boxes, 5 mm depth noise, 7 % invalid pixels)"},
                        "variant": args.variant, "mode": args.mode, "outputs": list(spec["outputs"]),
                        "stream_hint": bool(stream and args.mode == "fast"),
-                       "pairs_per_step_per_gpu": args.pairs, "pair_offsets": args.pair_offsets, "distinct_frames_per_gpu": int(depth.shape[0]),
+                       "pairs_per_step_per_gpu": args.pairs, "distinct_frames_per_gpu": int(depth.shape[0]),
                        "image": "640x480 depth u16 (+rgb u8x3 for dense)", "parallelism": f"dp{world}",
-                       "collation": "one RCCL all_gather of the job's per-pair records inside the timed region" if world > 1 else "none (1 GPU)"},
+                       "collation": ("one all_gather of the job's per-pair records inside the timed region ("
+                                     + ("gloo: ranks share GPUs" if share else "RCCL") + ")") if world > 1 else "none (1 GPU)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "mspa::pair_fast_tight_kernel" if args.mode == "fast" else "mspa::pair_exact_kernel",
+                         "traffic_source": (t["source"] + " -- committed PMC passes of this command, NOT measured in this run")
+                         if t else None,
+                         "traffic_GBs": round(traffic / (kern_ms * 1e-3) / 1e9, 1) if traffic else None,
+                         "traffic_frac": round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                         "kernel": "mspa::pair_fast_tight_kernel" if tight else "mspa::pair_exact_kernel",
                          "kernel_ms": round(kern_ms, 4), "bytes_per_pair": int(spec["bytes_per_px"] * P),
-                         "measured_ceilings_GBs": ceilings,
-                         "traffic_GBs": round(traffic / (kern_ms * 1e-3) / 1e9, 1) if traffic else None},
+                         "bytes_per_launch": int(bytes_per_launch),
+                         "measured_ceilings_GBs": ceilings},
             "cpu_baseline": cpu,
+            "sweep": sweep,
             "variants": extra,
             "device": info,
-            "visible_fraction": round(float(counts[:, 1].sum() / max(1, counts[:, 0].sum())), 4),
+            "visible_fraction": head_vis,
         }
+        if world > 1:
+            line["gpus_shared"] = bool(share)
+            line["physical_gpus"] = n_dev
         print(json.dumps(line), flush=True)
     if dist_ctx is not None:
         dist_ctx.barrier()          # leave together: no rank tears the communicator down under another one's feet

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MSPA_VERSION 110            /* 0.1.10: + mspa_track_pair_distances, mspa_track_rigidity_loss, mspa_object_extents, MSPA_PAIR_STREAM */
+#define MSPA_VERSION 120            /* 0.2.0: + mspa_pair_reproject_last_kernel; K2 tiled; K1 composed/guarded */
 
 #define MSPA_OK 0
 #define MSPA_EINVAL (-1)            /* bad argument (null pointer, size out of range, ...) */
@@ -109,6 +109,17 @@ int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, const double 
                         int16_t *out_pix_i16, float *out_xyz_f32, uint32_t *out_rgba,
                         double *out_xyz_f64, double *out_uv_f64, double *out_depth_f64,
                         int32_t *out_counts, uint32_t flags, mspa_stream_t stream);
+
+/* Which kernel the most recent mspa_pair_reproject call OF THE CALLING THREAD enqueued (a diagnostic the parity tests
+ * use to prove that the instantiation they mean to check is the one that ran; no effect on results). */
+#define MSPA_KERNEL_NONE 0
+#define MSPA_KERNEL_PAIR_EXACT 1          /* reference operation order */
+#define MSPA_KERNEL_PAIR_FAST 2           /* composed + guarded, any shape, stripe mapping */
+#define MSPA_KERNEL_PAIR_FAST_LINEAR 3    /* the same with the linear pixel mapping (bitset, W % 64 != 0) */
+#define MSPA_KERNEL_PAIR_FAST_TIGHT 4     /* whole-tile images (W % 64 == 0, H % 48 == 0, colour == depth grid), output set
+                                             corr / dense / minimal */
+#define MSPA_KERNEL_PAIR_FAST_SCALED 5    /* colour grid over a smaller depth grid (ScanNet: 1296x968 over 640x480) */
+int mspa_pair_reproject_last_kernel(void);
 
 /*
  * K1 -- vertex visibility, HOT LOOP 1 of CFR.process_scene (CFR:152-164) and

@@ -1070,6 +1070,10 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
 
 using namespace mspa;
 
+static thread_local int g_last_pair_kernel = MSPA_KERNEL_NONE;
+
+extern "C" int mspa_pair_reproject_last_kernel(void) { return g_last_pair_kernel; }
+
 extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, const double *frame_mats,
                                    int32_t n_frames, const int32_t *pairs, int64_t n_pairs, int32_t dh,
                                    int32_t dw, int32_t H, int32_t W, uint64_t *out_vis_bits,
@@ -1135,6 +1139,9 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
     const int64_t blocks = groups * 8 * a.strips;
     if (blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_pair_reproject: too many workgroups; split the batch");
     const dim3 grid((uint32_t)blocks), block(kThreads);
+    g_last_pair_kernel = !fast ? MSPA_KERNEL_PAIR_EXACT
+                         : tight24 ? MSPA_KERNEL_PAIR_FAST_TIGHT
+                         : linear ? MSPA_KERNEL_PAIR_FAST_LINEAR : MSPA_KERNEL_PAIR_FAST;
     if (!fast) {
         if (ident) hipLaunchKernelGGL(pair_exact_kernel<true>, grid, block, 0, s, depth, rgb, frame_mats, pairs, a);
         else hipLaunchKernelGGL(pair_exact_kernel<false>, grid, block, 0, s, depth, rgb, frame_mats, pairs, a);

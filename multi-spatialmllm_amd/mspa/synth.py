@@ -166,7 +166,14 @@ def make_scene(seed: int, n_points: int = 131072, n_frames: int = 64,
                color_hw: Tuple[int, int] = (480, 640), depth_hw: Tuple[int, int] = (480, 640),
                invalid_pose_frac: float = 0.02, zero_frac: float = 0.07, noise_mm: float = 5.0,
                frame_step: int = 5, with_color: bool = True, scene_id: Optional[str] = None,
-               walk_step: float = 0.15, target_jitter: float = 0.8) -> SynthScene:
+               walk_step: float = 0.15, target_jitter: float = 0.8, trajectory: str = "jitter",
+               target_step: float = 0.25) -> SynthScene:
+    """``trajectory="jitter"`` (default): every frame looks at the room centre +- an independent jitter.
+    ``trajectory="sweep"``: the look-at target itself performs a slow random walk (``target_step`` metres per frame), like
+    a hand-held scan -- neighbouring frames overlap strongly, distant ones little, so one scene populates every overlap
+    bin the reference samples from (VC_C:485-505: 6..35 %)."""
+    if trajectory not in ("jitter", "sweep"):
+        raise ValueError(f"unknown trajectory {trajectory!r}")
     rng = np.random.default_rng(np.random.PCG64(seed))
     boxes = _make_boxes(rng)
     K = intrinsics_for(color_hw)
@@ -199,7 +206,13 @@ def make_scene(seed: int, n_points: int = 131072, n_frames: int = 64,
             if not any(inside):
                 break
             eye = np.array([rng.uniform(0.6, 5.4), rng.uniform(0.6, 5.4), 1.9])
-        target = ROOM / 2 + rng.normal(0, target_jitter, 3) * [1, 1, 0.4]
+        if trajectory == "sweep":
+            if f == 0:
+                target = ROOM / 2 + rng.normal(0, target_jitter, 3) * [1, 1, 0.4]
+            else:
+                target = np.clip(target + rng.normal(0, target_step, 3) * [1, 1, 0.4], [0.3, 0.3, 0.2], ROOM - [0.3, 0.3, 0.2])
+        else:
+            target = ROOM / 2 + rng.normal(0, target_jitter, 3) * [1, 1, 0.4]
         E_al = _look_at(eye, target)
         E_f = _roundtrip_f(A_inv @ E_al)
         E_al = A @ E_f

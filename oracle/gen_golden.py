@@ -177,6 +177,57 @@ def golden_scannet_shape(ns):
     print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB; a7 rows {a7.shape[0]}, pair visible {int(v.sum())}")
 
 
+def golden_k3_640x480(ns):
+    """The reference at the BASELINE shape itself (colour = depth = 640x480, BASELINE.json configs[1]): two frames of a seeded
+    scene, both orders.  Per pair: project_mask_to_3d over the full frame (OPS:235-329), project_3d_point_to_image into the
+    other frame (IH:313-335), check_point_visibility (IH:375-386).  Frozen: SHA-256 of the float64 bytes, the visibility mask as
+    a bitset in frame-1 pixel order, the counters, and SHA-256 of the [P, 2] int16 pixel-index table in the layout K3 writes it
+    ((xi, yi) = IH:362-366's clipped half-to-even indices where the point lies inside frame 2 in front of the camera,
+    (-1, -1) elsewhere)."""
+    hw = (480, 640)
+    sc = synth.make_scene(6007, n_points=64, n_frames=2, color_hw=hw, depth_hw=hw, invalid_pose_frac=0.0, with_color=False,
+                          walk_step=0.1, target_jitter=0.3)
+    h = RH.make_handler(ns, [sc])
+    sid = sc.scene_id
+    g = scene_arrays(sc)
+    ids = h.get_all_extrinsic_valid_image_ids(sid)
+    assert len(ids) == 2
+    color = stable_color_image(hw)
+    P = hw[0] * hw[1]
+    g["pair_ids"] = np.array([[ids[0], ids[1]], [ids[1], ids[0]]])
+    for n, (f0, f1) in enumerate(g["pair_ids"]):
+        f0, f1 = str(f0), str(f1)
+        a7 = ns.OPS.project_mask_to_3d(sc.depth[f0], sc.K, sc.E[f0], None, sc.A, color)
+        valid = (sc.depth[f0].reshape(-1) > 0)
+        assert a7.shape[0] == int(valid.sum())
+        u, d = h.project_3d_point_to_image(sid, f1, a7[:, :3])
+        v = h.check_point_visibility(sid, f1, u, d)
+        inb = h.check_point_in_image_boundary(sid, u)
+        with np.errstate(invalid="ignore"):
+            inview = inb & (d > 0)
+            xi = np.clip(np.round(u[:, 0]).astype(int), 0, hw[1] - 1)          # IH:362-366 (sx = sy = 1)
+            yi = np.clip(np.round(u[:, 1]).astype(int), 0, hw[0] - 1)
+        pix = np.full((P, 2), -1, dtype=np.int16)
+        rows = np.nonzero(valid)[0]
+        pix[rows[inview], 0] = xi[inview]
+        pix[rows[inview], 1] = yi[inview]
+        vis_full = np.zeros(P, dtype=bool)
+        vis_full[rows] = v
+        g[f"pair{n}_rows"] = np.array(a7.shape[0])
+        g[f"pair{n}_n_vis"] = np.array(int(v.sum()))
+        g[f"pair{n}_n_inview"] = np.array(int(inview.sum()))
+        g[f"pair{n}_sha_xyz"], g[f"pair{n}_sha_rgb"] = np.array(sha(a7[:, :3])), np.array(sha(a7[:, 3:]))
+        g[f"pair{n}_sha_uv"], g[f"pair{n}_sha_depth"] = np.array(sha(u)), np.array(sha(d))
+        g[f"pair{n}_vis_bits"] = np.packbits(vis_full, bitorder="little")
+        g[f"pair{n}_sha_pix"] = np.array(sha(pix))
+        g[f"pair{n}_xyz_head"] = a7[:64, :3].copy()
+        print(f"k3_640x480 pair {n}: rows {a7.shape[0]}, in view {int(inview.sum())}, visible {int(v.sum())}")
+    g["meta"] = np.array(_meta())
+    path = os.path.join(GOLDEN_DIR, "k3_640x480.npz")
+    np.savez_compressed(path, **g)
+    print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def golden_cme256(ns):
     """G6 of SURVEY.md 8c: CME.build_training_sample answer_values for 256 pairs of a 24-frame walk -- both swap branches,
     yaw differences pushed beyond +-180 (wrap), a static pair, mirrored pairs."""
@@ -436,6 +487,8 @@ def main():
         return golden_scannet_shape(ns)
     if len(sys.argv) > 1 and sys.argv[1] == "cme256":
         return golden_cme256(ns)
+    if len(sys.argv) > 1 and sys.argv[1] == "k3_640x480":
+        return golden_k3_640x480(ns)
     golden_scene(ns, "scene_ident", 2001, (48, 64), (48, 64), n_points=700, n_frames=6, with_color=True)
     golden_scene(ns, "scene_scaled", 2002, (73, 98), (48, 64), n_points=700, n_frames=6, with_color=False)
     golden_ties(ns)
@@ -444,6 +497,7 @@ def main():
     golden_sens(ns)
     golden_scannet_shape(ns)
     golden_cme256(ns)
+    golden_k3_640x480(ns)
 
 
 if __name__ == "__main__":
