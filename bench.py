@@ -114,11 +114,30 @@ def self_launch(args):
 
 def make_base_scene(args, rank):
     """Host-only part of the inputs: the seeded synthetic scene (SURVEY.md 8d recipe; the camera follows a hand-held
-    sweep so that one scene populates every overlap bin the reference samples from)."""
+    sweep so that one scene populates every overlap bin the reference samples from).  Rendering 64 frames on the host
+    takes ~20 s, so the finished scene is cached under the temp directory (profiling runs the same command six times)."""
+    import pickle
+    import tempfile
     from mspa import synth
-    return synth.make_scene(1000 + rank, n_points=args.scene_points, n_frames=args.base_frames, color_hw=(H, W),
-                            depth_hw=(H, W), invalid_pose_frac=0.0, with_color=False, trajectory="sweep",
-                            walk_step=args.walk_step, target_step=args.target_step)
+    key = f"mspa_bench_scene_{1000 + rank}_{args.scene_points}_{args.base_frames}_{args.walk_step}_{args.target_step}.pkl"
+    path = os.path.join(tempfile.gettempdir(), key)
+    if os.path.exists(path):
+        try:
+            with open(path, "rb") as f:
+                return pickle.load(f)
+        except Exception:
+            pass
+    sc = synth.make_scene(1000 + rank, n_points=args.scene_points, n_frames=args.base_frames, color_hw=(H, W),
+                          depth_hw=(H, W), invalid_pose_frac=0.0, with_color=False, trajectory="sweep",
+                          walk_step=args.walk_step, target_step=args.target_step)
+    try:
+        tmp = path + f".{os.getpid()}"
+        with open(tmp, "wb") as f:
+            pickle.dump(sc, f, protocol=4)
+        os.replace(tmp, path)
+    except Exception:
+        pass
+    return sc
 
 
 def build_inputs(args, rank, device, sc):
