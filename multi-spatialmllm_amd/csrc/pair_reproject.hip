@@ -73,6 +73,7 @@ constexpr int kGroup = 4;                        // pixels per lane processed be
 
 constexpr double kGuardPx = 1e-6;                // fast path: distance to a rounding/bounds boundary
 constexpr double kGuardZ = 1e-9;                 // fast path: distance to a depth-test boundary (m)
+constexpr double kGuardZmm = 1e-6;               // the same in millimetres (tight kernel: millimetre-scaled composed matrix)
 
 // Makes a wave-uniform pointer opaque to LICM: loads through the result cannot be hoisted out of
 // the pixel loop, so at most one stage's matrices are live in SGPRs at a time (all five would
@@ -692,6 +693,34 @@ __device__ __forceinline__ int med3_0(int x, int hi) {   // clamp(x, 0, hi), hi 
     return r;
 }
 
+// Drop a wave-uniform 64-bit value (a ballot) into lane `lane` (wave-uniform) of a VGPR pair: 2 VALU issues.
+// v_writelane_b32 may name only ONE SGPR besides M0 (constant-bus rule of gfx9), so the lane select travels in M0.
+// Nothing else in the loop uses M0 (gfx9 LDS instructions do not; the tile's LDS-DMA requests were issued before it).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void writelane64(unsigned long long value, int lane, uint32_t &lo, uint32_t &hi) {
+    asm("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+        : "+v"(lo), "+v"(hi)
+        : "s"((uint32_t)value), "s"((uint32_t)(value >> 32)), "s"(__builtin_amdgcn_readfirstlane(lane))
+        : "m0");
+}
+#pragma clang diagnostic pop
+
+// Ballot of a lane predicate as the i1 it is.  (HIP's __ballot takes an int: the predicate is widened to 0/1 in a VGPR and
+// compared against zero again -- a v_cndmask + v_cmp per use that the optimiser does not always fold away.)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// Keeps a ballot opaque: no instruction, but the optimiser can no longer see that it came from a lane predicate.
+__device__ __forceinline__ unsigned long long opaque_mask(unsigned long long m) {
+    asm("" : "+s"(m));
+    return m;
+}
+
+__device__ __forceinline__ unsigned long long readlane64(uint32_t lo, uint32_t hi, int lane) {
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)lo, lane) |
+           ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)hi, lane) << 32);
+}
+
 template <uint32_t SET, bool STREAM>
 __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
                                                                    const uint8_t *__restrict__ rgb,
@@ -750,7 +779,10 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
         double row[4];
         compose_row(N, U, r, row);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) M[r][k] = uniform(k < 3 ? row[k] * 0.001 : row[k]);
+        // millimetre-scaled homogeneous coordinates: M maps (mx*d, my*d, d) with d the RAW millimetre sample to 1000 x the
+        // image-space triple, so u and v are unchanged and the third coordinate is the camera-2 depth in millimetres --
+        // directly comparable with the raw depth-2 sample (no 0.001 multiply per pixel)
+        for (int k = 0; k < 4; ++k) M[r][k] = uniform(k < 3 ? row[k] : row[k] * 1000.0);
         if (WANT_XYZ) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) Us[r][k] = k < 3 ? U[4 * r + k] * 0.001 : U[4 * r + k];
@@ -758,9 +790,8 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
     }
 
     __shared__ uint32_t lds_px[kThreads / kWave][kRowGroup * 64];        // pixel-index transpose stage
-    static_assert(kTightRows <= 64, "risky_rows is a 64-bit row mask");
-    __shared__ unsigned long long lds_rb[kThreads / kWave][kTightRows];   // risky-lane ballots of flagged rows
-    __shared__ unsigned long long lds_vm[kThreads / kWave][kTightRows];   // their fast-path visibility ballots
+    static_assert(kTightRows <= 64, "one lane per tile row holds that row's visibility word");
+    __shared__ unsigned long long lds_rb[kThreads / kWave][kTightRows];   // guarded-lane ballots of flagged rows (rare path)
     int n_valid = 0, n_vis = 0;
     if (tile_ok) {
         const uint32_t Wb = (uint32_t)a.W;
@@ -773,13 +804,13 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
         __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(a.vis_bits ? a.vis_bits + pair * c.words_per_pair : nullptr), 0,
             O::template has<O_VIS_BITS>(a.vis_bits) ? (int)(c.words_per_pair * 8) : 0, kRsrcFlags);
-        // Stores are issued per ROW GROUP, 16 bytes per lane: four dword-per-lane stores per group left the
+        // Pixel indices are stored per ROW GROUP, 16 bytes per lane: four dword-per-lane stores per group left the
         // kernel store-issue bound (~3.6 B/clk/CU).  The 4 x 64 pixel indices of a group are transposed
         // through 1 KB of LDS so that lane L owns 4 consecutive pixels of row L / 16.
         const int pix_voff = (int)((((uint32_t)c.lane >> 4) * Wb + stripe * 64u + ((uint32_t)c.lane & 15u) * 4u) * 4u);
         const uint32_t wpr = Wb >> 6;                                   // bitset words per image row
-        const int bits_voff = (int)(((uint32_t)c.lane & 3u) * wpr * 8u); // lanes 0..3 store the 4 row words
         const int hi_x = a.dw - 1, hi_y = a.dh - 1;
+        const uint32_t dw2 = (uint32_t)a.dw * 2u;
 
         const double mxd = (double)col;
         const double myd0 = (double)row0;
@@ -794,6 +825,10 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
         }
         const double Wd = (double)a.W, Hd = (double)a.H;
         unsigned long long risky_rows = 0;           // wave-uniform: rows with at least one guarded lane
+        // Lane r keeps the visibility word of tile row r: ballots are SGPR pairs and v_writelane drops them into one lane
+        // for 2 VALU issues per row; the tile's 48 words leave with ONE store at the end, after the cold loop has patched
+        // them in registers.
+        uint32_t bits_lo = 0, bits_hi = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's depth-1 samples have landed in LDS
 
         // ---- tile-level culling -------------------------------------------------------------------
@@ -803,6 +838,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
         // projected corners violate ONE of those half-spaces by a margin (>= 1e-4 px, 7 orders above the
         // rounding differences between evaluation orders), no pixel of the tile can land in frame 2:
         // the wave writes "nothing visible" for 48 x 64 pixels without projecting any of them.
+        // (Homogeneous coordinates are in pixel * millimetre here: M maps the raw millimetre sample.)
         bool culled = false;
         if (!WANT_XYZ && !O::template has<O_VALID_U8>(a.valid_u8) && !O::template has<O_RGBA>(a.rgba) &&
             !O::template has<O_VIS_U8>(a.vis_u8)) {
@@ -831,12 +867,12 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                 const double hx = __builtin_fma(__builtin_fma(M[0][1], cy, __builtin_fma(M[0][0], cx, M[0][2])), cd, M[0][3]);
                 const double hy = __builtin_fma(__builtin_fma(M[1][1], cy, __builtin_fma(M[1][0], cx, M[1][2])), cd, M[1][3]);
                 const double hz = __builtin_fma(__builtin_fma(M[2][1], cy, __builtin_fma(M[2][0], cx, M[2][2])), cd, M[2][3]);
-                const double kMargin = 1e-3;                              // homogeneous units (pixel * metre)
-                const bool all_behind = __ballot(hz <= -1e-6) == ~0ull;
-                const bool all_left = __ballot(hx < -kMargin) == ~0ull;
-                const bool all_right = __ballot(hx - (double)a.W * hz > kMargin) == ~0ull;
-                const bool all_above = __ballot(hy < -kMargin) == ~0ull;
-                const bool all_below = __ballot(hy - (double)a.H * hz > kMargin) == ~0ull;
+                const double kMargin = 1.0;                               // homogeneous units (pixel * millimetre)
+                const bool all_behind = ballot64(hz <= -1e-3) == ~0ull;
+                const bool all_left = ballot64(hx < -kMargin) == ~0ull;
+                const bool all_right = ballot64(hx - (double)a.W * hz > kMargin) == ~0ull;
+                const bool all_above = ballot64(hy < -kMargin) == ~0ull;
+                const bool all_below = ballot64(hy - (double)a.H * hz > kMargin) == ~0ull;
                 culled = all_behind | all_left | all_right | all_above | all_below;
             }
             if (culled) {
@@ -846,176 +882,169 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                 int cnt = (int)nz.x + (int)nz.y;
                 for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
                 n_valid = cnt;
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 none = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                if (O::template has<O_PIX>(a.pix_i16)) {
+                    const u32x4_t none = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 #pragma unroll 4
-                for (int r0 = 0; r0 < kTightRows; r0 += kRowGroup) {
-                    const uint32_t rowg = row0 + (uint32_t)r0;
-                    if (O::template has<O_VIS_BITS>(a.vis_bits) && c.lane < kRowGroup)
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rs_bits, bits_voff,
-                                                              (int)((rowg * wpr + stripe) * 8u), 0);
-                    if (O::template has<O_PIX>(a.pix_i16))
-                        buffer_store_b128_guarded(none, rs_pix, pix_voff, (int)(rowg * Wb * 4u));
+                    for (int r0 = 0; r0 < kTightRows; r0 += kRowGroup)
+                        buffer_store_b128_guarded(none, rs_pix, pix_voff, (int)((row0 + (uint32_t)r0) * Wb * 4u));
                 }
             }
         }
 
-        if (!culled)
+        if (!culled) {
 #pragma unroll 1
-        for (int r0 = 0; r0 < kTightRows; r0 += kRowGroup) {
-            uint32_t d16[kRowGroup];
-#pragma unroll
-            for (int j = 0; j < kRowGroup; ++j) d16[j] = lds_d1[wave][(r0 + j) * 64 + c.lane];
-            // ---- stage 1: project; "in view" with the guard band folded into the comparison constants:
-            // a lane the reference would accept (0 <= u < W, 0 <= v < H, depth > 0) always passes, and a lane
-            // that passes without being accepted sits inside a guard band and is re-evaluated exactly.
-            double u[kRowGroup], v[kRowGroup], qz[kRowGroup];
-            float fx[kRowGroup], fy[kRowGroup], fz[kRowGroup];
-            bool valid[kRowGroup], inview[kRowGroup];
-            unsigned long long any = 0;
-#pragma unroll
-            for (int j = 0; j < kRowGroup; ++j) {
-                valid[j] = d16[j] != 0u;                                     // OPS:297
-                const double dmm = (double)d16[j];
-                const double ix = __builtin_fma(t0, dmm, M[0][3]);
-                const double iy = __builtin_fma(t1, dmm, M[1][3]);
-                const double iz = __builtin_fma(t2, dmm, M[2][3]);
-                if (WANT_XYZ) {
-                    fx[j] = (float)__builtin_fma(s0, dmm, Us[0][3]);
-                    fy[j] = (float)__builtin_fma(s1, dmm, Us[1][3]);
-                    fz[j] = (float)__builtin_fma(s2, dmm, Us[2][3]);
-                    s0 += Us[0][1];
-                    s1 += Us[1][1];
-                    s2 += Us[2][1];
-                }
-                t0 += M[0][1];
-                t1 += M[1][1];
-                t2 += M[2][1];
-                double rz = __builtin_amdgcn_rcp(iz);
-                rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
-                u[j] = ix * rz;
-                v[j] = iy * rz;
-                qz[j] = iz;
-                inview[j] = valid[j] & (u[j] > -kGuardPx) & (u[j] < Wd + kGuardPx) & (v[j] > -kGuardPx) &
-                            (v[j] < Hd + kGuardPx) & (iz > -kGuardZ);
-                any |= __ballot(inview[j]);
-            }
-            if (any == 0) {
-                // ---- nothing of these 4 x 64 pixels can land in frame 2: no gather, no depth test ----
-                const uint32_t rowg = row0 + (uint32_t)r0;
-#pragma unroll
-                for (int j = 0; j < kRowGroup; ++j) n_valid += __popcll(__ballot(valid[j]));
-                if (O::template has<O_VIS_BITS>(a.vis_bits)) {
-                    if (c.lane < kRowGroup)
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rs_bits, bits_voff, (int)((rowg * wpr + stripe) * 8u), 0);
-                }
-                if (O::template has<O_PIX>(a.pix_i16)) {
-                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                    const u32x4 none = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-                    buffer_store_b128_guarded(none, rs_pix, pix_voff, (int)(rowg * Wb * 4u));
-                }
+            for (int r0 = 0; r0 < kTightRows; r0 += kRowGroup) {
+                uint32_t d16[kRowGroup];
 #pragma unroll
                 for (int j = 0; j < kRowGroup; ++j) {
-                    const uint32_t row = rowg + (uint32_t)j;
-                    const uint32_t i = row * Wb + col;
-                    const int64_t o = c.obase + (int64_t)i;
-                    if (O::template has<O_VIS_U8>(a.vis_u8)) a.vis_u8[o] = 0;
-                    if (O::template has<O_VALID_U8>(a.valid_u8)) a.valid_u8[o] = valid[j] ? 1 : 0;
-                    if (O::template has<O_XYZ32>(a.xyz_f32)) {
-                        float *q = a.xyz_f32 + 3 * o;
-                        const float fn = __builtin_nanf("");
-                        __builtin_nontemporal_store(valid[j] ? fx[j] : fn, q + 0);
-                        __builtin_nontemporal_store(valid[j] ? fy[j] : fn, q + 1);
-                        __builtin_nontemporal_store(valid[j] ? fz[j] : fn, q + 2);
-                    }
-                    if (O::template has<O_RGBA>(a.rgba)) {
-                        uint32_t colr = 0;
-                        if (c.rgb1) {
-                            const uint8_t *s = c.rgb1 + 3 * (int64_t)i;
-                            colr = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
-                        }
-                        __builtin_nontemporal_store(colr | (valid[j] ? 0xFF000000u : 0u), a.rgba + o);
-                    }
-                }
-                continue;
-            }
-            // ---- stage 2: pixel index, gather, guard ---------------------------------------------
-            int pix[kRowGroup];
-            uint32_t dv16[kRowGroup];
-            bool risky[kRowGroup];
+                    d16[j] = lds_d1[wave][(r0 + j) * 64 + c.lane];
+                    asm("" : "+v"(d16[j]));      // a plain 32-bit value from here on (ds_read_u16 zero-extends): otherwise the
+                }                                // compare below is narrowed to 16 bits and the conversion pays a v_and
+                // ---- stage 1: project; "in view" with the guard band folded into the comparison constants:
+                // a lane the reference would accept (0 <= u < W, 0 <= v < H, depth > 0) always passes, and a lane
+                // that passes without being accepted sits inside a guard band and is re-evaluated exactly.
+                // Lane predicates live as 64-bit ballots (SGPR pairs) from here on: carried as `bool` across the
+                // branch below the compiler parks them in 0/1 VGPRs and re-compares them (8 VALU issues per row);
+                // `opaque_mask` keeps it from folding inverse_ballot(ballot(x)) back into such a bool.
+                double u[kRowGroup], v[kRowGroup], qz[kRowGroup];
+                float fx[kRowGroup], fy[kRowGroup], fz[kRowGroup];
+                unsigned long long vmk[kRowGroup], ivm[kRowGroup];
+                unsigned long long any = 0;
 #pragma unroll
-            for (int j = 0; j < kRowGroup; ++j) {
-                const double ru = __builtin_rint(u[j]), rv = __builtin_rint(v[j]);
-                const int xi = med3_0((int)ru, hi_x);
-                const int yi = med3_0((int)rv, hi_y);
-                // every lane gathers: the clamped index is always inside the image
-                dv16[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, (yi * a.dw + xi) * 2, 0, 0);
-                pix[j] = (int)((uint32_t)xi | ((uint32_t)yi << 16));
-                // With t = u - rint(u) in [-0.5, 0.5] a decision can flip only if |t| is within the guard of
-                // 0.5 (rounding tie) or of 0 (u at an integer: the image bounds are integers), i.e. unless
-                // guard < |t| < 0.5 - guard  <=>  ||t| - 0.25| < 0.25 - guard.  NaN fails the ordered compare.
-                const double wu = __builtin_fabs(u[j] - ru) - 0.25;
-                const double wv = __builtin_fabs(v[j] - rv) - 0.25;
-                risky[j] = !(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx) |
-                           !(qz[j] > kGuardZ);
-            }
-            // ---- stage 3: depth test, outputs -------------------------------------------------------
-            unsigned long long vm[kRowGroup], rbm[kRowGroup];
-#pragma unroll
-            for (int j = 0; j < kRowGroup; ++j) {
-                const int g = r0 + j;
-                const uint32_t row = row0 + (uint32_t)g;
-                const double dv = (double)dv16[j] * 0.001;
-                const bool vis = inview[j] & (qz[j] < dv);
-                const bool rk = inview[j] & (risky[j] | !(__builtin_fabs(qz[j] - dv) > kGuardZ));
-                vm[j] = __ballot(vis);
-                rbm[j] = __ballot(rk);
-                n_vis += __popcll(vm[j]);
-                n_valid += __popcll(__ballot(valid[j]));
-                if (O::template has<O_PIX>(a.pix_i16)) lds_px[wave][j * 64 + c.lane] = (uint32_t)(inview[j] ? pix[j] : -1);
-                const uint32_t i = row * Wb + col;
-                const int64_t o = c.obase + (int64_t)i;
-                if (O::template has<O_VIS_U8>(a.vis_u8)) a.vis_u8[o] = vis ? 1 : 0;
-                if (O::template has<O_VALID_U8>(a.valid_u8)) a.valid_u8[o] = valid[j] ? 1 : 0;
-                if (O::template has<O_XYZ32>(a.xyz_f32)) {
-                    float *q = a.xyz_f32 + 3 * o;
-                    const float fn = __builtin_nanf("");
-                    __builtin_nontemporal_store(valid[j] ? fx[j] : fn, q + 0);
-                    __builtin_nontemporal_store(valid[j] ? fy[j] : fn, q + 1);
-                    __builtin_nontemporal_store(valid[j] ? fz[j] : fn, q + 2);
-                }
-                if (O::template has<O_RGBA>(a.rgba)) {
-                    uint32_t colr = 0;
-                    if (c.rgb1) {
-                        const uint8_t *s = c.rgb1 + 3 * (int64_t)i;
-                        colr = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
+                for (int j = 0; j < kRowGroup; ++j) {
+                    const double dmm = (double)d16[j];
+                    const double ix = __builtin_fma(t0, dmm, M[0][3]);
+                    const double iy = __builtin_fma(t1, dmm, M[1][3]);
+                    const double iz = __builtin_fma(t2, dmm, M[2][3]);          // camera-2 depth, millimetres
+                    if (WANT_XYZ) {
+                        fx[j] = (float)__builtin_fma(s0, dmm, Us[0][3]);
+                        fy[j] = (float)__builtin_fma(s1, dmm, Us[1][3]);
+                        fz[j] = (float)__builtin_fma(s2, dmm, Us[2][3]);
+                        s0 += Us[0][1];
+                        s1 += Us[1][1];
+                        s2 += Us[2][1];
                     }
-                    __builtin_nontemporal_store(colr | (valid[j] ? 0xFF000000u : 0u), a.rgba + o);
+                    t0 += M[0][1];
+                    t1 += M[1][1];
+                    t2 += M[2][1];
+                    double rz = __builtin_amdgcn_rcp(iz);
+                    rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
+                    u[j] = ix * rz;
+                    v[j] = iy * rz;
+                    qz[j] = iz;
+                    // every ballot is the SGPR result of ONE compare; the conjunctions are scalar ANDs of those words
+                    // (a ballot of an AND of predicates is lowered to v_cndmask 0/1 + v_cmp again)
+                    vmk[j] = ballot64(d16[j] != 0u);                             // OPS:297
+                    ivm[j] = vmk[j] & ballot64(u[j] > -kGuardPx) & ballot64(u[j] < Wd + kGuardPx) & ballot64(v[j] > -kGuardPx) &
+                             ballot64(v[j] < Hd + kGuardPx) & ballot64(iz > -kGuardZmm);
+                    any |= ivm[j];
                 }
-            }
-            if (rbm[0] | rbm[1] | rbm[2] | rbm[3]) {                 // wave-uniform, rare: one branch per group, not per row
-#pragma unroll
-                for (int j = 0; j < kRowGroup; ++j)
-                    if (rbm[j]) {
-                        if (c.lane == 0) {
-                            lds_rb[wave][r0 + j] = rbm[j];
-                            lds_vm[wave][r0 + j] = vm[j];
-                        }
-                        risky_rows |= 1ull << (r0 + j);
-                    }
-            }
-            {
                 const uint32_t rowg = row0 + (uint32_t)r0;
-                if (O::template has<O_VIS_BITS>(a.vis_bits)) {
-                    static_assert(kRowGroup == 4, "lanes 0..3 each store one row word");
-                    const unsigned long long w = c.lane == 0 ? vm[0] : c.lane == 1 ? vm[1] : c.lane == 2 ? vm[2] : vm[3];
-                    if (c.lane < kRowGroup)
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)w, (uint32_t)(w >> 32)}, rs_bits, bits_voff, (int)((rowg * wpr + stripe) * 8u), 0);
+                unsigned long long vm[kRowGroup] = {0, 0, 0, 0};       // visibility words of the group's rows
+                if (any == 0) {
+                    // ---- nothing of these 4 x 64 pixels can land in frame 2: no gather, no depth test ----
+                    if (O::template has<O_PIX>(a.pix_i16)) {
+                        const u32x4_t none = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                        buffer_store_b128_guarded(none, rs_pix, pix_voff, (int)(rowg * Wb * 4u));
+                    }
+                    if (SET & (O_VIS_U8 | O_VALID_U8 | O_XYZ32 | O_RGBA)) {
+#pragma unroll
+                        for (int j = 0; j < kRowGroup; ++j) {
+                            const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmk[j]);
+                            const uint32_t i = (rowg + (uint32_t)j) * Wb + col;
+                            const int64_t o = c.obase + (int64_t)i;
+                            if (O::template has<O_VIS_U8>(a.vis_u8)) a.vis_u8[o] = 0;
+                            if (O::template has<O_VALID_U8>(a.valid_u8)) a.valid_u8[o] = valid ? 1 : 0;
+                            if (O::template has<O_XYZ32>(a.xyz_f32)) {
+                                float *q = a.xyz_f32 + 3 * o;
+                                const float fn = __builtin_nanf("");
+                                __builtin_nontemporal_store(valid ? fx[j] : fn, q + 0);
+                                __builtin_nontemporal_store(valid ? fy[j] : fn, q + 1);
+                                __builtin_nontemporal_store(valid ? fz[j] : fn, q + 2);
+                            }
+                            if (O::template has<O_RGBA>(a.rgba)) {
+                                uint32_t colr = 0;
+                                if (c.rgb1) {
+                                    const uint8_t *s = c.rgb1 + 3 * (int64_t)i;
+                                    colr = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
+                                }
+                                __builtin_nontemporal_store(colr | (valid ? 0xFF000000u : 0u), a.rgba + o);
+                            }
+                        }
+                    }
+                } else {
+                    // ---- stage 2: pixel index, gather, guard ---------------------------------------------
+                    int pix[kRowGroup];
+                    uint32_t dv16[kRowGroup];
+                    unsigned long long rkc[kRowGroup];
+#pragma unroll
+                    for (int j = 0; j < kRowGroup; ++j) {
+                        const double ru = __builtin_rint(u[j]), rv = __builtin_rint(v[j]);
+                        const int xi = med3_0((int)ru, hi_x);
+                        const int yi = med3_0((int)rv, hi_y);
+                        // every lane gathers: the clamped index is always inside the image
+                        dv16[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, (int)(__umul24((uint32_t)yi, dw2) + ((uint32_t)xi << 1)), 0, 0);
+                        pix[j] = (int)((uint32_t)xi | ((uint32_t)yi << 16));
+                        // With t = u - rint(u) in [-0.5, 0.5] a decision can flip only if |t| is within the guard of
+                        // 0.5 (rounding tie) or of 0 (u at an integer: the image bounds are integers), i.e. unless
+                        // guard < |t| < 0.5 - guard  <=>  ||t| - 0.25| < 0.25 - guard.  NaN fails the ordered compare.
+                        const double wu = __builtin_fabs(u[j] - ru) - 0.25;
+                        const double wv = __builtin_fabs(v[j] - rv) - 0.25;
+                        rkc[j] = ballot64(!(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx)) |
+                                 ballot64(!(qz[j] > kGuardZmm));
+                    }
+                    // ---- stage 3: depth test, outputs -------------------------------------------------------
+                    unsigned long long rbm[kRowGroup];
+#pragma unroll
+                    for (int j = 0; j < kRowGroup; ++j) {
+                        const bool inview = __builtin_amdgcn_inverse_ballot_w64(ivm[j]);
+                        const double sd = qz[j] - (double)dv16[j];              // millimetres; IH:368-371 compares metres
+                        vm[j] = ivm[j] & ballot64(sd < 0.0);
+                        rbm[j] = ivm[j] & (rkc[j] | ballot64(!(__builtin_fabs(sd) > kGuardZmm)));
+                        if (O::template has<O_PIX>(a.pix_i16)) lds_px[wave][j * 64 + c.lane] = (uint32_t)(inview ? pix[j] : -1);
+                        if (SET & (O_VIS_U8 | O_VALID_U8 | O_XYZ32 | O_RGBA)) {
+                            const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmk[j]);
+                            const bool vis = __builtin_amdgcn_inverse_ballot_w64(vm[j]);
+                            const uint32_t i = (rowg + (uint32_t)j) * Wb + col;
+                            const int64_t o = c.obase + (int64_t)i;
+                            if (O::template has<O_VIS_U8>(a.vis_u8)) a.vis_u8[o] = vis ? 1 : 0;
+                            if (O::template has<O_VALID_U8>(a.valid_u8)) a.valid_u8[o] = valid ? 1 : 0;
+                            if (O::template has<O_XYZ32>(a.xyz_f32)) {
+                                float *q = a.xyz_f32 + 3 * o;
+                                const float fn = __builtin_nanf("");
+                                __builtin_nontemporal_store(valid ? fx[j] : fn, q + 0);
+                                __builtin_nontemporal_store(valid ? fy[j] : fn, q + 1);
+                                __builtin_nontemporal_store(valid ? fz[j] : fn, q + 2);
+                            }
+                            if (O::template has<O_RGBA>(a.rgba)) {
+                                uint32_t colr = 0;
+                                if (c.rgb1) {
+                                    const uint8_t *s = c.rgb1 + 3 * (int64_t)i;
+                                    colr = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
+                                }
+                                __builtin_nontemporal_store(colr | (valid ? 0xFF000000u : 0u), a.rgba + o);
+                            }
+                        }
+                    }
+                    if (rbm[0] | rbm[1] | rbm[2] | rbm[3]) {             // wave-uniform, rare: one branch per group, not per row
+#pragma unroll
+                        for (int j = 0; j < kRowGroup; ++j)
+                            if (rbm[j]) {
+                                if (c.lane == 0) lds_rb[wave][r0 + j] = rbm[j];
+                                risky_rows |= 1ull << (r0 + j);
+                            }
+                    }
+                    if (O::template has<O_PIX>(a.pix_i16)) {
+                        const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][c.lane * 4]);
+                        buffer_store_b128_guarded(q, rs_pix, pix_voff, (int)(rowg * Wb * 4u));
+                    }
                 }
-                if (O::template has<O_PIX>(a.pix_i16)) {
-                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                    const u32x4 q = *reinterpret_cast<const u32x4 *>(&lds_px[wave][c.lane * 4]);
-                    buffer_store_b128_guarded(q, rs_pix, pix_voff, (int)(rowg * Wb * 4u));
+                // ---- common tail: counters (scalar) and the rows' visibility words (zero after an early-out) ----
+#pragma unroll
+                for (int j = 0; j < kRowGroup; ++j) {
+                    n_valid += __popcll(vmk[j]);
+                    n_vis += __popcll(vm[j]);
+                    writelane64(vm[j], r0 + j, bits_lo, bits_hi);
                 }
             }
         }
@@ -1024,10 +1053,10 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
         if (risky_rows) {
             __builtin_amdgcn_s_waitcnt(0);                 // the fast path's stores are in L2, LDS writes landed
             while (risky_rows) {                            // wave-uniform
-                const int g = __builtin_ctzll(risky_rows);
+                const int g = __builtin_amdgcn_readfirstlane(__builtin_ctzll(risky_rows));
                 risky_rows &= risky_rows - 1ull;
                 const unsigned long long rb = lds_rb[wave][g];
-                const unsigned long long old = lds_vm[wave][g];
+                const unsigned long long old = readlane64(bits_lo, bits_hi, g);
                 const uint32_t row = row0 + (uint32_t)g;
                 const uint32_t i = row * Wb + col;
                 const bool mine = (rb >> c.lane) & 1ull;
@@ -1040,12 +1069,15 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                     vis = p.vis;
                     store_pixel<O, true>(a, c, i, true, true, p);
                 }
-                const unsigned long long fresh = __ballot(vis);
+                const unsigned long long fresh = ballot64(vis);
                 n_vis += __popcll(fresh) - __popcll(old);
-                if (O::template has<O_VIS_BITS>(a.vis_bits) && c.lane == 0)
-                    a.vis_bits[pair * c.words_per_pair + (int64_t)(i >> 6)] = fresh;
+                writelane64(fresh, g, bits_lo, bits_hi);
             }
         }
+        // the tile's visibility words: lane r stores the word of row row0 + r (8 bytes; rows are W/8 bytes apart)
+        if (O::template has<O_VIS_BITS>(a.vis_bits) && c.lane < kTightRows)
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{bits_lo, bits_hi}, rs_bits, (int)((uint32_t)c.lane * wpr * 8u),
+                                                  (int)((row0 * wpr + stripe) * 8u), 0);
     }
     if (O::template has<O_COUNTS>(a.counts)) {
         __shared__ int red[2][kThreads / kWave];
