@@ -178,7 +178,7 @@ def scene_overlap_table(sc, device):
     depth = engine.depth_to_device(np.stack([sc.depth[i] for i in ids]), device)
     xyz = torch.from_numpy(np.ascontiguousarray(sc.points[:, :3])).to(device)
     vis = engine.vertex_visibility(xyz, cam, depth, (H, W), ("bits",))
-    return engine.pair_overlap(vis["bits"], engine.all_pairs(len(ids), device)).cpu().numpy()
+    return engine.scene_overlap(vis["bits"]).cpu().numpy()
 
 
 def workload_pairs(overlap, nb, reps, n_pairs, kind, rank):
@@ -299,7 +299,7 @@ def time_scene_kernels(device, n_points=131072, n_frames=320, reps=5):
         ev[0].record()
         vis = engine.vertex_visibility(xyz, cam, depth, (H, W), ("bits", "count"))
         ev[1].record()
-        ov = engine.pair_overlap(vis["bits"], pairs)
+        ov = engine.scene_overlap(vis["bits"])           # tiled all-pairs K2
         ev[2].record()
         pose = engine.pair_pose(E_t, cam[:, 0, :].contiguous(), yaw_t, pitch_t, pairs)
         ev[3].record()

@@ -168,6 +168,26 @@ int mspa_pair_overlap(const uint64_t *bits, int32_t n_images, int64_t n_words, c
                       mspa_stream_t stream);
 
 /*
+ * K2, tiled forms.  The reference visits every pair of a scene (CFR:176-189: F(F-1)/2 calls of
+ * calculate_camera_overlap) and, for object visibility, every (object, image) combination
+ * (compute_object_visibility.py:72-152).  These two entry points do a whole scene / rectangle in one pass: 32 x 32
+ * blocks of rows, bitset chunks staged in LDS, only |a & b| counted (|a | b| = |a| + |b| - |a & b|).  Results are
+ * identical to mspa_pair_overlap's.  `workspace` is caller-owned scratch of at least
+ * mspa_overlap_workspace_bytes(n_a, n_b, n_words) bytes (4-byte aligned); its contents are undefined afterwards.
+ *
+ * mspa_scene_overlap: all pairs i < j of one scene in the reference's nested-loop order (CFR:176-178),
+ *   out_overlap [F(F-1)/2] float64 (NaN for an empty union, CFR:136), out_inter / out_union [F(F-1)/2] int32 optional.
+ * mspa_overlap_matrix: out_inter [n_a, n_b] int32 = |a_i & b_j| (bits_a == bits_b with n_a == n_b is recognised as
+ *   symmetric: half the blocks are computed, the matrix is returned full; its diagonal holds the row popcounts).
+ */
+int64_t mspa_overlap_workspace_bytes(int32_t n_a, int32_t n_b, int64_t n_words);
+int mspa_scene_overlap(const uint64_t *bits, int32_t n_images, int64_t n_words, void *workspace,
+                       int64_t workspace_bytes, double *out_overlap, int32_t *out_inter, int32_t *out_union,
+                       mspa_stream_t stream);
+int mspa_overlap_matrix(const uint64_t *bits_a, int32_t n_a, const uint64_t *bits_b, int32_t n_b, int64_t n_words,
+                        void *workspace, int64_t workspace_bytes, int32_t *out_inter, mspa_stream_t stream);
+
+/*
  * K4 -- per-pair camera relations: the distance / yaw / pitch columns of CFR.process_scene's pair
  * table (CFR:176-189) and the relative-pose translation of CME.build_training_sample (CME:185-190).
  *

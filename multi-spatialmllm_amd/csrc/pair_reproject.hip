@@ -684,7 +684,15 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 //     vector pipe); risky rows are recorded per wave (ballot -> LDS) instead of per-lane bit masks;
 //   * 48 rows per wave tile amortise the per-tile matrix composition;
 //   * a group of 4 rows none of whose 256 pixels can land in frame 2 skips gather, guard and depth test.
-constexpr int kTightRows = 48;
+#ifndef MSPA_TIGHT_ROWS
+#define MSPA_TIGHT_ROWS 48
+#endif
+#ifndef MSPA_TIGHT_BLOCK_WAVES
+#define MSPA_TIGHT_BLOCK_WAVES 4
+#endif
+constexpr int kTightRows = MSPA_TIGHT_ROWS;
+constexpr int kTightBW = MSPA_TIGHT_BLOCK_WAVES;      // waves (= tiles) per workgroup
+constexpr int kTightThreads = kTightBW * kWave;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int med3_0(int x, int hi) {   // clamp(x, 0, hi), hi wave-uniform
@@ -722,7 +730,7 @@ __device__ __forceinline__ unsigned long long readlane64(uint32_t lo, uint32_t h
 }
 
 template <uint32_t SET, bool STREAM>
-__global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
+__global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
                                                                    const uint8_t *__restrict__ rgb,
                                                                    const double *__restrict__ mats,
                                                                    const int32_t *__restrict__ pairs, PairArgs a) {
@@ -747,7 +755,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
 
     // wave tile -> (row band, column stripe); both wave-uniform
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = tgroup * (kThreads / kWave) + wave;
+    const uint32_t tile = tgroup * kTightBW + wave;
     const uint32_t band = a.n_stripes == 1 ? tile : __umulhi(tile, a.stripe_magic);
     const uint32_t stripe = tile - band * (uint32_t)a.n_stripes;
     const bool tile_ok = tile < (uint32_t)a.n_tiles;
@@ -759,7 +767,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
     // requests are in flight before any arithmetic and cost no VGPRs; their latency hides behind the
     // matrix composition below.  (A register prefetch one row group ahead left the kernel latency
     // bound once skipped groups made an iteration shorter than a memory round trip.)
-    __shared__ uint16_t lds_d1[kThreads / kWave][kTightRows * 64];
+    __shared__ uint16_t lds_d1[kTightBW][kTightRows * 64];
     if (tile_ok) {
         typedef __attribute__((address_space(1))) const void gvoid_t;
         typedef __attribute__((address_space(3))) void lvoid_t;
@@ -789,9 +797,9 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
         }
     }
 
-    __shared__ uint32_t lds_px[kThreads / kWave][kRowGroup * 64];        // pixel-index transpose stage
+    __shared__ uint32_t lds_px[kTightBW][kRowGroup * 64];        // pixel-index transpose stage
     static_assert(kTightRows <= 64, "one lane per tile row holds that row's visibility word");
-    __shared__ unsigned long long lds_rb[kThreads / kWave][kTightRows];   // guarded-lane ballots of flagged rows (rare path)
+    __shared__ unsigned long long lds_rb[kTightBW][kTightRows];   // guarded-lane ballots of flagged rows (rare path)
     int n_valid = 0, n_vis = 0;
     if (tile_ok) {
         const uint32_t Wb = (uint32_t)a.W;
@@ -1080,7 +1088,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
                                                   (int)((row0 * wpr + stripe) * 8u), 0);
     }
     if (O::template has<O_COUNTS>(a.counts)) {
-        __shared__ int red[2][kThreads / kWave];
+        __shared__ int red[2][kTightBW];
         if (c.lane == 0) {
             red[0][wave] = n_valid;
             red[1][wave] = n_vis;
@@ -1088,7 +1096,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_tight_kernel(const uint16_
         __syncthreads();
         if (threadIdx.x == 0) {
             int sv = 0, ss = 0;
-            for (int j = 0; j < kThreads / kWave; ++j) {
+            for (int j = 0; j < kTightBW; ++j) {
                 sv += red[0][j];
                 ss += red[1][j];
             }
@@ -1162,7 +1170,8 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
         a.n_tiles = linear ? (int)((P + (int64_t)kTileRows * 64 - 1) / ((int64_t)kTileRows * 64))
                            : a.n_stripes * ((H + tile_rows - 1) / tile_rows);
         a.stripe_magic = (uint32_t)((1ull << 32) / (uint64_t)a.n_stripes) + 1u;
-        a.strips = (a.n_tiles + (kThreads / kWave) - 1) / (kThreads / kWave);
+        const int bw = tight24 ? kTightBW : (kThreads / kWave);
+        a.strips = (a.n_tiles + bw - 1) / bw;
     } else {
         a.n_stripes = a.n_tiles = 0;
         a.stripe_magic = 0;
@@ -1181,9 +1190,9 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
 #define MSPA_LAUNCH_TIGHT(SET_) \
     do { \
         if (flags & MSPA_PAIR_STREAM) \
-            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, true>), grid, block, 0, s, depth, rgb, frame_mats, pairs, a); \
+            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, true>), grid, dim3(kTightThreads), 0, s, depth, rgb, frame_mats, pairs, a); \
         else \
-            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, false>), grid, block, 0, s, depth, rgb, frame_mats, pairs, a); \
+            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, false>), grid, dim3(kTightThreads), 0, s, depth, rgb, frame_mats, pairs, a); \
     } while (0)
         if (set == kSetCorr) MSPA_LAUNCH_TIGHT(kSetCorr);
         else if (set == kSetDense) MSPA_LAUNCH_TIGHT(kSetDense);

@@ -199,6 +199,50 @@ def pair_overlap(bits: torch.Tensor, pairs: torch.Tensor, want_counts: bool = Fa
     return (overlap, inter, uni) if want_counts else overlap
 
 
+def _overlap_workspace(n_a: int, n_b: int, n_words: int, device) -> torch.Tensor:
+    nbytes = int(_lib.load().mspa_overlap_workspace_bytes(n_a, n_b, n_words))
+    return torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.int32, device=device)
+
+
+def scene_overlap(bits: torch.Tensor, want_counts: bool = False):
+    """Enqueue the tiled K2 over ALL pairs i < j of a scene's bitsets, in ``all_pairs`` order (CFR:176-178).
+    Returns overlap [F(F-1)/2] f64 (+ inter, union int32) -- identical to ``pair_overlap(bits, all_pairs(F))``."""
+    _require_gpu()
+    lib = _lib.load()
+    _require(bits.dtype == torch.int64 and bits.dim() == 2 and bits.is_contiguous() and bits.is_cuda,
+             "bits: contiguous device int64 [F, n_words]")
+    F, n_words = bits.shape
+    n_pairs = F * (F - 1) // 2
+    dev = bits.device
+    overlap = torch.empty((n_pairs,), dtype=torch.float64, device=dev)
+    inter = torch.empty((n_pairs,), dtype=torch.int32, device=dev) if want_counts else None
+    uni = torch.empty((n_pairs,), dtype=torch.int32, device=dev) if want_counts else None
+    if n_pairs and n_words:
+        ws = _overlap_workspace(F, F, n_words, dev)
+        _lib.check(lib.mspa_scene_overlap(bits.data_ptr(), F, n_words, ws.data_ptr(), ws.numel() * 4, overlap.data_ptr(),
+                                          _ptr(inter), _ptr(uni), _stream_ptr()))
+    return (overlap, inter, uni) if want_counts else overlap
+
+
+def overlap_matrix(bits_a: torch.Tensor, bits_b: torch.Tensor) -> torch.Tensor:
+    """Enqueue the tiled K2 on a rectangle: |a_i & b_j| for every row pair, [n_a, n_b] int32 (object visibility:
+    objects x images, compute_object_visibility.py:72-152)."""
+    _require_gpu()
+    lib = _lib.load()
+    for t in (bits_a, bits_b):
+        _require(t.dtype == torch.int64 and t.dim() == 2 and t.is_contiguous() and t.is_cuda,
+                 "bits: contiguous device int64 [rows, n_words]")
+    _require(bits_a.shape[1] == bits_b.shape[1], "both bitset tables must have the same word count")
+    n_a, n_words = bits_a.shape
+    n_b = bits_b.shape[0]
+    out = torch.empty((n_a, n_b), dtype=torch.int32, device=bits_a.device)
+    if n_a and n_b and n_words:
+        ws = _overlap_workspace(n_a, n_b, n_words, bits_a.device)
+        _lib.check(lib.mspa_overlap_matrix(bits_a.data_ptr(), n_a, bits_b.data_ptr(), n_b, n_words, ws.data_ptr(),
+                                           ws.numel() * 4, out.data_ptr(), _stream_ptr()))
+    return out
+
+
 def extract_yaw_pitch_host(E_aligned_list: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
     """Per-frame angles exactly as CFR:86-100 computes them (NumPy on the host: F values per scene,
     and the reference's own libm calls are the only way to be bit-identical with it)."""

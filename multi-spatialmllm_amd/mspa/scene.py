@@ -58,7 +58,7 @@ class SceneOnDevice:
         vis = self._visibility()
         F = len(self.ids)
         pairs = engine.all_pairs(F, self.device)
-        overlap = engine.pair_overlap(vis["bits"], pairs)
+        overlap = engine.scene_overlap(vis["bits"])               # tiled K2: every pair of the scene in one pass
         yaw, pitch = engine.extract_yaw_pitch_host(self.E_aligned)
         E_t = torch.from_numpy(np.stack(self.E_aligned).reshape(F, 16)).to(self.device) if F else \
             torch.zeros((0, 16), dtype=torch.float64, device=self.device)
@@ -188,11 +188,7 @@ def object_visibility_from_bits(image_bits: torch.Tensor, image_ids: Sequence[st
     dev = image_bits.device
     obj_bits = torch.from_numpy(pack_index_lists([p for _, p in objs], n_points)).to(dev)
     F, O = image_bits.shape[0], len(objs)
-    allbits = torch.cat([image_bits, obj_bits], dim=0).contiguous()
-    oo, ff = torch.meshgrid(torch.arange(O, device=dev), torch.arange(F, device=dev), indexing="ij")
-    pairs = torch.stack([F + oo.reshape(-1), ff.reshape(-1)], dim=1).to(torch.int32).contiguous()
-    _, inter, _ = engine.pair_overlap(allbits, pairs, want_counts=True)
-    inter = inter.cpu().numpy().reshape(O, F)
+    inter = engine.overlap_matrix(obj_bits, image_bits.contiguous()).cpu().numpy()       # [O, F] masked popcounts
     for k, (obj, pts) in enumerate(objs):                     # object-major, then image order: as upstream
         total = len(pts)
         threshold = max(1, int(min_fraction * total))

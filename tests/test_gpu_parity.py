@@ -333,6 +333,44 @@ def test_pair_overlap(n_bits):
             assert same_f64(overlap[p], ref)
 
 
+@pytest.mark.parametrize("F,n_bits", [(2, 64), (9, 700), (33, 4096 + 64), (70, 131072), (97, 131072 + 64 * 3), (320, 8192)])
+def test_scene_overlap_tiled(F, n_bits):
+    """The tiled all-pairs K2 (32 x 32 row blocks, LDS-staged chunks, word slices reduced through the workspace) against the
+    one-wave-per-pair kernel (bit-equal: same integers, same float64 division) and the oracle; odd word counts, row counts
+    that are not multiples of the tile, empty rows (NaN for an empty union, CFR:136)."""
+    rng = np.random.default_rng(F * 1000 + n_bits)
+    masks = rng.random((F, n_bits)) < rng.random((F, 1)) * 0.4
+    masks[F // 2] = False
+    if F > 3:
+        masks[3] = False
+    n_words = (n_bits + 63) // 64
+    padded = np.zeros((F, n_words * 64), dtype=bool)
+    padded[:, :n_bits] = masks
+    bits = torch.from_numpy(np.ascontiguousarray(np.packbits(padded, axis=1, bitorder="little").view(np.int64))).to(DEV)
+    pairs = engine.all_pairs(F, DEV)
+    ref_o, ref_i, ref_u = engine.pair_overlap(bits, pairs, want_counts=True)
+    got_o, got_i, got_u = engine.scene_overlap(bits, want_counts=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ref_i, got_i) and torch.equal(ref_u, got_u)
+    assert nan_equal_bits(got_o.cpu().numpy(), ref_o.cpu().numpy())
+    assert np.isnan(got_o.cpu().numpy()).sum() == (1 if F > 3 else 0)
+    pn = pairs.cpu().numpy()
+    for p in rng.choice(len(pn), size=min(len(pn), 40), replace=False):
+        i, j = pn[p]
+        ref = O.calculate_camera_overlap(masks[i], masks[j])
+        assert (np.isnan(ref) and np.isnan(float(got_o[p]))) or same_f64(float(got_o[p]), ref)
+    # rectangle form: |a_i & b_j| for two different row sets, and the symmetric shortcut
+    nb = max(1, F // 3)
+    other = rng.random((nb, n_bits)) < 0.3
+    padded_b = np.zeros((nb, n_words * 64), dtype=bool)
+    padded_b[:, :n_bits] = other
+    bits_b = torch.from_numpy(np.ascontiguousarray(np.packbits(padded_b, axis=1, bitorder="little").view(np.int64))).to(DEV)
+    rect = engine.overlap_matrix(bits_b, bits).cpu().numpy()
+    assert np.array_equal(rect, other.astype(np.int64) @ masks.astype(np.int64).T)
+    sym = engine.overlap_matrix(bits, bits).cpu().numpy()
+    assert np.array_equal(sym, masks.astype(np.int64) @ masks.astype(np.int64).T)
+
+
 # ------------------------------------------------------------------------------------------
 # size-independent properties at BASELINE.json's full configuration (config 2: 1k 640x480 pairs)
 # ------------------------------------------------------------------------------------------

@@ -65,6 +65,22 @@ def test_size_limits_are_rejected():
     assert rc == _lib.MSPA_EINVAL and b"too long" in lib.mspa_last_error_string()
 
 
+def test_tiled_overlap_entry_points_validate_before_launching():
+    lib = _lib.load()
+    dummy = ctypes.c_void_p(64)
+    need = lib.mspa_overlap_workspace_bytes(320, 320, 2048)
+    assert need > 0 and need % 4096 == 0 and lib.mspa_overlap_workspace_bytes(0, 5, 7) == 0
+    assert lib.mspa_overlap_workspace_bytes(40, 320, 2048) > 0
+    assert lib.mspa_scene_overlap(dummy, 320, 2048, dummy, need - 1, dummy, None, None, None) == _lib.MSPA_EINVAL
+    assert b"workspace smaller" in lib.mspa_last_error_string()
+    assert lib.mspa_scene_overlap(dummy, 320, 2048, None, need, dummy, None, None, None) == _lib.MSPA_EINVAL
+    assert lib.mspa_scene_overlap(None, 1, 2048, None, 0, None, None, None, None) == _lib.MSPA_OK       # no pair
+    assert lib.mspa_scene_overlap(dummy, 320, 1 << 26, dummy, 1 << 40, dummy, None, None, None) == _lib.MSPA_EINVAL
+    assert lib.mspa_overlap_matrix(dummy, 0, dummy, 5, 7, None, 0, None, None) == _lib.MSPA_OK
+    assert lib.mspa_overlap_matrix(dummy, 3, dummy, 5, 7, dummy, 8, dummy, None) == _lib.MSPA_EINVAL
+    assert lib.mspa_overlap_matrix(dummy, 3, None, 5, 7, dummy, 1 << 20, dummy, None) == _lib.MSPA_EINVAL
+
+
 def test_new_entry_points_validate_before_launching():
     """K5c / K7 / K8: bad sizes and null pointers come back as MSPA_EINVAL, empty inputs as MSPA_OK -- no HIP call either way."""
     lib = _lib.load()

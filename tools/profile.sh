@@ -16,4 +16,4 @@ run sq2 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_A
 run fetch --pmc FETCH_SIZE
 run write --pmc WRITE_SIZE
 run tcc --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum
-python $ROOT/tools/rocprof_summary.py $OUT | tee $OUT/summary.md
+python $ROOT/tools/rocprof_summary.py $OUT ${MSPA_PROF_PATTERN:-pair_} | tee $OUT/summary.md
