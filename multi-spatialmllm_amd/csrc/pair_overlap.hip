@@ -58,18 +58,22 @@ __global__ __launch_bounds__(kOThreads) void pair_overlap_kernel(OverlapArgs a) 
 // ---------------------------------------------------------------------------------------------------------
 // Tiled form (all pairs of a scene, or an [objects x images] rectangle): the reference's HOT LOOP 2 (CFR:176-189)
 // visits F(F-1)/2 pairs, and one wave per pair re-reads both 16 KB rows from L2 for each of them (1.67 GB through L2
-// for a 320-frame scene).  Here a one-wave workgroup owns a 32 x 32 block of (a, b) rows and a slice of the words:
-// 16-word chunks of the 64 rows are staged in LDS (coalesced 16-byte loads, 128 contiguous bytes per row), every lane
-// keeps a 4 x 4 sub-block of pair counters in registers and reads 4 + 4 row fragments per two words (ds_read_b128) for
-// 32 pair-words -- 4 bytes of LDS traffic per pair-word instead of 16 bytes of L2 traffic, and only |a & b| is counted:
-// the union is |a| + |b| - |a & b| with |a| = the diagonal entry.  The word dimension is split over workgroups so that a
-// scene fills the chip; partial counts go to a caller-provided workspace (no atomics: device-scope atomics on 10^5
-// addresses would serialise at the fabric) and a second kernel reduces the slices and forms the float64 percentage
-// exactly as NumPy does (int / int true divide, * 100; 0 / 0 -> NaN, CFR:136).
+// for a 320-frame scene) and popcounts a & b AND a | b.  Here a workgroup owns a 32 x 32 block of (a, b) rows and a
+// 64-word slice of the bitsets; each of its four waves takes one 16-word chunk of that slice: the 64 rows' chunk is staged
+// in the wave's own LDS region (coalesced 16-byte loads, 128 contiguous bytes per row), every lane keeps a 4 x 4 sub-block
+// of pair counters in registers and reads 4 + 4 row fragments per two words (ds_read_b128) for 32 pair-words -- 4 bytes of
+// LDS traffic per pair-word instead of 16 bytes of L2 traffic -- and only |a & b| is counted: the union is
+// |a| + |b| - |a & b| with |a| the diagonal entry.  The four waves' counters are summed through LDS, and the block writes
+// ONE partial 32 x 32 table to a caller-provided workspace (no atomics: device-scope atomics on 10^5 addresses serialise
+// at the fabric); small kernels reduce the slices and form the float64 percentage exactly as NumPy does (int / int true
+// divide, * 100; 0 / 0 -> NaN, CFR:136).  Work is cut this finely because the popcounts are VALU-bound (v_and + v_bcnt per
+// 32 bits, ~7 M wave instructions for 51 040 pairs of 131 072 bits): a 320-frame scene must become several waves per SIMD.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kTile = 32;                  // rows of a and of b per workgroup
-constexpr int kChunkWords = 16;            // bitset words staged per step
+constexpr int kChunkWords = 16;            // bitset words staged per wave
 constexpr int kRowDw = kChunkWords * 2 + 4;   // LDS row stride in dwords: 16-byte aligned, bank-skewed (36)
+constexpr int kTileWaves = 4;              // waves per workgroup = chunks per slice
+constexpr int kSliceWords = kChunkWords * kTileWaves;
 
 struct TileArgs {
     const uint64_t *bits_a;
@@ -78,7 +82,6 @@ struct TileArgs {
     int64_t n_words;
     int tiles_b;
     int slices;
-    int64_t words_per_slice;       // multiple of kChunkWords
     int symmetric;                 // bits_a == bits_b: tiles below the diagonal are skipped
     int32_t *partial;              // [tiles_a * tiles_b][slices][kTile * kTile]
 };
@@ -86,21 +89,22 @@ struct TileArgs {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <bool ALIGNED16>
-__global__ __launch_bounds__(kWave) void overlap_tile_kernel(TileArgs a) {
+__global__ __launch_bounds__(kTileWaves *kWave) void overlap_tile_kernel(TileArgs a) {
     const int tile = blockIdx.x;
     const int ta = tile / a.tiles_b, tb = tile - ta * a.tiles_b;
     if (a.symmetric && tb < ta) return;
     const int slice = blockIdx.y;
-    const int lane = threadIdx.x;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * kTile * kRowDw];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // per wave: 64 staged rows of 36 dwords (9 216 B); reused for the 32 x 32 counter table (4 096 B) of the reduction
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kTileWaves][2 * kTile * kRowDw];
+    uint32_t *const my = lds[wave];
     // staging: 8 lanes cover one row's 128-byte chunk, a wave instruction covers 8 rows
     const int lrow = lane >> 3, lcol = lane & 7;
     const int ti = lane >> 3, tj = lane & 7;          // this lane's rows: a: ti + 8r, b: tj + 8c
     int acc[4][4] = {};
-    const int64_t w_begin = (int64_t)slice * a.words_per_slice;
-    const int64_t w_end = min(w_begin + a.words_per_slice, a.n_words);
-    for (int64_t w0 = w_begin; w0 < w_end; w0 += kChunkWords) {
-        u32x4 stage[8];
+    const int64_t w0 = (int64_t)slice * kSliceWords + (int64_t)wave * kChunkWords;
+    if (w0 < a.n_words) {                              // wave-uniform
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int r = k * 8 + lrow;                                  // 0..31 = a rows, 32..63 = b rows
@@ -112,26 +116,21 @@ __global__ __launch_bounds__(kWave) void overlap_tile_kernel(TileArgs a) {
             u32x4 v = {0u, 0u, 0u, 0u};
             if (row_ok) {
                 if (ALIGNED16) {
-                    if (w < w_end) v = *reinterpret_cast<const u32x4 *>(src + w);   // n_words even: w + 1 exists too
+                    if (w < a.n_words) v = *reinterpret_cast<const u32x4 *>(src + w);   // n_words even: w + 1 exists too
                 } else {
-                    const uint64_t x = w < w_end ? src[w] : 0ull, y = (w + 1) < w_end ? src[w + 1] : 0ull;
+                    const uint64_t x = w < a.n_words ? src[w] : 0ull, y = (w + 1) < a.n_words ? src[w + 1] : 0ull;
                     v = u32x4{(uint32_t)x, (uint32_t)(x >> 32), (uint32_t)y, (uint32_t)(y >> 32)};
                 }
             }
-            stage[k] = v;
+            *reinterpret_cast<u32x4 *>(&my[r * kRowDw + lcol * 4]) = v;   // the wave's own region: no barrier needed
         }
-        __syncthreads();                                                 // the previous chunk has been consumed
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            *reinterpret_cast<u32x4 *>(&lds[(k * 8 + lrow) * kRowDw + lcol * 4]) = stage[k];
-        __syncthreads();
 #pragma unroll
         for (int s2 = 0; s2 < kChunkWords / 2; ++s2) {
             u32x4 va[4], vb[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) va[r] = *reinterpret_cast<const u32x4 *>(&lds[(ti + 8 * r) * kRowDw + s2 * 4]);
+            for (int r = 0; r < 4; ++r) va[r] = *reinterpret_cast<const u32x4 *>(&my[(ti + 8 * r) * kRowDw + s2 * 4]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) vb[c] = *reinterpret_cast<const u32x4 *>(&lds[(kTile + tj + 8 * c) * kRowDw + s2 * 4]);
+            for (int c = 0; c < 4; ++c) vb[c] = *reinterpret_cast<const u32x4 *>(&my[(kTile + tj + 8 * c) * kRowDw + s2 * 4]);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -140,24 +139,39 @@ __global__ __launch_bounds__(kWave) void overlap_tile_kernel(TileArgs a) {
                                  __popc(va[r].w & vb[c].w);
         }
     }
-    int32_t *dst = a.partial + ((int64_t)tile * a.slices + slice) * (kTile * kTile);
+    // the wave's 32 x 32 counters into its region (element (i, j) at i * 32 + j), then 256 threads sum the four tables
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) dst[(ti + 8 * r) * kTile + (tj + 8 * c)] = acc[r][c];
+        for (int c = 0; c < 4; ++c) my[(ti + 8 * r) * kTile + (tj + 8 * c)] = (uint32_t)acc[r][c];
+    __syncthreads();
+    int32_t *dst = a.partial + ((int64_t)tile * a.slices + slice) * (kTile * kTile);
+#pragma unroll
+    for (int q = 0; q < (kTile * kTile) / (kTileWaves * kWave); ++q) {
+        const int e = q * (kTileWaves * kWave) + (int)threadIdx.x;
+        dst[e] = (int32_t)(lds[0][e] + lds[1][e] + lds[2][e] + lds[3][e]);
+    }
 }
 
-__device__ __forceinline__ int reduce_slices(const int32_t *partial, int tiles_b, int slices, int i, int j) {
+// sum over the slices of element (i, j); the loads are independent (unrolled), a lane's neighbours read neighbouring ints
+__device__ __forceinline__ int reduce_slices(const int32_t *__restrict__ partial, int tiles_b, int slices, int i, int j) {
     const int tile = (i / kTile) * tiles_b + (j / kTile);
     const int32_t *p = partial + (int64_t)tile * slices * (kTile * kTile) + (i % kTile) * kTile + (j % kTile);
-    int sum = 0;
-    for (int s = 0; s < slices; ++s) sum += p[(int64_t)s * (kTile * kTile)];
-    return sum;
+    int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int s = 0;
+    for (; s + 4 <= slices; s += 4) {
+        s0 += p[(int64_t)(s + 0) * (kTile * kTile)];
+        s1 += p[(int64_t)(s + 1) * (kTile * kTile)];
+        s2 += p[(int64_t)(s + 2) * (kTile * kTile)];
+        s3 += p[(int64_t)(s + 3) * (kTile * kTile)];
+    }
+    for (; s < slices; ++s) s0 += p[(int64_t)s * (kTile * kTile)];
+    return (s0 + s1) + (s2 + s3);
 }
 
 // [n_a, n_b] intersection counts; symmetric input: entries below the diagonal are mirrored
-__global__ __launch_bounds__(256) void overlap_reduce_kernel(const int32_t *partial, int n_a, int n_b, int tiles_b,
-                                                             int slices, int symmetric, int32_t *out) {
+__global__ __launch_bounds__(256) void overlap_reduce_kernel(const int32_t *__restrict__ partial, int n_a, int n_b,
+                                                             int tiles_b, int slices, int symmetric, int32_t *out) {
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     if (j >= n_b) return;
     const bool flip = symmetric && (j / kTile) < (i / kTile);
@@ -165,14 +179,22 @@ __global__ __launch_bounds__(256) void overlap_reduce_kernel(const int32_t *part
                                      : reduce_slices(partial, tiles_b, slices, i, j);
 }
 
+// row popcounts |a_i| = the diagonal of the intersection table
+__global__ __launch_bounds__(256) void overlap_diag_kernel(const int32_t *__restrict__ partial, int F, int tiles_b, int slices,
+                                                           int32_t *counts) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < F) counts[i] = reduce_slices(partial, tiles_b, slices, i, i);
+}
+
 // all pairs i < j in the reference's nested-loop order (CFR:176-178): p = i*F - i(i+1)/2 + (j - i - 1)
-__global__ __launch_bounds__(256) void scene_overlap_finalize_kernel(const int32_t *partial, int F, int tiles_b, int slices,
-                                                                     double *overlap, int32_t *inter_out,
+__global__ __launch_bounds__(256) void scene_overlap_finalize_kernel(const int32_t *__restrict__ partial,
+                                                                     const int32_t *__restrict__ counts, int F, int tiles_b,
+                                                                     int slices, double *overlap, int32_t *inter_out,
                                                                      int32_t *union_out) {
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     if (j >= F || j <= i) return;
     const int inter = reduce_slices(partial, tiles_b, slices, i, j);
-    const int uni = reduce_slices(partial, tiles_b, slices, i, i) + reduce_slices(partial, tiles_b, slices, j, j) - inter;
+    const int uni = counts[i] + counts[j] - inter;
     const int64_t p = (int64_t)i * F - (int64_t)i * (i + 1) / 2 + (j - i - 1);
     overlap[p] = (double)inter / (double)uni * 100.0;          // 0/0 -> NaN as in CFR:136
     if (inter_out) inter_out[p] = inter;
@@ -181,32 +203,26 @@ __global__ __launch_bounds__(256) void scene_overlap_finalize_kernel(const int32
 
 struct TilePlan {
     int tiles_a, tiles_b, slices;
-    int64_t words_per_slice, bytes;
+    int64_t partial_bytes, bytes;      // partial tables; + row counts (scene form)
 };
 
-static TilePlan plan_tiles(int n_a, int n_b, int64_t n_words, bool symmetric) {
+static TilePlan plan_tiles(int n_a, int n_b, int64_t n_words) {
     TilePlan p;
     p.tiles_a = (n_a + kTile - 1) / kTile;
     p.tiles_b = (n_b + kTile - 1) / kTile;
-    const int64_t active = symmetric ? (int64_t)p.tiles_a * (p.tiles_a + 1) / 2 : (int64_t)p.tiles_a * p.tiles_b;
-    const int64_t chunks = (n_words + kChunkWords - 1) / kChunkWords;
-    int64_t slices = (2048 + active - 1) / active;            // ~2 waves per SIMD of one-wave workgroups
-    if (slices < 1) slices = 1;
-    if (slices > chunks) slices = chunks;
-    const int64_t chunks_per_slice = (chunks + slices - 1) / slices;
-    p.words_per_slice = chunks_per_slice * kChunkWords;
-    p.slices = (int)((chunks + chunks_per_slice - 1) / chunks_per_slice);
-    p.bytes = (int64_t)p.tiles_a * p.tiles_b * p.slices * (kTile * kTile) * (int64_t)sizeof(int32_t);
+    p.slices = (int)((n_words + kSliceWords - 1) / kSliceWords);
+    p.partial_bytes = (int64_t)p.tiles_a * p.tiles_b * p.slices * (kTile * kTile) * (int64_t)sizeof(int32_t);
+    p.bytes = p.partial_bytes + (int64_t)((n_a > n_b ? n_a : n_b) + 3) / 4 * 4 * (int64_t)sizeof(int32_t);
     return p;
 }
 
 static int launch_tiles(const uint64_t *bits_a, int n_a, const uint64_t *bits_b, int n_b, int64_t n_words, bool symmetric,
                         const TilePlan &p, int32_t *partial, hipStream_t s) {
-    TileArgs t{bits_a, bits_b, n_a, n_b, n_words, p.tiles_b, p.slices, p.words_per_slice, symmetric ? 1 : 0, partial};
+    TileArgs t{bits_a, bits_b, n_a, n_b, n_words, p.tiles_b, p.slices, symmetric ? 1 : 0, partial};
     const dim3 grid((uint32_t)(p.tiles_a * p.tiles_b), (uint32_t)p.slices);
     const bool aligned = (n_words % 2 == 0) && (((uintptr_t)bits_a & 15u) == 0) && (((uintptr_t)bits_b & 15u) == 0);
-    if (aligned) hipLaunchKernelGGL(overlap_tile_kernel<true>, grid, dim3(kWave), 0, s, t);
-    else hipLaunchKernelGGL(overlap_tile_kernel<false>, grid, dim3(kWave), 0, s, t);
+    if (aligned) hipLaunchKernelGGL(overlap_tile_kernel<true>, grid, dim3(kTileWaves * kWave), 0, s, t);
+    else hipLaunchKernelGGL(overlap_tile_kernel<false>, grid, dim3(kTileWaves * kWave), 0, s, t);
     return check_hip(hipGetLastError(), "overlap_tile_kernel launch");
 }
 
@@ -216,9 +232,7 @@ using namespace mspa;
 
 extern "C" int64_t mspa_overlap_workspace_bytes(int32_t n_a, int32_t n_b, int64_t n_words) {
     if (n_a <= 0 || n_b <= 0 || n_words <= 0) return 0;
-    // the symmetric plan never needs more than the rectangular one of the same size
-    const TilePlan r = plan_tiles(n_a, n_b, n_words, false), q = plan_tiles(n_a, n_b, n_words, n_a == n_b);
-    return r.bytes > q.bytes ? r.bytes : q.bytes;
+    return plan_tiles(n_a, n_b, n_words).bytes;
 }
 
 extern "C" int mspa_overlap_matrix(const uint64_t *bits_a, int32_t n_a, const uint64_t *bits_b, int32_t n_b,
@@ -228,11 +242,12 @@ extern "C" int mspa_overlap_matrix(const uint64_t *bits_a, int32_t n_a, const ui
     if (n_a == 0 || n_b == 0) return MSPA_OK;
     if (!bits_a || !bits_b || !out_inter || !workspace) return fail(MSPA_EINVAL, "mspa_overlap_matrix: null pointer");
     if (n_words > (1LL << 25)) return fail(MSPA_EINVAL, "mspa_overlap_matrix: bitset too long for int32 counts");
-    if (n_a > 65535 * kTile / 2 || n_b > 65535) return fail(MSPA_EINVAL, "mspa_overlap_matrix: too many rows; split the batch");
-    const bool symmetric = (bits_a == bits_b) && (n_a == n_b);
-    const TilePlan p = plan_tiles(n_a, n_b, n_words, symmetric);
+    const TilePlan p = plan_tiles(n_a, n_b, n_words);
+    if ((int64_t)p.tiles_a * p.tiles_b > 0x7fffffffLL || p.slices > 65535 || n_a > 65535)
+        return fail(MSPA_EINVAL, "mspa_overlap_matrix: too many rows / words; split the batch");
     if (workspace_bytes < p.bytes) return fail(MSPA_EINVAL, "mspa_overlap_matrix: workspace smaller than mspa_overlap_workspace_bytes()");
     if (((uintptr_t)workspace & 3u) != 0) return fail(MSPA_EINVAL, "mspa_overlap_matrix: workspace must be 4-byte aligned");
+    const bool symmetric = (bits_a == bits_b) && (n_a == n_b);
     hipStream_t s = (hipStream_t)stream;
     int rc = launch_tiles(bits_a, n_a, bits_b, n_b, n_words, symmetric, p, (int32_t *)workspace, s);
     if (rc) return rc;
@@ -249,17 +264,22 @@ extern "C" int mspa_scene_overlap(const uint64_t *bits, int32_t n_images, int64_
     if (!bits || !out_overlap || !workspace) return fail(MSPA_EINVAL, "mspa_scene_overlap: null pointer");
     if (n_words > (1LL << 25)) return fail(MSPA_EINVAL, "mspa_scene_overlap: bitset too long for int32 counts");
     if (n_images > 65535) return fail(MSPA_EINVAL, "mspa_scene_overlap: too many images; split the scene");
-    const TilePlan p = plan_tiles(n_images, n_images, n_words, true);
+    const TilePlan p = plan_tiles(n_images, n_images, n_words);
+    if (p.slices > 65535) return fail(MSPA_EINVAL, "mspa_scene_overlap: bitset too long; split the scene");
     if (workspace_bytes < p.bytes) return fail(MSPA_EINVAL, "mspa_scene_overlap: workspace smaller than mspa_overlap_workspace_bytes()");
     if (((uintptr_t)workspace & 3u) != 0) return fail(MSPA_EINVAL, "mspa_scene_overlap: workspace must be 4-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    int rc = launch_tiles(bits, n_images, bits, n_images, n_words, true, p, (int32_t *)workspace, s);
+    int32_t *partial = (int32_t *)workspace;
+    int32_t *counts = (int32_t *)((char *)workspace + p.partial_bytes);
+    int rc = launch_tiles(bits, n_images, bits, n_images, n_words, true, p, partial, s);
     if (rc) return rc;
+    hipLaunchKernelGGL(overlap_diag_kernel, dim3((uint32_t)((n_images + 255) / 256)), dim3(256), 0, s, (const int32_t *)partial,
+                       n_images, p.tiles_b, p.slices, counts);
     hipLaunchKernelGGL(scene_overlap_finalize_kernel, dim3((uint32_t)((n_images + 255) / 256), (uint32_t)n_images), dim3(256),
-                       0, s, (const int32_t *)workspace, n_images, p.tiles_b, p.slices, out_overlap, out_inter, out_union);
+                       0, s, (const int32_t *)partial, (const int32_t *)counts, n_images, p.tiles_b, p.slices, out_overlap,
+                       out_inter, out_union);
     return check_hip(hipGetLastError(), "scene_overlap_finalize_kernel launch");
 }
-
 extern "C" int mspa_pair_overlap(const uint64_t *bits, int32_t n_images, int64_t n_words, const int32_t *pairs,
                                  int64_t n_pairs, double *out_overlap, int32_t *out_inter, int32_t *out_union,
                                  mspa_stream_t stream) {

@@ -90,6 +90,144 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_kernel(const doub
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fast form (no float64 outputs requested): the two 3x4 products of IH:57-66 are composed ONCE per image --
+// M = K * inv(A E), twelve entries, one per thread of the block, parked in LDS -- and a vertex costs 9 FMAs, a
+// reciprocal with one Newton step and two multiplies instead of 24 FP64 operations and two IEEE divisions.  Bit-exactness
+// is kept exactly as in K3's fast path: a lane whose decisions (half-to-even rounding of the pixel index, the image bounds,
+// the strict depth comparison) sit within a guard band of a decision boundary (1e-6 px, 1e-9 m: five orders of magnitude
+// above the rounding differences between the two evaluation orders) is re-evaluated with the reference chain.
+// Needs a pinhole K (third row 0 0 1 0: the third homogeneous coordinate IS the camera depth); any other image takes
+// the reference chain for all its lanes.  The composed matrix is scaled by 1000: u and v are unchanged and the third
+// coordinate is the camera depth in millimetres, directly comparable with the raw depth sample.
+// ---------------------------------------------------------------------------------------------------------
+constexpr double kVGuardPx = 1e-6;
+constexpr double kVGuardZmm = 1e-6;
+#ifndef MSPA_VBATCH
+#define MSPA_VBATCH 4
+#endif
+constexpr int kVBatch = MSPA_VBATCH;             // images whose depth gathers are in flight together
+
+template <bool IDENT>
+__global__ __launch_bounds__(kVThreads) void vertex_visibility_fast_kernel(const double *__restrict__ xyz,
+                                                                           const double *__restrict__ cam_mats,
+                                                                           const uint16_t *__restrict__ depth,
+                                                                           VertexArgs a) {
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t slot = blockIdx.x >> 3;
+    const uint32_t vblock = slot % a.vblocks;
+    const uint32_t group = (slot / a.vblocks) * 8u + xcd;
+    if (group >= a.igroups) return;
+    const int img0 = (int)group * kImgPerBlock;
+    const int img1 = min(img0 + kImgPerBlock, a.n_images);
+
+    __shared__ double lds_m[kImgPerBlock][12];
+    __shared__ int lds_pinhole[kImgPerBlock];
+    if (threadIdx.x < kImgPerBlock * 12) {
+        const int im = threadIdx.x / 12, e = threadIdx.x % 12, r = e / 4, cidx = e % 4;
+        if (img0 + im < img1) {
+            const double *__restrict__ Einv = cam_mats + (int64_t)(img0 + im) * 32;
+            const double *__restrict__ K = Einv + 16;
+            double acc = K[4 * r + 0] * Einv[0 + cidx];
+            acc = __builtin_fma(K[4 * r + 1], Einv[4 + cidx], acc);
+            acc = __builtin_fma(K[4 * r + 2], Einv[8 + cidx], acc);
+            if (cidx == 3) acc += K[4 * r + 3];
+            lds_m[im][e] = acc * 1000.0;
+            if (e == 0) lds_pinhole[im] = (K[8] == 0.0 && K[9] == 0.0 && K[10] == 1.0 && K[11] == 0.0) ? 1 : 0;
+        }
+    }
+    const int64_t i = (int64_t)vblock * kVThreads + threadIdx.x;
+    const bool live = i < a.n_points;
+    const int64_t ic = live ? i : a.n_points - 1;
+    const int lane = threadIdx.x & 63;
+    const double x = xyz[ic * a.point_stride];
+    const double y = xyz[ic * a.point_stride + a.comp_stride];
+    const double z = xyz[ic * a.point_stride + 2 * a.comp_stride];
+    const int64_t dpix = (int64_t)a.dh * a.dw;
+    const double Wd = (double)a.W, Hd = (double)a.H;
+    const int hi_x = a.dw - 1, hi_y = a.dh - 1;
+    __syncthreads();
+
+    // Images go through in batches of kVBatch: all projections and depth gathers of a batch are issued before the first
+    // sample is used, so a wave pays ONE memory round trip per batch instead of one per image (eight dependent round
+    // trips per wave left the kernel latency-bound at 8 waves per SIMD).  Lane predicates travel as ballot words (SGPRs).
+    for (int b0 = img0; b0 < img1; b0 += kVBatch) {
+        double izs[kVBatch];
+        uint32_t dv[kVBatch];
+        unsigned long long cand_m[kVBatch], risky_m[kVBatch];
+#pragma unroll
+        for (int q = 0; q < kVBatch; ++q) {
+            const int img = min(b0 + q, img1 - 1);               // a ragged last batch repeats its last image (not stored)
+            const int im = img - img0;
+            const uint16_t *__restrict__ dimg = depth + (int64_t)img * dpix;
+            const double *m = lds_m[im];
+            const double ix = __builtin_fma(m[0], x, __builtin_fma(m[1], y, __builtin_fma(m[2], z, m[3])));
+            const double iy = __builtin_fma(m[4], x, __builtin_fma(m[5], y, __builtin_fma(m[6], z, m[7])));
+            const double iz = __builtin_fma(m[8], x, __builtin_fma(m[9], y, __builtin_fma(m[10], z, m[11])));   // mm
+            double rz = __builtin_amdgcn_rcp(iz);
+            rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
+            const double u = ix * rz, v = iy * rz;
+            const double us = IDENT ? u : u * a.sx, vs = IDENT ? v : v * a.sy;
+            const double ru = __builtin_rint(us), rv = __builtin_rint(vs);
+            int xi = (int)ru, yi = (int)rv;                      // saturating conversion; NaN -> 0
+            xi = min(max(xi, 0), hi_x);
+            yi = min(max(yi, 0), hi_y);
+            // candidate = what the reference would accept, widened by the guard (a lane inside the widening is risky)
+            const bool cand = live & (u > -kVGuardPx) & (u < Wd + kVGuardPx) & (v > -kVGuardPx) & (v < Hd + kVGuardPx) &
+                              (iz > -kVGuardZmm);
+            // guard < |t| < 0.5 - guard for both coordinates  <=>  max(||tu| - .25|, ||tv| - .25|) < .25 - guard
+            const double wu = __builtin_fabs(us - ru) - 0.25, wv = __builtin_fabs(vs - rv) - 0.25;
+            unsigned long long rk = __builtin_amdgcn_ballot_w64(!(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kVGuardPx)) |
+                                    __builtin_amdgcn_ballot_w64(!(iz > kVGuardZmm));
+            if (!IDENT) {   // the bounds are integers of the COLOUR grid, the rounding ties belong to the depth grid
+                const double bu = __builtin_fmin(__builtin_fabs(u), __builtin_fabs(u - Wd));
+                const double bv = __builtin_fmin(__builtin_fabs(v), __builtin_fabs(v - Hd));
+                rk |= __builtin_amdgcn_ballot_w64(!(__builtin_fmin(bu, bv) > kVGuardPx));
+            }
+            dv[q] = dimg[cand ? (yi * a.dw + xi) : 0];
+            izs[q] = iz;
+            cand_m[q] = __builtin_amdgcn_ballot_w64(cand);
+            risky_m[q] = rk;
+        }
+#pragma unroll
+        for (int q = 0; q < kVBatch; ++q) {
+            const int img = b0 + q;
+            if (img >= img1) break;                              // block-uniform
+            const int im = img - img0;
+            const double sd = izs[q] - (double)dv[q];
+            unsigned long long word = cand_m[q] & __builtin_amdgcn_ballot_w64(sd < 0.0);
+            const unsigned long long rk = cand_m[q] & (risky_m[q] | __builtin_amdgcn_ballot_w64(!(__builtin_fabs(sd) > kVGuardZmm)));
+            const bool pin = lds_pinhole[im] != 0;               // block-uniform
+            if (rk != 0 || !pin) {                               // rare: the reference chain (IH:57-69, 337-386) for those lanes
+                const double *__restrict__ Einv = cam_mats + (int64_t)img * 32;
+                const double *__restrict__ K = Einv + 16;
+                const uint16_t *__restrict__ dimg = depth + (int64_t)img * dpix;
+                const bool mine = pin ? (((rk >> lane) & 1ull) != 0) : live;
+                bool vis = ((word >> lane) & 1ull) != 0;
+                if (mine) {
+                    const double qx = affine_row(Einv + 0, x, y, z);
+                    const double qy = affine_row(Einv + 4, x, y, z);
+                    const double qz = affine_row(Einv + 8, x, y, z);
+                    const double jx = affine_row(K + 0, qx, qy, qz);
+                    const double jy = affine_row(K + 4, qx, qy, qz);
+                    const double jz = affine_row(K + 8, qx, qy, qz);
+                    int ex, ey;
+                    vis = depth_test(true, jx / jz, jy / jz, qz, dimg, a.dh, a.dw, a.H, a.W, a.sx, a.sy, ex, ey);
+                }
+                word = __builtin_amdgcn_ballot_w64(vis);
+            }
+            if (lane == 0) {
+                if (a.bits && (i < a.n_points)) a.bits[(int64_t)img * a.n_words + (i >> 6)] = word;
+                if (a.count_atomic) {
+                    const int c = __popcll(word);
+                    if (c) atomicAdd(a.count_atomic + img, c);
+                }
+            }
+            if (live && a.mask) a.mask[(int64_t)img * a.n_points + i] = (uint8_t)((word >> lane) & 1ull);
+        }
+    }
+}
+
 // visible vertices per image = popcount of its bitset: one wave per image
 __global__ __launch_bounds__(kVThreads) void bits_count_kernel(const uint64_t *__restrict__ bits, int64_t n_words,
                                                                int n_images, int32_t *__restrict__ count) {
@@ -182,7 +320,14 @@ extern "C" int mspa_vertex_visibility(const double *xyz, int64_t n_points, int64
     if (bx > 0x7fffffffLL || blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_vertex_visibility: batch too large; split it");
     a.vblocks = (uint32_t)bx;
     a.igroups = (uint32_t)by;
-    hipLaunchKernelGGL(vertex_visibility_kernel, dim3((uint32_t)blocks), dim3(kVThreads), 0, s, xyz, cam_mats, depth, a);
+    // float64 outputs are DEFINED as the reference's operation order; everything else (bitset, byte mask, counts) takes the
+    // composed + guarded kernel, which reproduces the same integers
+    if (out_uv || out_depth)
+        hipLaunchKernelGGL(vertex_visibility_kernel, dim3((uint32_t)blocks), dim3(kVThreads), 0, s, xyz, cam_mats, depth, a);
+    else if (dh == H && dw == W)
+        hipLaunchKernelGGL(vertex_visibility_fast_kernel<true>, dim3((uint32_t)blocks), dim3(kVThreads), 0, s, xyz, cam_mats, depth, a);
+    else
+        hipLaunchKernelGGL(vertex_visibility_fast_kernel<false>, dim3((uint32_t)blocks), dim3(kVThreads), 0, s, xyz, cam_mats, depth, a);
     int rc = check_hip(hipGetLastError(), "vertex_visibility_kernel launch");
     if (rc || !count_from_bits) return rc;
     const int per_block = kVThreads / kWave;

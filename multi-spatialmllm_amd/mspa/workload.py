@@ -78,7 +78,18 @@ def select_pairs(overlap_ij: np.ndarray, n_frames: int, n_pairs: int, kind: str,
     else:
         raise ValueError(f"unknown workload {kind!r}")
     if len(idx) == 0:
-        raise ValueError(f"workload {kind!r}: the scene has no pair of that kind")
+        # a tiny scene (tests) may have no pair in the named range: fall back to the nearest tenth of the candidates by overlap
+        finite = np.where(np.isfinite(ov), ov, 0.0)
+        order = np.argsort(finite, kind="stable")
+        n10 = max(1, len(order) // 10)
+        if kind == "low":
+            pool = order[:n10]
+        elif kind == "high":
+            pool = order[-n10:]
+        else:
+            raise ValueError(f"workload {kind!r}: the scene has no pair with overlap in {VC_OVERLAP_MIN}..{VC_OVERLAP_MAX} %")
+        idx = rng.choice(pool, size=n_pairs, replace=len(pool) < n_pairs)
+        rule += f" -- none in this scene: the {'lowest' if kind == 'low' else 'highest'} tenth of its pairs instead"
     if len(idx) < n_pairs:      # every bin exhausted (tiny scenes): top up with repeats, frames differ per replica anyway
         idx = np.concatenate([idx, rng.choice(idx, size=n_pairs - len(idx), replace=True)])
     idx = rng.permutation(idx)

@@ -281,6 +281,63 @@ def test_vertex_visibility_scene_products():
         assert np.where(mask[k])[0].tolist() == ref["image_to_points"][image_id]
 
 
+@pytest.mark.parametrize("name", ["scene_ident", "scene_scaled", "ties"])
+def test_vertex_visibility_fast_golden(name):
+    """The composed + guarded K1 kernel (what runs when no float64 output is requested) against the reference's frozen masks,
+    engineered rounding ties and depth equalities included."""
+    g = GoldenScene(name)
+    ids = g.valid_image_ids
+    t = torch.from_numpy(np.ascontiguousarray(g.points[:, :3])).to(DEV)
+    res = run_vertices(t, g.K, g.A, [g.E[i] for i in ids], [g.depth[i] for i in ids], g.color_hw, want=("bits", "mask", "count"))
+    n = g.points.shape[0]
+    for k in range(len(ids)):
+        ref_vis = g["ref_vis"][k] if g["ref_vis"].ndim == 2 else g["ref_vis"]
+        assert np.array_equal(res["mask"][k].astype(bool), ref_vis)
+        assert np.array_equal(unpack_bits(res["bits"][k], n), ref_vis)
+        assert res["count"][k] == int(ref_vis.sum())
+
+
+@pytest.mark.parametrize("color_hw,depth_hw", [((480, 640), (480, 640)), ((968, 1296), (480, 640)), ((61, 83), (37, 53))])
+def test_vertex_visibility_fast_equals_exact_random_poses(color_hw, depth_hw):
+    """Adversarial cameras (looking away, inside the geometry, coincident with vertices, grazing) and vertices engineered onto
+    the camera plane / the optical axis: bitsets of the fast kernel == bitsets of the reference-order kernel (which is
+    bit-identical to the C oracle, test_vertex_visibility_golden), also for a non-pinhole K (reference chain per image)."""
+    rng = np.random.default_rng(41)
+    K = synth.intrinsics_for(color_hw)
+    Kd = K.copy()
+    Kd[0] *= depth_hw[1] / color_hw[1]
+    Kd[1] *= depth_hw[0] / color_hw[0]
+    boxes = synth._make_boxes(rng)
+    pts = synth._sample_surface_points(rng, boxes, 20000)
+    E, depth = [], []
+    for k in range(20):
+        eye = rng.uniform([0.3, 0.3, 0.3], [5.7, 5.7, 2.7])
+        tgt = synth.ROOM / 2 + rng.normal(0, 1.5, 3)
+        e = synth._look_at(eye, tgt)
+        if k % 5 == 1:
+            e[:3, 3] = pts[rng.integers(len(pts))]                 # camera centre ON a vertex: z = 0, u = v = NaN
+        if k % 5 == 2:
+            e[:3, 3] = pts[rng.integers(len(pts))] - e[:3, 2] * 0.5   # a vertex exactly on the optical axis
+        e = synth._roundtrip_f(e)
+        E.append(e)
+        z = synth.render_depth(e, Kd, depth_hw, boxes)
+        mm = np.clip(np.rint(z * 1000.0 + rng.normal(0, 3.0, z.shape)), 0, 65535).astype(np.uint16)
+        mm[rng.random(mm.shape) < 0.05] = 0
+        depth.append(mm)
+    t = torch.from_numpy(np.ascontiguousarray(pts)).to(DEV)
+    A = np.eye(4)
+    fast = run_vertices(t, K, A, E, depth, color_hw, want=("bits", "mask", "count"))
+    exact = run_vertices(t, K, A, E, depth, color_hw, want=("bits", "mask", "count", "uv"))
+    for k in ("bits", "mask", "count"):
+        assert np.array_equal(fast[k], exact[k]), k
+    assert int(exact["count"].sum()) > 5000
+    K2 = K.copy()
+    K2[2, 3] = 0.25                                                  # not a pinhole: third row 0 0 1 0.25
+    fast2 = run_vertices(t, K2, A, E[:9], depth[:9], color_hw, want=("bits", "count"))
+    exact2 = run_vertices(t, K2, A, E[:9], depth[:9], color_hw, want=("bits", "count", "depth"))
+    assert np.array_equal(fast2["bits"], exact2["bits"]) and np.array_equal(fast2["count"], exact2["count"])
+
+
 def test_vertex_visibility_large_and_edge():
     sc = synth.make_scene(1005, n_points=131072 + 37, n_frames=11, color_hw=(480, 640), invalid_pose_frac=0,
                           with_color=False)

@@ -69,7 +69,7 @@ def test_tiled_overlap_entry_points_validate_before_launching():
     lib = _lib.load()
     dummy = ctypes.c_void_p(64)
     need = lib.mspa_overlap_workspace_bytes(320, 320, 2048)
-    assert need > 0 and need % 4096 == 0 and lib.mspa_overlap_workspace_bytes(0, 5, 7) == 0
+    assert need >= 100 * 32 * 4096 and lib.mspa_overlap_workspace_bytes(0, 5, 7) == 0
     assert lib.mspa_overlap_workspace_bytes(40, 320, 2048) > 0
     assert lib.mspa_scene_overlap(dummy, 320, 2048, dummy, need - 1, dummy, None, None, None) == _lib.MSPA_EINVAL
     assert b"workspace smaller" in lib.mspa_last_error_string()

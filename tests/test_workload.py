@@ -52,7 +52,12 @@ def test_select_pairs_kinds_and_orders():
     again, _ = workload.select_pairs(ov, 48, 1000, "vc", seed=5)
     assert np.array_equal(again, workload.select_pairs(ov, 48, 1000, "vc", seed=5)[0])
     with pytest.raises(ValueError):
-        workload.select_pairs(np.zeros(6), 4, 10, "high", seed=0)
+        workload.select_pairs(np.zeros(6), 4, 10, "vc", seed=0)
+    # a scene without pairs of the named kind falls back to its extreme tenth (tiny test scenes)
+    pairs, info = workload.select_pairs(np.full(28, 12.0), 8, 10, "low", seed=0)
+    assert pairs.shape == (10, 2) and "lowest tenth" in info["rule"]
+    pairs, info = workload.select_pairs(np.linspace(1, 20, 28), 8, 10, "high", seed=0)
+    assert "highest tenth" in info["rule"] and info["overlap_pct_min"] > 18
 
 
 def test_bench_refuses_to_run_without_gpu_and_self_launches():

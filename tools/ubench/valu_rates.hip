@@ -44,6 +44,13 @@
 #define MED3(x) asm volatile("v_med3_i32 %0, %0, %1, %1" : "+v"(x) : "v"(jj));
 #define LSHLOR(x) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(x) : "v"(jj));
 #define CMPU(x) asm volatile("v_cmp_ne_u32 vcc, %0, %1" : : "v"(x), "v"(jj) : "vcc");
+#define BCNT(x) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(x) : "v"(jj));
+#define AND32(x) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(jj));
+#define BITOP3(x) asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(x) : "v"(jj));
+#define MULLO(x) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x) : "v"(jj));
+#define MAD24(x) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(x) : "v"(jj));
+#define WRLANE(x) asm volatile("v_writelane_b32 %0, s20, 5" : "+v"(x) : : "s20");
+#define DIVFIX(x) asm volatile("v_rcp_f32 %0, %0" : "+v"(x));
 
 KERNEL(k_fma, D8, X8(FMA), (void)0)
 KERNEL(k_add, D8, X8(ADD), (void)0)
@@ -63,6 +70,13 @@ KERNEL(k_lshl_add_u64, D8; L8, XL8(LSHLADD64), a0 += (double)(l0 + l1 + l2 + l3 
 KERNEL(k_med3, D8; I8, XI8(MED3), ISUM)
 KERNEL(k_lshl_or, D8; I8, XI8(LSHLOR), ISUM)
 KERNEL(k_cmp_u32, D8; I8, XI8(CMPU), ISUM)
+KERNEL(k_bcnt, D8; I8, XI8(BCNT), ISUM)
+KERNEL(k_and32, D8; I8, XI8(AND32), ISUM)
+KERNEL(k_bitop3, D8; I8, XI8(BITOP3), ISUM)
+KERNEL(k_mullo, D8; I8, XI8(MULLO), ISUM)
+KERNEL(k_mad24, D8; I8, XI8(MAD24), ISUM)
+KERNEL(k_wrlane, D8; I8, XI8(WRLANE), ISUM)
+KERNEL(k_rcp_f32, D8; F8, XF8(DIVFIX), a0 += f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7;)
 
 template <typename F>
 void run(const char *name, F kern, int waves_per_simd) {
@@ -87,7 +101,7 @@ void run(const char *name, F kern, int waves_per_simd) {
 }
 
 int main() {
-    for (int w : {4, 8}) {
+    for (int w : {1, 4, 8}) {
         run("v_fma_f64", k_fma, w);
         run("v_add_f64", k_add, w);
         run("v_mul_f64", k_mul, w);
@@ -106,6 +120,13 @@ int main() {
         run("v_fma_f32", k_fma_f32, w);
         run("v_lshl_add_u64", k_lshl_add_u64, w);
         run("v_med3_i32", k_med3, w);
+        run("v_bcnt_u32_b32", k_bcnt, w);
+        run("v_and_b32", k_and32, w);
+        run("v_bitop3_b32", k_bitop3, w);
+        run("v_mul_lo_u32", k_mullo, w);
+        run("v_mad_u32_u24", k_mad24, w);
+        run("v_writelane_b32", k_wrlane, w);
+        run("v_rcp_f32", k_rcp_f32, w);
     }
     return 0;
 }
