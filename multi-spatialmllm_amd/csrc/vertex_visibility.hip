@@ -24,6 +24,7 @@ struct VertexArgs {
     double *depth_out;
     int32_t *count_atomic;
     uint32_t vblocks, igroups;     // vertex blocks, image groups of kImgPerBlock (grid decode)
+    uint32_t n_xcd;                // XCDs the hardware deals workgroups over (1 = plain linear decode)
 };
 
 constexpr int kVThreads = 256;
@@ -33,13 +34,14 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_kernel(const doub
                                                                       const double *__restrict__ cam_mats,
                                                                       const uint16_t *__restrict__ depth,
                                                                       VertexArgs a) {
-    // XCD-aware decode of the 1-D grid: workgroup b runs on XCD b % 8, and each XCD has its own L2.  All vertex blocks of one
+    // XCD-aware decode of the 1-D grid: workgroup b runs on XCD b % n_xcd (8 on an MI355X in SPX mode; the host passes 1 when
+    // the device reports anything else, which degrades to a plain linear decode), and each XCD has its own L2.  All vertex blocks of one
     // image group go to the same XCD, so a group's depth frames are gathered through ONE L2 instead of eight (measured before
     // the change: 672 MB fetched per 320-image scene against 197 MB of depth frames).
-    const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t slot = blockIdx.x >> 3;
+    const uint32_t xcd = blockIdx.x % a.n_xcd;
+    const uint32_t slot = blockIdx.x / a.n_xcd;
     const uint32_t vblock = slot % a.vblocks;
-    const uint32_t group = (slot / a.vblocks) * 8u + xcd;
+    const uint32_t group = (slot / a.vblocks) * a.n_xcd + xcd;
     if (group >= a.igroups) return;
     const int64_t i = (int64_t)vblock * kVThreads + threadIdx.x;
     const bool live = i < a.n_points;
@@ -113,10 +115,10 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_fast_kernel(const
                                                                            const double *__restrict__ cam_mats,
                                                                            const uint16_t *__restrict__ depth,
                                                                            VertexArgs a) {
-    const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t slot = blockIdx.x >> 3;
+    const uint32_t xcd = blockIdx.x % a.n_xcd;
+    const uint32_t slot = blockIdx.x / a.n_xcd;
     const uint32_t vblock = slot % a.vblocks;
-    const uint32_t group = (slot / a.vblocks) * 8u + xcd;
+    const uint32_t group = (slot / a.vblocks) * a.n_xcd + xcd;
     if (group >= a.igroups) return;
     const int img0 = (int)group * kImgPerBlock;
     const int img1 = min(img0 + kImgPerBlock, a.n_images);
@@ -268,6 +270,18 @@ __global__ __launch_bounds__(kVThreads) void check_visibility_kernel(const doubl
 
 using namespace mspa;
 
+// Workgroups of a 1-D grid are dealt round-robin over the XCDs.  An MI355X in SPX mode exposes 256 CUs = 8 XCDs of 32; a
+// partitioned device (CPX: 32 CUs) or any other part gets 1, i.e. no XCD-aware regrouping (results never depend on it).
+static int xcd_count() {
+    static thread_local int cached = 0;
+    if (cached) return cached;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
+    cached = (prop.multiProcessorCount == 256) ? 8 : 1;
+    return cached;
+}
+
 extern "C" int mspa_check_visibility(const double *uv, const double *point_depth, int64_t n,
                                      const uint16_t *depth_image, int32_t dh, int32_t dw, int32_t H, int32_t W,
                                      uint8_t *out_in_bounds, uint8_t *out_by_depth, uint8_t *out_visible,
@@ -316,10 +330,12 @@ extern "C" int mspa_vertex_visibility(const double *xyz, int64_t n_points, int64
     a.count_atomic = count_from_bits ? nullptr : out_count;
     const int64_t bx = (n_points + kVThreads - 1) / kVThreads;
     const int64_t by = (n_images + kImgPerBlock - 1) / kImgPerBlock;
-    const int64_t blocks = bx * ((by + 7) / 8) * 8;
+    const int64_t n_xcd = xcd_count();
+    const int64_t blocks = bx * ((by + n_xcd - 1) / n_xcd) * n_xcd;
     if (bx > 0x7fffffffLL || blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_vertex_visibility: batch too large; split it");
     a.vblocks = (uint32_t)bx;
     a.igroups = (uint32_t)by;
+    a.n_xcd = (uint32_t)n_xcd;
     // float64 outputs are DEFINED as the reference's operation order; everything else (bitset, byte mask, counts) takes the
     // composed + guarded kernel, which reproduces the same integers
     if (out_uv || out_depth)

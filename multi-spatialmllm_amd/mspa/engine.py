@@ -134,6 +134,12 @@ def pair_reproject(depth: torch.Tensor, mats: torch.Tensor, pairs: torch.Tensor,
     _require(pairs.dtype == torch.int32 and pairs.dim() == 2 and pairs.shape[1] == 2, "pairs.dtype == torch.int32 and pairs.dim() == 2 and pairs.shape[1] == 2")
     F, DH, DW = depth.shape
     _require(mats.shape[0] == F, "mats.shape[0] == F")
+    if flags & _lib.PAIR_FAST:
+        # MSPA_PAIR_FAST reads the camera-2 depth off the third image row: K's third row must be 0 0 1 0 (include/mspa.h).
+        # The frame records carry K (slot 4); one 32-byte read-back of the first frame's row per call.
+        k_row = mats[0, _lib.MAT_K, 8:12].cpu().numpy() if F else np.array([0.0, 0.0, 1.0, 0.0])
+        _require(bool(np.array_equal(k_row, np.array([0.0, 0.0, 1.0, 0.0]))),
+                 "MSPA_PAIR_FAST needs a pinhole K (third row 0 0 1 0); use flags=0 for this camera")
     H, W = image_hw
     if rgb is not None:
         _require(rgb.dtype == torch.uint8 and tuple(rgb.shape) == (F, H, W, 3), "rgb.dtype == torch.uint8 and tuple(rgb.shape) == (F, H, W, 3)")
@@ -171,9 +177,9 @@ def vertex_visibility(xyz: torch.Tensor, cam_mats: torch.Tensor, depth: torch.Te
         out["depth"] = torch.empty((I, n), dtype=torch.float64, device=dev)
     if "count" in want:
         out["count"] = torch.empty((I,), dtype=torch.int32, device=dev)
-    _require(cam_mats.is_contiguous() and depth.is_contiguous(), "cam_mats.is_contiguous() and depth.is_contiguous()")
+    _require(depth.dtype in (torch.int16, torch.uint16), "depth.dtype in (torch.int16, torch.uint16)")
     _lib.check(lib.mspa_vertex_visibility(
-        xyz.data_ptr(), n, ps, cs, cam_mats.data_ptr(), I, depth.data_ptr(), DH, DW, H, W,
+        xyz.data_ptr(), n, ps, cs, _ptr(cam_mats), I, _ptr(depth), DH, DW, H, W,
         _ptr(out.get("bits")), _ptr(out.get("mask")), _ptr(out.get("uv")), _ptr(out.get("depth")),
         _ptr(out.get("count")), _stream_ptr()))
     return out
@@ -346,7 +352,9 @@ def project_samples(xyz: torch.Tensor, cam_mats: torch.Tensor, depth: torch.Tens
     _require(xyz.dtype == torch.float64 and xyz.dim() == 2 and xyz.shape[1] >= 3, "xyz.dtype == torch.float64 and xyz.dim() == 2 and xyz.shape[1] >= 3")
     _require(samples.dtype == torch.int32 and samples.dim() == 2 and samples.shape[1] == 2, "samples.dtype == torch.int32 and samples.dim() == 2 and samples.shape[1] == 2")
     I, DH, DW = depth.shape
-    _require(tuple(cam_mats.shape) == (I, 2, 16) and cam_mats.is_contiguous() and depth.is_contiguous(), "tuple(cam_mats.shape) == (I, 2, 16) and cam_mats.is_contiguous() and depth.is_contiguous()")
+    _require(xyz.is_cuda and xyz.stride(0) > 0 and xyz.stride(1) > 0, "xyz: device tensor with positive strides")
+    _require(depth.dtype in (torch.int16, torch.uint16), "depth.dtype in (torch.int16, torch.uint16)")
+    _require(cam_mats.dtype == torch.float64 and tuple(cam_mats.shape) == (I, 2, 16), "cam_mats: float64 [n_images, 2, 16]")
     n = samples.shape[0]
     dev = xyz.device
     uv = torch.empty((n, 2), dtype=torch.float64, device=dev)

@@ -35,9 +35,11 @@ def pair_table_rows(scene_idx: int, scene) -> np.ndarray:
     import torch
     from . import engine
     F = len(scene.ids)
+    if F < 2:
+        return torch.zeros((0, 7), dtype=torch.float64, device=scene.device)
     pairs = engine.all_pairs(F, scene.device)
     vis = scene._visibility()
-    overlap = engine.pair_overlap(vis["bits"], pairs)
+    overlap = engine.scene_overlap(vis["bits"])
     yaw, pitch = engine.extract_yaw_pitch_host(scene.E_aligned)
     E_t = torch.from_numpy(np.stack(scene.E_aligned).reshape(F, 16)).to(scene.device)
     pose = engine.pair_pose(E_t, scene.cam_mats[:, 0, :].contiguous(), torch.from_numpy(yaw).to(scene.device),

@@ -30,7 +30,12 @@ class SceneOnDevice:
         self.image_hw = tuple(int(v) for v in image_hw)
         self.device = device
         self.E_aligned = [self.A @ np.asarray(E[k], np.float64) for k in self.ids]        # IH:113-124
-        self.depth = engine.depth_to_device(np.stack([depth[k] for k in self.ids]), device)
+        if self.ids:
+            self.depth = engine.depth_to_device(np.stack([depth[k] for k in self.ids]), device)
+        else:       # no frame with a finite pose: the reference returns empty tables for such a scene (CFR:176-189 loops over nothing)
+            any_frame = next(iter(depth.values()), None)
+            dh, dw = (any_frame.shape if any_frame is not None else self.image_hw)
+            self.depth = torch.zeros((0, int(dh), int(dw)), dtype=torch.int16, device=device)
         self.frame_mats = torch.from_numpy(engine.frame_matrices(self.K, self.A, [E[k] for k in self.ids])).to(device)
         self.cam_mats = torch.from_numpy(engine.camera_matrices(self.K, self.E_aligned)).to(device)
         self.rgb = None
@@ -55,8 +60,12 @@ class SceneOnDevice:
     # ---- CFR.process_scene ------------------------------------------------------------------
     def frames_relations_arrays(self) -> Dict[str, np.ndarray]:
         """The pair table in columns: frame indices i < j (key order of CFR:176-178) and overlap / distance / yaw / pitch."""
-        vis = self._visibility()
         F = len(self.ids)
+        if F < 2:                                                  # nothing to pair (CFR:176-178 loops over nothing)
+            e = np.zeros(0, dtype=np.float64)
+            z = np.zeros(0, dtype=np.int32)
+            return {"i": z, "j": z.copy(), "overlap": e, "distance": e.copy(), "yaw": e.copy(), "pitch": e.copy()}
+        vis = self._visibility()
         pairs = engine.all_pairs(F, self.device)
         overlap = engine.scene_overlap(vis["bits"])               # tiled K2: every pair of the scene in one pass
         yaw, pitch = engine.extract_yaw_pitch_host(self.E_aligned)
@@ -86,6 +95,9 @@ class SceneOnDevice:
     # ---- MVI.process_scene ------------------------------------------------------------------
     def visibility_index(self) -> Dict[str, dict]:
         """{"image_to_points": {img: [idx...]}, "point_to_images": {idx: [img...]}} (MVI:103-123)."""
+        if not self.ids:                                           # MVI:103-123 with no valid frame: every vertex unseen
+            n = 0 if self.xyz is None else int(self.xyz.shape[0])
+            return {"image_to_points": {}, "point_to_images": {v: [] for v in range(n)}}
         mask = self.vertex_visibility(("mask",))["mask"]
         n = mask.shape[1]
         image_to_points = {}

@@ -127,12 +127,13 @@ def process_scene_columns(scene_id, scene_infos, warning_file) -> PairTable:
     return PairTable(scene_id, list(scene.ids), arrays)
 
 
-def run_split(scene_info_path, output_parquet, warning_file, num_workers=15, save_interval=20):
+def run_split(scene_info_path, output_parquet, warning_file, num_workers=15, save_interval=20, keep=True):
     """Pair tables of every scene of a split -> ``output_parquet`` (+ ``*_nonzero.parquet``) (reference: :200-253).
     ``num_workers`` is accepted and ignored: scenes run back to back on the GPU (a ScanNet-sized scene takes ~0.25 ms of
     kernel time).  The tables stay columnar from the kernels to the parquet row groups -- ScanNet's 106.8 M pairs as a
     dict with one entry per pair would not fit in memory -- and both files are streamed, one row group per scene, instead
-    of being rewritten every ``save_interval`` scenes.  Returns {scene_id: PairTable}."""
+    of being rewritten every ``save_interval`` scenes.  Returns {scene_id: PairTable}; with ``keep=False`` each table is
+    dropped once its row groups are written (48 B per pair: ~5 GB for ScanNet's 106.8 M pairs) and {} is returned."""
     import pyarrow.parquet as pq
     from spatial_engine.utils.scannet_utils.handler.info_handler import SceneInfoHandler
     scene_infos = SceneInfoHandler(scene_info_path)
@@ -149,7 +150,8 @@ def run_split(scene_info_path, output_parquet, warning_file, num_workers=15, sav
     try:
         for count, scene_id in enumerate(all_scene_ids):
             t = process_scene_columns(scene_id, scene_infos, warning_file)
-            tables[scene_id] = t
+            if keep:
+                tables[scene_id] = t
             for w, (path, nz) in enumerate(((output_parquet, False), (nonzero_parquet, True))):
                 arrow = t.to_arrow(nz)
                 if writers[w] is None:
@@ -181,7 +183,8 @@ def main():
                                  ("val", "data/scannet/scannet_instance_data/scenes_val_info_i_D5.pkl", val_dir)):
         out = os.path.join(out_dir, f"{split}_camera_info_D5{suffix}.parquet")
         print(f"[main] Processing {split} split -> {out}")
-        run_split(info, out, os.path.join(out_dir, f"{split}_warning_D5{suffix}.txt"), num_workers=25, save_interval=20)
+        run_split(info, out, os.path.join(out_dir, f"{split}_warning_D5{suffix}.txt"), num_workers=25, save_interval=20,
+                  keep=False)
 
 
 if __name__ == "__main__":

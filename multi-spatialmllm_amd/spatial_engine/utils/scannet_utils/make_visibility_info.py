@@ -100,7 +100,7 @@ def main():
         out = os.path.join(root, f"{split}_visibility_info_D5{suffix}.parquet")
         print(f"[main] Generating {split} visibility -> {out}")
         run_split(os.path.join(root, f"scenes_{split}_info_i_D5.pkl"), out,
-                  os.path.join(root, f"make_visibility_{split}_warning{suffix}.txt"), num_workers=25)
+                  os.path.join(root, f"make_visibility_{split}_warning{suffix}.txt"), num_workers=25, keep=False)
 
 
 if __name__ == "__main__":

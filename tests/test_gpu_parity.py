@@ -219,6 +219,51 @@ def test_pair_reproject_errors():
         engine.frame_matrices(sc.K, sc.A, [np.full((4, 4), -np.inf)])
 
 
+def test_fast_flag_needs_pinhole_and_bad_tensors_are_rejected():
+    """MSPA_PAIR_FAST with a K whose third row is not 0 0 1 0 is refused on the host (the kernel would read the camera depth
+    off the wrong row); CPU tensors / float depth never reach a kernel."""
+    sc = synth.make_scene(1004, n_points=64, n_frames=2, color_hw=(48, 64), depth_hw=(48, 64), invalid_pose_frac=0, with_color=False)
+    ids = sc.valid_image_ids
+    K2 = sc.K.copy()
+    K2[2, 3] = 0.5
+    depth = engine.depth_to_device(np.stack([sc.depth[i] for i in ids]), DEV)
+    mats = torch.from_numpy(engine.frame_matrices(K2, sc.A, [sc.E[i] for i in ids])).to(DEV)
+    pairs = torch.tensor([[0, 1]], dtype=torch.int32, device=DEV)
+    out = engine.alloc_pair_outputs(1, sc.color_hw, ("vis_bits", "counts"), DEV)
+    with pytest.raises(ValueError, match="pinhole"):
+        engine.pair_reproject(depth, mats, pairs, sc.color_hw, out, flags=_lib.PAIR_FAST)
+    engine.pair_reproject(depth, mats, pairs, sc.color_hw, out, flags=0)              # the exact kernel takes any affine K
+    ref = C.frame_pair(sc.depth[ids[0]], sc.depth[ids[1]], K2, sc.E[ids[0]], sc.E[ids[1]], sc.A, sc.color_hw)
+    torch.cuda.synchronize()
+    assert tuple(out["counts"][0].tolist()) == (ref["n_valid"], ref["n_vis"])
+    xyz = torch.from_numpy(np.ascontiguousarray(sc.points[:, :3])).to(DEV)
+    cam = torch.from_numpy(engine.camera_matrices(sc.K, [sc.A @ sc.E[i] for i in ids])).to(DEV)
+    with pytest.raises(ValueError):
+        engine.vertex_visibility(xyz, cam.cpu(), depth, sc.color_hw)                    # CPU matrices
+    with pytest.raises(ValueError):
+        engine.vertex_visibility(xyz, cam, depth.to(torch.float32), sc.color_hw)        # depth dtype
+    with pytest.raises(ValueError):
+        engine.project_samples(xyz.cpu(), cam, depth, sc.color_hw, torch.zeros((1, 2), dtype=torch.int32, device=DEV))
+
+
+def test_scene_without_valid_frames_gives_empty_tables():
+    """All poses non-finite: the reference's loops run over nothing (CFR:176-189, MVI:103-123) -- empty tables, no exception."""
+    from mspa.scene import SceneOnDevice
+    sc = synth.make_scene(1004, n_points=128, n_frames=3, color_hw=(48, 64), depth_hw=(48, 64), invalid_pose_frac=0, with_color=False)
+    E = {k: np.full((4, 4), -np.inf) for k in sc.E}
+    scene = SceneOnDevice(sc.K, sc.A, E, sc.depth, sc.color_hw, sc.points, DEV)
+    assert scene.ids == [] and scene.frames_relations() == {}
+    t = scene.frames_relations_arrays()
+    assert all(len(v) == 0 for v in t.values())
+    idx = scene.visibility_index()
+    assert idx["image_to_points"] == {} and len(idx["point_to_images"]) == 128 and idx["point_to_images"][5] == []
+    one = {k: (sc.E[k] if n == 0 else np.full((4, 4), np.nan)) for n, k in enumerate(sc.E)}
+    scene1 = SceneOnDevice(sc.K, sc.A, one, sc.depth, sc.color_hw, sc.points, DEV)
+    assert len(scene1.ids) == 1 and scene1.frames_relations() == {}
+    from mspa import pipeline
+    assert pipeline.pair_table_rows(0, scene1).shape == (0, 7)
+
+
 # ------------------------------------------------------------------------------------------
 # K1 vertex visibility
 # ------------------------------------------------------------------------------------------
