@@ -21,6 +21,8 @@
 //     addressing and 16-byte stores (see the comment above it).
 #include "mspa_common.h"
 
+#include <type_traits>
+
 namespace mspa {
 
 // Inputs are separate `const T *__restrict__` kernel parameters (not struct members) on purpose:
@@ -1106,6 +1108,333 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// fast path, colour grid over a SMALLER depth grid -- ScanNet's own shape: 1296 x 968 colour over 640 x 480 depth
+// (extract_posed_images.py:93-97; OPS:272-290 scales colour pixels onto the depth frame, IH:359-366 scales projections)
+// --------------------------------------------------------------------------------------------
+// Same arithmetic, guard and bookkeeping as pair_fast_tight_kernel (scalar ballot words, visibility words in VGPR lanes,
+// 16-byte index stores through an LDS transpose).  What the shape adds, and how it is kept off the per-pixel path:
+//   * W = 1296 is 20.25 words of 64 bits: a 64-column stripe's ballot would straddle two words of the bitset in three
+//     rows out of four.  The stripe therefore WOBBLES: in row r it starts at column 64 s + off(r), off = 0, 48, 32, 16 for
+//     r mod 4 = 0..3, exactly where a word of the row-major bitset begins, so every ballot is one whole word.  The lane's
+//     column moves by a wave-uniform amount per row (+48, -16, -16, -16), i.e. the per-row update of the affine terms stays
+//     three adds with scalar operands.  The word that straddles the end of a row (3 rows out of 4) and the 21st word of
+//     rows with r mod 4 = 0 belong to the LAST stripe's tiles: their lanes beyond column W - 1 are pixels of the next row
+//     (per-lane correction of the affine terms, only in those tiles: 1 tile in 20).
+//   * the two grid scalings.  OPS:285-290's colour -> depth pixel (round_clip(my * sy), round_clip(mx * sx)) is two small
+//     tables per workgroup (byte offsets, built once with the reference's own float64 expression); a row's samples are one
+//     or two cache lines.  IH:362-366's projection -> depth pixel is folded into the composed matrix (rows 0, 1 times sx,
+//     sy): the kernel works on us = u * sx directly, bounds 0 <= u < W become 0 <= us < dw up to 1e-13 -- inside the guard
+//     band, where lanes are re-evaluated with the reference chain anyway -- and the "near an integer" guard of the depth
+//     grid covers the image bounds just as in the equal-grid kernel.
+template <int W_, int H_, int DW_, int DH_, uint32_t SET, bool STREAM>
+__global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16_t *__restrict__ depth,
+                                                                    const uint8_t *__restrict__ rgb,
+                                                                    const double *__restrict__ mats,
+                                                                    const int32_t *__restrict__ pairs, PairArgs a) {
+    using O = Outs<SET, false>;
+    static_assert(W_ % 16 == 0 && H_ % 4 == 0 && W_ >= 192, "four rows are a whole number of bitset words");
+    static_assert((SET & ~(O_VIS_BITS | O_PIX | O_COUNTS)) == 0, "correspondence / minimal output sets");
+    constexpr int S = W_ / 64;                       // full stripes; the last one also owns the row-straddling words
+    constexpr int kPeriodWords = 4 * W_ / 64;        // 81: four rows of bitset words
+    constexpr int kRows = 48;                        // rows per tile
+    // r mod 4 = j: first word of the row relative to the period, column where it starts
+    constexpr int kC1 = (W_ + 63) / 64, kC2 = (2 * W_ + 63) / 64, kC3 = (3 * W_ + 63) / 64;
+    constexpr int kOff1 = kC1 * 64 - W_, kOff2 = kC2 * 64 - 2 * W_, kOff3 = kC3 * 64 - 3 * W_;
+    constexpr bool kExtra0 = (kC1 > S);              // rows with r mod 4 == 0 start S + 1 words (1296: yes)
+    static_assert(kExtra0 && kC2 - kC1 == S && kC3 - kC2 == S && kPeriodWords - kC3 == S, "word pattern of the shape");
+    constexpr int kOff[4] = {0, kOff1, kOff2, kOff3};
+    constexpr int kC[4] = {0, kC1, kC2, kC3};
+
+    int64_t pair;
+    uint32_t tgroup;
+    if (!decode_block(a, pair, tgroup)) return;
+    const int f1 = pairs[2 * pair + 0];
+    const int f2 = pairs[2 * pair + 1];
+    const double *m1 = mats + (int64_t)f1 * (MSPA_FRAME_MATS * 16);
+    const double *m2 = mats + (int64_t)f2 * (MSPA_FRAME_MATS * 16);
+    constexpr int64_t dpix = (int64_t)DH_ * DW_;
+    constexpr uint32_t P = (uint32_t)W_ * H_;
+    Ctx c;
+    c.depth1 = depth + (int64_t)f1 * dpix;
+    c.depth2 = depth + (int64_t)f2 * dpix;
+    c.rgb1 = nullptr;
+    c.obase = pair * (int64_t)P;
+    c.words_per_pair = (P + 63) >> 6;
+    c.pair = pair;
+    c.lane = threadIdx.x & 63;
+
+    // ---- colour -> depth pixel tables of the workgroup (OPS:285-290), as byte offsets into a depth frame ----
+    __shared__ uint16_t lds_dx[W_ + 64];             // columns W .. W+63 repeat 0 .. 63 (lanes that run into the next row)
+    __shared__ uint32_t lds_dy[H_ + 4];
+    for (int k = threadIdx.x; k < W_ + 64; k += kThreads)
+        lds_dx[k] = (uint16_t)(2 * round_clip((double)(k < W_ ? k : k - W_) * a.sx, DW_ - 1));
+    for (int k = threadIdx.x; k < H_ + 4; k += kThreads)
+        lds_dy[k] = (uint32_t)(round_clip((double)(k < H_ ? k : H_ - 1) * a.sy, DH_ - 1) * (DW_ * 2));
+    __shared__ uint32_t lds_px[kThreads / kWave][(kRowGroup + 1) * 64];     // index transpose stage (+ the extra word)
+    __shared__ int red[2][kThreads / kWave];
+    __syncthreads();
+
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = tgroup * (kThreads / kWave) + wave;
+    constexpr uint32_t kBands = (H_ + kRows - 1) / kRows;
+    const uint32_t band = tile / (uint32_t)S;
+    const uint32_t stripe = tile - band * (uint32_t)S;
+    const bool tile_ok = tile < kBands * (uint32_t)S;
+    const uint32_t row0 = band * (uint32_t)kRows;
+    const bool last = stripe == (uint32_t)(S - 1);                        // wave-uniform
+    const int n_groups = tile_ok ? (int)(min((uint32_t)kRows, (uint32_t)H_ - row0) / 4u) : 0;
+
+    // composed matrix, millimetre-scaled, rows 0 / 1 additionally scaled onto the depth grid (us = u * sx, vs = v * sy)
+    const double *__restrict__ U = m1 + MSPA_MAT_UNPROJ * 16;
+    const double *__restrict__ N = m2 + MSPA_MAT_REPROJ * 16;
+    double M[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double row[4];
+        compose_row(N, U, r, row);
+        const double sc = r == 0 ? a.sx : r == 1 ? a.sy : 1.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) M[r][k] = uniform((k < 3 ? row[k] : row[k] * 1000.0) * sc);
+    }
+
+    int n_valid = 0, n_vis = 0;
+    if (n_groups > 0) {
+        const int kRsrcFlags = 0x00020000;
+        __amdgpu_buffer_rsrc_t rs_d1 = __builtin_amdgcn_make_buffer_rsrc((void *)c.depth1, 0, (int)(dpix * 2), kRsrcFlags);
+        __amdgpu_buffer_rsrc_t rs_d2 = __builtin_amdgcn_make_buffer_rsrc((void *)c.depth2, 0, (int)(dpix * 2), kRsrcFlags);
+        __amdgpu_buffer_rsrc_t rs_pix = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.pix_i16 ? a.pix_i16 + 2 * c.obase : nullptr), 0, O::template has<O_PIX>(a.pix_i16) ? (int)(P * 4) : 0,
+            kRsrcFlags);
+        __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.vis_bits ? a.vis_bits + pair * c.words_per_pair : nullptr), 0,
+            O::template has<O_VIS_BITS>(a.vis_bits) ? (int)(c.words_per_pair * 8) : 0, kRsrcFlags);
+        const uint32_t colL = stripe * 64u + (uint32_t)c.lane;             // the lane's column in rows with r mod 4 == 0
+        const uint32_t period0 = row0 >> 2;                                // row0 is a multiple of 4
+        // 16-byte index store of a row group: lane L owns pixels 4 (L & 15) .. + 3 of the word of row j = L >> 4
+        const uint32_t jL = (uint32_t)c.lane >> 4;
+        const uint32_t wordL = (uint32_t)(jL == 0 ? kC[0] : jL == 1 ? kC[1] : jL == 2 ? kC[2] : kC[3]) + stripe;
+        const int pix_voff = (int)((wordL * 64u + ((uint32_t)c.lane & 15u) * 4u) * 4u);
+        const int hi_x = DW_ - 1, hi_y = DH_ - 1;
+        constexpr double DWd = (double)DW_, DHd = (double)DH_;
+        // affine terms of row row0 (off = 0): t_k = M[k][0] * col + M[k][1] * row + M[k][2]
+        const double mxd = (double)colL, myd0 = (double)row0;
+        double t0 = __builtin_fma(M[0][1], myd0, __builtin_fma(M[0][0], mxd, M[0][2]));
+        double t1 = __builtin_fma(M[1][1], myd0, __builtin_fma(M[1][0], mxd, M[1][2]));
+        double t2 = __builtin_fma(M[2][1], myd0, __builtin_fma(M[2][0], mxd, M[2][2]));
+        // wave-uniform per-row steps (SGPR pairs): to the next row of the group, and from row 3 to the next group's row 0
+        double D[4][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            D[0][k] = uniform(M[k][1] + (double)(kOff[1] - kOff[0]) * M[k][0]);
+            D[1][k] = uniform(M[k][1] + (double)(kOff[2] - kOff[1]) * M[k][0]);
+            D[2][k] = uniform(M[k][1] + (double)(kOff[3] - kOff[2]) * M[k][0]);
+            D[3][k] = uniform(M[k][1] + (double)(0 - kOff[3]) * M[k][0]);
+        }
+        double E64[3], Wr[3];                        // 64 columns to the right; one row down and W columns to the left
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            E64[k] = uniform(64.0 * M[k][0]);
+            Wr[k] = uniform(M[k][1] - (double)W_ * M[k][0]);
+        }
+        // The tile body once per kind of stripe (compile-time LAST): a run-time flag inside the row loop would keep both
+        // variants' masks and corrections live at once (52 spilled SGPRs).
+        auto run_tile = [&](auto last_c) {
+            constexpr bool LAST = decltype(last_c)::value;
+            unsigned long long risky_chunks = 0;         // wave-uniform: chunk slots with at least one guarded lane
+            uint32_t bits_lo = 0, bits_hi = 0, rb_lo = 0, rb_hi = 0;   // lane = chunk slot (5 per group in the last stripe, else 4)
+            constexpr int NCH = LAST ? 5 : 4;               // words per row group: the last stripe also owns the 21st word of row 0
+            constexpr int slots_per_group = NCH;
+
+            // one chunk = 64 consecutive pixel indices = one word.  (tk) affine terms of the chunk's lanes, (rowc, colc) the
+            // lanes' pixel, (wrapped) lanes that belong to the next row.  Returns the visibility word; fills pixv / riskw.
+            auto depth1_offset = [&](uint32_t rowu, int col_add, bool may_wrap, bool &wrapped) -> int {
+                const uint32_t colw = colL + (uint32_t)col_add;                          // may run past W in the last stripe
+                wrapped = may_wrap && (colw >= (uint32_t)W_);
+                const uint32_t dyo = wrapped ? lds_dy[rowu + 1] : lds_dy[rowu];
+                return (int)(dyo + (uint32_t)lds_dx[colw]);
+            };
+
+    #pragma unroll 1
+            for (int g = 0; g < n_groups; ++g) {
+                const uint32_t rowg = row0 + 4u * (uint32_t)g;
+                // ---- depth-1 samples of the group's chunks (1-2 cache lines each) ----
+                uint32_t d16[NCH];
+                bool wrapped[NCH];
+    #pragma unroll
+                for (int e = 0; e < NCH; ++e) {
+                    // e = 0..3: rows rowg + e at this stripe; e = 4 (last stripe only): the extra word of row rowg, 64 columns on
+                    const int j = e < 4 ? e : 0;
+                    const int col_add = kOff[j] + (e == 4 ? 64 : 0);
+                    const bool can_wrap = (e == 4) || (kOff[j] + 64 * S > W_);            // compile time: which words straddle a row end
+                    const int off = depth1_offset(rowg + (uint32_t)j, col_add, LAST && can_wrap, wrapped[e]);
+                    d16[e] = __builtin_amdgcn_raw_buffer_load_b16(rs_d1, off, 0, STREAM ? 2 : 0);
+                    asm("" : "+v"(d16[e]));
+                }
+                // ---- stage 1 ----
+                double u[NCH], v[NCH], qz[NCH];
+                unsigned long long vmk[NCH], ivm[NCH];
+                unsigned long long any = 0;
+                double t0e = 0, t1e = 0, t2e = 0;
+    #pragma unroll
+                for (int e = 0; e < NCH; ++e) {
+                    double a0 = t0, a1 = t1, a2 = t2;
+                    if (e == 4) {                         // 64 columns to the right of the row-0 chunk
+                        a0 = t0e; a1 = t1e; a2 = t2e;
+                    }
+                    const bool can_wrap = (e == 4) || (kOff[e < 4 ? e : 0] + 64 * S > W_);
+                    if (LAST && can_wrap) {               // lanes past the end of the row are pixels of the next row
+                        const bool w = wrapped[e];
+                        a0 = w ? a0 + Wr[0] : a0;
+                        a1 = w ? a1 + Wr[1] : a1;
+                        a2 = w ? a2 + Wr[2] : a2;
+                    }
+                    const double dmm = (double)d16[e];
+                    const double ix = __builtin_fma(a0, dmm, M[0][3]);
+                    const double iy = __builtin_fma(a1, dmm, M[1][3]);
+                    const double iz = __builtin_fma(a2, dmm, M[2][3]);
+                    if (e < 4) {                          // step to the next row of the group (or to the next group)
+                        if (LAST && e == 0) { t0e = t0 + E64[0]; t1e = t1 + E64[1]; t2e = t2 + E64[2]; }
+                        t0 += D[e][0];
+                        t1 += D[e][1];
+                        t2 += D[e][2];
+                    }
+                    double rz = __builtin_amdgcn_rcp(iz);
+                    rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
+                    u[e] = ix * rz;                       // depth-grid units
+                    v[e] = iy * rz;
+                    qz[e] = iz;
+                    vmk[e] = ballot64(d16[e] != 0u);
+                    ivm[e] = vmk[e] & ballot64(u[e] > -kGuardPx) & ballot64(u[e] < DWd + kGuardPx) & ballot64(v[e] > -kGuardPx) &
+                             ballot64(v[e] < DHd + kGuardPx) & ballot64(iz > -kGuardZmm);
+                    any |= ivm[e];
+                }
+                unsigned long long vm[NCH] = {};
+                const int slot0 = g * slots_per_group;
+                const uint32_t wbase = (period0 + (uint32_t)g) * (uint32_t)kPeriodWords;     // word of (rowg, column 0)
+                if (any == 0) {
+                    if (O::template has<O_PIX>(a.pix_i16)) {
+                        const u32x4_t none = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                        buffer_store_b128_guarded(none, rs_pix, pix_voff, (int)(wbase * 256u));
+                        if (LAST) __builtin_amdgcn_raw_buffer_store_b32(0xFFFFFFFFu, rs_pix, (int)((uint32_t)c.lane * 4u),
+                                                                        (int)((wbase + (uint32_t)S) * 256u), 0);
+                    }
+                } else {
+                    int pix[NCH];
+                    uint32_t dv16[NCH];
+                    unsigned long long rkc[NCH];
+    #pragma unroll
+                    for (int e = 0; e < NCH; ++e) {
+                        const double ru = __builtin_rint(u[e]), rv = __builtin_rint(v[e]);
+                        const int xi = med3_0((int)ru, hi_x);
+                        const int yi = med3_0((int)rv, hi_y);
+                        dv16[e] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, (int)(__umul24((uint32_t)yi, (uint32_t)(DW_ * 2)) + ((uint32_t)xi << 1)), 0, 0);
+                        pix[e] = (int)((uint32_t)xi | ((uint32_t)yi << 16));
+                        const double wu = __builtin_fabs(u[e] - ru) - 0.25;
+                        const double wv = __builtin_fabs(v[e] - rv) - 0.25;
+                        rkc[e] = ballot64(!(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx)) |
+                                 ballot64(!(qz[e] > kGuardZmm));
+                    }
+                    unsigned long long rbm[NCH];
+    #pragma unroll
+                    for (int e = 0; e < NCH; ++e) {
+                        const bool inview = __builtin_amdgcn_inverse_ballot_w64(ivm[e]);
+                        const double sd = qz[e] - (double)dv16[e];
+                        vm[e] = ivm[e] & ballot64(sd < 0.0);
+                        rbm[e] = ivm[e] & (rkc[e] | ballot64(!(__builtin_fabs(sd) > kGuardZmm)));
+                        if (O::template has<O_PIX>(a.pix_i16)) lds_px[wave][e * 64 + c.lane] = (uint32_t)(inview ? pix[e] : -1);
+                    }
+                    unsigned long long rb_any = 0;
+    #pragma unroll
+                    for (int e = 0; e < NCH; ++e) rb_any |= rbm[e];
+                    if (rb_any) {
+    #pragma unroll
+                        for (int e = 0; e < NCH; ++e)
+                            if (rbm[e]) {
+                                writelane64(rbm[e], slot0 + e, rb_lo, rb_hi);
+                                risky_chunks |= 1ull << (slot0 + e);
+                            }
+                    }
+                    if (O::template has<O_PIX>(a.pix_i16)) {
+                        const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][c.lane * 4]);
+                        buffer_store_b128_guarded(q, rs_pix, pix_voff, (int)(wbase * 256u));
+                        if (LAST) __builtin_amdgcn_raw_buffer_store_b32(lds_px[wave][4 * 64 + c.lane], rs_pix, (int)((uint32_t)c.lane * 4u),
+                                                                        (int)((wbase + (uint32_t)S) * 256u), 0);
+                    }
+                }
+    #pragma unroll
+                for (int e = 0; e < NCH; ++e) {
+                    n_valid += __popcll(vmk[e]);
+                    n_vis += __popcll(vm[e]);
+                    writelane64(vm[e], slot0 + e, bits_lo, bits_hi);
+                }
+            }
+
+            // chunk slot -> (word within the pair, row of its first lane, column of its first lane)
+            auto slot_word = [&](int slot, uint32_t &row, uint32_t &col0) -> uint32_t {
+                const int g = slot / slots_per_group, e = slot - g * slots_per_group;
+                const int j = e < 4 ? e : 0;
+                row = row0 + 4u * (uint32_t)g + (uint32_t)j;
+                col0 = stripe * 64u + (uint32_t)kOff[j] + (e == 4 ? 64u : 0u);
+                return (period0 + (uint32_t)g) * (uint32_t)kPeriodWords + (uint32_t)kC[j] + stripe + (e == 4 ? 1u : 0u);
+            };
+            // ---- cold loop: chunks with guarded lanes are re-evaluated with the exact chain ----
+            if (risky_chunks) {
+                __builtin_amdgcn_s_waitcnt(0);
+                while (risky_chunks) {
+                    const int slot = __builtin_amdgcn_readfirstlane(__builtin_ctzll(risky_chunks));
+                    risky_chunks &= risky_chunks - 1ull;
+                    const unsigned long long rb = readlane64(rb_lo, rb_hi, slot);
+                    const unsigned long long old = readlane64(bits_lo, bits_hi, slot);
+                    uint32_t row, col0;
+                    const uint32_t w = slot_word(slot, row, col0);
+                    uint32_t col = col0 + (uint32_t)c.lane;
+                    if (col >= (uint32_t)W_) { col -= (uint32_t)W_; row += 1; }
+                    const uint32_t i = w * 64u + (uint32_t)c.lane;                       // == row * W + col
+                    const bool mine = (rb >> c.lane) & 1ull;
+                    bool vis = (old >> c.lane) & 1ull;
+                    if (mine) {
+                        const uint32_t dd = c.depth1[round_clip((double)row * a.sy, DH_ - 1) * DW_ + round_clip((double)col * a.sx, DW_ - 1)];
+                        Pixel p;
+                        exact_unproject(m1, (double)col, (double)row, (double)dd * 0.001, p.ax, p.ay, p.az);
+                        exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
+                        p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, DH_, DW_, H_, W_, a.sx, a.sy, p.xi, p.yi, &p.inview);
+                        vis = p.vis;
+                        store_pixel<O, true>(a, c, i, true, true, p);
+                    }
+                    const unsigned long long fresh = ballot64(vis);
+                    n_vis += __popcll(fresh) - __popcll(old);
+                    writelane64(fresh, slot, bits_lo, bits_hi);
+                }
+            }
+            // the tile's visibility words: lane = chunk slot
+            if (O::template has<O_VIS_BITS>(a.vis_bits) && c.lane < n_groups * slots_per_group) {
+                uint32_t row, col0;
+                const uint32_t w = slot_word(c.lane, row, col0);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{bits_lo, bits_hi}, rs_bits, (int)(w * 8u), 0, 0);
+            }
+        };
+        if (last) run_tile(std::true_type{});
+        else run_tile(std::false_type{});
+    }
+    if (O::template has<O_COUNTS>(a.counts)) {
+        if (c.lane == 0) {
+            red[0][wave] = n_valid;
+            red[1][wave] = n_vis;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int sv = 0, ss = 0;
+            for (int j = 0; j < kThreads / kWave; ++j) {
+                sv += red[0][j];
+                ss += red[1][j];
+            }
+            atomicAdd(a.counts + 2 * pair + 0, sv);
+            atomicAdd(a.counts + 2 * pair + 1, ss);
+        }
+    }
+}
+
 }  // namespace mspa
 
 using namespace mspa;
@@ -1164,7 +1493,15 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
                          (((uintptr_t)out_vis_bits & 7u) == 0);
     const bool tight24 = fast && ident && aligned && (W % 64 == 0) && (H % kTightRows == 0) && (P * 4 < (1ull << 31)) &&
                          (set == kSetCorr || set == kSetDense || set == kSetMinimal);
-    if (fast) {
+    // ScanNet's own shape (1296 x 968 colour over 640 x 480 depth) has a kernel of its own
+    const bool scaled = fast && !tight24 && aligned && W == 1296 && H == 968 && dw == 640 && dh == 480 &&
+                        (set == kSetCorr || set == kSetMinimal);
+    if (scaled) {
+        a.n_stripes = 1296 / 64;
+        a.n_tiles = a.n_stripes * ((968 + 47) / 48);
+        a.stripe_magic = 0;
+        a.strips = (a.n_tiles + (kThreads / kWave) - 1) / (kThreads / kWave);
+    } else if (fast) {
         const int tile_rows = tight24 ? kTightRows : kTileRows;
         a.n_stripes = (W + 63) / 64;
         a.n_tiles = linear ? (int)((P + (int64_t)kTileRows * 64 - 1) / ((int64_t)kTileRows * 64))
@@ -1181,11 +1518,19 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
     if (blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_pair_reproject: too many workgroups; split the batch");
     const dim3 grid((uint32_t)blocks), block(kThreads);
     g_last_pair_kernel = !fast ? MSPA_KERNEL_PAIR_EXACT
+                         : scaled ? MSPA_KERNEL_PAIR_FAST_SCALED
                          : tight24 ? MSPA_KERNEL_PAIR_FAST_TIGHT
                          : linear ? MSPA_KERNEL_PAIR_FAST_LINEAR : MSPA_KERNEL_PAIR_FAST;
     if (!fast) {
         if (ident) hipLaunchKernelGGL(pair_exact_kernel<true>, grid, block, 0, s, depth, rgb, frame_mats, pairs, a);
         else hipLaunchKernelGGL(pair_exact_kernel<false>, grid, block, 0, s, depth, rgb, frame_mats, pairs, a);
+    } else if (scaled) {
+        const bool st = (flags & MSPA_PAIR_STREAM) != 0;
+#define MSPA_LAUNCH_SCALED(SET_, ST_) \
+    hipLaunchKernelGGL((pair_fast_scaled_kernel<1296, 968, 640, 480, SET_, ST_>), grid, block, 0, s, depth, rgb, frame_mats, pairs, a)
+        if (set == kSetCorr) { if (st) MSPA_LAUNCH_SCALED(kSetCorr, true); else MSPA_LAUNCH_SCALED(kSetCorr, false); }
+        else { if (st) MSPA_LAUNCH_SCALED(kSetMinimal, true); else MSPA_LAUNCH_SCALED(kSetMinimal, false); }
+#undef MSPA_LAUNCH_SCALED
     } else if (tight24) {
 #define MSPA_LAUNCH_TIGHT(SET_) \
     do { \

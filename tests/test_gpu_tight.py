@@ -232,3 +232,68 @@ def test_kernels_reproduce_reference_at_640x480(g640):
                     assert np.array_equal(np.packbits(res["vis_u8"][n], bitorder="little"), g[f"pair{n}_vis_bits"]), tag
                 if "pix_i16" in res:
                     assert sha(res["pix_i16"][n]) == str(g[f"pair{n}_sha_pix"]), tag
+
+
+# ---- ScanNet's own shape: 1296 x 968 colour over 640 x 480 depth (pair_fast_scaled_kernel) ---------------------
+SCANNET_HW, SCANNET_DHW = (968, 1296), (480, 640)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stream", [False, True], ids=["plain", "stream"])
+@pytest.mark.parametrize("name", ["corr", "minimal"])
+def test_scaled_kernel_equals_exact_on_adversarial_poses(name, stream):
+    """The kernel specialised for ScanNet's shape (wobbling stripes, row-straddling words in the last stripe, both grid
+    scalings) against the exact kernel: 96 adversarial pairs + identity pairs, every integer output."""
+    rng = np.random.default_rng(99)
+    K, A, E = adversarial_pairs(rng, 12, SCANNET_HW)
+    Kd = K.copy()
+    Kd[0] *= SCANNET_DHW[1] / SCANNET_HW[1]
+    Kd[1] *= SCANNET_DHW[0] / SCANNET_HW[0]
+    boxes = synth._make_boxes(rng)
+    depth_np = []
+    for e in E:
+        z = synth.render_depth(A @ e, Kd, SCANNET_DHW, boxes)
+        mm = np.clip(np.rint(z * 1000.0 + rng.normal(0, 4.0, z.shape)), 0, 65535).astype(np.uint16)
+        mm[rng.random(mm.shape) < 0.07] = 0
+        depth_np.append(mm)
+    depth = engine.depth_to_device(np.stack(depth_np), DEV)
+    mats = torch.from_numpy(engine.frame_matrices(K, A, E)).to(DEV)
+    pair_np = np.stack([rng.integers(0, len(E), 96), rng.integers(0, len(E), 96)], 1).astype(np.int32)
+    pair_np[:12] = np.arange(12)[:, None]
+    pairs = torch.from_numpy(pair_np).to(DEV)
+    flags = _lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0)
+    outs = SETS[name]
+    fast = engine.alloc_pair_outputs(len(pair_np), SCANNET_HW, outs, DEV)
+    exact = engine.alloc_pair_outputs(len(pair_np), SCANNET_HW, outs, DEV)
+    for t in fast.values():
+        t.fill_(23)
+    engine.pair_reproject(depth, mats, pairs, SCANNET_HW, fast, flags=flags)
+    assert _lib.load().mspa_pair_reproject_last_kernel() == _lib.KERNEL_PAIR_FAST_SCALED
+    engine.pair_reproject(depth, mats, pairs, SCANNET_HW, exact, flags=0)
+    assert _lib.load().mspa_pair_reproject_last_kernel() == _lib.KERNEL_PAIR_EXACT
+    torch.cuda.synchronize()
+    for k in outs:
+        if not torch.equal(fast[k], exact[k]):
+            bad = (fast[k] != exact[k]).reshape(len(pair_np), -1).any(dim=1).nonzero().flatten().tolist()
+            raise AssertionError(f"{name}/{'stream' if stream else 'plain'}: {k} differs from the exact kernel in pairs {bad[:8]}")
+    assert int(exact["counts"][:, 1].sum()) > 100000
+
+
+@pytest.mark.gpu
+def test_scaled_kernel_reproduces_reference_digest():
+    """tests/golden/scannet_shape.npz: the reference's visibility mask of the full-frame pair (SHA-256 over the valid rows)."""
+    g = GoldenScene("scannet_shape")
+    f0, f1 = (str(x) for x in g["pair_ids"][0])
+    depth = engine.depth_to_device(np.stack([g.depth[f0], g.depth[f1]]), DEV)
+    mats = torch.from_numpy(engine.frame_matrices(g.K, g.A, [g.E[f0], g.E[f1]])).to(DEV)
+    pairs = torch.tensor([[0, 1], [1, 0]], dtype=torch.int32, device=DEV)
+    P = g.color_hw[0] * g.color_hw[1]
+    ex, _ = launch(depth, mats, None, pairs, g.color_hw, ("valid_u8", "vis_bits", "pix_i16", "counts"), 0)
+    for stream in (False, True):
+        res, kern = launch(depth, mats, None, pairs, g.color_hw, SETS["corr"], _lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0))
+        assert kern == _lib.KERNEL_PAIR_FAST_SCALED
+        valid = ex["valid_u8"][0].astype(bool)
+        vis = unpack_bits(res["vis_bits"][0], P)
+        assert sha(vis[valid]) == str(g["pair_sha_vis"]) and int(vis.sum()) == int(g["pair_n_vis"]) == int(res["counts"][0, 1])
+        for k in ("vis_bits", "pix_i16", "counts"):
+            assert np.array_equal(res[k], ex[k]), k
