@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MSPA_VERSION 120            /* 0.2.0: + mspa_pair_reproject_last_kernel; K2 tiled; K1 composed/guarded */
+#define MSPA_VERSION 120            /* 0.2.0: + mspa_pair_reproject_last_kernel, tiled K2 (mspa_scene_overlap, mspa_overlap_matrix), K9 bitset -> index lists */
 
 #define MSPA_OK 0
 #define MSPA_EINVAL (-1)            /* bad argument (null pointer, size out of range, ...) */
@@ -186,6 +186,22 @@ int mspa_scene_overlap(const uint64_t *bits, int32_t n_images, int64_t n_words, 
                        mspa_stream_t stream);
 int mspa_overlap_matrix(const uint64_t *bits_a, int32_t n_a, const uint64_t *bits_b, int32_t n_b, int64_t n_words,
                         void *workspace, int64_t workspace_bytes, int32_t *out_inter, mspa_stream_t stream);
+
+/*
+ * K9 -- visibility bitsets -> index lists on the device: what MVI.process_scene (make_visibility_info.py:103-118) builds as
+ * Python lists -- np.where(mask)[0].tolist() per image, and per vertex the sorted ids of the images that see it -- as CSR
+ * tables.  The second table is the compaction of the TRANSPOSED bit matrix.
+ *   mspa_bits_popcount   out_counts[i] = popcount(bits[i]) over a flat table of n_words_total words
+ *   mspa_bits_expand     bits [n_rows, n_words]; word_offsets [n_rows * n_words] int64 = exclusive prefix sum of the
+ *                        popcounts (row r's list starts at word_offsets[r * n_words]); out_indices[k] int32 = position of
+ *                        the k-th set bit WITHIN ITS ROW, rows back to back, ascending within a row
+ *   mspa_bits_transpose  bits [n_rows, n_words] -> out [n_words * 64, ceil(n_rows / 64)]: bit (r & 63) of
+ *                        out[c, r >> 6] = bit (c & 63) of bits[r, c >> 6]; padding bits are zero
+ */
+int mspa_bits_popcount(const uint64_t *bits, int64_t n_words_total, int32_t *out_counts, mspa_stream_t stream);
+int mspa_bits_expand(const uint64_t *bits, int64_t n_rows, int64_t n_words, const int64_t *word_offsets,
+                     int32_t *out_indices, mspa_stream_t stream);
+int mspa_bits_transpose(const uint64_t *bits, int32_t n_rows, int64_t n_words, uint64_t *out, mspa_stream_t stream);
 
 /*
  * K4 -- per-pair camera relations: the distance / yaw / pitch columns of CFR.process_scene's pair

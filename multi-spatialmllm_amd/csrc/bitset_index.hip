@@ -1,0 +1,112 @@
+// K9: visibility bitsets -> index lists, on the device.
+//
+// MVI.process_scene (make_visibility_info.py:103-118) turns every image's visibility mask into
+// `np.where(mask)[0].tolist()` and, per vertex, collects the sorted ids of the images that see it.  With K1's bitsets
+// ([n_images, ceil(N/64)] uint64) both are compactions of a bit matrix -- the second one of its transpose -- and
+// neither needs a Python list: the results are CSR tables (row offsets + int32 indices) that go to arrow / parquet as
+// columns (mspa/visindex.py).
+//
+//   mspa_bits_popcount   per-word popcounts (their exclusive prefix sum -- one cumsum of the host layer -- positions
+//                        every set bit in the output)
+//   mspa_bits_expand     a wave walks 64 words; for each word lane L owns bit L and writes its index at
+//                        base(word) + popcount(word & lanes below L): consecutive positions, coalesced stores
+//   mspa_bits_transpose  64 x 64 bit tiles through ballots: lane r holds row r's word, ballot(bit b of my word) IS row b of
+//                        the transposed tile (lane b keeps it)
+#include "mspa_common.h"
+
+namespace mspa {
+
+constexpr int kBThreads = 256;
+
+__global__ __launch_bounds__(kBThreads) void bits_popcount_kernel(const uint64_t *__restrict__ bits, int64_t n, int32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBThreads + threadIdx.x;
+    if (i < n) out[i] = __popcll(bits[i]);
+}
+
+// one wave per 64 consecutive words of the flat [n_rows * n_words] table
+__global__ __launch_bounds__(kBThreads) void bits_expand_kernel(const uint64_t *__restrict__ bits, int64_t n_total, int64_t n_words,
+                                                                const int64_t *__restrict__ word_offsets,
+                                                                int32_t *__restrict__ out) {
+    const int64_t w0 = ((int64_t)blockIdx.x * (kBThreads / kWave) + (threadIdx.x >> 6)) * kWave;
+    if (w0 >= n_total) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t wi = w0 + lane;
+    const bool live = wi < n_total;
+    const uint64_t mine = live ? bits[wi] : 0ull;
+    const int64_t base = live ? word_offsets[wi] : 0;
+    const uint32_t col = live ? (uint32_t)(wi % n_words) : 0u;                  // word index within its row
+    const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
+    const uint32_t blo = (uint32_t)base, bhi = (uint32_t)((uint64_t)base >> 32);
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;        // lanes (= bits) below this one
+    const int n_here = (int)min((int64_t)kWave, n_total - w0);
+    for (int k = 0; k < n_here; ++k) {                                            // wave-uniform trip count
+        const unsigned long long word = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mlo, k) |
+                                        ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mhi, k) << 32);
+        if (word == 0) continue;                                                  // uniform
+        const int64_t b = (int64_t)((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)blo, k) |
+                                    ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)bhi, k) << 32));
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)col, k);
+        if ((word >> lane) & 1ull) out[b + __popcll(word & below)] = (int32_t)(c * 64u + (uint32_t)lane);
+    }
+}
+
+// out[(64 wq + b), rq] bit r  =  in[(64 rq + r), wq] bit b
+__global__ __launch_bounds__(kBThreads) void bits_transpose_kernel(const uint64_t *__restrict__ in, int n_rows, int64_t n_words,
+                                                                   int64_t row_blocks, uint64_t *__restrict__ out) {
+    const int64_t tile = (int64_t)blockIdx.x * (kBThreads / kWave) + (threadIdx.x >> 6);
+    if (tile >= n_words * row_blocks) return;
+    const int64_t wq = tile / row_blocks, rq = tile - wq * row_blocks;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = rq * 64 + lane;
+    const uint64_t mine = r < n_rows ? in[r * n_words + wq] : 0ull;
+    uint64_t mineT = 0;
+#pragma unroll 8
+    for (int b = 0; b < 64; ++b) {
+        const unsigned long long t = __builtin_amdgcn_ballot_w64(((mine >> b) & 1ull) != 0);   // row b of the transposed tile
+        mineT = (lane == b) ? t : mineT;
+    }
+    out[(wq * 64 + lane) * row_blocks + rq] = mineT;
+}
+
+}  // namespace mspa
+
+using namespace mspa;
+
+extern "C" int mspa_bits_popcount(const uint64_t *bits, int64_t n_words_total, int32_t *out_counts, mspa_stream_t stream) {
+    if (n_words_total < 0) return fail(MSPA_EINVAL, "mspa_bits_popcount: bad size");
+    if (n_words_total == 0) return MSPA_OK;
+    if (!bits || !out_counts) return fail(MSPA_EINVAL, "mspa_bits_popcount: null pointer");
+    const int64_t blocks = (n_words_total + kBThreads - 1) / kBThreads;
+    if (blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_bits_popcount: table too large; split it");
+    hipLaunchKernelGGL(bits_popcount_kernel, dim3((uint32_t)blocks), dim3(kBThreads), 0, (hipStream_t)stream, bits, n_words_total,
+                       out_counts);
+    return check_hip(hipGetLastError(), "bits_popcount_kernel launch");
+}
+
+extern "C" int mspa_bits_expand(const uint64_t *bits, int64_t n_rows, int64_t n_words, const int64_t *word_offsets,
+                                int32_t *out_indices, mspa_stream_t stream) {
+    if (n_rows < 0 || n_words < 0) return fail(MSPA_EINVAL, "mspa_bits_expand: bad size");
+    if (n_rows == 0 || n_words == 0) return MSPA_OK;
+    if (!bits || !word_offsets || !out_indices) return fail(MSPA_EINVAL, "mspa_bits_expand: null pointer");
+    if (n_words > (1LL << 25)) return fail(MSPA_EINVAL, "mspa_bits_expand: rows longer than 2^31 bits");
+    const int64_t total = n_rows * n_words;
+    const int64_t waves = (total + kWave - 1) / kWave;
+    const int64_t blocks = (waves + (kBThreads / kWave) - 1) / (kBThreads / kWave);
+    if (blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_bits_expand: table too large; split it");
+    hipLaunchKernelGGL(bits_expand_kernel, dim3((uint32_t)blocks), dim3(kBThreads), 0, (hipStream_t)stream, bits, total, n_words,
+                       word_offsets, out_indices);
+    return check_hip(hipGetLastError(), "bits_expand_kernel launch");
+}
+
+extern "C" int mspa_bits_transpose(const uint64_t *bits, int32_t n_rows, int64_t n_words, uint64_t *out, mspa_stream_t stream) {
+    if (n_rows < 0 || n_words < 0) return fail(MSPA_EINVAL, "mspa_bits_transpose: bad size");
+    if (n_rows == 0 || n_words == 0) return MSPA_OK;
+    if (!bits || !out) return fail(MSPA_EINVAL, "mspa_bits_transpose: null pointer");
+    const int64_t row_blocks = ((int64_t)n_rows + 63) / 64;
+    const int64_t tiles = n_words * row_blocks;
+    const int64_t blocks = (tiles + (kBThreads / kWave) - 1) / (kBThreads / kWave);
+    if (blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_bits_transpose: table too large; split it");
+    hipLaunchKernelGGL(bits_transpose_kernel, dim3((uint32_t)blocks), dim3(kBThreads), 0, (hipStream_t)stream, bits, (int)n_rows,
+                       n_words, row_blocks, out);
+    return check_hip(hipGetLastError(), "bits_transpose_kernel launch");
+}

@@ -42,6 +42,9 @@ _SIGNATURES = {
     "mspa_overlap_workspace_bytes": (c_int64, [c_int32, c_int32, c_int64]),
     "mspa_scene_overlap": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mspa_overlap_matrix": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mspa_bits_popcount": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "mspa_bits_expand": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "mspa_bits_transpose": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
     "mspa_check_visibility": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "mspa_pair_pose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p,

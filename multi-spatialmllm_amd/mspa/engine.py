@@ -249,6 +249,44 @@ def overlap_matrix(bits_a: torch.Tensor, bits_b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def bitset_csr(bits: torch.Tensor):
+    """K9: rows of a bit matrix -> CSR of their set bits.  bits [R, n_words] int64 (device) -> (offsets [R+1] int64,
+    indices [nnz] int32), both on the device; row r's set-bit positions, ascending, are indices[offsets[r]:offsets[r+1]]."""
+    _require_gpu()
+    lib = _lib.load()
+    _require(bits.dtype == torch.int64 and bits.dim() == 2 and bits.is_contiguous() and bits.is_cuda,
+             "bits: contiguous device int64 [rows, n_words]")
+    R, n_words = bits.shape
+    dev = bits.device
+    if R == 0 or n_words == 0:
+        return torch.zeros((R + 1,), dtype=torch.int64, device=dev), torch.zeros((0,), dtype=torch.int32, device=dev)
+    counts = torch.empty((R * n_words,), dtype=torch.int32, device=dev)
+    _lib.check(lib.mspa_bits_popcount(bits.data_ptr(), R * n_words, counts.data_ptr(), _stream_ptr()))
+    incl = torch.cumsum(counts, dim=0, dtype=torch.int64)              # torch as plumbing: one prefix sum
+    word_offsets = (incl - counts).contiguous()
+    total = int(incl[-1].item())
+    indices = torch.empty((total,), dtype=torch.int32, device=dev)
+    if total:
+        _lib.check(lib.mspa_bits_expand(bits.data_ptr(), R, n_words, word_offsets.data_ptr(), indices.data_ptr(), _stream_ptr()))
+    offsets = torch.cat([word_offsets[::n_words], incl[-1:]])
+    return offsets, indices
+
+
+def bits_transpose(bits: torch.Tensor) -> torch.Tensor:
+    """K9: [R, n_words] int64 bit matrix -> its transpose [n_words * 64, ceil(R / 64)] (padding bits zero)."""
+    _require_gpu()
+    lib = _lib.load()
+    _require(bits.dtype == torch.int64 and bits.dim() == 2 and bits.is_contiguous() and bits.is_cuda,
+             "bits: contiguous device int64 [rows, n_words]")
+    R, n_words = bits.shape
+    out = torch.empty((n_words * 64, (R + 63) // 64), dtype=torch.int64, device=bits.device)
+    if R and n_words:
+        _lib.check(lib.mspa_bits_transpose(bits.data_ptr(), R, n_words, out.data_ptr(), _stream_ptr()))
+    else:
+        out.zero_()
+    return out
+
+
 def extract_yaw_pitch_host(E_aligned_list: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
     """Per-frame angles exactly as CFR:86-100 computes them (NumPy on the host: F values per scene,
     and the reference's own libm calls are the only way to be bit-identical with it)."""

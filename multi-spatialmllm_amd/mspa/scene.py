@@ -81,11 +81,11 @@ class SceneOnDevice:
     def frames_relations(self) -> Dict[Tuple[str, str], Dict[str, float]]:
         """{(id1, id2): {overlap, distance, yaw, pitch}} for all i < j in key order (CFR:176-189)."""
         t = self.frames_relations_arrays()
-        table = {}
-        for n, (i, j) in enumerate(zip(t["i"], t["j"])):
-            table[(self.ids[i], self.ids[j])] = {"overlap": np.float64(t["overlap"][n]), "distance": np.float64(t["distance"][n]),
-                                                 "yaw": np.float64(t["yaw"][n]), "pitch": np.float64(t["pitch"][n])}
-        return table
+        # one pass over plain Python lists (tolist) instead of a NumPy scalar per value: 8 064 pairs in ~6 ms instead of 100
+        ids = self.ids
+        keys = zip([ids[i] for i in t["i"].tolist()], [ids[j] for j in t["j"].tolist()])
+        return {k: {"overlap": o, "distance": d, "yaw": y, "pitch": p}
+                for k, o, d, y, p in zip(keys, t["overlap"].tolist(), t["distance"].tolist(), t["yaw"].tolist(), t["pitch"].tolist())}
 
     def empty_frames(self) -> List[str]:
         """Frames that see no vertex at all (the reference logs them, CFR:159-161 / MVI:110-113)."""
@@ -93,31 +93,21 @@ class SceneOnDevice:
         return [k for k, c in zip(self.ids, cnt) if c == 0]
 
     # ---- MVI.process_scene ------------------------------------------------------------------
+    def visibility_csr(self):
+        """The visibility index as two CSR tables compacted on the device (mspa/visindex.py): what ``run_split`` streams to
+        parquet without ever building a Python list."""
+        from . import visindex
+        if self.xyz is None:
+            raise ValueError("scene uploaded without vertices")
+        n = int(self.xyz.shape[0])
+        if not self.ids or n == 0:                                  # MVI:103-123 with nothing to loop over
+            return visindex.from_bits(None, self.ids, n)
+        return visindex.from_bits(self._visibility()["bits"], self.ids, n)
+
     def visibility_index(self) -> Dict[str, dict]:
-        """{"image_to_points": {img: [idx...]}, "point_to_images": {idx: [img...]}} (MVI:103-123)."""
-        if not self.ids:                                           # MVI:103-123 with no valid frame: every vertex unseen
-            n = 0 if self.xyz is None else int(self.xyz.shape[0])
-            return {"image_to_points": {}, "point_to_images": {v: [] for v in range(n)}}
-        mask = self.vertex_visibility(("mask",))["mask"]
-        n = mask.shape[1]
-        image_to_points = {}
-        nz = torch.nonzero(mask)                                  # row-major: (image, point) ascending
-        img = nz[:, 0].cpu().numpy()
-        pt = nz[:, 1].cpu().numpy()
-        bounds = np.searchsorted(img, np.arange(len(self.ids) + 1))
-        for k, image_id in enumerate(self.ids):
-            image_to_points[image_id] = pt[bounds[k]:bounds[k + 1]].tolist()
-        order = np.lexsort((img, pt))                             # by point, then image index
-        pt_s, img_s = pt[order], img[order]
-        pb = np.searchsorted(pt_s, np.arange(n + 1))
-        # image ids are zero-padded strings, so index order == sorted() order whenever the ids are sorted;
-        # sort explicitly otherwise (MVI:117 uses sorted())
-        sorted_ids = self.ids == sorted(self.ids)
-        point_to_images = {}
-        for v in range(n):
-            lst = [self.ids[k] for k in img_s[pb[v]:pb[v + 1]]]
-            point_to_images[v] = lst if sorted_ids else sorted(lst)
-        return {"image_to_points": image_to_points, "point_to_images": point_to_images}
+        """{"image_to_points": {img: [idx...]}, "point_to_images": {idx: [img...]}} (MVI:103-123): the reference's nested
+        dict, built from the CSR tables (image ids per vertex in sorted() order, MVI:117)."""
+        return self.visibility_csr().to_dict()
 
     # ---- correspondence primitives (VC_C:280-344) ---------------------------------------------
     def common_visible_points(self, image_id1: str, image_id2: str) -> np.ndarray:

@@ -48,6 +48,18 @@ def process_scene(scene_id, scene_infos, warning_file):
     return scene_id, result
 
 
+def process_scene_columns(scene_id, scene_infos, warning_file):
+    """The same index as two CSR tables compacted on the device (mspa.visindex.VisibilityCSR): what ``run_split`` streams to
+    parquet.  Empty images are logged exactly as ``process_scene`` logs them."""
+    print(f"[process_scene] Start: {scene_id}")
+    csr = scene_infos.scene_on_device(scene_id).visibility_csr()
+    for image_id in csr.empty_images():
+        with open(warning_file, "a") as f:
+            f.write(f"[Warning] {scene_id}: {image_id} has no in-bound points.\n")
+    print(f"[process_scene] Done: {scene_id}")
+    return csr
+
+
 def run_split(scene_info_path, output_file, warning_file, num_workers=8, keep=True):
     """Visibility index of every scene of a split -> ``output_file`` (.parquet in the readers' format, or
     .pkl as the nested dict).  ``num_workers`` is accepted and ignored (GPU loop); ``keep=False`` drops each scene's
@@ -76,10 +88,12 @@ def run_split(scene_info_path, output_file, warning_file, num_workers=8, keep=Tr
         writer, n = None, 0
         try:
             for scene_id in all_scene_ids:
-                _, vis = process_scene(scene_id, scene_infos, warning_file)
+                # columns all the way: bitsets -> CSR on the device -> JSON text by arrow compute kernels; the nested dict is
+                # only built when the caller wants it back
+                csr = process_scene_columns(scene_id, scene_infos, warning_file)
                 if keep:
-                    scene_visibility_dict[scene_id] = vis
-                table = pa.Table.from_pandas(visibility_dict_to_frame({scene_id: vis}), preserve_index=False)
+                    scene_visibility_dict[scene_id] = csr.to_dict()
+                table = csr.to_arrow(scene_id)
                 if writer is None:
                     writer = pq.ParquetWriter(output_file, table.schema)
                 writer.write_table(table)

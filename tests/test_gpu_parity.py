@@ -473,6 +473,52 @@ def test_scene_overlap_tiled(F, n_bits):
     assert np.array_equal(sym, masks.astype(np.int64) @ masks.astype(np.int64).T)
 
 
+@pytest.mark.parametrize("R,n_bits", [(1, 64), (5, 700), (64, 4096 + 64), (70, 131072), (320, 8192 + 64 * 5)])
+def test_bitset_csr_and_transpose(R, n_bits):
+    """K9: device-side compaction of a bit matrix and of its transpose == np.nonzero, row by row."""
+    rng = np.random.default_rng(R * 7 + n_bits)
+    masks = rng.random((R, n_bits)) < rng.random((R, 1)) * 0.3
+    masks[R // 2] = False
+    masks[0, :3] = True
+    masks[-1, -1] = True
+    n_words = (n_bits + 63) // 64
+    padded = np.zeros((R, n_words * 64), dtype=bool)
+    padded[:, :n_bits] = masks
+    bits = torch.from_numpy(np.ascontiguousarray(np.packbits(padded, axis=1, bitorder="little").view(np.int64))).to(DEV)
+    off, idx = engine.bitset_csr(bits)
+    torch.cuda.synchronize()
+    off, idx = off.cpu().numpy(), idx.cpu().numpy()
+    assert off.shape == (R + 1,) and off[0] == 0 and off[-1] == masks.sum() == len(idx)
+    for r in range(R):
+        assert np.array_equal(idx[off[r]:off[r + 1]], np.nonzero(masks[r])[0])
+    t = engine.bits_transpose(bits)
+    torch.cuda.synchronize()
+    assert tuple(t.shape) == (n_words * 64, (R + 63) // 64)
+    tb = np.unpackbits(t.cpu().numpy().view(np.uint8), axis=1, bitorder="little")
+    assert np.array_equal(tb[:n_bits, :R].astype(bool), masks.T) and not tb[:, R:].any() and not tb[n_bits:].any()
+    off2, idx2 = engine.bitset_csr(t[:n_bits].contiguous())
+    off2, idx2 = off2.cpu().numpy(), idx2.cpu().numpy()
+    for v in rng.choice(n_bits, size=min(n_bits, 200), replace=False):
+        assert np.array_equal(idx2[off2[v]:off2[v + 1]], np.nonzero(masks[:, v])[0])
+
+
+def test_visibility_index_from_csr_equals_reference():
+    """MVI.process_scene through the device-side compaction: the reference's frozen index (tests/golden) and the arrow
+    table the split writer streams (same rows as the reference's pkl -> parquet conversion)."""
+    from mspa.scene import SceneOnDevice
+    from spatial_engine.utils.scannet_utils.make_visibility_info import visibility_dict_to_frame
+    g = GoldenScene("scene_ident")
+    scene = SceneOnDevice(g.K, g.A, g.E, g.depth, g.color_hw, g.points, DEV)
+    ref = g.json("mvi_json")
+    csr = scene.visibility_csr()
+    got = csr.to_dict()
+    assert got["image_to_points"] == ref["image_to_points"]
+    assert {str(k): v for k, v in got["point_to_images"].items()} == ref["point_to_images"]
+    frame = visibility_dict_to_frame({"scene_x": got})
+    table = csr.to_arrow("scene_x").to_pandas()
+    assert table["key"].tolist() == frame["key"].tolist() and table["values"].tolist() == frame["values"].tolist()
+
+
 # ------------------------------------------------------------------------------------------
 # size-independent properties at BASELINE.json's full configuration (config 2: 1k 640x480 pairs)
 # ------------------------------------------------------------------------------------------
