@@ -204,6 +204,26 @@ int mspa_bits_expand(const uint64_t *bits, int64_t n_rows, int64_t n_words, cons
 int mspa_bits_transpose(const uint64_t *bits, int32_t n_rows, int64_t n_words, uint64_t *out, mspa_stream_t stream);
 
 /*
+ * Host-side text formatting of index columns (HOST pointers).  The visibility parquet stores each list as its JSON text
+ * (json.dumps form: "[1, 2, 3]", "[\"00000\", \"00005\"]", "[]"; make_visibility_info.py:38-73) under keys
+ * "scene:point_to_images:idx"; these write that text straight into arrow's string layout (int32 offsets + UTF-8 data) from
+ * the CSR tables K9 produces.  Each returns the number of bytes written (>= 0) or a negative MSPA_E* code;
+ * out_text_offsets_host has n + 1 entries.  A buffer of 2 + 13 * len bytes per integer list, 2 + (longest token + 2) * len
+ * per token list and strlen(prefix) + 21 per key is always large enough.
+ *   mspa_format_int_lists_host    list k = values[offsets[k] .. offsets[k+1])
+ *   mspa_format_token_lists_host  list k = tokens named by token_ids[offsets[k] .. offsets[k+1]); token t is the text
+ *                                 tokens[token_offsets[t] .. token_offsets[t+1]) (e.g. an already quoted image id)
+ *   mspa_format_int_keys_host     key k = prefix followed by the decimal text of first + k
+ */
+int64_t mspa_format_int_lists_host(const int64_t *offsets_host, const int32_t *values_host, int64_t n_lists,
+                                   char *out_text_host, int64_t capacity, int32_t *out_text_offsets_host);
+int64_t mspa_format_token_lists_host(const int64_t *offsets_host, const int32_t *token_ids_host, int64_t n_lists,
+                                     const char *tokens_host, const int32_t *token_offsets_host, int32_t n_tokens,
+                                     char *out_text_host, int64_t capacity, int32_t *out_text_offsets_host);
+int64_t mspa_format_int_keys_host(const char *prefix_host, int64_t first, int64_t n, char *out_text_host,
+                                  int64_t capacity, int32_t *out_text_offsets_host);
+
+/*
  * K4 -- per-pair camera relations: the distance / yaw / pitch columns of CFR.process_scene's pair
  * table (CFR:176-189) and the relative-pose translation of CME.build_training_sample (CME:185-190).
  *

@@ -14,6 +14,8 @@
 //                        the transposed tile (lane b keeps it)
 #include "mspa_common.h"
 
+#include <cstring>
+
 namespace mspa {
 
 constexpr int kBThreads = 256;
@@ -109,4 +111,107 @@ extern "C" int mspa_bits_transpose(const uint64_t *bits, int32_t n_rows, int64_t
     hipLaunchKernelGGL(bits_transpose_kernel, dim3((uint32_t)blocks), dim3(kBThreads), 0, (hipStream_t)stream, bits, (int)n_rows,
                        n_words, row_blocks, out);
     return check_hip(hipGetLastError(), "bits_transpose_kernel launch");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Host-side text formatting of the index columns (HOST pointers; names end in _host).  The visibility parquet stores every
+// list as the JSON text json.dumps gives it (make_visibility_info.py:38-73): 1.2 M numbers and 131 k keys per 64-frame
+// scene.  Formatting them with Python objects or generic string kernels costs 0.15-0.5 s per scene -- three orders of
+// magnitude more than the kernels that produce the lists -- so the text is written here, straight into arrow's
+// (offsets, data) layout.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+inline char *put_uint(char *p, uint64_t v) {
+    char tmp[20];
+    int n = 0;
+    do {
+        tmp[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+inline char *put_int(char *p, int64_t v) {
+    if (v < 0) {
+        *p++ = '-';
+        return put_uint(p, (uint64_t)(-(v + 1)) + 1u);
+    }
+    return put_uint(p, (uint64_t)v);
+}
+
+}  // namespace
+
+extern "C" int64_t mspa_format_int_lists_host(const int64_t *offsets_host, const int32_t *values_host, int64_t n_lists,
+                                              char *out_text_host, int64_t capacity, int32_t *out_text_offsets_host) {
+    if (n_lists < 0 || capacity < 0 || (n_lists > 0 && (!offsets_host || !out_text_host || !out_text_offsets_host)))
+        return fail(MSPA_EINVAL, "mspa_format_int_lists_host: bad argument");
+    char *p = out_text_host, *const end = out_text_host + capacity;
+    if (out_text_offsets_host) out_text_offsets_host[0] = 0;
+    for (int64_t k = 0; k < n_lists; ++k) {
+        const int64_t a = offsets_host[k], b = offsets_host[k + 1];
+        if (b < a || (b > a && !values_host)) return fail(MSPA_EINVAL, "mspa_format_int_lists_host: offsets not ascending");
+        if (end - p < 2 + (b - a) * 13) return fail(MSPA_EINVAL, "mspa_format_int_lists_host: output buffer too small");
+        *p++ = '[';
+        for (int64_t e = a; e < b; ++e) {
+            if (e > a) { *p++ = ','; *p++ = ' '; }
+            p = put_int(p, values_host[e]);
+        }
+        *p++ = ']';
+        if (p - out_text_host > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_format_int_lists_host: more than 2 GiB of text");
+        out_text_offsets_host[k + 1] = (int32_t)(p - out_text_host);
+    }
+    return (int64_t)(p - out_text_host);
+}
+
+extern "C" int64_t mspa_format_token_lists_host(const int64_t *offsets_host, const int32_t *token_ids_host, int64_t n_lists,
+                                                const char *tokens_host, const int32_t *token_offsets_host, int32_t n_tokens,
+                                                char *out_text_host, int64_t capacity, int32_t *out_text_offsets_host) {
+    if (n_lists < 0 || capacity < 0 || n_tokens < 0 ||
+        (n_lists > 0 && (!offsets_host || !out_text_host || !out_text_offsets_host)) || (n_tokens > 0 && (!tokens_host || !token_offsets_host)))
+        return fail(MSPA_EINVAL, "mspa_format_token_lists_host: bad argument");
+    int32_t longest = 0;
+    for (int32_t t = 0; t < n_tokens; ++t) {
+        const int32_t len = token_offsets_host[t + 1] - token_offsets_host[t];
+        if (len < 0) return fail(MSPA_EINVAL, "mspa_format_token_lists_host: token offsets not ascending");
+        longest = len > longest ? len : longest;
+    }
+    char *p = out_text_host, *const end = out_text_host + capacity;
+    if (out_text_offsets_host) out_text_offsets_host[0] = 0;
+    for (int64_t k = 0; k < n_lists; ++k) {
+        const int64_t a = offsets_host[k], b = offsets_host[k + 1];
+        if (b < a || (b > a && !token_ids_host)) return fail(MSPA_EINVAL, "mspa_format_token_lists_host: offsets not ascending");
+        if (end - p < 2 + (b - a) * (int64_t)(longest + 2)) return fail(MSPA_EINVAL, "mspa_format_token_lists_host: output buffer too small");
+        *p++ = '[';
+        for (int64_t e = a; e < b; ++e) {
+            const int32_t t = token_ids_host[e];
+            if (t < 0 || t >= n_tokens) return fail(MSPA_EINVAL, "mspa_format_token_lists_host: token id out of range");
+            if (e > a) { *p++ = ','; *p++ = ' '; }
+            const int32_t len = token_offsets_host[t + 1] - token_offsets_host[t];
+            memcpy(p, tokens_host + token_offsets_host[t], (size_t)len);
+            p += len;
+        }
+        *p++ = ']';
+        if (p - out_text_host > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_format_token_lists_host: more than 2 GiB of text");
+        out_text_offsets_host[k + 1] = (int32_t)(p - out_text_host);
+    }
+    return (int64_t)(p - out_text_host);
+}
+
+extern "C" int64_t mspa_format_int_keys_host(const char *prefix_host, int64_t first, int64_t n, char *out_text_host,
+                                             int64_t capacity, int32_t *out_text_offsets_host) {
+    if (n < 0 || capacity < 0 || !prefix_host || (n > 0 && (!out_text_host || !out_text_offsets_host)))
+        return fail(MSPA_EINVAL, "mspa_format_int_keys_host: bad argument");
+    const size_t plen = strlen(prefix_host);
+    char *p = out_text_host, *const end = out_text_host + capacity;
+    if (out_text_offsets_host) out_text_offsets_host[0] = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        if (end - p < (int64_t)plen + 21) return fail(MSPA_EINVAL, "mspa_format_int_keys_host: output buffer too small");
+        memcpy(p, prefix_host, plen);
+        p = put_int(p + plen, first + k);
+        if (p - out_text_host > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_format_int_keys_host: more than 2 GiB of text");
+        out_text_offsets_host[k + 1] = (int32_t)(p - out_text_host);
+    }
+    return (int64_t)(p - out_text_host);
 }

@@ -45,6 +45,10 @@ _SIGNATURES = {
     "mspa_bits_popcount": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "mspa_bits_expand": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "mspa_bits_transpose": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
+    "mspa_format_int_lists_host": (c_int64, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "mspa_format_token_lists_host": (c_int64, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_int64,
+                                               c_void_p]),
+    "mspa_format_int_keys_host": (c_int64, [c_char_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "mspa_check_visibility": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "mspa_pair_pose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p,

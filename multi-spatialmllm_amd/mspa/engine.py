@@ -51,24 +51,39 @@ def check_affine(name: str, m: np.ndarray):
     return m
 
 
+def _check_affine_stack(name: str, m: np.ndarray) -> np.ndarray:
+    m = np.asarray(m, dtype=np.float64)
+    if m.ndim != 3 or m.shape[1:] != (4, 4) or not np.all(np.isfinite(m)):
+        raise ValueError(f"{name}: expected finite 4x4 matrices")
+    if not np.array_equal(m[:, 3, :], np.broadcast_to(_AFFINE_ROW, (m.shape[0], 4))):
+        bad = int(np.nonzero(~(m[:, 3, :] == _AFFINE_ROW).all(axis=1))[0][0])
+        raise ValueError(f"{name}[{bad}]: last row must be exactly [0, 0, 0, 1], got {m[bad, 3]}")
+    return m
+
+
 def frame_matrices(K: np.ndarray, A: Optional[np.ndarray], E_list: Sequence[np.ndarray]) -> np.ndarray:
-    """[F, 7, 16] float64 frame records for mspa_pair_reproject (slot order of include/mspa.h)."""
+    """[F, 7, 16] float64 frame records for mspa_pair_reproject (slot order of include/mspa.h).  All frames in one batched
+    ``A @ E`` / ``np.linalg.inv`` call: NumPy runs the same per-matrix dgemm / dgesv as for a single 4x4, so every entry is
+    bit-identical to the reference's one-frame-at-a-time expressions (tests/test_host_cpu.py pins that)."""
     K = check_affine("K", K)
     A = np.eye(4) if A is None else check_affine("A", A)
     Kinv = check_affine("inv(K)", np.linalg.inv(K))                       # OPS:313
-    out = np.empty((len(E_list), _lib.FRAME_MATS, 16), dtype=np.float64)
-    for f, E in enumerate(E_list):
-        E = check_affine(f"E[{f}]", E)
-        Einv_al = check_affine(f"inv(A@E[{f}])", np.linalg.inv(A @ E))  # IH:113-124, IH:57
-        out[f, _lib.MAT_KINV] = Kinv.reshape(16)
-        out[f, _lib.MAT_E] = E.reshape(16)
-        out[f, _lib.MAT_A] = A.reshape(16)
-        out[f, _lib.MAT_EINV_ALIGNED] = Einv_al.reshape(16)
-        out[f, _lib.MAT_K] = K.reshape(16)
-        # composed products for MSPA_PAIR_FAST (any float64 evaluation order will do: lanes near a
-        # decision boundary are re-evaluated with the exact chain inside the kernel)
-        out[f, _lib.MAT_UNPROJ] = (A @ E @ Kinv).reshape(16)
-        out[f, _lib.MAT_REPROJ] = (K @ Einv_al).reshape(16)
+    F = len(E_list)
+    out = np.empty((F, _lib.FRAME_MATS, 16), dtype=np.float64)
+    if F == 0:
+        return out
+    E = _check_affine_stack("E", np.stack([np.asarray(e, dtype=np.float64) for e in E_list]))
+    AE = A @ E                                                             # IH:113-124
+    Einv_al = _check_affine_stack("inv(A@E)", np.linalg.inv(AE))          # IH:57
+    out[:, _lib.MAT_KINV] = Kinv.reshape(16)
+    out[:, _lib.MAT_E] = E.reshape(F, 16)
+    out[:, _lib.MAT_A] = A.reshape(16)
+    out[:, _lib.MAT_EINV_ALIGNED] = Einv_al.reshape(F, 16)
+    out[:, _lib.MAT_K] = K.reshape(16)
+    # composed products for MSPA_PAIR_FAST (any float64 evaluation order will do: lanes near a
+    # decision boundary are re-evaluated with the exact chain inside the kernel)
+    out[:, _lib.MAT_UNPROJ] = (AE @ Kinv).reshape(F, 16)
+    out[:, _lib.MAT_REPROJ] = (K @ Einv_al).reshape(F, 16)
     return out
 
 
@@ -78,13 +93,15 @@ def fast_path_ok(K: np.ndarray) -> bool:
 
 
 def camera_matrices(K: np.ndarray, E_aligned_list: Sequence[np.ndarray]) -> np.ndarray:
-    """[n, 2, 16] float64 records for mspa_vertex_visibility: inv(E_aligned), K."""
+    """[n, 2, 16] float64 records for mspa_vertex_visibility: inv(E_aligned), K (one batched inverse, see frame_matrices)."""
     K = check_affine("K", K)
-    out = np.empty((len(E_aligned_list), 2, 16), dtype=np.float64)
-    for f, E in enumerate(E_aligned_list):
-        E = check_affine(f"E_aligned[{f}]", E)
-        out[f, 0] = check_affine("inv(E_aligned)", np.linalg.inv(E)).reshape(16)   # IH:57
-        out[f, 1] = K.reshape(16)
+    n = len(E_aligned_list)
+    out = np.empty((n, 2, 16), dtype=np.float64)
+    if n == 0:
+        return out
+    E = _check_affine_stack("E_aligned", np.stack([np.asarray(e, dtype=np.float64) for e in E_aligned_list]))
+    out[:, 0] = _check_affine_stack("inv(E_aligned)", np.linalg.inv(E)).reshape(n, 16)   # IH:57
+    out[:, 1] = K.reshape(16)
     return out
 
 

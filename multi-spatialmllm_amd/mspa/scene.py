@@ -46,6 +46,21 @@ class SceneOnDevice:
             self.xyz = torch.from_numpy(np.ascontiguousarray(np.asarray(points_xyz, np.float64)[:, :3])).to(device)
         self._vis = None
 
+    @classmethod
+    def from_resident(cls, K, A, ids, E_aligned, depth, frame_mats, cam_mats, xyz, image_hw, device):
+        """A scene whose tensors are already on the device (mspa/upload.py: staged through pinned memory on a copy stream)."""
+        self = cls.__new__(cls)
+        self.K, self.A = np.asarray(K, np.float64), np.asarray(A, np.float64)
+        self.ids = list(ids)
+        self.index = {k: n for n, k in enumerate(self.ids)}
+        self.image_hw = tuple(int(v) for v in image_hw)
+        self.device = device
+        self.E_aligned = list(E_aligned)
+        self.depth, self.frame_mats, self.cam_mats, self.xyz = depth, frame_mats, cam_mats, xyz
+        self.rgb = None
+        self._vis = None
+        return self
+
     # ---- K1 -------------------------------------------------------------------------------
     def vertex_visibility(self, want=("bits", "count")) -> Dict[str, torch.Tensor]:
         if self.xyz is None:

@@ -56,25 +56,47 @@ class VisibilityCSR:
 
     def to_arrow(self, scene_id: str):
         """pyarrow table (key: string, values: string), image_to_points rows first -- the order and the text of
-        ``visibility_dict_to_frame``."""
+        ``visibility_dict_to_frame``.  The JSON text is written by libmspa's host-side formatters straight into arrow's
+        (offsets, data) buffers: no Python object per row, no intermediate string arrays."""
         import pyarrow as pa
-        import pyarrow.compute as pc
+        from . import _lib
+        lib = _lib.load()
 
-        def json_lists(offsets, elements):
-            lists = pa.ListArray.from_arrays(pa.array(offsets.astype(np.int32)), elements)
-            body = pc.binary_join(lists, ", ")
-            return pc.binary_join_element_wise(pa.scalar("["), body, pa.scalar("]"), pa.scalar(""))
+        def string_array(n, text, offsets, nbytes):
+            if nbytes < 0:
+                _lib.check(int(nbytes))
+            return pa.StringArray.from_buffers(n, pa.py_buffer(offsets), pa.py_buffer(text[:nbytes]))
 
-        if self.i2p_offsets[-1] >= 2 ** 31 or self.p2i_offsets[-1] >= 2 ** 31:
-            raise ValueError("more than 2^31 entries in one scene's index")
-        i2p_vals = json_lists(self.i2p_offsets, pc.cast(pa.array(self.i2p_indices), pa.string()))
-        quoted = pa.array([json.dumps(i) for i in self.image_ids], type=pa.string())
-        p2i_vals = json_lists(self.p2i_offsets, quoted.take(pa.array(self._p2i_sorted_ids())) if len(self.p2i_indices)
-                              else pa.array([], type=pa.string()))
+        def ptr(a):
+            return a.ctypes.data if a.size else None
+
+        F, N = len(self.image_ids), self.n_points
+        i2p_off = np.ascontiguousarray(self.i2p_offsets, dtype=np.int64)
+        i2p_idx = np.ascontiguousarray(self.i2p_indices, dtype=np.int32)
+        p2i_off = np.ascontiguousarray(self.p2i_offsets, dtype=np.int64)
+        p2i_idx = np.ascontiguousarray(self._p2i_sorted_ids(), dtype=np.int32)
+        # values of image_to_points: integer lists
+        cap = 2 * F + 13 * len(i2p_idx) + 16
+        text, offs = np.empty(cap, dtype=np.uint8), np.empty(F + 1, dtype=np.int32)
+        nb = lib.mspa_format_int_lists_host(ptr(i2p_off), ptr(i2p_idx), F, text.ctypes.data, cap, offs.ctypes.data) if F else 0
+        i2p_vals = string_array(F, text, offs, nb) if F else pa.array([], type=pa.string())
+        # values of point_to_images: lists of quoted image ids
+        quoted = [json.dumps(i).encode() for i in self.image_ids]
+        tok_off = np.concatenate([[0], np.cumsum([len(q) for q in quoted])]).astype(np.int32)
+        tokens = np.frombuffer(b"".join(quoted) or b"\0", dtype=np.uint8)
+        longest = max([len(q) for q in quoted], default=0)
+        cap = 2 * N + (longest + 2) * len(p2i_idx) + 16
+        text, offs = np.empty(cap, dtype=np.uint8), np.empty(N + 1, dtype=np.int32)
+        nb = lib.mspa_format_token_lists_host(ptr(p2i_off), ptr(p2i_idx), N, tokens.ctypes.data, tok_off.ctypes.data, F,
+                                              text.ctypes.data, cap, offs.ctypes.data) if N else 0
+        p2i_vals = string_array(N, text, offs, nb) if N else pa.array([], type=pa.string())
+        # keys
         i2p_keys = pa.array([f"{scene_id}:image_to_points:{i}" for i in self.image_ids], type=pa.string())
-        p2i_keys = pc.binary_join_element_wise(pa.scalar(f"{scene_id}:point_to_images:"),
-                                               pc.cast(pa.array(np.arange(self.n_points, dtype=np.int64)), pa.string()),
-                                               pa.scalar(""))
+        prefix = f"{scene_id}:point_to_images:".encode()
+        cap = (len(prefix) + 21) * N + 16
+        text, offs = np.empty(cap, dtype=np.uint8), np.empty(N + 1, dtype=np.int32)
+        nb = lib.mspa_format_int_keys_host(prefix, 0, N, text.ctypes.data, cap, offs.ctypes.data) if N else 0
+        p2i_keys = string_array(N, text, offs, nb) if N else pa.array([], type=pa.string())
         return pa.table({"key": pa.concat_arrays([i2p_keys, p2i_keys]), "values": pa.concat_arrays([i2p_vals, p2i_vals])})
 
 

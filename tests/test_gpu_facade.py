@@ -471,3 +471,26 @@ def test_object_movement_scene_level(tmp_path):
                               max_samples=10)
     lines = [json.loads(line) for line in open(out)]
     assert 0 < len(lines) <= 10 and all("text" in r for r in lines)
+
+
+def test_scene_prefetcher_matches_direct_upload():
+    """mspa.upload.ScenePrefetcher (pinned staging, copy stream, recycled slots) hands out scenes whose products equal those of
+    the plain SceneOnDevice constructor -- threaded and unthreaded, scenes of different sizes through the same two slots."""
+    from mspa import upload
+    from mspa.scene import SceneOnDevice
+    scs = [synth.make_scene(3100 + k, n_points=2000 + 700 * k, n_frames=3 + 2 * k, color_hw=(48, 64), depth_hw=(48, 64),
+                            invalid_pose_frac=0.2 if k == 1 else 0.0, with_color=False) for k in range(4)]
+    want = []
+    for sc in scs:
+        d = SceneOnDevice(sc.K, sc.A, sc.E, sc.depth, sc.color_hw, sc.points, "cuda")
+        want.append((d.ids, d.frames_relations_arrays(), d.visibility_csr()))
+    for threaded in (False, True):
+        got = []
+        for scene in upload.ScenePrefetcher(scs, "cuda", threaded=threaded):
+            got.append((scene.ids, scene.frames_relations_arrays(), scene.visibility_csr()))
+        assert len(got) == len(want)
+        for (ids, rel, csr), (ids0, rel0, csr0) in zip(got, want):
+            assert ids == ids0
+            for k in rel0:
+                assert np.array_equal(rel[k], rel0[k], equal_nan=True), k
+            assert np.array_equal(csr.i2p_indices, csr0.i2p_indices) and np.array_equal(csr.p2i_offsets, csr0.p2i_offsets)
