@@ -476,7 +476,7 @@ def test_object_movement_scene_level(tmp_path):
 def test_scene_prefetcher_matches_direct_upload():
     """mspa.upload.ScenePrefetcher (pinned staging, copy stream, recycled slots) hands out scenes whose products equal those of
     the plain SceneOnDevice constructor -- threaded and unthreaded, scenes of different sizes through the same two slots."""
-    from mspa import upload
+    from mspa import synth, upload
     from mspa.scene import SceneOnDevice
     scs = [synth.make_scene(3100 + k, n_points=2000 + 700 * k, n_frames=3 + 2 * k, color_hw=(48, 64), depth_hw=(48, 64),
                             invalid_pose_frac=0.2 if k == 1 else 0.0, with_color=False) for k in range(4)]
