@@ -799,7 +799,8 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
         }
     }
 
-    __shared__ uint32_t lds_px[kTightBW][kRowGroup * 64];        // pixel-index transpose stage
+    // transpose stage: the group's pixel indices, then (dense set) its rgba words, then its 4 x 64 x 3 point coordinates
+    __shared__ __attribute__((aligned(16))) uint32_t lds_px[kTightBW][kRowGroup * 64 * (WANT_XYZ ? 3 : 1)];
     static_assert(kTightRows <= 64, "one lane per tile row holds that row's visibility word");
     __shared__ unsigned long long lds_rb[kTightBW][kTightRows];   // guarded-lane ballots of flagged rows (rare path)
     int n_valid = 0, n_vis = 0;
@@ -819,6 +820,24 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
         // through 1 KB of LDS so that lane L owns 4 consecutive pixels of row L / 16.
         const int pix_voff = (int)((((uint32_t)c.lane >> 4) * Wb + stripe * 64u + ((uint32_t)c.lane & 15u) * 4u) * 4u);
         const uint32_t wpr = Wb >> 6;                                   // bitset words per image row
+        // dense payload: byte mask (lane L: 4 pixels of row L >> 4), colour in / rgba out, points (16-byte pieces of the
+        // group's 4 x 768 bytes: piece 64 k + L lies in row (16 (64 k + L)) / 768)
+        __amdgpu_buffer_rsrc_t rs_vis = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.vis_u8 ? a.vis_u8 + c.obase : nullptr), 0, (SET & O_VIS_U8) ? (int)a.P : 0, kRsrcFlags);
+        __amdgpu_buffer_rsrc_t rs_rgb = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)c.rgb1, 0, ((SET & O_RGBA) && c.rgb1) ? (int)(a.P * 3) : 0, kRsrcFlags);
+        __amdgpu_buffer_rsrc_t rs_rgba = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.rgba ? a.rgba + c.obase : nullptr), 0, (SET & O_RGBA) ? (int)(a.P * 4) : 0, kRsrcFlags);
+        __amdgpu_buffer_rsrc_t rs_xyz = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.xyz_f32 ? a.xyz_f32 + 3 * c.obase : nullptr), 0, (SET & O_XYZ32) ? (int)(a.P * 12) : 0, kRsrcFlags);
+        const int vis_voff = (int)(((uint32_t)c.lane >> 4) * Wb + stripe * 64u + ((uint32_t)c.lane & 15u) * 4u);
+        const int rgb_voff = (int)(stripe * 192u + (c.lane == 0 ? 0u : (uint32_t)c.lane * 3u - 1u));
+        int xyz_voff[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t o = (uint32_t)(64 * k + c.lane) * 16u;
+            xyz_voff[k] = (int)((o / 768u) * Wb * 12u + stripe * 768u + (o % 768u));
+        }
         const int hi_x = a.dw - 1, hi_y = a.dh - 1;
         const uint32_t dw2 = (uint32_t)a.dw * 2u;
 
@@ -957,31 +976,6 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
                         const u32x4_t none = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
                         buffer_store_b128_guarded(none, rs_pix, pix_voff, (int)(rowg * Wb * 4u));
                     }
-                    if (SET & (O_VIS_U8 | O_VALID_U8 | O_XYZ32 | O_RGBA)) {
-#pragma unroll
-                        for (int j = 0; j < kRowGroup; ++j) {
-                            const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmk[j]);
-                            const uint32_t i = (rowg + (uint32_t)j) * Wb + col;
-                            const int64_t o = c.obase + (int64_t)i;
-                            if (O::template has<O_VIS_U8>(a.vis_u8)) a.vis_u8[o] = 0;
-                            if (O::template has<O_VALID_U8>(a.valid_u8)) a.valid_u8[o] = valid ? 1 : 0;
-                            if (O::template has<O_XYZ32>(a.xyz_f32)) {
-                                float *q = a.xyz_f32 + 3 * o;
-                                const float fn = __builtin_nanf("");
-                                __builtin_nontemporal_store(valid ? fx[j] : fn, q + 0);
-                                __builtin_nontemporal_store(valid ? fy[j] : fn, q + 1);
-                                __builtin_nontemporal_store(valid ? fz[j] : fn, q + 2);
-                            }
-                            if (O::template has<O_RGBA>(a.rgba)) {
-                                uint32_t colr = 0;
-                                if (c.rgb1) {
-                                    const uint8_t *s = c.rgb1 + 3 * (int64_t)i;
-                                    colr = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
-                                }
-                                __builtin_nontemporal_store(colr | (valid ? 0xFF000000u : 0u), a.rgba + o);
-                            }
-                        }
-                    }
                 } else {
                     // ---- stage 2: pixel index, gather, guard ---------------------------------------------
                     int pix[kRowGroup];
@@ -1012,29 +1006,6 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
                         vm[j] = ivm[j] & ballot64(sd < 0.0);
                         rbm[j] = ivm[j] & (rkc[j] | ballot64(!(__builtin_fabs(sd) > kGuardZmm)));
                         if (O::template has<O_PIX>(a.pix_i16)) lds_px[wave][j * 64 + c.lane] = (uint32_t)(inview ? pix[j] : -1);
-                        if (SET & (O_VIS_U8 | O_VALID_U8 | O_XYZ32 | O_RGBA)) {
-                            const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmk[j]);
-                            const bool vis = __builtin_amdgcn_inverse_ballot_w64(vm[j]);
-                            const uint32_t i = (rowg + (uint32_t)j) * Wb + col;
-                            const int64_t o = c.obase + (int64_t)i;
-                            if (O::template has<O_VIS_U8>(a.vis_u8)) a.vis_u8[o] = vis ? 1 : 0;
-                            if (O::template has<O_VALID_U8>(a.valid_u8)) a.valid_u8[o] = valid ? 1 : 0;
-                            if (O::template has<O_XYZ32>(a.xyz_f32)) {
-                                float *q = a.xyz_f32 + 3 * o;
-                                const float fn = __builtin_nanf("");
-                                __builtin_nontemporal_store(valid ? fx[j] : fn, q + 0);
-                                __builtin_nontemporal_store(valid ? fy[j] : fn, q + 1);
-                                __builtin_nontemporal_store(valid ? fz[j] : fn, q + 2);
-                            }
-                            if (O::template has<O_RGBA>(a.rgba)) {
-                                uint32_t colr = 0;
-                                if (c.rgb1) {
-                                    const uint8_t *s = c.rgb1 + 3 * (int64_t)i;
-                                    colr = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
-                                }
-                                __builtin_nontemporal_store(colr | (valid ? 0xFF000000u : 0u), a.rgba + o);
-                            }
-                        }
                     }
                     if (rbm[0] | rbm[1] | rbm[2] | rbm[3]) {             // wave-uniform, rare: one branch per group, not per row
 #pragma unroll
@@ -1054,7 +1025,50 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
                 for (int j = 0; j < kRowGroup; ++j) {
                     n_valid += __popcll(vmk[j]);
                     n_vis += __popcll(vm[j]);
-                    writelane64(vm[j], r0 + j, bits_lo, bits_hi);
+                    writelane64(vm[j], r0 + j, bits_lo, bits_hi);      // also what the cold loop reads back
+                }
+                // ---- dense payload of the group (byte mask, coloured points): every store is a whole-wave, 4- or 16-byte
+                // per lane store.  The previous form -- a byte store per pixel for the mask, three byte loads and a dword
+                // store per pixel for the colour, three dword stores per pixel for the point -- issued 37 vector-memory
+                // instructions per row group against 14 now, and the texture-address path, not HBM, set the pace. ----
+                if (SET & O_VIS_U8) {
+                    // lane L owns pixels 4 (L & 15) .. + 3 of row L >> 4: four bits of that row's ballot, spread to four bytes
+                    const uint32_t sh = ((uint32_t)c.lane & 15u) * 4u;
+                    const uint32_t n0 = (uint32_t)(vm[0] >> sh), n1 = (uint32_t)(vm[1] >> sh), n2 = (uint32_t)(vm[2] >> sh),
+                                   n3 = (uint32_t)(vm[3] >> sh);
+                    const uint32_t jl = (uint32_t)c.lane >> 4;
+                    const uint32_t nib = (jl == 0 ? n0 : jl == 1 ? n1 : jl == 2 ? n2 : n3) & 0xFu;
+                    const uint32_t bytes4 = (nib * 0x00204081u) & 0x01010101u;      // bit k -> byte k
+                    __builtin_amdgcn_raw_buffer_store_b32(bytes4, rs_vis, vis_voff, (int)(rowg * Wb), 0);
+                }
+                if (SET & O_RGBA) {
+#pragma unroll
+                    for (int j = 0; j < kRowGroup; ++j) {
+                        // the row's 192 colour bytes: one (unaligned) dword per lane at byte 3 L - 1 (lane 0: byte 0), never
+                        // past the end of the row
+                        const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(rs_rgb, rgb_voff, (int)((rowg + (uint32_t)j) * Wb * 3u), 0);
+                        const uint32_t colr = c.lane == 0 ? (w & 0xFFFFFFu) : (w >> 8);
+                        const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmk[j]);
+                        lds_px[wave][j * 64 + c.lane] = colr | (valid ? 0xFF000000u : 0u);
+                    }
+                    const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][c.lane * 4]);
+                    buffer_store_b128_guarded(q, rs_rgba, pix_voff, (int)(rowg * Wb * 4u));
+                }
+                if (SET & O_XYZ32) {
+                    const uint32_t fnan = 0x7FC00000u;
+#pragma unroll
+                    for (int j = 0; j < kRowGroup; ++j) {
+                        const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmk[j]);
+                        uint32_t *dst = &lds_px[wave][(j * 64 + c.lane) * 3];
+                        dst[0] = valid ? __float_as_uint(fx[j]) : fnan;
+                        dst[1] = valid ? __float_as_uint(fy[j]) : fnan;
+                        dst[2] = valid ? __float_as_uint(fz[j]) : fnan;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][(k * 64 + c.lane) * 4]);
+                        buffer_store_b128_guarded(q, rs_xyz, xyz_voff[k], (int)(rowg * Wb * 12u));
+                    }
                 }
             }
         }
