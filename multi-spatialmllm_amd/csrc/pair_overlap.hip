@@ -179,11 +179,17 @@ __global__ __launch_bounds__(256) void overlap_reduce_kernel(const int32_t *__re
                                      : reduce_slices(partial, tiles_b, slices, i, j);
 }
 
-// row popcounts |a_i| = the diagonal of the intersection table
-__global__ __launch_bounds__(256) void overlap_diag_kernel(const int32_t *__restrict__ partial, int F, int tiles_b, int slices,
-                                                           int32_t *counts) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < F) counts[i] = reduce_slices(partial, tiles_b, slices, i, i);
+// row popcounts |a_i| = the diagonal of the intersection table: one wave per row, lane s sums slices s, s + 64, ... (one
+// memory round trip instead of `slices` dependent ones), wave reduction
+__global__ __launch_bounds__(kWave) void overlap_diag_kernel(const int32_t *__restrict__ partial, int F, int tiles_b, int slices,
+                                                             int32_t *counts) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int tile = (i / kTile) * tiles_b + (i / kTile);
+    const int32_t *p = partial + (int64_t)tile * slices * (kTile * kTile) + (i % kTile) * kTile + (i % kTile);
+    int sum = 0;
+    for (int s = lane; s < slices; s += kWave) sum += p[(int64_t)s * (kTile * kTile)];
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if (lane == 0) counts[i] = sum;
 }
 
 // all pairs i < j in the reference's nested-loop order (CFR:176-178): p = i*F - i(i+1)/2 + (j - i - 1)
@@ -273,8 +279,8 @@ extern "C" int mspa_scene_overlap(const uint64_t *bits, int32_t n_images, int64_
     int32_t *counts = (int32_t *)((char *)workspace + p.partial_bytes);
     int rc = launch_tiles(bits, n_images, bits, n_images, n_words, true, p, partial, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(overlap_diag_kernel, dim3((uint32_t)((n_images + 255) / 256)), dim3(256), 0, s, (const int32_t *)partial,
-                       n_images, p.tiles_b, p.slices, counts);
+    hipLaunchKernelGGL(overlap_diag_kernel, dim3((uint32_t)n_images), dim3(kWave), 0, s, (const int32_t *)partial, n_images,
+                       p.tiles_b, p.slices, counts);
     hipLaunchKernelGGL(scene_overlap_finalize_kernel, dim3((uint32_t)((n_images + 255) / 256), (uint32_t)n_images), dim3(256),
                        0, s, (const int32_t *)partial, (const int32_t *)counts, n_images, p.tiles_b, p.slices, out_overlap,
                        out_inter, out_union);
