@@ -292,14 +292,18 @@ class VisibilityInfoHandler:
         print(f"[VisibilityInfoHandler] Reading visibility info from {self.visibility_info_path}.")
         if visibility_info_path.endswith(".parquet"):
             import pandas as pd
-            df = pd.read_parquet(visibility_info_path)
             self.info_format = "parquet"
-            self.visibility_info = dict(zip(df["key"].tolist(), df["values"].tolist()))
+            print("[VisibilityInfoHandler] Converting parquet file to dict.")
+            self.visibility_info = self.convert_parquet_to_dict(pd.read_parquet(visibility_info_path))
         elif visibility_info_path.endswith(".pkl"):
             self.info_format = "pkl"
             self.visibility_info = _load_any(visibility_info_path)
         else:
             raise ValueError(f"Unsupported file format: {self.visibility_info_path}")
+
+    def convert_parquet_to_dict(self, parquet_df):
+        """The (key, values) frame back as {key: JSON text} (reference: IH:486-500)."""
+        return dict(zip(parquet_df["key"].tolist(), parquet_df["values"].tolist()))
 
     def _get(self, scene_id, kind, item):
         if self.info_format == "parquet":
