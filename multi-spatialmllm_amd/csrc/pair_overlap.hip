@@ -70,10 +70,23 @@ __global__ __launch_bounds__(kOThreads) void pair_overlap_kernel(OverlapArgs a) 
 // 32 bits, ~7 M wave instructions for 51 040 pairs of 131 072 bits): a 320-frame scene must become several waves per SIMD.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kTile = 32;                  // rows of a and of b per workgroup
-constexpr int kChunkWords = 16;            // bitset words staged per wave
-constexpr int kRowDw = kChunkWords * 2 + 4;   // LDS row stride in dwords: 16-byte aligned, bank-skewed (36)
-constexpr int kTileWaves = 4;              // waves per workgroup = chunks per slice
-constexpr int kSliceWords = kChunkWords * kTileWaves;
+#ifndef MSPA_K2_CHUNK_WORDS
+#define MSPA_K2_CHUNK_WORDS 8
+#endif
+#ifndef MSPA_K2_WAVE_CHUNKS
+#define MSPA_K2_WAVE_CHUNKS 2
+#endif
+#ifndef MSPA_K2_MIN_WAVES
+#define MSPA_K2_MIN_WAVES 5
+#endif
+constexpr int kChunkWords = MSPA_K2_CHUNK_WORDS;          // bitset words staged per step (8: 5 KB of LDS per wave)
+constexpr int kRowDw = kChunkWords * 2 + 4;               // LDS row stride in dwords: 16-byte aligned, bank-skewed
+constexpr int kTileWaves = 4;                             // waves per workgroup
+constexpr int kWaveChunks = MSPA_K2_WAVE_CHUNKS;          // chunks per wave; the next chunk's loads fly while this one is counted
+constexpr int kSliceWords = kChunkWords * kTileWaves * kWaveChunks;
+constexpr int kLoadsPerChunk = kChunkWords / 2;           // 16-byte loads per lane and chunk (64 rows x kChunkWords x 8 B / 64 lanes)
+constexpr int kLanesPerRow = kChunkWords / 2;             // lanes covering one row's chunk
+constexpr int kRowsPerLoad = kWave / kLanesPerRow;        // rows a wave-wide load covers
 
 struct TileArgs {
     const uint64_t *bits_a;
@@ -88,56 +101,92 @@ struct TileArgs {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// one chunk of the tile's 64 rows: kLoadsPerChunk 16-byte loads per lane (kLanesPerRow lanes cover a row's chunk)
 template <bool ALIGNED16>
-__global__ __launch_bounds__(kTileWaves *kWave) void overlap_tile_kernel(TileArgs a) {
-    const int tile = blockIdx.x;
-    const int ta = tile / a.tiles_b, tb = tile - ta * a.tiles_b;
-    if (a.symmetric && tb < ta) return;
+__device__ __forceinline__ void load_chunk(const TileArgs &a, int ta, int tb, int64_t w0, int lrow, int lcol,
+                                           u32x4 (&v)[kLoadsPerChunk]) {
+#pragma unroll
+    for (int k = 0; k < kLoadsPerChunk; ++k) {
+        const int r = k * kRowsPerLoad + lrow;                           // 0..31 = a rows, 32..63 = b rows
+        const bool is_b = r >= kTile;
+        const int row = is_b ? tb * kTile + (r - kTile) : ta * kTile + r;
+        const bool row_ok = row < (is_b ? a.n_b : a.n_a);
+        const uint64_t *src = (is_b ? a.bits_b : a.bits_a) + (int64_t)row * a.n_words;
+        const int64_t w = w0 + lcol * 2;
+        u32x4 x = {0u, 0u, 0u, 0u};
+        if (row_ok && w0 < a.n_words) {
+            if (ALIGNED16) {
+                if (w < a.n_words) x = *reinterpret_cast<const u32x4 *>(src + w);      // n_words even: w + 1 exists too
+            } else {
+                const uint64_t p = w < a.n_words ? src[w] : 0ull, q = (w + 1) < a.n_words ? src[w + 1] : 0ull;
+                x = u32x4{(uint32_t)p, (uint32_t)(p >> 32), (uint32_t)q, (uint32_t)(q >> 32)};
+            }
+        }
+        v[k] = x;
+    }
+}
+
+__device__ __forceinline__ void count_chunk(uint32_t *my, int lrow, int lcol, int ti, int tj, const u32x4 (&v)[kLoadsPerChunk],
+                                            int (&acc)[4][4]) {
+#pragma unroll
+    for (int k = 0; k < kLoadsPerChunk; ++k)                             // the wave's own region: no barrier needed
+        *reinterpret_cast<u32x4 *>(&my[(k * kRowsPerLoad + lrow) * kRowDw + lcol * 4]) = v[k];
+#pragma unroll
+    for (int s2 = 0; s2 < kChunkWords / 2; ++s2) {
+        u32x4 va[4], vb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) va[r] = *reinterpret_cast<const u32x4 *>(&my[(ti + 8 * r) * kRowDw + s2 * 4]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) vb[c] = *reinterpret_cast<const u32x4 *>(&my[(kTile + tj + 8 * c) * kRowDw + s2 * 4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[r][c] += __popc(va[r].x & vb[c].x) + __popc(va[r].y & vb[c].y) + __popc(va[r].z & vb[c].z) +
+                             __popc(va[r].w & vb[c].w);
+    }
+}
+
+// Occupancy is the point of the sizes above: a wave issues one VALU instruction every ~5.7 cycles on its own
+// (profiles/r02_valu_rates.txt: 5.7 cycles per instruction at one wave per SIMD, 2.2 at eight), so this popcount-bound
+// kernel needs many resident waves, i.e. few registers (one staged chunk at a time, the next one in flight) and little LDS.
+template <bool ALIGNED16>
+__global__ __launch_bounds__(kTileWaves *kWave, MSPA_K2_MIN_WAVES) void overlap_tile_kernel(TileArgs a) {
+    // tile list: all (ta, tb) for a rectangle; for a symmetric problem only ta <= tb, enumerated row by row of the triangle
+    int ta, tb;
+    if (a.symmetric) {
+        const int T = a.tiles_b, t = blockIdx.x;
+        // largest ta with ta * T - ta (ta - 1) / 2 <= t  (float estimate, then exact fix-up)
+        const float disc = (float)(2 * T + 1) * (float)(2 * T + 1) - 8.0f * (float)t;
+        ta = (int)(((float)(2 * T + 1) - __builtin_sqrtf(disc > 0.f ? disc : 0.f)) * 0.5f);
+        ta = min(max(ta, 0), T - 1);
+        while (ta > 0 && ta * T - ta * (ta - 1) / 2 > t) --ta;
+        while (ta + 1 < T && (ta + 1) * T - (ta + 1) * ta / 2 <= t) ++ta;
+        tb = ta + (t - (ta * T - ta * (ta - 1) / 2));
+    } else {
+        ta = blockIdx.x / a.tiles_b;
+        tb = blockIdx.x - ta * a.tiles_b;
+    }
+    const int tile = ta * a.tiles_b + tb;
     const int slice = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // per wave: 64 staged rows of 36 dwords (9 216 B); reused for the 32 x 32 counter table (4 096 B) of the reduction
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kTileWaves][2 * kTile * kRowDw];
+    // per wave: 64 staged rows (kRowDw dwords each); the first 4 096 bytes are reused for the 32 x 32 counter table
+    constexpr int kRegionDw = (2 * kTile * kRowDw) > (kTile * kTile) ? (2 * kTile * kRowDw) : (kTile * kTile);
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kTileWaves][kRegionDw];
     uint32_t *const my = lds[wave];
-    // staging: 8 lanes cover one row's 128-byte chunk, a wave instruction covers 8 rows
-    const int lrow = lane >> 3, lcol = lane & 7;
+    const int lrow = lane / kLanesPerRow, lcol = lane % kLanesPerRow;
     const int ti = lane >> 3, tj = lane & 7;          // this lane's rows: a: ti + 8r, b: tj + 8c
     int acc[4][4] = {};
-    const int64_t w0 = (int64_t)slice * kSliceWords + (int64_t)wave * kChunkWords;
-    if (w0 < a.n_words) {                              // wave-uniform
+    const int64_t w0 = (int64_t)slice * kSliceWords + (int64_t)wave * (kChunkWords * kWaveChunks);
+    u32x4 cur[kLoadsPerChunk], nxt[kLoadsPerChunk];
+    load_chunk<ALIGNED16>(a, ta, tb, w0, lrow, lcol, cur);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int r = k * 8 + lrow;                                  // 0..31 = a rows, 32..63 = b rows
-            const bool is_b = r >= kTile;
-            const int row = is_b ? tb * kTile + (r - kTile) : ta * kTile + r;
-            const bool row_ok = row < (is_b ? a.n_b : a.n_a);
-            const uint64_t *src = (is_b ? a.bits_b : a.bits_a) + (int64_t)row * a.n_words;
-            const int64_t w = w0 + lcol * 2;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (row_ok) {
-                if (ALIGNED16) {
-                    if (w < a.n_words) v = *reinterpret_cast<const u32x4 *>(src + w);   // n_words even: w + 1 exists too
-                } else {
-                    const uint64_t x = w < a.n_words ? src[w] : 0ull, y = (w + 1) < a.n_words ? src[w + 1] : 0ull;
-                    v = u32x4{(uint32_t)x, (uint32_t)(x >> 32), (uint32_t)y, (uint32_t)(y >> 32)};
-                }
-            }
-            *reinterpret_cast<u32x4 *>(&my[r * kRowDw + lcol * 4]) = v;   // the wave's own region: no barrier needed
-        }
+    for (int q = 0; q < kWaveChunks; ++q) {
+        if (q + 1 < kWaveChunks) load_chunk<ALIGNED16>(a, ta, tb, w0 + (q + 1) * kChunkWords, lrow, lcol, nxt);
+        if (w0 + q * kChunkWords < a.n_words) count_chunk(my, lrow, lcol, ti, tj, cur, acc);      // wave-uniform condition
 #pragma unroll
-        for (int s2 = 0; s2 < kChunkWords / 2; ++s2) {
-            u32x4 va[4], vb[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) va[r] = *reinterpret_cast<const u32x4 *>(&my[(ti + 8 * r) * kRowDw + s2 * 4]);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) vb[c] = *reinterpret_cast<const u32x4 *>(&my[(kTile + tj + 8 * c) * kRowDw + s2 * 4]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    acc[r][c] += __popc(va[r].x & vb[c].x) + __popc(va[r].y & vb[c].y) + __popc(va[r].z & vb[c].z) +
-                                 __popc(va[r].w & vb[c].w);
-        }
+        for (int k = 0; k < kLoadsPerChunk; ++k) cur[k] = nxt[k];
     }
     // the wave's 32 x 32 counters into its region (element (i, j) at i * 32 + j), then 256 threads sum the four tables
 #pragma unroll
@@ -225,7 +274,8 @@ static TilePlan plan_tiles(int n_a, int n_b, int64_t n_words) {
 static int launch_tiles(const uint64_t *bits_a, int n_a, const uint64_t *bits_b, int n_b, int64_t n_words, bool symmetric,
                         const TilePlan &p, int32_t *partial, hipStream_t s) {
     TileArgs t{bits_a, bits_b, n_a, n_b, n_words, p.tiles_b, p.slices, symmetric ? 1 : 0, partial};
-    const dim3 grid((uint32_t)(p.tiles_a * p.tiles_b), (uint32_t)p.slices);
+    const int64_t n_tiles = symmetric ? (int64_t)p.tiles_a * (p.tiles_a + 1) / 2 : (int64_t)p.tiles_a * p.tiles_b;
+    const dim3 grid((uint32_t)n_tiles, (uint32_t)p.slices);
     const bool aligned = (n_words % 2 == 0) && (((uintptr_t)bits_a & 15u) == 0) && (((uintptr_t)bits_b & 15u) == 0);
     if (aligned) hipLaunchKernelGGL(overlap_tile_kernel<true>, grid, dim3(kTileWaves * kWave), 0, s, t);
     else hipLaunchKernelGGL(overlap_tile_kernel<false>, grid, dim3(kTileWaves * kWave), 0, s, t);
