@@ -238,6 +238,15 @@ int mspa_pair_pose(const double *E_aligned, const double *Einv_aligned, const do
                    double *out, mspa_stream_t stream);
 
 /*
+ * extract_yaw_pitch (CFR:86-100) for a batch of frames: yaw = degrees(atan2(z_y, z_x)), pitch = degrees(asin(z_z / |z|)) of
+ * the rotated z axis z = E[:3, 2].   E_aligned [n_frames, 16] f64  ->  out_yaw, out_pitch [n_frames] f64 (degrees).
+ * Device libm: within a few ulp of NumPy, not bit-identical (float64 quantity; the host layer keeps a NumPy path for
+ * callers that need the reference's exact bits).
+ */
+int mspa_extract_yaw_pitch(const double *E_aligned, int32_t n_frames, double *out_yaw, double *out_pitch,
+                           mspa_stream_t stream);
+
+/*
  * K5a -- TAPVid-3D tracks: camera->world (OM_C:446-454) and the normalised pinhole projection with
  * its validity test (TwoFrameVideoQAEngine.project_point, OM_C:293-315) for every (frame, point).
  *

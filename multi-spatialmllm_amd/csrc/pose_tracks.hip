@@ -42,6 +42,21 @@ __global__ __launch_bounds__(256) void pair_pose_kernel(const double *__restrict
     }
 }
 
+// extract_yaw_pitch (CFR:86-100) per frame: z = E[:3, 2]; yaw = degrees(atan2(z_y, z_x)); pitch = degrees(asin(z_z / ||z||)).
+// np.degrees(x) = x * (180 / pi) with the double constant; np.linalg.norm of a 3-vector = sqrt of the pairwise-summed squares.
+// The device libm (ocml) is not glibc: results agree to a few ulp, not bit for bit -- these are float64 quantities (1e-5 bar);
+// callers that need the reference's exact bits (the parquet writers) keep the NumPy path (engine.extract_yaw_pitch_host).
+__global__ __launch_bounds__(256) void yaw_pitch_kernel(const double *__restrict__ E, int n, double *__restrict__ yaw,
+                                                        double *__restrict__ pitch) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= n) return;
+    const double *M = E + (int64_t)f * 16;
+    const double zx = M[2], zy = M[6], zz = M[10];
+    const double kDeg = 57.29577951308232;                       // 180 / pi as NumPy's degrees() multiplies
+    yaw[f] = atan2(zy, zx) * kDeg;
+    pitch[f] = asin(zz / norm3_sum(zx, zy, zz)) * kDeg;
+}
+
 __global__ __launch_bounds__(256) void track_world_kernel(const double *__restrict__ tracks, const double *__restrict__ c2w,
                                                           int T, int P, double fx, double fy, double cx, double cy,
                                                           double Wd, double Hd, double *__restrict__ world,
@@ -190,6 +205,16 @@ extern "C" int mspa_pair_pose(const double *E_aligned, const double *Einv_aligne
     hipLaunchKernelGGL(pair_pose_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, E_aligned,
                        Einv_aligned, yaw, pitch, pairs, n_pairs, out);
     return check_hip(hipGetLastError(), "pair_pose_kernel launch");
+}
+
+extern "C" int mspa_extract_yaw_pitch(const double *E_aligned, int32_t n_frames, double *out_yaw, double *out_pitch,
+                                      mspa_stream_t stream) {
+    if (n_frames < 0) return fail(MSPA_EINVAL, "mspa_extract_yaw_pitch: bad count");
+    if (n_frames == 0) return MSPA_OK;
+    if (!E_aligned || !out_yaw || !out_pitch) return fail(MSPA_EINVAL, "mspa_extract_yaw_pitch: null pointer");
+    hipLaunchKernelGGL(yaw_pitch_kernel, dim3((uint32_t)((n_frames + 255) / 256)), dim3(256), 0, (hipStream_t)stream, E_aligned,
+                       (int)n_frames, out_yaw, out_pitch);
+    return check_hip(hipGetLastError(), "yaw_pitch_kernel launch");
 }
 
 extern "C" int mspa_track_to_world(const double *tracks_xyz, const double *c2w, int32_t T, int32_t P,

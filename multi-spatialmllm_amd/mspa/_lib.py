@@ -53,6 +53,7 @@ _SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "mspa_pair_pose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_void_p,
                                c_void_p]),
+    "mspa_extract_yaw_pitch": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "mspa_track_to_world": (c_int, [c_void_p, c_void_p, c_int32, c_int32, POINTER(c_double), c_int32, c_int32,
                                     c_void_p, c_void_p, c_void_p, c_void_p]),
     "mspa_select_common_point": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),

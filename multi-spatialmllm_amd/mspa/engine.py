@@ -315,6 +315,20 @@ def extract_yaw_pitch_host(E_aligned_list: Sequence[np.ndarray]) -> Tuple[np.nda
     return np.array(yaw, dtype=np.float64), np.array(pitch, dtype=np.float64)
 
 
+def extract_yaw_pitch(E_aligned: torch.Tensor):
+    """Device form of CFR:86-100 for frames that are already resident: E_aligned [F,16] f64 -> (yaw [F], pitch [F]) in
+    degrees.  Within a few ulp of ``extract_yaw_pitch_host`` (device libm is not glibc); the pair-table writers keep the
+    host path so that the parquet columns are the reference's bits."""
+    _require_gpu()
+    lib = _lib.load()
+    _require(E_aligned.dtype == torch.float64 and E_aligned.dim() == 2 and E_aligned.shape[1] == 16, "E_aligned: float64 [F, 16]")
+    F = E_aligned.shape[0]
+    yaw = torch.empty((F,), dtype=torch.float64, device=E_aligned.device)
+    pitch = torch.empty((F,), dtype=torch.float64, device=E_aligned.device)
+    _lib.check(lib.mspa_extract_yaw_pitch(_ptr(E_aligned), F, _ptr(yaw), _ptr(pitch), _stream_ptr()))
+    return yaw, pitch
+
+
 def pair_pose(E_aligned: torch.Tensor, Einv_aligned: torch.Tensor, yaw: torch.Tensor, pitch: torch.Tensor,
               pairs: torch.Tensor) -> torch.Tensor:
     """Enqueue K4.  E_aligned / Einv_aligned [F,16] f64, yaw / pitch [F] f64, pairs [n,2] i32 ->

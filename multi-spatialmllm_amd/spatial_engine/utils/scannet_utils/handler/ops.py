@@ -31,8 +31,13 @@ def project_mask_to_3d(depth_image, intrinsic_matrix, extrinsic_matrix, mask=Non
     pairs = torch.zeros((1, 2), dtype=torch.int32, device="cuda")
     out = engine.alloc_pair_outputs(1, (H, W), ("xyz_f64", "valid_u8"), "cuda")
     engine.pair_reproject(depth, mats, pairs, (H, W), out)
-    keep = out["valid_u8"][0].cpu().numpy().astype(bool) & (mask.reshape(-1) != 0)
-    xyz = out["xyz_f64"][0].cpu().numpy()[keep]
+    # only the mask's rows cross PCIe: the selection happens on the device (a 5 % mask downloads 0.4 MB instead of 7.4 MB)
+    full = bool(mask.all())
+    keep_t = out["valid_u8"][0].bool() if full else \
+        (out["valid_u8"][0].bool() & torch.from_numpy(np.ascontiguousarray(mask.reshape(-1) != 0)).cuda())
+    idx = torch.nonzero(keep_t).flatten()                         # row-major mask order, as np.where gives it (OPS:276-278)
+    xyz = out["xyz_f64"][0].index_select(0, idx).cpu().numpy()
+    keep = idx.cpu().numpy()
     if world_to_axis_align_matrix is None:
         pass    # A = identity: x*1 + 0*y + 0*z + 0 is exact, the result equals E @ cam
     if color_image is not None:

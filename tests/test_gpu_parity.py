@@ -614,6 +614,29 @@ def test_pair_pose_golden(name):
         assert int(np.linalg.norm(d) * 1000) == a["total_distance"]
 
 
+def test_extract_yaw_pitch_device_vs_reference_values():
+    """mspa_extract_yaw_pitch against the reference's per-frame angles (engine.extract_yaw_pitch_host is its NumPy restatement,
+    pinned through the pair table's yaw / pitch columns in test_pair_pose_golden): float64 quantity, 1e-12 absolute in degrees
+    (bar 1e-5 relative); degenerate axes included."""
+    g = GoldenScene("scene_ident")
+    Ea = [g.A @ g.E[i] for i in g.valid_image_ids]
+    rng = np.random.default_rng(8)
+    for _ in range(200):
+        q, _r = np.linalg.qr(rng.normal(size=(3, 3)))
+        e = np.eye(4)
+        e[:3, :3] = q
+        Ea.append(e)
+    up = np.eye(4)
+    up[:3, :3] = [[1, 0, 0], [0, 0, -1], [0, 1, 0]]           # z axis along +y: yaw exactly 90
+    Ea.append(up)
+    yaw_h, pitch_h = engine.extract_yaw_pitch_host(Ea)
+    E_t = torch.from_numpy(np.stack(Ea).reshape(-1, 16)).to(DEV)
+    yaw_d, pitch_d = engine.extract_yaw_pitch(E_t)
+    torch.cuda.synchronize()
+    assert np.abs(yaw_d.cpu().numpy() - yaw_h).max() < 1e-12 and np.abs(pitch_d.cpu().numpy() - pitch_h).max() < 1e-12
+    assert abs(float(yaw_d[-1]) - 90.0) < 1e-12 and abs(float(pitch_d[-1])) < 1e-12
+
+
 def test_track_geometry_golden():
     """K5 against the reference's TAPVid records (tests/golden/tracks.npz) and the oracle."""
     import os
