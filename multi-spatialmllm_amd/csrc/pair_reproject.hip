@@ -1269,22 +1269,32 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
                 return (int)(dyo + (uint32_t)lds_dx[colw]);
             };
 
-    #pragma unroll 1
-            for (int g = 0; g < n_groups; ++g) {
+            // depth-1 samples of a group's chunks (1-2 cache lines each), requested ONE GROUP AHEAD: the loads of group g + 1
+            // fly while group g is projected (they were the exposed latency at the top of every iteration)
+            bool wrapped[NCH];
+            auto load_group = [&](int g, uint32_t (&d)[NCH]) {
                 const uint32_t rowg = row0 + 4u * (uint32_t)g;
-                // ---- depth-1 samples of the group's chunks (1-2 cache lines each) ----
-                uint32_t d16[NCH];
-                bool wrapped[NCH];
     #pragma unroll
                 for (int e = 0; e < NCH; ++e) {
                     // e = 0..3: rows rowg + e at this stripe; e = 4 (last stripe only): the extra word of row rowg, 64 columns on
                     const int j = e < 4 ? e : 0;
                     const int col_add = kOff[j] + (e == 4 ? 64 : 0);
                     const bool can_wrap = (e == 4) || (kOff[j] + 64 * S > W_);            // compile time: which words straddle a row end
-                    const int off = depth1_offset(rowg + (uint32_t)j, col_add, LAST && can_wrap, wrapped[e]);
-                    d16[e] = __builtin_amdgcn_raw_buffer_load_b16(rs_d1, off, 0, STREAM ? 2 : 0);
+                    const int off = depth1_offset(rowg + (uint32_t)j, col_add, LAST && can_wrap, wrapped[e]);   // wrapped: same every group
+                    d[e] = __builtin_amdgcn_raw_buffer_load_b16(rs_d1, off, 0, STREAM ? 2 : 0);
+                }
+            };
+            uint32_t d16n[NCH];
+            load_group(0, d16n);
+    #pragma unroll 1
+            for (int g = 0; g < n_groups; ++g) {
+                uint32_t d16[NCH];
+    #pragma unroll
+                for (int e = 0; e < NCH; ++e) {
+                    d16[e] = d16n[e];
                     asm("" : "+v"(d16[e]));
                 }
+                if (g + 1 < n_groups) load_group(g + 1, d16n);
                 // ---- stage 1 ----
                 double u[NCH], v[NCH], qz[NCH];
                 unsigned long long vmk[NCH], ivm[NCH];
