@@ -627,14 +627,14 @@ def test_extract_yaw_pitch_device_vs_reference_values():
         e[:3, :3] = q
         Ea.append(e)
     up = np.eye(4)
-    up[:3, :3] = [[1, 0, 0], [0, 0, -1], [0, 1, 0]]           # z axis along +y: yaw exactly 90
+    up[:3, :3] = [[1, 0, 0], [0, 0, -1], [0, 1, 0]]           # camera z axis (third column) along -y: yaw exactly -90
     Ea.append(up)
     yaw_h, pitch_h = engine.extract_yaw_pitch_host(Ea)
     E_t = torch.from_numpy(np.stack(Ea).reshape(-1, 16)).to(DEV)
     yaw_d, pitch_d = engine.extract_yaw_pitch(E_t)
     torch.cuda.synchronize()
     assert np.abs(yaw_d.cpu().numpy() - yaw_h).max() < 1e-12 and np.abs(pitch_d.cpu().numpy() - pitch_h).max() < 1e-12
-    assert abs(float(yaw_d[-1]) - 90.0) < 1e-12 and abs(float(pitch_d[-1])) < 1e-12
+    assert abs(float(yaw_d[-1]) + 90.0) < 1e-12 and abs(float(pitch_d[-1])) < 1e-12
 
 
 def test_track_geometry_golden():
