@@ -348,7 +348,7 @@ def time_scene_kernels(device, n_points=131072, n_frames=320, reps=5):
                             "note": "CFR.process_scene for one ScanNet-sized scene (every-5th-frame average)"}}
 
 
-def time_scene_pipeline(device, n_scenes=6, n_points=131072, n_frames=320):
+def time_scene_pipeline(device, n_scenes=24, n_points=131072, n_frames=320):
     """End to end, host memory -> pair table: scenes of 320 frames x 131 072 vertices (the every-5th-frame ScanNet average)
     go through mspa.upload.ScenePrefetcher (pinned staging on a worker thread + H2D on a copy stream, overlapped with the
     previous scene's kernels), K1 + K2 + K4, and the pair-table columns come back to the host.  The scene's 8 rendered
@@ -373,7 +373,7 @@ def time_scene_pipeline(device, n_scenes=6, n_points=131072, n_frames=320):
         torch.cuda.synchronize()
         return pairs
 
-    run(2)                                           # slots, pinned buffers, kernels warm
+    run(upload.UPLOAD_SLOTS + 1)                     # slots, pinned buffers, kernels warm
     t0 = time.perf_counter()
     pairs = run(n_scenes)
     dt = time.perf_counter() - t0

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MSPA_VERSION 120            /* 0.2.0: + mspa_pair_reproject_last_kernel, tiled K2 (mspa_scene_overlap, mspa_overlap_matrix), K9 bitset -> index lists */
+#define MSPA_VERSION 121            /* 0.2.0: + mspa_pair_reproject_last_kernel, tiled K2 (mspa_scene_overlap, mspa_overlap_matrix), K9 bitset -> index lists */
 
 #define MSPA_OK 0
 #define MSPA_EINVAL (-1)            /* bad argument (null pointer, size out of range, ...) */
@@ -222,6 +222,14 @@ int64_t mspa_format_token_lists_host(const int64_t *offsets_host, const int32_t 
                                      char *out_text_host, int64_t capacity, int32_t *out_text_offsets_host);
 int64_t mspa_format_int_keys_host(const char *prefix_host, int64_t first, int64_t n, char *out_text_host,
                                   int64_t capacity, int32_t *out_text_offsets_host);
+
+/*
+ * Host-side staging of a scene's depth frames (the loop that fills the frame stack in the reference: CFR / MVI read one
+ * image per frame into its own array): n_blocks equally sized host blocks are gathered into one contiguous destination
+ * -- the pinned buffer the H2D copy reads -- by up to n_threads copy threads.  Host pointers only; no device work.
+ */
+int mspa_gather_blocks_host(const void *const *src_blocks_host, int64_t n_blocks, int64_t block_bytes, void *dst_host,
+                            int32_t n_threads);
 
 /*
  * K4 -- per-pair camera relations: the distance / yaw / pitch columns of CFR.process_scene's pair

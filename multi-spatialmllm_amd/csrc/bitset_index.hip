@@ -15,6 +15,8 @@
 #include "mspa_common.h"
 
 #include <cstring>
+#include <thread>
+#include <vector>
 
 namespace mspa {
 
@@ -214,4 +216,32 @@ extern "C" int64_t mspa_format_int_keys_host(const char *prefix_host, int64_t fi
         out_text_offsets_host[k + 1] = (int32_t)(p - out_text_host);
     }
     return (int64_t)(p - out_text_host);
+}
+
+// Host-side staging: n equally sized blocks (a scene's depth frames as the image reader left them, one allocation each)
+// gathered into one contiguous destination -- the pinned buffer the H2D copy reads -- by up to n_threads copy threads.
+// A single thread writes pinned memory at ~20 GB/s, below what the PCIe link takes; the caller (mspa/upload.py) holds no
+// interpreter lock while this runs.
+extern "C" int mspa_gather_blocks_host(const void *const *src_blocks_host, int64_t n_blocks, int64_t block_bytes,
+                                       void *dst_host, int32_t n_threads) {
+    if (n_blocks < 0 || block_bytes < 0 || (n_blocks > 0 && block_bytes > 0 && (!src_blocks_host || !dst_host)))
+        return fail(MSPA_EINVAL, "mspa_gather_blocks_host: bad argument");
+    for (int64_t k = 0; k < n_blocks; ++k)
+        if (block_bytes > 0 && !src_blocks_host[k]) return fail(MSPA_EINVAL, "mspa_gather_blocks_host: null block");
+    if (n_blocks == 0 || block_bytes == 0) return MSPA_OK;
+    const int64_t nt = n_threads < 1 ? 1 : (n_threads > n_blocks ? n_blocks : (int64_t)n_threads);
+    auto work = [&](int64_t t) {
+        const int64_t lo = n_blocks * t / nt, hi = n_blocks * (t + 1) / nt;
+        for (int64_t k = lo; k < hi; ++k) memcpy((char *)dst_host + k * block_bytes, src_blocks_host[k], (size_t)block_bytes);
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (int64_t t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    } catch (...) {                      // thread creation refused: the blocks nobody took are copied here
+        const int64_t started = (int64_t)pool.size();
+        for (int64_t t = started + 1; t < nt; ++t) work(t);
+    }
+    work(0);
+    for (auto &th : pool) th.join();
+    return MSPA_OK;
 }

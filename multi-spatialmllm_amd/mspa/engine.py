@@ -7,6 +7,7 @@ the kernels is bit-identical to what the reference would multiply with.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Dict, Iterable, Optional, Sequence, Tuple
 
 import numpy as np
@@ -109,6 +110,23 @@ def depth_to_device(depth: np.ndarray, device="cuda") -> torch.Tensor:
     """uint16 depth frames -> device int16 tensor holding the same bits (torch has few uint16 ops)."""
     d = np.ascontiguousarray(depth, dtype=np.uint16)
     return torch.from_numpy(d.view(np.int16)).to(device)
+
+
+def gather_blocks_host(blocks, dst: np.ndarray, n_threads: int = 4) -> None:
+    """``dst[k] = blocks[k]`` for equally shaped, C-contiguous host arrays of ``dst``'s dtype, copied by ``n_threads``
+    native threads (mspa_gather_blocks_host): the staging of a scene's depth frames into pinned memory."""
+    n = len(blocks)
+    if n == 0:
+        return
+    if dst.shape[0] < n or not dst.flags.c_contiguous:
+        raise ValueError("gather_blocks_host: destination too small or not contiguous")
+    block_bytes = int(dst[0].nbytes)
+    ptrs = (ctypes.c_void_p * n)()
+    for k, b in enumerate(blocks):
+        if b.nbytes != block_bytes or b.dtype.itemsize != dst.dtype.itemsize or not b.flags.c_contiguous:
+            raise ValueError("gather_blocks_host: block %d is not a contiguous array of the destination's frame size" % k)
+        ptrs[k] = b.ctypes.data
+    _lib.check(_lib.load().mspa_gather_blocks_host(ptrs, n, block_bytes, dst.ctypes.data, int(n_threads)))
 
 
 PAIR_OUTPUTS = ("vis_bits", "vis_u8", "valid_u8", "pix_i16", "xyz_f32", "rgba", "xyz_f64", "uv_f64",
@@ -305,14 +323,19 @@ def bits_transpose(bits: torch.Tensor) -> torch.Tensor:
 
 
 def extract_yaw_pitch_host(E_aligned_list: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
-    """Per-frame angles exactly as CFR:86-100 computes them (NumPy on the host: F values per scene,
-    and the reference's own libm calls are the only way to be bit-identical with it)."""
-    yaw, pitch = [], []
-    for E in E_aligned_list:
-        z = np.asarray(E)[:3, 2]
-        yaw.append(np.degrees(np.arctan2(z[1], z[0])))
-        pitch.append(np.degrees(np.arcsin(z[2] / np.linalg.norm(z))))
-    return np.array(yaw, dtype=np.float64), np.array(pitch, dtype=np.float64)
+    """Per-frame angles as CFR:86-100 computes them, with NumPy on the host (the reference's own libm / BLAS calls are the
+    only way to be bit-identical with it).  The arctan2 / arcsin / degrees ufuncs run once over all frames (the same
+    element loops a scalar call goes through); the norm stays one ``dot`` per frame, because that is what
+    ``np.linalg.norm`` of a 3-vector is and a vectorised sum of squares rounds differently.  tests/test_host_cpu.py holds
+    this against the oracle's literal per-frame form bit for bit."""
+    n = len(E_aligned_list)
+    if n == 0:
+        return np.zeros(0, dtype=np.float64), np.zeros(0, dtype=np.float64)
+    Z = np.ascontiguousarray(np.stack([np.asarray(E) for E in E_aligned_list])[:, :3, 2], dtype=np.float64)
+    yaw = np.degrees(np.arctan2(Z[:, 1], Z[:, 0]))
+    norm = np.sqrt(np.array([z.dot(z) for z in Z], dtype=np.float64))       # np.linalg.norm(z) == sqrt(z.dot(z)) for real 1-D z
+    pitch = np.degrees(np.arcsin(Z[:, 2] / norm))
+    return yaw, pitch
 
 
 def extract_yaw_pitch(E_aligned: torch.Tensor):

@@ -118,10 +118,7 @@ def camera_movement_numeric(scene, rows: Sequence[dict]):
     F = len(scene.ids)
     idx = np.array([[scene.index[r["image_id1"]], scene.index[r["image_id2"]]] for r in rows], dtype=np.int32)
     both = torch.from_numpy(np.concatenate([idx, idx[:, ::-1]], axis=0).copy()).to(scene.device)
-    yaw, pitch = engine.extract_yaw_pitch_host(scene.E_aligned)
-    E_t = torch.from_numpy(np.stack(scene.E_aligned).reshape(F, 16)).to(scene.device)
-    out = engine.pair_pose(E_t, scene.cam_mats[:, 0, :].contiguous(), torch.from_numpy(yaw).to(scene.device),
-                           torch.from_numpy(pitch).to(scene.device), both).cpu().numpy()
+    out = engine.pair_pose(*scene.pose_tables(), both).cpu().numpy()
     n = len(rows)
     return out[:n, 3:6], out[n:, 3:6]
 

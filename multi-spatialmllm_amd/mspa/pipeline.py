@@ -40,10 +40,7 @@ def pair_table_rows(scene_idx: int, scene) -> np.ndarray:
     pairs = engine.all_pairs(F, scene.device)
     vis = scene._visibility()
     overlap = engine.scene_overlap(vis["bits"])
-    yaw, pitch = engine.extract_yaw_pitch_host(scene.E_aligned)
-    E_t = torch.from_numpy(np.stack(scene.E_aligned).reshape(F, 16)).to(scene.device)
-    pose = engine.pair_pose(E_t, scene.cam_mats[:, 0, :].contiguous(), torch.from_numpy(yaw).to(scene.device),
-                            torch.from_numpy(pitch).to(scene.device), pairs)
+    pose = engine.pair_pose(*scene.pose_tables(), pairs)
     out = torch.empty((pairs.shape[0], 7), dtype=torch.float64, device=scene.device)
     out[:, 0] = scene_idx
     out[:, 1:3] = pairs.to(torch.float64)

@@ -17,7 +17,14 @@ from . import engine
 
 def valid_image_ids(E: Dict[str, np.ndarray]) -> List[str]:
     """Frames whose pose holds inf/nan are dropped before any projection (IH:184-189, 409-418)."""
-    return [k for k, e in E.items() if np.all(np.isfinite(np.asarray(e, dtype=np.float64)))]
+    keys = list(E)
+    if not keys:
+        return []
+    try:
+        ok = np.isfinite(np.stack([E[k] for k in keys]).astype(np.float64, copy=False)).all(axis=(1, 2))   # one pass, not one per frame
+    except ValueError:                        # ragged pose shapes: let the per-frame form decide
+        return [k for k, e in E.items() if np.all(np.isfinite(np.asarray(e, dtype=np.float64)))]
+    return [k for k, o in zip(keys, ok.tolist()) if o]
 
 
 class SceneOnDevice:
@@ -45,10 +52,12 @@ class SceneOnDevice:
         if points_xyz is not None:
             self.xyz = torch.from_numpy(np.ascontiguousarray(np.asarray(points_xyz, np.float64)[:, :3])).to(device)
         self._vis = None
+        self._pose = None
 
     @classmethod
-    def from_resident(cls, K, A, ids, E_aligned, depth, frame_mats, cam_mats, xyz, image_hw, device):
-        """A scene whose tensors are already on the device (mspa/upload.py: staged through pinned memory on a copy stream)."""
+    def from_resident(cls, K, A, ids, E_aligned, depth, frame_mats, cam_mats, xyz, image_hw, device, pose_tables=None):
+        """A scene whose tensors are already on the device (mspa/upload.py: staged through pinned memory on a copy stream).
+        ``pose_tables`` = (E_aligned [F,16], yaw [F], pitch [F]) device tensors when the uploader staged them as well."""
         self = cls.__new__(cls)
         self.K, self.A = np.asarray(K, np.float64), np.asarray(A, np.float64)
         self.ids = list(ids)
@@ -59,7 +68,21 @@ class SceneOnDevice:
         self.depth, self.frame_mats, self.cam_mats, self.xyz = depth, frame_mats, cam_mats, xyz
         self.rgb = None
         self._vis = None
+        self._pose = None if pose_tables is None else (pose_tables[0], cam_mats[:, 0, :].contiguous(), pose_tables[1],
+                                                       pose_tables[2])
         return self
+
+    def pose_tables(self):
+        """K4's per-frame inputs on the device: (A @ E [F,16], inv(A @ E) [F,16], yaw [F], pitch [F]); the angles are the
+        reference's own host arithmetic (engine.extract_yaw_pitch_host), uploaded once per scene."""
+        if getattr(self, "_pose", None) is None:
+            F = len(self.ids)
+            yaw, pitch = engine.extract_yaw_pitch_host(self.E_aligned)
+            E_t = torch.from_numpy(np.stack(self.E_aligned).reshape(F, 16)).to(self.device) if F else \
+                torch.zeros((0, 16), dtype=torch.float64, device=self.device)
+            self._pose = (E_t, self.cam_mats[:, 0, :].contiguous(), torch.from_numpy(yaw).to(self.device),
+                          torch.from_numpy(pitch).to(self.device))
+        return self._pose
 
     # ---- K1 -------------------------------------------------------------------------------
     def vertex_visibility(self, want=("bits", "count")) -> Dict[str, torch.Tensor]:
@@ -83,12 +106,7 @@ class SceneOnDevice:
         vis = self._visibility()
         pairs = engine.all_pairs(F, self.device)
         overlap = engine.scene_overlap(vis["bits"])               # tiled K2: every pair of the scene in one pass
-        yaw, pitch = engine.extract_yaw_pitch_host(self.E_aligned)
-        E_t = torch.from_numpy(np.stack(self.E_aligned).reshape(F, 16)).to(self.device) if F else \
-            torch.zeros((0, 16), dtype=torch.float64, device=self.device)
-        Einv_t = self.cam_mats[:, 0, :].contiguous()
-        pose = engine.pair_pose(E_t, Einv_t, torch.from_numpy(yaw).to(self.device),
-                                torch.from_numpy(pitch).to(self.device), pairs)
+        pose = engine.pair_pose(*self.pose_tables(), pairs)
         overlap, pose, pairs = overlap.cpu().numpy(), pose.cpu().numpy(), pairs.cpu().numpy()
         return {"i": pairs[:, 0], "j": pairs[:, 1], "overlap": overlap, "distance": pose[:, 0], "yaw": pose[:, 1],
                 "pitch": pose[:, 2]}

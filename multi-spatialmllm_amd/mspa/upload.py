@@ -3,12 +3,13 @@
 A ScanNet sweep is bounded by getting the depth frames onto the device (196 MB for a 320-frame scene against 0.2 ms of
 kernels), so the upload is what has to overlap: ``ScenePrefetcher`` stages scene n+1 into pinned memory on a worker
 thread (NumPy copies and the LAPACK inverses release the GIL) and enqueues its H2D copy on a side stream while the caller
-runs K1 / K2 / K4 on scene n; two slots, recycled through events, no allocation in steady state.
+runs K1 / K2 / K4 on scene n; three slots, recycled through events, no allocation in steady state.
 
 torch is plumbing here (pinned allocations, streams, events); nothing is computed.
 """
 from __future__ import annotations
 
+import os
 import queue
 import threading
 from typing import Iterable, Iterator, Optional
@@ -20,6 +21,13 @@ from . import engine
 from .scene import SceneOnDevice, valid_image_ids
 
 
+# Three slots, not two: with two, the producer cannot start staging scene n+2 before the consumer has released scene n, and
+# staging (3 ms), H2D (4 ms) and the consumer's kernels + download (1.2 ms) run back to back instead of side by side.
+UPLOAD_SLOTS = int(os.environ.get("MSPA_UPLOAD_SLOTS", "3"))
+STAGE_THREADS = int(os.environ.get("MSPA_STAGE_THREADS", "4"))           # native copy threads per staged chunk
+STAGE_CHUNK_FRAMES = int(os.environ.get("MSPA_STAGE_CHUNK_FRAMES", "160"))  # frames per chunk (98 MB at 640 x 480)
+
+
 class UploadSlot:
     """Pinned host buffers + device buffers of one scene; grown to the largest scene seen, then reused."""
 
@@ -28,7 +36,7 @@ class UploadSlot:
         self.cap_frames = self.cap_points = 0
         self.depth_hw = None
         self.h_depth = self.d_depth = self.h_xyz = self.d_xyz = None
-        self.h_fmats = self.d_fmats = self.h_cmats = self.d_cmats = None
+        self.h_fmats = self.d_fmats = self.h_cmats = self.d_cmats = self.h_pose = self.d_pose = None
         self.ready = torch.cuda.Event()          # recorded on the copy stream when the scene's tensors are resident
         self.free = None                         # recorded on the consumer's stream when it is done with them
 
@@ -42,6 +50,8 @@ class UploadSlot:
             self.d_fmats = torch.empty_like(self.h_fmats, device=self.device)
             self.h_cmats = torch.empty((self.cap_frames, 2, 16), dtype=torch.float64).pin_memory()
             self.d_cmats = torch.empty_like(self.h_cmats, device=self.device)
+            self.h_pose = torch.empty((self.cap_frames * 18,), dtype=torch.float64).pin_memory()   # A @ E, yaw, pitch (K4)
+            self.d_pose = torch.empty_like(self.h_pose, device=self.device)
         if n_points > self.cap_points:
             self.cap_points = n_points
             self.h_xyz = torch.empty((n_points, 3), dtype=torch.float64).pin_memory()
@@ -57,25 +67,62 @@ class UploadSlot:
         if self.free is not None:
             self.free.synchronize()              # the previous user of this slot has finished (host-side wait: we overwrite
         self._ensure(max(F, 1), tuple(first.shape), max(N, 1))       # pinned memory the earlier copy may still be reading)
-        hd = self.h_depth.numpy()
-        for k, i in enumerate(ids):              # straight into pinned memory: no np.stack temporary
-            np.copyto(hd[k].view(np.uint16), sc.depth[i], casting="same_kind")
+        # Depth frames: straight into pinned memory (no np.stack temporary), a chunk of frames at a time by native copy
+        # threads, each chunk's H2D enqueued as soon as it is staged -- the link is busy while the next chunk is gathered
+        # and while the matrices below are prepared.
+        hd = self.h_depth.numpy().view(np.uint16)
+        frames = []
+        for i in ids:
+            f = sc.depth[i]
+            if f.dtype != np.uint16 or not f.flags.c_contiguous:
+                f = np.ascontiguousarray(f, dtype=np.uint16)
+            frames.append(f)
+        def depth_job():                                # on a helper thread: the gather holds no interpreter lock, so the matrix
+            torch.cuda.set_device(copy_stream.device)   # preparation below runs beside it
+            with torch.cuda.stream(copy_stream):
+                for lo in range(0, F, STAGE_CHUNK_FRAMES):
+                    hi = min(F, lo + STAGE_CHUNK_FRAMES)
+                    engine.gather_blocks_host(frames[lo:hi], hd[lo:hi], STAGE_THREADS)
+                    self.d_depth[lo:hi].copy_(self.h_depth[lo:hi], non_blocking=True)
+
+        depth_done = _stage_pool().submit(depth_job)
         K, A = np.asarray(sc.K, np.float64), np.asarray(sc.A, np.float64)
-        E_al = [A @ np.asarray(sc.E[i], np.float64) for i in ids]
+        # one batched matmul; bit-identical to A @ E per frame (tests/test_host_cpu.py)
+        E_al = list(np.matmul(A, np.stack([np.asarray(sc.E[i], np.float64) for i in ids]))) if F else []
         if F:
             self.h_fmats.numpy()[:F] = engine.frame_matrices(K, A, [sc.E[i] for i in ids])
             self.h_cmats.numpy()[:F] = engine.camera_matrices(K, E_al)
+            # K4's per-frame tables travel with the scene: uploaded by the consumer they would be pageable copies queued
+            # behind the next scene's 197 MB on the same copy engine
+            hp = self.h_pose.numpy()
+            hp[:16 * F].reshape(F, 16)[:] = np.stack(E_al).reshape(F, 16)
+            hp[16 * F:17 * F], hp[17 * F:18 * F] = engine.extract_yaw_pitch_host(E_al)
         if N:
             np.copyto(self.h_xyz.numpy()[:N], np.asarray(points, np.float64)[:, :3])
+        depth_done.result()                      # re-raises what the helper raised; the depth copies are enqueued
         with torch.cuda.stream(copy_stream):
-            self.d_depth[:F].copy_(self.h_depth[:F], non_blocking=True)
             self.d_fmats[:F].copy_(self.h_fmats[:F], non_blocking=True)
             self.d_cmats[:F].copy_(self.h_cmats[:F], non_blocking=True)
+            self.d_pose[:18 * F].copy_(self.h_pose[:18 * F], non_blocking=True)
             if N:
                 self.d_xyz[:N].copy_(self.h_xyz[:N], non_blocking=True)
             self.ready.record(copy_stream)
         return SceneOnDevice.from_resident(K, A, ids, E_al, self.d_depth[:F], self.d_fmats[:F], self.d_cmats[:F],
-                                           self.d_xyz[:N] if N else None, tuple(sc.color_hw), self.device)
+                                           self.d_xyz[:N] if N else None, tuple(sc.color_hw), self.device,
+                                           pose_tables=(self.d_pose[:16 * F].view(F, 16), self.d_pose[16 * F:17 * F],
+                                                        self.d_pose[17 * F:18 * F]))
+
+
+_STAGE_POOL = None
+
+
+def _stage_pool():
+    """One helper thread for the depth gather of the scene being staged (created on first use)."""
+    global _STAGE_POOL
+    if _STAGE_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _STAGE_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mspa-stage")
+    return _STAGE_POOL
 
 
 _SLOT_POOL: dict = {}     # device -> idle UploadSlots: pinning 40-200 MB costs tens of milliseconds, so slots outlive a prefetcher
@@ -100,7 +147,7 @@ class ScenePrefetcher:
     resident (the consumer's stream waits on the upload event, the host does not), while the next scene is being staged and
     copied.  A yielded scene is valid until the next iteration step (its slot is recycled two scenes later)."""
 
-    def __init__(self, scenes: Iterable, device="cuda", slots: int = 2, threaded: bool = True):
+    def __init__(self, scenes: Iterable, device="cuda", slots: int = UPLOAD_SLOTS, threaded: bool = True):
         self.scenes = scenes
         self.device = torch.device(device)
         self.n_slots = max(2, int(slots))

@@ -494,3 +494,11 @@ def test_scene_prefetcher_matches_direct_upload():
             for k in rel0:
                 assert np.array_equal(rel[k], rel0[k], equal_nan=True), k
             assert np.array_equal(csr.i2p_indices, csr0.i2p_indices) and np.array_equal(csr.p2i_offsets, csr0.p2i_offsets)
+
+
+@pytest.mark.gpu
+def test_host_pose_prep_bitwise_on_this_host():
+    """The same bit-identity check as tests/test_host_cpu.py, repeated on the GPU box's host CPU: NumPy picks its ufunc
+    loops (SVML / AVX-512) per machine, and the vectorised preparation must equal the per-frame form on each."""
+    from test_host_cpu import check_host_pose_prep_bitwise
+    check_host_pose_prep_bitwise()

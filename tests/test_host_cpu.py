@@ -237,3 +237,71 @@ def test_batched_matrix_preparation_is_bit_identical_to_per_frame_numpy():
     with pytest.raises(ValueError, match=r"E\[3\]"):
         engine.frame_matrices(sc.K, sc.A, bad)
     assert engine.frame_matrices(sc.K, sc.A, []).shape == (0, _lib.FRAME_MATS, 16)
+
+
+def test_gather_blocks_host_matches_per_frame_copies():
+    """mspa_gather_blocks_host (the staging copy of mspa/upload.py) against np.copyto frame by frame: any thread count, more
+    threads than blocks, repeated source blocks, zero blocks; wrong-sized and non-contiguous blocks are refused."""
+    from mspa import engine
+    rng = np.random.default_rng(11)
+    src = [rng.integers(0, 65535, (48, 64), dtype=np.uint16) for _ in range(5)]
+    blocks = [src[k % 5] for k in range(23)]
+    for nt in (1, 3, 8, 64):
+        dst = np.zeros((25, 48, 64), np.uint16)
+        engine.gather_blocks_host(blocks, dst, nt)
+        assert all((dst[k] == blocks[k]).all() for k in range(23)) and not dst[23:].any()
+    engine.gather_blocks_host([], np.zeros((0, 48, 64), np.uint16), 4)
+    as_i16 = np.zeros((23, 48, 64), np.int16)                      # the pinned stack is int16 holding the same bits
+    engine.gather_blocks_host(blocks, as_i16, 2)
+    assert (as_i16.view(np.uint16)[7] == blocks[7]).all()
+    with pytest.raises(ValueError):
+        engine.gather_blocks_host([src[0][:10]], np.zeros((1, 48, 64), np.uint16))
+    with pytest.raises(ValueError):
+        engine.gather_blocks_host([src[0].T.copy().T], np.zeros((1, 48, 64), np.uint16))
+    with pytest.raises(ValueError):
+        engine.gather_blocks_host(blocks, np.zeros((3, 48, 64), np.uint16))
+
+
+def _pose_cases(seed=21, n=400):
+    rng = np.random.default_rng(seed)
+    Es = []
+    for _ in range(n):
+        q, _r = np.linalg.qr(rng.normal(size=(3, 3)))
+        e = np.eye(4)
+        e[:3, :3] = q * rng.uniform(0.5, 2.0)          # not exactly orthonormal: the norm matters
+        e[:3, 3] = rng.normal(size=3) * 3
+        Es.append(e)
+    for z in ([0, 0, 1], [0, 0, -1], [1, 0, 0], [0, -1, 0], [1e-300, 0, 1], [-1, 1e-17, 0]):
+        e = np.eye(4)
+        e[:3, 2] = z
+        Es.append(e)
+    return Es
+
+
+def check_host_pose_prep_bitwise():
+    """The vectorised host preparation (angles over all frames at once, one batched A @ E, one isfinite pass) against the
+    oracle's literal per-frame forms, bit for bit."""
+    from oracle import np_oracle as O
+    from mspa.scene import valid_image_ids
+    Es = _pose_cases()
+    bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+    yaw, pitch = engine.extract_yaw_pitch_host(Es)
+    ref = [O.extract_yaw_pitch(e) for e in Es]
+    assert np.array_equal(bits(yaw), bits(np.array([r[0] for r in ref])))
+    assert np.array_equal(bits(pitch), bits(np.array([r[1] for r in ref])))
+    assert engine.extract_yaw_pitch_host([])[0].shape == (0,)
+    A = np.eye(4)
+    A[:3, :3] = np.linalg.qr(np.random.default_rng(2).normal(size=(3, 3)))[0]
+    A[:3, 3] = [0.3, -1.2, 0.05]
+    batched = np.matmul(A, np.stack(Es))
+    assert all(np.array_equal(bits(batched[k]), bits(A @ Es[k])) for k in range(len(Es)))
+    E = {f"f{k}": e.copy() for k, e in enumerate(Es[:50])}
+    E["f7"][1, 2] = np.inf
+    E["f31"][0, 0] = np.nan
+    E["f40"] = E["f40"].astype(np.float32)
+    assert valid_image_ids(E) == O.valid_image_ids(E) and len(valid_image_ids(E)) == 48
+    assert valid_image_ids({}) == []
+
+
+def test_host_pose_prep_is_bit_identical_to_per_frame_numpy():
+    check_host_pose_prep_bitwise()
