@@ -692,6 +692,9 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 #ifndef MSPA_TIGHT_BLOCK_WAVES
 #define MSPA_TIGHT_BLOCK_WAVES 4
 #endif
+#ifndef MSPA_TIGHT_DMA16
+#define MSPA_TIGHT_DMA16 1
+#endif
 constexpr int kTightRows = MSPA_TIGHT_ROWS;
 constexpr int kTightBW = MSPA_TIGHT_BLOCK_WAVES;      // waves (= tiles) per workgroup
 constexpr int kTightThreads = kTightBW * kWave;
@@ -769,16 +772,28 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
     // requests are in flight before any arithmetic and cost no VGPRs; their latency hides behind the
     // matrix composition below.  (A register prefetch one row group ahead left the kernel latency
     // bound once skipped groups made an iteration shorter than a memory round trip.)
-    __shared__ uint16_t lds_d1[kTightBW][kTightRows * 64];
+    __shared__ __attribute__((aligned(16))) uint16_t lds_d1[kTightBW][kTightRows * 64];
     if (tile_ok) {
         typedef __attribute__((address_space(1))) const void gvoid_t;
         typedef __attribute__((address_space(3))) void lvoid_t;
+#if MSPA_TIGHT_DMA16
+        // gfx950's 16-byte LDS-DMA: eight lanes fetch a row's 128 bytes, one wave instruction lands eight rows (1 KB,
+        // contiguous in LDS: lane L writes bytes 16 L .. 16 L + 15 past the base) -- 6 requests per tile instead of 24
+        static_assert(kTightRows % 8 == 0, "eight rows per 16-byte LDS-DMA request");
+        const uint16_t *src = c.depth1 + (int64_t)(row0 + (uint32_t)(c.lane >> 3)) * a.W + stripe * 64u +
+                              (uint32_t)(c.lane & 7) * 8u;
+#pragma unroll
+        for (int k = 0; k < kTightRows / 8; ++k)
+            __builtin_amdgcn_global_load_lds((gvoid_t *)(src + (int64_t)(8 * k) * a.W),
+                                             (lvoid_t *)&lds_d1[wave][k * 512], 16, 0, STREAM ? 2 : 0);  // aux 2 = nt
+#else
         const uint16_t *src = c.depth1 + (int64_t)(row0 + (uint32_t)(c.lane >> 5)) * a.W + stripe * 64u +
                               (uint32_t)(c.lane & 31) * 2u;
 #pragma unroll
         for (int k = 0; k < kTightRows / 2; ++k)
             __builtin_amdgcn_global_load_lds((gvoid_t *)(src + (int64_t)(2 * k) * a.W),
                                              (lvoid_t *)&lds_d1[wave][k * 128], 4, 0, STREAM ? 2 : 0);   // aux 2 = nt
+#endif
     }
 
     const double *__restrict__ U = m1 + MSPA_MAT_UNPROJ * 16;
