@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MSPA_VERSION 121            /* 0.2.0: + mspa_pair_reproject_last_kernel, tiled K2 (mspa_scene_overlap, mspa_overlap_matrix), K9 bitset -> index lists */
+#define MSPA_VERSION 122            /* 0.2.0: + mspa_pair_reproject_last_kernel, tiled K2 (mspa_scene_overlap, mspa_overlap_matrix), K9 bitset -> index lists */
 
 #define MSPA_OK 0
 #define MSPA_EINVAL (-1)            /* bad argument (null pointer, size out of range, ...) */
@@ -230,6 +230,15 @@ int64_t mspa_format_int_keys_host(const char *prefix_host, int64_t first, int64_
  */
 int mspa_gather_blocks_host(const void *const *src_blocks_host, int64_t n_blocks, int64_t block_bytes, void *dst_host,
                             int32_t n_threads);
+
+/*
+ * Host-side ingest of zlib-compressed frames: the depth payloads of a ScanNet .sens stream (`zlib_ushort`,
+ * extract_posed_images.py:49-57 inflates them one by one).  Block k (src_bytes_host[k] bytes at src_blocks_host[k], e.g.
+ * inside a memory-mapped file) is inflated into dst_host + k * block_bytes by up to n_threads threads.  Every block
+ * must inflate to exactly block_bytes; otherwise MSPA_EINVAL and the error string names the block.
+ */
+int mspa_inflate_blocks_host(const void *const *src_blocks_host, const int64_t *src_bytes_host, int64_t n_blocks,
+                             int64_t block_bytes, void *dst_host, int32_t n_threads);
 
 /*
  * K4 -- per-pair camera relations: the distance / yaw / pitch columns of CFR.process_scene's pair

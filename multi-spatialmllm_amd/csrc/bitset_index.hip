@@ -14,9 +14,12 @@
 //                        the transposed tile (lane b keeps it)
 #include "mspa_common.h"
 
+#include <atomic>
+#include <cstdio>
 #include <cstring>
 #include <thread>
 #include <vector>
+#include <zlib.h>
 
 namespace mspa {
 
@@ -243,5 +246,47 @@ extern "C" int mspa_gather_blocks_host(const void *const *src_blocks_host, int64
     }
     work(0);
     for (auto &th : pool) th.join();
+    return MSPA_OK;
+}
+
+// Host-side ingest of zlib-compressed frames (the depth payloads of a ScanNet .sens stream, SENS:49-57 `zlib_ushort`): block k is
+// inflated straight into dst + k * block_bytes by up to n_threads threads (blocks are handed out one at a time: payload
+// sizes differ).  A block that does not inflate to exactly block_bytes fails the call and names the block.
+extern "C" int mspa_inflate_blocks_host(const void *const *src_blocks_host, const int64_t *src_bytes_host, int64_t n_blocks,
+                                        int64_t block_bytes, void *dst_host, int32_t n_threads) {
+    if (n_blocks < 0 || block_bytes <= 0 || (n_blocks > 0 && (!src_blocks_host || !src_bytes_host || !dst_host)))
+        return fail(MSPA_EINVAL, "mspa_inflate_blocks_host: bad argument");
+    if (block_bytes > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_inflate_blocks_host: block larger than 2 GiB");
+    for (int64_t k = 0; k < n_blocks; ++k)
+        if (!src_blocks_host[k] || src_bytes_host[k] <= 0 || src_bytes_host[k] > 0x7fffffffLL)
+            return fail(MSPA_EINVAL, "mspa_inflate_blocks_host: null or empty block");
+    if (n_blocks == 0) return MSPA_OK;
+    const int64_t nt = n_threads < 1 ? 1 : (n_threads > n_blocks ? n_blocks : (int64_t)n_threads);
+    std::atomic<int64_t> next{0}, bad{-1};
+    auto work = [&]() {
+        for (;;) {
+            const int64_t k = next.fetch_add(1);
+            if (k >= n_blocks) return;
+            uLongf got = (uLongf)block_bytes;
+            const int rc = uncompress((Bytef *)dst_host + k * block_bytes, &got, (const Bytef *)src_blocks_host[k],
+                                      (uLong)src_bytes_host[k]);
+            if (rc != Z_OK || (int64_t)got != block_bytes) {
+                int64_t none = -1;
+                bad.compare_exchange_strong(none, k);
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (int64_t t = 1; t < nt; ++t) pool.emplace_back(work);
+    } catch (...) {
+    }                                                    // fewer threads than asked for: the rest of the blocks go to those running
+    work();
+    for (auto &th : pool) th.join();
+    if (bad.load() >= 0) {
+        char msg[128];
+        snprintf(msg, sizeof msg, "mspa_inflate_blocks_host: block %lld is not a zlib stream of the expected size", (long long)bad.load());
+        return fail(MSPA_EINVAL, msg);
+    }
     return MSPA_OK;
 }

@@ -49,60 +49,118 @@ class SensScene:
     timestamps: np.ndarray             # [F,2] uint64 (colour, depth)
     depth: np.ndarray                  # [F,DH,DW] uint16
     color_jpeg: Optional[List[bytes]]  # undecoded payloads (None if not requested)
+    export_position: Optional[List[int]] = None   # position of each kept frame among the frames upstream exports (names)
 
     @staticmethod
     def index_to_str(index: int) -> str:
         return str(index).zfill(5)     # SENS:133-135
 
 
-def read_sens(path: str, frame_skip: int = 1, want_color: bool = False) -> SensScene:
-    """Parse a .sens file keeping every ``frame_skip``-th frame (SENS:106-116).  Skipped frames are seeked over,
-    depth payloads are inflated straight into one [F, DH, DW] uint16 array."""
+def read_sens(path: str, frame_skip: int = 1, want_color: bool = False, keep_every: int = 1, n_threads: int = 0,
+              native: Optional[bool] = None) -> SensScene:
+    """Parse a .sens file keeping every ``frame_skip``-th frame (SENS:106-116) -- the frames upstream exports -- and, of
+    those, only every ``keep_every``-th (UPD:20-68 keeps every 5th exported frame; the others need not be inflated at
+    all).  One pass over the memory-mapped file collects the frame headers; the kept depth payloads are then inflated
+    straight from the mapping into one [F, DH, DW] uint16 array by the library's copy threads
+    (``mspa_inflate_blocks_host``; ``native=False`` or a missing library falls back to ``zlib`` frame by frame -- same
+    bytes, this is file parsing, not the compute path)."""
+    import mmap
     with open(path, "rb") as f:
-        (version,) = struct.unpack("<I", f.read(4))
+        size = os.fstat(f.fileno()).st_size
+        if size < 4:
+            raise ValueError(f"{path}: truncated header")
+        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+    try:
+        view = memoryview(mm)
+        pos = 0
+
+        def take(n):
+            nonlocal pos
+            if pos + n > size:
+                raise ValueError(f"{path}: truncated header")
+            out = view[pos:pos + n]
+            pos += n
+            return out
+
+        (version,) = struct.unpack("<I", take(4))
         if version != VERSION:
             raise AssertionError(f"unsupported .sens version {version}")          # SENS:71
-        (strlen,) = struct.unpack("<Q", f.read(8))
-        name = f.read(strlen)
-        mats = [np.frombuffer(f.read(64), dtype="<f4").reshape(4, 4).copy() for _ in range(4)]
-        c_comp, d_comp = struct.unpack("<ii", f.read(8))
-        cw, ch, dw, dh = struct.unpack("<IIII", f.read(16))
-        (shift,) = struct.unpack("<f", f.read(4))
-        (n_frames,) = struct.unpack("<Q", f.read(8))
+        (strlen,) = struct.unpack("<Q", take(8))
+        name = bytes(take(strlen))
+        mats = [np.frombuffer(take(64), dtype="<f4").reshape(4, 4).copy() for _ in range(4)]
+        c_comp, d_comp = struct.unpack("<ii", take(8))
+        cw, ch, dw, dh = struct.unpack("<IIII", take(16))
+        (shift,) = struct.unpack("<f", take(4))
+        (n_frames,) = struct.unpack("<Q", take(8))
         color_compression, depth_compression = COLOR_COMPRESSION[c_comp], DEPTH_COMPRESSION[d_comp]
-        keep = list(range(0, n_frames, frame_skip))
-        keep_set = set(keep)
-        poses = np.empty((len(keep), 4, 4), dtype=np.float32)
-        stamps = np.empty((len(keep), 2), dtype=np.uint64)
-        depth = np.empty((len(keep), dh, dw), dtype=np.uint16)
-        jpeg: Optional[List[bytes]] = [] if want_color else None
-        k = 0
+        if depth_compression not in ("zlib_ushort", "raw_ushort"):
+            raise AssertionError(f"depth compression {depth_compression} not supported")   # SENS:51
+        keep, positions, heads, d_off, d_len, c_off, c_len = [], [], [], [], [], [], []
         for i in range(n_frames):
-            head = f.read(_FRAME_HEAD.size)
-            if len(head) != _FRAME_HEAD.size:
+            if pos + _FRAME_HEAD.size > size:
                 raise ValueError(f"{path}: truncated at frame {i}")
-            vals = _FRAME_HEAD.unpack(head)
+            vals = _FRAME_HEAD.unpack_from(view, pos)
+            pos += _FRAME_HEAD.size
             c_bytes, d_bytes = vals[18], vals[19]
-            if i not in keep_set:
-                f.seek(c_bytes + d_bytes, os.SEEK_CUR)
-                continue
+            if pos + c_bytes + d_bytes > size:
+                raise ValueError(f"{path}: truncated at frame {i}")
+            if i % frame_skip == 0 and (i // frame_skip) % keep_every == 0:
+                keep.append(i)
+                positions.append(i // frame_skip)
+                heads.append(vals)
+                c_off.append(pos)
+                c_len.append(c_bytes)
+                d_off.append(pos + c_bytes)
+                d_len.append(d_bytes)
+            pos += c_bytes + d_bytes
+        F = len(keep)
+        poses = np.empty((F, 4, 4), dtype=np.float32)
+        stamps = np.empty((F, 2), dtype=np.uint64)
+        for k, vals in enumerate(heads):
             poses[k] = np.asarray(vals[:16], dtype=np.float32).reshape(4, 4)
             stamps[k] = (vals[16], vals[17])
-            if want_color:
-                jpeg.append(f.read(c_bytes))
+        depth = np.empty((F, dh, dw), dtype=np.uint16)
+        frame_bytes = dh * dw * 2
+        jpeg: Optional[List[bytes]] = [bytes(view[o:o + n]) for o, n in zip(c_off, c_len)] if want_color else None
+        if depth_compression == "raw_ushort":
+            for k in range(F):
+                if d_len[k] != frame_bytes:
+                    raise ValueError(f"{path}: frame {keep[k]} holds {d_len[k]} depth bytes, expected {frame_bytes}")
+                depth[k] = np.frombuffer(view[d_off[k]:d_off[k] + frame_bytes], dtype="<u2").reshape(dh, dw)
+        elif F:
+            if native is None or native:
+                try:
+                    from . import _lib
+                    lib = _lib.load()
+                except Exception:
+                    if native:
+                        raise
+                    lib = None
             else:
-                f.seek(c_bytes, os.SEEK_CUR)
-            payload = f.read(d_bytes)
-            if depth_compression == "zlib_ushort":
-                raw = zlib.decompress(payload)
-            elif depth_compression == "raw_ushort":
-                raw = payload
+                lib = None
+            if lib is not None:
+                import ctypes
+                whole = np.frombuffer(view, dtype=np.uint8)                 # zero-copy view of the mapping
+                base = whole.ctypes.data
+                ptrs = (ctypes.c_void_p * F)(*[base + o for o in d_off])
+                lens = (ctypes.c_int64 * F)(*d_len)
+                threads = n_threads if n_threads > 0 else min(64, os.cpu_count() or 1)
+                _lib.check(lib.mspa_inflate_blocks_host(ptrs, lens, F, frame_bytes, depth.ctypes.data, threads))
+                del whole
             else:
-                raise AssertionError(f"depth compression {depth_compression} not supported")   # SENS:51
-            depth[k] = np.frombuffer(raw, dtype="<u2").reshape(dh, dw)
-            k += 1
+                for k in range(F):
+                    raw = zlib.decompress(view[d_off[k]:d_off[k] + d_len[k]])
+                    if len(raw) != frame_bytes:
+                        raise ValueError(f"{path}: frame {keep[k]} inflates to {len(raw)} bytes, expected {frame_bytes}")
+                    depth[k] = np.frombuffer(raw, dtype="<u2").reshape(dh, dw)
+        view.release()
+    finally:
+        try:
+            mm.close()
+        except BufferError:                   # a view escaped (error path): the mapping goes with the garbage collector
+            pass
     return SensScene(name, mats[0], mats[1], mats[2], mats[3], color_compression, depth_compression, (ch, cw), (dh, dw),
-                     float(shift), int(n_frames), keep, poses, stamps, depth, jpeg)
+                     float(shift), int(n_frames), keep, poses, stamps, depth, jpeg, positions)
 
 
 def text_roundtrip(matrix: np.ndarray) -> np.ndarray:
@@ -120,12 +178,21 @@ def matrix_text(matrix: np.ndarray) -> str:
     return buf.getvalue()
 
 
+def _kept(sens: SensScene, image_frame_skip: int):
+    """(row in the arrays, exported position) of the frames UPD:20-68 keeps: every ``image_frame_skip``-th exported frame."""
+    pos = sens.export_position if sens.export_position is not None else list(range(len(sens.frame_index)))
+    out = [(k, e) for k, e in enumerate(pos) if e % image_frame_skip == 0]
+    if pos and len(out) != len(range(0, pos[-1] + 1, image_frame_skip)):
+        raise ValueError("the stream was read with a keep_every that drops frames image_frame_skip needs")
+    return out
+
+
 def scene_info_entries(scene_id: str, sens: SensScene, image_frame_skip: int = 5) -> dict:
     """num_posed_images / images_info / intrinsic_matrix of one scene as UPD:20-68 builds them from the exported
     folder: frames are named by their position among the exported ones, every ``image_frame_skip``-th is kept."""
     images = {}
-    for k in range(0, len(sens.frame_index), image_frame_skip):
-        image_id = SensScene.index_to_str(k)
+    for k, e in _kept(sens, image_frame_skip):
+        image_id = SensScene.index_to_str(e)
         images[image_id] = {"image_path": f"posed_images/{scene_id}/{image_id}.jpg",
                             "depth_image_path": f"posed_images/{scene_id}/{image_id}.png",
                             "extrinsic_matrix": text_roundtrip(sens.camera_to_world[k])}
@@ -135,7 +202,7 @@ def scene_info_entries(scene_id: str, sens: SensScene, image_frame_skip: int = 5
 
 def depth_frames(sens: SensScene, image_frame_skip: int = 5) -> Dict[str, np.ndarray]:
     """{image_id: uint16 depth frame} for the frames ``scene_info_entries`` keeps (views, no copies)."""
-    return {SensScene.index_to_str(k): sens.depth[k] for k in range(0, len(sens.frame_index), image_frame_skip)}
+    return {SensScene.index_to_str(e): sens.depth[k] for k, e in _kept(sens, image_frame_skip)}
 
 
 def export_posed_images(sens: SensScene, output_path: str, with_depth_png: bool = True):
@@ -145,8 +212,9 @@ def export_posed_images(sens: SensScene, output_path: str, with_depth_png: bool 
     os.makedirs(output_path, exist_ok=True)
     with open(os.path.join(output_path, "intrinsic.txt"), "w") as f:
         f.write(matrix_text(sens.intrinsic_color))
-    for k in range(len(sens.frame_index)):
-        stem = os.path.join(output_path, SensScene.index_to_str(k))
+    pos = sens.export_position if sens.export_position is not None else list(range(len(sens.frame_index)))
+    for k, e in enumerate(pos):
+        stem = os.path.join(output_path, SensScene.index_to_str(e))
         with open(stem + ".txt", "w") as f:
             f.write(matrix_text(sens.camera_to_world[k]))
         if sens.color_jpeg is not None:

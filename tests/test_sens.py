@@ -161,3 +161,59 @@ def test_extract_posed_images_mirror(gold, tmp_path, monkeypatch):
         assert np.array_equal(src["intrinsic_matrix"], z["skip1_info_K"])
         assert np.array_equal(np.stack([v["extrinsic_matrix"] for v in src["images_info"].values()]), z["skip1_info_E"])
         assert list(src["images_info"]) == ["00000", "00005", "00010"] and src["num_objects"] == 0
+
+
+def test_native_inflate_keep_every_and_corrupt_payload(tmp_path):
+    """The two-pass reader: native multi-threaded inflate == zlib frame by frame; ``keep_every`` inflates only the frames
+    UPD:20-68 keeps and names them by their exported position; a corrupt payload is refused with the frame named."""
+    from mspa import _lib
+    rng = np.random.default_rng(9)
+    n = 23
+    depth = [(rng.integers(0, 40, (12, 16)) + 100 * k).astype(np.uint16) for k in range(n)]
+    poses = [rng.normal(size=(4, 4)).astype(np.float32) for _ in range(n)]
+    path = str(tmp_path / "s.sens")
+    S.write_sens(path, np.eye(4, dtype=np.float32), poses, depth, color_hw=(12, 16), color_payloads=[b"jpg%d" % k for k in range(n)])
+    a = S.read_sens(path, frame_skip=2, native=True, n_threads=5, want_color=True)
+    b = S.read_sens(path, frame_skip=2, native=False, want_color=True)
+    assert np.array_equal(a.depth, b.depth) and np.array_equal(a.depth, np.stack(depth)[::2])
+    assert a.color_jpeg == b.color_jpeg == [b"jpg%d" % k for k in range(0, n, 2)]
+    assert a.export_position == list(range(12))
+    full = S.scene_info_entries("scene0000_00", a, image_frame_skip=5)
+    thin = S.read_sens(path, frame_skip=2, keep_every=5, native=True)
+    assert thin.frame_index == [0, 10, 20] and thin.export_position == [0, 5, 10]
+    got = S.scene_info_entries("scene0000_00", thin, image_frame_skip=5)
+    assert list(got["images_info"]) == list(full["images_info"]) == ["00000", "00005", "00010"]
+    for k in got["images_info"]:
+        assert np.array_equal(got["images_info"][k]["extrinsic_matrix"], full["images_info"][k]["extrinsic_matrix"])
+    fa, ft = S.depth_frames(a, 5), S.depth_frames(thin, 5)
+    assert list(fa) == list(ft) and all(np.array_equal(fa[k], ft[k]) for k in fa)
+    with pytest.raises(ValueError):
+        S.scene_info_entries("s", S.read_sens(path, frame_skip=2, keep_every=2), image_frame_skip=5)
+    # corrupt one payload: flip bytes in the middle of frame 4's zlib stream
+    raw = bytearray(open(path, "rb").read())
+    probe = S.read_sens(path)                                    # offsets via a second parse of the headers
+    blob = zlib_payload_offset(raw, 4)
+    raw[blob + 6:blob + 12] = b"\xff" * 6
+    bad = str(tmp_path / "bad.sens")
+    open(bad, "wb").write(raw)
+    with pytest.raises(_lib.MspaError, match="block 4"):
+        S.read_sens(bad, native=True)
+    with pytest.raises(Exception):
+        S.read_sens(bad, native=False)
+    assert probe.n_frames_total == n
+
+
+def zlib_payload_offset(raw, frame):
+    """Byte offset of frame ``frame``'s depth payload in a stream written by write_sens."""
+    pos = 4
+    (strlen,) = struct.unpack_from("<Q", raw, pos)
+    pos += 8 + strlen + 4 * 64 + 8 + 16 + 4
+    (n,) = struct.unpack_from("<Q", raw, pos)
+    pos += 8
+    for i in range(n):
+        vals = struct.unpack_from("<16f4Q", raw, pos)
+        pos += struct.calcsize("<16f4Q")
+        if i == frame:
+            return pos + vals[18]
+        pos += vals[18] + vals[19]
+    raise IndexError(frame)

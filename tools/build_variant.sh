@@ -11,5 +11,5 @@ for f in api pair_reproject vertex_visibility pair_overlap pose_tracks samples o
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-result "$@" -c $f.hip -o $B/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/ab/libmspa_$NAME.so $B/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/ab/libmspa_$NAME.so $B/*.o -lz
 echo built tools/ab/libmspa_$NAME.so

@@ -123,6 +123,56 @@ def main():
     timed("host memory -> pair-table columns, scenes prefetched (upload of scene n+1 under K1+K2+K4 of scene n)",
           pipeline_scenes, "pairs", "-")
 
+    # File format in: one ScanNet-style .sens stream per scene (zlib depth payloads, float32 poses; 5 x args.frames frames so
+    # that the every-5th-frame rule of update_info_file_with_images.py keeps args.frames), page cache warm.  Upstream exports
+    # every frame to PNG / text and re-reads them per call; here the kept payloads are inflated from the mapped file by the
+    # library's threads and the scene goes through the same prefetcher as above.
+    import tempfile
+    from mspa import sens as S
+    sens_dir = tempfile.mkdtemp(prefix="mspa_sens_")
+    sens_paths = []
+    for sc in scenes:
+        ids = sc.valid_image_ids
+        every = [ids[(k // 5) % len(ids)] for k in range(5 * len(ids))]
+        path = os.path.join(sens_dir, sc.scene_id + ".sens")
+        S.write_sens(path, sc.K.astype(np.float32), [sc.E[i].astype(np.float32) for i in every], [sc.depth[i] for i in every],
+                     color_hw=(480, 640))
+        sens_paths.append((path, sc))
+    sens_mb = sum(os.path.getsize(p) for p, _ in sens_paths) / 1e6
+
+    class SensHostScene:
+        def __init__(self, path, sc):
+            st = S.read_sens(path, frame_skip=1, keep_every=5)
+            info = S.scene_info_entries(sc.scene_id, st, image_frame_skip=5)
+            self.K, self.A, self.color_hw, self.points = info["intrinsic_matrix"], sc.A, sc.color_hw, sc.points
+            self.E = {k: v["extrinsic_matrix"] for k, v in info["images_info"].items()}
+            self.depth = S.depth_frames(st, 5)
+
+    def sens_scenes():
+        for path, sc in sens_paths:
+            yield SensHostScene(path, sc)
+
+    def sens_pipeline():
+        from mspa import upload
+        n = 0
+        for scene in upload.ScenePrefetcher(sens_scenes(), dev):
+            n += len(scene.ids)
+            scene.frames_relations_arrays()
+        return n
+    sens_pipeline()
+    timed(".sens files (%.0f MB, zlib depth, %d frames each of which every 5th is kept) -> inflate (library threads) -> prefetcher "
+          "-> K1 + K2 + K4 -> pair-table columns" % (sens_mb, 5 * args.frames), sens_pipeline, "frames", "-")
+
+    def sens_read_only():
+        return sum(len(S.read_sens(p, frame_skip=1, keep_every=5).frame_index) for p, _ in sens_paths)
+    timed("... the .sens parse + inflate alone (up to 64 library threads)", sens_read_only, "frames", "-")
+
+    def sens_read_python():
+        return sum(len(S.read_sens(p, frame_skip=1, keep_every=5, native=False).frame_index) for p, _ in sens_paths[:1])
+    timed("... the .sens parse with zlib frame by frame in the interpreter (1 scene)", sens_read_python, "frames", "-")
+    import shutil
+    shutil.rmtree(sens_dir, ignore_errors=True)
+
     rng = random.Random(0)
     by_id = {sc.scene_id: sc for sc in scenes}
     usable = [r for r in table if r["overlap"] >= 1.0]        # the reference samples overlap bins 6..35 %
