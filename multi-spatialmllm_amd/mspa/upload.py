@@ -86,19 +86,23 @@ class UploadSlot:
                     self.d_depth[lo:hi].copy_(self.h_depth[lo:hi], non_blocking=True)
 
         depth_done = _stage_pool().submit(depth_job)
-        K, A = np.asarray(sc.K, np.float64), np.asarray(sc.A, np.float64)
-        # one batched matmul; bit-identical to A @ E per frame (tests/test_host_cpu.py)
-        E_al = list(np.matmul(A, np.stack([np.asarray(sc.E[i], np.float64) for i in ids]))) if F else []
-        if F:
-            self.h_fmats.numpy()[:F] = engine.frame_matrices(K, A, [sc.E[i] for i in ids])
-            self.h_cmats.numpy()[:F] = engine.camera_matrices(K, E_al)
-            # K4's per-frame tables travel with the scene: uploaded by the consumer they would be pageable copies queued
-            # behind the next scene's 197 MB on the same copy engine
-            hp = self.h_pose.numpy()
-            hp[:16 * F].reshape(F, 16)[:] = np.stack(E_al).reshape(F, 16)
-            hp[16 * F:17 * F], hp[17 * F:18 * F] = engine.extract_yaw_pitch_host(E_al)
-        if N:
-            np.copyto(self.h_xyz.numpy()[:N], np.asarray(points, np.float64)[:, :3])
+        try:
+            K, A = np.asarray(sc.K, np.float64), np.asarray(sc.A, np.float64)
+            # one batched matmul; bit-identical to A @ E per frame (tests/test_host_cpu.py)
+            E_al = list(np.matmul(A, np.stack([np.asarray(sc.E[i], np.float64) for i in ids]))) if F else []
+            if F:
+                self.h_fmats.numpy()[:F] = engine.frame_matrices(K, A, [sc.E[i] for i in ids])
+                self.h_cmats.numpy()[:F] = engine.camera_matrices(K, E_al)
+                # K4's per-frame tables travel with the scene: uploaded by the consumer they would be pageable copies queued
+                # behind the next scene's 197 MB on the same copy engine
+                hp = self.h_pose.numpy()
+                hp[:16 * F].reshape(F, 16)[:] = np.stack(E_al).reshape(F, 16)
+                hp[16 * F:17 * F], hp[17 * F:18 * F] = engine.extract_yaw_pitch_host(E_al)
+            if N:
+                np.copyto(self.h_xyz.numpy()[:N], np.asarray(points, np.float64)[:, :3])
+        except BaseException:
+            depth_done.exception()               # a bad pose must not leave the helper writing into a slot that is handed back
+            raise
         depth_done.result()                      # re-raises what the helper raised; the depth copies are enqueued
         with torch.cuda.stream(copy_stream):
             self.d_fmats[:F].copy_(self.h_fmats[:F], non_blocking=True)

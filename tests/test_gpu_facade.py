@@ -494,6 +494,17 @@ def test_scene_prefetcher_matches_direct_upload():
             for k in rel0:
                 assert np.array_equal(rel[k], rel0[k], equal_nan=True), k
             assert np.array_equal(csr.i2p_indices, csr0.i2p_indices) and np.array_equal(csr.p2i_offsets, csr0.p2i_offsets)
+    # a scene whose pose is not affine fails in the staging thread: the error reaches the consumer, the slots go back to the
+    # pool intact (the depth helper is waited for) and the next prefetcher works
+    import copy
+    bad = copy.copy(scs[2])
+    bad.E = {k: v.copy() for k, v in scs[2].E.items()}
+    bad.E[scs[2].valid_image_ids[1]][3, 1] = 1e-3
+    with pytest.raises(ValueError, match="affine|last row|E"):
+        for _scene in upload.ScenePrefetcher([scs[0], bad, scs[3]], "cuda"):
+            pass
+    again = [s.ids for s in upload.ScenePrefetcher([scs[0], scs[3]], "cuda")]
+    assert again == [want[0][0], want[3][0]]
 
 
 @pytest.mark.gpu
