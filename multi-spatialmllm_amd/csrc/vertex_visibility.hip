@@ -28,7 +28,10 @@ struct VertexArgs {
 };
 
 constexpr int kVThreads = 256;
-constexpr int kImgPerBlock = 8;
+#ifndef MSPA_VIMG
+#define MSPA_VIMG 8
+#endif
+constexpr int kImgPerBlock = MSPA_VIMG;
 
 __global__ __launch_bounds__(kVThreads) void vertex_visibility_kernel(const double *__restrict__ xyz,
                                                                       const double *__restrict__ cam_mats,
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_kernel(const doub
 constexpr double kVGuardPx = 1e-6;
 constexpr double kVGuardZmm = 1e-6;
 #ifndef MSPA_VBATCH
-#define MSPA_VBATCH 4
+#define MSPA_VBATCH 8
 #endif
 constexpr int kVBatch = MSPA_VBATCH;             // images whose depth gathers are in flight together
 
