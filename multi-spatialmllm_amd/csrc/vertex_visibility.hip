@@ -177,8 +177,9 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_fast_kernel(const
             const double ru = __builtin_rint(us), rv = __builtin_rint(vs);
             // saturating conversion (NaN -> 0), clamp by v_med3; the gather goes through a buffer resource of the frame with a
             // 32-bit byte offset (64-bit address arithmetic cost five more instructions per image in an instruction-bound
-            // kernel).  Non-candidates read sample 0: letting them gather at their clamped border pixel instead was 18 % slower
-            // (three quarters of the lanes, spread along the frame's edges)
+            // kernel).  The `cand ? offset : 0` below compiles to an exec-masked load: non-candidates (three lanes in four)
+            // never reach the address unit.  Letting them gather at their clamped border pixel was 18 % slower, a plain
+            // v_cndmask select (all lanes load, non-candidates sample 0) 25 % slower
             int xi, yi;
             asm("v_med3_i32 %0, %1, 0, %2" : "=v"(xi) : "v"((int)ru), "s"(hi_x));
             asm("v_med3_i32 %0, %1, 0, %2" : "=v"(yi) : "v"((int)rv), "s"(hi_y));
