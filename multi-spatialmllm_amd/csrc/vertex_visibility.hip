@@ -27,7 +27,11 @@ struct VertexArgs {
     uint32_t n_xcd;                // XCDs the hardware deals workgroups over (1 = plain linear decode)
 };
 
-constexpr int kVThreads = 256;
+#ifndef MSPA_VTHREADS
+#define MSPA_VTHREADS 256
+#endif
+constexpr int kVThreads = MSPA_VTHREADS;
+static_assert(kVThreads % 64 == 0 && kVThreads <= 256, "the compacted kernel packs the thread index into eight bits");
 #ifndef MSPA_VIMG
 #define MSPA_VIMG 8
 #endif
@@ -240,6 +244,217 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_fast_kernel(const
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Compacted form of the fast kernel.  Three (vertex, image) pairs in four fail the frustum test, yet on an unordered vertex
+// array every wave holds some candidate for every image, so no wave-level early-out ever fires and the fast kernel spends
+// its ~55 VALU issues per (wave, image) on mostly idle lanes -- and it is instruction-bound.  Here the block works in phases:
+//   A  every thread decides candidacy of its vertex for the block's images on the homogeneous triple, BEFORE the division
+//      (iz > 0:  u > -b  <=>  ix > -b iz;  u < W + b  <=>  ix < (W + b) iz), 17 issues per image, and the candidates
+//      (vertex, image) are compacted into an LDS list (ballot + mbcnt ranks, one LDS atomic per wave);
+//   B  the threads walk the dense list: projection again for the listed pair (vertex from LDS, matrix row set of its image
+//      from LDS), reciprocal, rounding, guards, depth gather (one buffer resource spans the block's frames), depth test;
+//      guarded lanes take the reference chain exactly as before; visible pairs OR their bit into an LDS bit table;
+//   C  the table leaves as the same coalesced bitset words / byte mask / counts.
+// The tie guard of phase B is TWICE the candidate band of phase A, so a lane the band let in from just outside the image
+// (|u| < b) is always re-evaluated; lanes with |iz| under the depth guard and images with a non-pinhole K are listed
+// unconditionally and re-evaluated.  Same integers as the other two kernels (tests/test_gpu_parity.py: goldens, adversarial
+// cameras, ScanNet's two grids, non-pinhole K).
+// ---------------------------------------------------------------------------------------------------------
+#ifndef MSPA_VCOMPACT
+#define MSPA_VCOMPACT 1
+#endif
+#ifndef MSPA_VCOMPACT_ENTRIES
+#define MSPA_VCOMPACT_ENTRIES 1
+#endif
+constexpr double kVBandPx = 1e-6;            // phase A: candidate band around the image, on the homogeneous coordinates
+constexpr double kVTiePx = 2e-6;             // phase B: tie / bound guard on the divided coordinates
+
+#ifndef MSPA_VCOMPACT_WAVES
+#define MSPA_VCOMPACT_WAVES 8
+#endif
+template <bool IDENT>
+__global__ __launch_bounds__(kVThreads)
+#if MSPA_VCOMPACT_WAVES
+__attribute__((amdgpu_waves_per_eu(MSPA_VCOMPACT_WAVES, MSPA_VCOMPACT_WAVES)))
+#endif
+void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
+                                                                              const double *__restrict__ cam_mats,
+                                                                              const uint16_t *__restrict__ depth,
+                                                                              VertexArgs a) {
+    const uint32_t xcd = blockIdx.x % a.n_xcd;
+    const uint32_t slot = blockIdx.x / a.n_xcd;
+    const uint32_t vblock = slot % a.vblocks;
+    const uint32_t group = (slot / a.vblocks) * a.n_xcd + xcd;
+    if (group >= a.igroups) return;
+    const int img0 = (int)group * kImgPerBlock;
+    const int img1 = min(img0 + kImgPerBlock, a.n_images);
+    const int nimg = img1 - img0;
+    const int tid = threadIdx.x, lane = tid & 63;
+
+    __shared__ __attribute__((aligned(16))) double lds_m[kImgPerBlock][12];
+    __shared__ int lds_pinhole[kImgPerBlock];
+    __shared__ __attribute__((aligned(16))) double lds_xyz[kVThreads][3];
+    __shared__ uint16_t lds_list[kVThreads * kImgPerBlock];
+    __shared__ uint32_t lds_bits[kImgPerBlock][kVThreads / 32];
+    __shared__ uint32_t lds_n;
+    if (tid < kImgPerBlock * 12) {
+        const int im = tid / 12, e = tid % 12, r = e / 4, cidx = e % 4;
+        if (im < nimg) {
+            const double *__restrict__ Einv = cam_mats + (int64_t)(img0 + im) * 32;
+            const double *__restrict__ K = Einv + 16;
+            double acc = K[4 * r + 0] * Einv[0 + cidx];
+            acc = __builtin_fma(K[4 * r + 1], Einv[4 + cidx], acc);
+            acc = __builtin_fma(K[4 * r + 2], Einv[8 + cidx], acc);
+            if (cidx == 3) acc += K[4 * r + 3];
+            lds_m[im][e] = acc * 1000.0;
+            if (e == 0) lds_pinhole[im] = (K[8] == 0.0 && K[9] == 0.0 && K[10] == 1.0 && K[11] == 0.0) ? 1 : 0;
+        }
+    }
+    if (tid < kImgPerBlock * (kVThreads / 32)) (&lds_bits[0][0])[tid] = 0u;
+    if (tid == 0) lds_n = 0u;
+    const int64_t i = (int64_t)vblock * kVThreads + tid;
+    const bool live = i < a.n_points;
+    const int64_t ic = live ? i : a.n_points - 1;
+    const double x = xyz[ic * a.point_stride];
+    const double y = xyz[ic * a.point_stride + a.comp_stride];
+    const double z = xyz[ic * a.point_stride + 2 * a.comp_stride];
+    lds_xyz[tid][0] = x;
+    lds_xyz[tid][1] = y;
+    lds_xyz[tid][2] = z;
+    const unsigned long long live_m = __builtin_amdgcn_ballot_w64(live);
+    const double Wd = (double)a.W, Hd = (double)a.H;
+    __syncthreads();
+
+    // ---- phase A: candidates of this wave's 64 vertices for the block's images ----
+    unsigned long long cm[kImgPerBlock];
+    int total = 0;
+#pragma unroll
+    for (int q = 0; q < kImgPerBlock; ++q) {
+        unsigned long long c = 0;
+        if (q < nimg) {                                               // block-uniform
+            const double *m = lds_m[q];
+            const double ix = __builtin_fma(m[0], x, __builtin_fma(m[1], y, __builtin_fma(m[2], z, m[3])));
+            const double iy = __builtin_fma(m[4], x, __builtin_fma(m[5], y, __builtin_fma(m[6], z, m[7])));
+            const double iz = __builtin_fma(m[8], x, __builtin_fma(m[9], y, __builtin_fma(m[10], z, m[11])));   // mm
+            const double gz = kVBandPx * iz;
+            const unsigned long long near0 = __builtin_amdgcn_ballot_w64(!(iz > kVGuardZmm));   // NaN lands here too
+            const unsigned long long inside =
+                __builtin_amdgcn_ballot_w64(ix > -gz) & __builtin_amdgcn_ballot_w64(ix < (Wd + kVBandPx) * iz) &
+                __builtin_amdgcn_ballot_w64(iy > -gz) & __builtin_amdgcn_ballot_w64(iy < (Hd + kVBandPx) * iz);
+            c = lds_pinhole[q] ? (live_m & __builtin_amdgcn_ballot_w64(!(iz <= -kVGuardZmm)) & (near0 | inside)) : live_m;
+        }
+        cm[q] = c;
+        total += __popcll(c);
+    }
+    uint32_t run = 0;
+    if (total) {                                                      // wave-uniform
+        if (lane == 0) run = atomicAdd(&lds_n, (uint32_t)total);
+        run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
+#pragma unroll
+        for (int q = 0; q < kImgPerBlock; ++q) {
+            if (cm[q] == 0) continue;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm[q], 0u));
+            if ((cm[q] >> lane) & 1ull) lds_list[run + rank] = (uint16_t)(tid | (q << 8));
+            run += (uint32_t)__popcll(cm[q]);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: the dense list ----
+    const uint32_t n = lds_n;
+    const int64_t dpix = (int64_t)a.dh * a.dw;
+    const int hi_x = a.dw - 1, hi_y = a.dh - 1;
+    const uint32_t dw2 = (uint32_t)a.dw * 2u, dpix2 = (uint32_t)(dpix * 2);
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(depth + (int64_t)img0 * dpix), 0, (int)((int64_t)nimg * dpix * 2), 0x00020000);
+    constexpr int kEnt = MSPA_VCOMPACT_ENTRIES;                       // list entries per thread and trip: their gathers fly together
+    for (uint32_t e0 = 0; e0 < n; e0 += kVThreads * kEnt) {           // block-uniform trip count
+        bool active[kEnt], risky[kEnt];
+        uint32_t vv[kEnt], qq[kEnt], d[kEnt];
+        double pxs[kEnt], pys[kEnt], pzs[kEnt], izs[kEnt];
+#pragma unroll
+        for (int k = 0; k < kEnt; ++k) {
+            const uint32_t e = e0 + (uint32_t)(k * kVThreads + tid);
+            active[k] = e < n;
+            const uint32_t ent = active[k] ? (uint32_t)lds_list[e] : 0u;
+            const uint32_t v = ent & 255u, q = ent >> 8;
+            vv[k] = v;
+            qq[k] = q;
+            const double px = lds_xyz[v][0], py = lds_xyz[v][1], pz = lds_xyz[v][2];
+            pxs[k] = px;
+            pys[k] = py;
+            pzs[k] = pz;
+            const double *m = lds_m[q];
+            const double ix = __builtin_fma(m[0], px, __builtin_fma(m[1], py, __builtin_fma(m[2], pz, m[3])));
+            const double iy = __builtin_fma(m[4], px, __builtin_fma(m[5], py, __builtin_fma(m[6], pz, m[7])));
+            const double iz = __builtin_fma(m[8], px, __builtin_fma(m[9], py, __builtin_fma(m[10], pz, m[11])));
+            izs[k] = iz;
+            double rz = __builtin_amdgcn_rcp(iz);
+            rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
+            const double u = ix * rz, w = iy * rz;
+            const double us = IDENT ? u : u * a.sx, vs = IDENT ? w : w * a.sy;
+            const double ru = __builtin_rint(us), rv = __builtin_rint(vs);
+            int xi, yi;                                               // saturating conversion; NaN -> 0
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(xi) : "v"((int)ru), "s"(hi_x));
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(yi) : "v"((int)rv), "s"(hi_y));
+            const double wu = __builtin_fabs(us - ru) - 0.25, wv = __builtin_fabs(vs - rv) - 0.25;
+            bool rk = !(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kVTiePx) | !(iz > kVGuardZmm) |
+                      (lds_pinhole[q] == 0);
+            if (!IDENT) {   // the bounds are integers of the COLOUR grid, the rounding ties belong to the depth grid
+                const double bu = __builtin_fmin(__builtin_fabs(u), __builtin_fabs(u - Wd));
+                const double bv = __builtin_fmin(__builtin_fabs(w), __builtin_fabs(w - Hd));
+                rk |= !(__builtin_fmin(bu, bv) > kVTiePx);
+            }
+            risky[k] = rk;
+            d[k] = 0;
+            if (active[k])
+                d[k] = __builtin_amdgcn_raw_buffer_load_b16(rs, (int)(q * dpix2 + __umul24((uint32_t)yi, dw2) + ((uint32_t)xi << 1)), 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < kEnt; ++k) {
+            const double sd = izs[k] - (double)d[k];
+            bool vis = sd < 0.0;
+            const bool rk = active[k] & (risky[k] | !(__builtin_fabs(sd) > kVGuardZmm));
+            if (__builtin_amdgcn_ballot_w64(rk) != 0ull) {            // rare: the reference chain (IH:57-69, 337-386)
+                if (rk) {
+                    const int img = img0 + (int)qq[k];
+                    const double *__restrict__ Einv = cam_mats + (int64_t)img * 32;
+                    const double *__restrict__ K = Einv + 16;
+                    const double qx = affine_row(Einv + 0, pxs[k], pys[k], pzs[k]);
+                    const double qy = affine_row(Einv + 4, pxs[k], pys[k], pzs[k]);
+                    const double qz = affine_row(Einv + 8, pxs[k], pys[k], pzs[k]);
+                    const double jx = affine_row(K + 0, qx, qy, qz);
+                    const double jy = affine_row(K + 4, qx, qy, qz);
+                    const double jz = affine_row(K + 8, qx, qy, qz);
+                    int ex, ey;
+                    vis = depth_test(true, jx / jz, jy / jz, qz, depth + (int64_t)img * dpix, a.dh, a.dw, a.H, a.W, a.sx, a.sy, ex, ey);
+                }
+            }
+            if (active[k] & vis) atomicOr(&lds_bits[qq[k]][vv[k] >> 5], 1u << (vv[k] & 31u));
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: the block's 256 x nimg bits leave as bitset words / byte mask / counts ----
+    constexpr int kWordsPerBlock = kVThreads / 64;
+    if (a.bits && tid < nimg * kWordsPerBlock) {
+        const int q = tid / kWordsPerBlock, w = tid % kWordsPerBlock;
+        const int64_t word = (int64_t)vblock * (kVThreads / 64) + w;
+        if (word < a.n_words)
+            a.bits[(int64_t)(img0 + q) * a.n_words + word] =
+                (uint64_t)lds_bits[q][2 * w] | ((uint64_t)lds_bits[q][2 * w + 1] << 32);
+    }
+    if (a.mask && live) {
+        for (int q = 0; q < nimg; ++q)
+            a.mask[(int64_t)(img0 + q) * a.n_points + i] = (uint8_t)((lds_bits[q][tid >> 5] >> (tid & 31)) & 1u);
+    }
+    if (a.count_atomic && tid < nimg) {
+        int c = 0;
+        for (int k = 0; k < kVThreads / 32; ++k) c += __popc(lds_bits[tid][k]);
+        if (c) atomicAdd(a.count_atomic + img0 + tid, c);
+    }
+}
+
 // visible vertices per image = popcount of its bitset: one wave per image
 __global__ __launch_bounds__(kVThreads) void bits_count_kernel(const uint64_t *__restrict__ bits, int64_t n_words,
                                                                int n_images, int32_t *__restrict__ count) {
@@ -349,8 +564,13 @@ extern "C" int mspa_vertex_visibility(const double *xyz, int64_t n_points, int64
     a.n_xcd = (uint32_t)n_xcd;
     // float64 outputs are DEFINED as the reference's operation order; everything else (bitset, byte mask, counts) takes the
     // composed + guarded kernel, which reproduces the same integers
+    const bool compact = MSPA_VCOMPACT && (int64_t)kImgPerBlock * dh * dw * 2 < 0x7fffffffLL && kImgPerBlock * 12 <= kVThreads;
     if (out_uv || out_depth)
         hipLaunchKernelGGL(vertex_visibility_kernel, dim3((uint32_t)blocks), dim3(kVThreads), 0, s, xyz, cam_mats, depth, a);
+    else if (compact && dh == H && dw == W)
+        hipLaunchKernelGGL(vertex_visibility_compact_kernel<true>, dim3((uint32_t)blocks), dim3(kVThreads), 0, s, xyz, cam_mats, depth, a);
+    else if (compact)
+        hipLaunchKernelGGL(vertex_visibility_compact_kernel<false>, dim3((uint32_t)blocks), dim3(kVThreads), 0, s, xyz, cam_mats, depth, a);
     else if (dh == H && dw == W)
         hipLaunchKernelGGL(vertex_visibility_fast_kernel<true>, dim3((uint32_t)blocks), dim3(kVThreads), 0, s, xyz, cam_mats, depth, a);
     else
