@@ -383,6 +383,57 @@ def test_vertex_visibility_fast_equals_exact_random_poses(color_hw, depth_hw):
     assert np.array_equal(fast2["bits"], exact2["bits"]) and np.array_equal(fast2["count"], exact2["count"])
 
 
+def test_vertex_visibility_compacted_list_extremes():
+    """The compacted K1 kernel's candidate list at its extremes, against the reference-order kernel: every (vertex, image) pair
+    a candidate (a wall seen head-on: the list is full, 2 048 entries per block), none (cameras looking away: empty list),
+    vertices with NaN / inf coordinates and vertices behind the camera mixed in, an image count and a vertex count that leave a
+    ragged last group / last block / last bitset word, depth frames with zeros and with samples that tie the projected depth."""
+    rng = np.random.default_rng(77)
+    hw = (96, 128)
+    K = synth.intrinsics_for(hw)
+    n = 256 * 5 + 67
+    wall = np.stack([rng.uniform(2.4, 3.6, n), rng.uniform(2.5, 3.5, n), np.full(n, 0.0)], axis=1)      # on the floor z = 0
+    E_see, E_away = [], []
+    for k in range(9):
+        eye = np.array([3.0 + 0.05 * k, 3.0 - 0.04 * k, 2.6])
+        E_see.append(synth._roundtrip_f(synth._look_at(eye, np.array([3.4, 3.3, 0.0]))))
+        E_away.append(synth._roundtrip_f(synth._look_at(eye, np.array([3.4, 3.3, 6.0]))))
+    def frames(E_list, pts):
+        out = []
+        for e in E_list:
+            d = np.full(hw, 0, np.uint16)
+            cam = (np.linalg.inv(e) @ np.c_[pts, np.ones(len(pts))].T).T
+            ok = cam[:, 2] > 0.05
+            uvz = (K[:3, :3] @ cam[ok, :3].T).T
+            u, v = np.rint(uvz[:, 0] / uvz[:, 2]).astype(int), np.rint(uvz[:, 1] / uvz[:, 2]).astype(int)
+            inb = (u >= 0) & (u < hw[1]) & (v >= 0) & (v < hw[0])
+            mm = np.rint(cam[ok, 2][inb] * 1000.0).astype(np.int64)
+            d[v[inb], u[inb]] = np.clip(mm + rng.integers(-1, 2, mm.shape), 0, 65535).astype(np.uint16)   # -1 / 0 / +1 mm: ties included
+            d[rng.random(hw) < 0.02] = 0
+            out.append(d)
+        return out
+    pts = wall.copy()
+    pts[5] = [np.nan, 1.0, 1.0]
+    pts[300] = [np.inf, 0.0, 0.0]
+    pts[301] = [3.0, 3.0, 9.0]                                           # behind the cameras that look down
+    A = np.eye(4)
+    t = torch.from_numpy(np.ascontiguousarray(pts)).to(DEV)
+    for E_list in (E_see, E_away, E_see[:3] + E_away[:2] + E_see[3:7]):
+        depth = frames(E_list, wall)
+        fast = run_vertices(t, K, A, E_list, depth, hw, want=("bits", "mask", "count"))
+        exact = run_vertices(t, K, A, E_list, depth, hw, want=("bits", "mask", "count", "uv"))
+        for k in ("bits", "mask", "count"):
+            assert np.array_equal(fast[k], exact[k]), k
+        only_bits = run_vertices(t, K, A, E_list, depth, hw, want=("bits",))
+        assert np.array_equal(only_bits["bits"], exact["bits"])
+        only_count = run_vertices(t, K, A, E_list, depth, hw, want=("count",))          # the per-block atomic form of the counts
+        assert np.array_equal(only_count["count"], exact["count"])
+    seen = run_vertices(t, K, A, E_see, frames(E_see, wall), hw, want=("count",))["count"]
+    assert seen.min() > 0.2 * n                                          # the full-list case really is dense
+    away = run_vertices(t, K, A, E_away, frames(E_away, wall), hw, want=("count",))["count"]
+    assert away.sum() == 0
+
+
 def test_vertex_visibility_large_and_edge():
     sc = synth.make_scene(1005, n_points=131072 + 37, n_frames=11, color_hw=(480, 640), invalid_pose_frac=0,
                           with_color=False)
