@@ -57,13 +57,14 @@ class SensScene:
 
 
 def read_sens(path: str, frame_skip: int = 1, want_color: bool = False, keep_every: int = 1, n_threads: int = 0,
-              native: Optional[bool] = None) -> SensScene:
+              native: Optional[bool] = None, want_depth: bool = True) -> SensScene:
     """Parse a .sens file keeping every ``frame_skip``-th frame (SENS:106-116) -- the frames upstream exports -- and, of
     those, only every ``keep_every``-th (UPD:20-68 keeps every 5th exported frame; the others need not be inflated at
     all).  One pass over the memory-mapped file collects the frame headers; the kept depth payloads are then inflated
     straight from the mapping into one [F, DH, DW] uint16 array by the library's copy threads
     (``mspa_inflate_blocks_host``; ``native=False`` or a missing library falls back to ``zlib`` frame by frame -- same
-    bytes, this is file parsing, not the compute path)."""
+    bytes, this is file parsing, not the compute path).  ``want_depth=False`` reads headers and poses only (what the
+    scene-info update needs): no payload is touched and ``depth`` comes back with zero frames."""
     import mmap
     with open(path, "rb") as f:
         size = os.fstat(f.fileno()).st_size
@@ -119,10 +120,12 @@ def read_sens(path: str, frame_skip: int = 1, want_color: bool = False, keep_eve
         for k, vals in enumerate(heads):
             poses[k] = np.asarray(vals[:16], dtype=np.float32).reshape(4, 4)
             stamps[k] = (vals[16], vals[17])
-        depth = np.empty((F, dh, dw), dtype=np.uint16)
+        depth = np.empty((F if want_depth else 0, dh, dw), dtype=np.uint16)
         frame_bytes = dh * dw * 2
         jpeg: Optional[List[bytes]] = [bytes(view[o:o + n]) for o, n in zip(c_off, c_len)] if want_color else None
-        if depth_compression == "raw_ushort":
+        if not want_depth:
+            pass
+        elif depth_compression == "raw_ushort":
             for k in range(F):
                 if d_len[k] != frame_bytes:
                     raise ValueError(f"{path}: frame {keep[k]} holds {d_len[k]} depth bytes, expected {frame_bytes}")

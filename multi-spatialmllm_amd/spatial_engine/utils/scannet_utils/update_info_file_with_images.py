@@ -38,8 +38,10 @@ def update_info_file(scene_infos_file="data/scannet/scannet_instance_data/scenes
     for scene_id in scene_infos:
         if sens_root is not None:
             from mspa import sens
-            entries = sens.scene_info_entries(scene_id, sens.read_sens(os.path.join(sens_root, scene_id, f"{scene_id}.sens")),
-                                              frame_skip)
+            # headers and poses of the kept frames only: no depth payload is inflated for the info file
+            stream = sens.read_sens(os.path.join(sens_root, scene_id, f"{scene_id}.sens"), keep_every=frame_skip,
+                                    want_depth=False)
+            entries = sens.scene_info_entries(scene_id, stream, frame_skip)
         else:
             entries = scene_entries_from_folder(base_dir, scene_id, frame_skip)
         scene_infos[scene_id].update(entries)

@@ -217,3 +217,22 @@ def zlib_payload_offset(raw, frame):
             return pos + vals[18]
         pos += vals[18] + vals[19]
     raise IndexError(frame)
+
+
+def test_headers_only_read(tmp_path):
+    """want_depth=False: poses, timestamps and names as usual, no payload touched (a corrupt payload does not matter)."""
+    rng = np.random.default_rng(4)
+    depth = [rng.integers(0, 60000, (6, 8), dtype=np.uint16) for _ in range(11)]
+    poses = [rng.normal(size=(4, 4)).astype(np.float32) for _ in range(11)]
+    path = str(tmp_path / "h.sens")
+    S.write_sens(path, np.eye(4, dtype=np.float32), poses, depth, color_hw=(12, 16))
+    raw = bytearray(open(path, "rb").read())
+    off = zlib_payload_offset(raw, 5)
+    raw[off + 4:off + 9] = b"\x00" * 5
+    open(path, "wb").write(raw)
+    full_names = list(S.scene_info_entries("s", S.read_sens(path, want_depth=False), 5)["images_info"])
+    thin = S.read_sens(path, keep_every=5, want_depth=False)
+    assert thin.depth.shape == (0, 6, 8) and thin.frame_index == [0, 5, 10]
+    info = S.scene_info_entries("s", thin, 5)
+    assert list(info["images_info"]) == full_names == ["00000", "00005", "00010"]
+    assert np.array_equal(info["images_info"]["00005"]["extrinsic_matrix"], S.text_roundtrip(poses[5]))
