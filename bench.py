@@ -50,8 +50,26 @@ VARIANTS = {
     "dense": {"outputs": ("vis_u8", "pix_i16", "xyz_f32", "rgba", "counts"), "rgb": True,
               "bytes_per_px": 2 + 2 + 3 + 1 + 4 + 12},    # SURVEY.md 8d canonical dense = 7,372,800 B/pair; the rgba output
                                                              # (4 B/px) this variant also writes is NOT counted
-    "minimal": {"outputs": ("vis_bits", "counts"), "rgb": False, "bytes_per_px": 2 + 2 + 1 / 8},
+    "minimal": {"outputs": ("vis_bits", "counts"), "rgb": False, "bytes_per_px": 2 + 2 + 1 / 8,
+                "note": "this build's smallest set (rgb = 0, bit mask only) -- NOT SURVEY 8d's 'minimal', which also reads rgb "
+                        "(2,188,800 B/pair)"},
+    # SURVEY.md 8d's formula with rgb = 0: byte mask, pixel index, float32 point -- the dense set without the colour words
+    "dense_xyz": {"outputs": ("vis_u8", "pix_i16", "xyz_f32", "counts"), "rgb": False, "bytes_per_px": 2 + 2 + 1 + 4 + 12},
+    # compacted correspondences (mspa_pair_correspondences): bit mask + 4 B per VISIBLE pixel + a count per tile;
+    # `bytes_per_px` is the fixed part, the visible part is added from the launch's own counters (variant_bytes)
+    "compact": {"outputs": ("vis_bits", "cpix", "tile_counts", "counts"), "rgb": False, "bytes_per_px": 2 + 2 + 1 / 8,
+                "compact": True},
 }
+
+
+def variant_bytes(variant, n_pairs, out=None):
+    """Algorithmic HBM bytes of one launch of `variant` over n_pairs pairs.  The compacted set's output size depends on the
+    data: 4 bytes per visible pixel (read off the launch's own counters) + 4 bytes per tile count."""
+    spec = VARIANTS[variant]
+    b = spec["bytes_per_px"] * P * n_pairs
+    if spec.get("compact") and out is not None:
+        b += 4.0 * float(out["counts"][:, 1].sum().item()) + 4.0 * out["tile_counts"].numel()
+    return b
 
 
 def _legs(spec):
@@ -87,7 +105,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scene-legs", action="store_true", help="skip the K1/K2 informational legs")
     ap.add_argument("--no-sweep", action="store_true", help="skip the low / high overlap legs of the sweep")
-    ap.add_argument("--also", default="corr:exact,dense:fast,dense:exact,minimal:fast",
+    ap.add_argument("--also", default="compact:fast,corr:exact,dense:fast,dense_xyz:fast,dense:exact,minimal:fast",
                     help="comma list of extra variant:mode legs timed briefly on rank 0 ('none' = skip)")
     return ap.parse_args()
 
@@ -209,7 +227,9 @@ def time_variant(variant, mode, depth, mats, rgb, pairs, steps, warmup, dist_ctx
     # pipeline's exchange step is per job (mspa/pipeline.py), not per launch.  (Collating after every launch was
     # measured at +13 % per step: the RCCL kernel competes with K3 for CUs and HBM.)
     n = pairs.shape[0]
-    out = engine.alloc_pair_outputs(n, (H, W), spec["outputs"], depth.device)
+    compact = bool(spec.get("compact"))
+    out = (engine.alloc_pair_correspondences(n, (H, W), depth.device) if compact
+           else engine.alloc_pair_outputs(n, (H, W), spec["outputs"], depth.device))
     job_counts = torch.zeros((max(steps, warmup, 1), n, 2), dtype=torch.int32, device=depth.device) \
         if dist_ctx is not None else None
     rgb_in = rgb if spec["rgb"] else None
@@ -220,7 +240,10 @@ def time_variant(variant, mode, depth, mats, rgb, pairs, steps, warmup, dist_ctx
             out["counts"] = job_counts[k]
         if timed:
             ev[k][0].record()
-        engine.pair_reproject(depth, mats, pairs, (H, W), out, rgb=rgb_in, flags=flags)
+        if compact:
+            engine.pair_correspondences(depth, mats, pairs, (H, W), out, flags=flags)
+        else:
+            engine.pair_reproject(depth, mats, pairs, (H, W), out, rgb=rgb_in, flags=flags)
         if timed:
             ev[k][1].record()
 
@@ -534,7 +557,7 @@ def main():
     pairs_per_step = args.pairs * world
     value = pairs_per_step * args.steps / wall
     spec = VARIANTS[args.variant]
-    bytes_per_launch = spec["bytes_per_px"] * P * args.pairs
+    bytes_per_launch = variant_bytes(args.variant, args.pairs, out)
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
 
     def vis_fraction(o):
@@ -552,12 +575,20 @@ def main():
 
     def leg(v, m, prs, steps, wl):
         w2, k2, o2 = time_variant(v, m, depth, mats, rgb, prs, steps, 1, None, stream)
-        b2 = VARIANTS[v]["bytes_per_px"] * P * args.pairs
-        return with_traffic({"pairs_per_s_1gpu": round(args.pairs / (k2 * 1e-3), 1), "kernel_ms": round(k2, 4),
-                             "achieved_GBs": round(b2 / (k2 * 1e-3) / 1e9, 1),
-                             "frac": round(b2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                             "bytes_per_pair": int(VARIANTS[v]["bytes_per_px"] * P), "visible_fraction": vis_fraction(o2)},
-                            v, m, wl, k2)
+        b2 = variant_bytes(v, args.pairs, o2)
+        d = {"pairs_per_s_1gpu": round(args.pairs / (k2 * 1e-3), 1), "kernel_ms": round(k2, 4),
+             "achieved_GBs": round(b2 / (k2 * 1e-3) / 1e9, 1),
+             "frac": round(b2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+             "bytes_per_pair": int(b2 / args.pairs), "visible_fraction": vis_fraction(o2)}
+        if VARIANTS[v].get("compact"):
+            d["bytes_formula"] = "P * (2 + 2 + 1/8) + 4 * n_visible + 4 * n_tiles per pair (n_visible from this launch's counters)"
+        if v == "dense":     # the set also writes 4 B/px of rgba, which SURVEY 8d's formula leaves out: both readings
+            bw = (VARIANTS[v]["bytes_per_px"] + 4) * P * args.pairs
+            d["frac_counting_rgba_out"] = round(bw / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            d["bytes_per_pair_counting_rgba_out"] = int(bw / args.pairs)
+        if "note" in VARIANTS[v]:
+            d["note"] = VARIANTS[v]["note"]
+        return with_traffic(d, v, m, wl, k2)
 
     extra, sweep = {}, {}
     head_vis = vis_fraction(out) if rank == 0 else None
@@ -569,7 +600,7 @@ def main():
                     sweep[kind] = with_traffic({"pairs_per_s_1gpu": round(args.pairs / (kern_ms * 1e-3), 1),
                                                 "kernel_ms": round(kern_ms, 4), "achieved_GBs": round(achieved, 1),
                                                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                                                "bytes_per_pair": int(spec["bytes_per_px"] * P), "visible_fraction": head_vis,
+                                                "bytes_per_pair": int(bytes_per_launch / args.pairs), "visible_fraction": head_vis,
                                                 "pairs": winfo, "headline": True}, args.variant, args.mode, kind, kern_ms)
                     continue
                 p2, _, i2 = workload_pairs(overlap, nb, reps, args.pairs, kind, rank)
@@ -629,7 +660,7 @@ def main():
                          "traffic_GBs": round(traffic / (kern_ms * 1e-3) / 1e9, 1) if traffic else None,
                          "traffic_frac": round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                          "kernel": "mspa::pair_fast_tight_kernel" if tight else "mspa::pair_exact_kernel",
-                         "kernel_ms": round(kern_ms, 4), "bytes_per_pair": int(spec["bytes_per_px"] * P),
+                         "kernel_ms": round(kern_ms, 4), "bytes_per_pair": int(bytes_per_launch / args.pairs),
                          "bytes_per_launch": int(bytes_per_launch),
                          "measured_ceilings_GBs": ceilings},
             "cpu_baseline": cpu,

@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define MSPA_VERSION 122            /* 0.2.0: + mspa_pair_reproject_last_kernel, tiled K2 (mspa_scene_overlap, mspa_overlap_matrix), K9 bitset -> index lists */
+#define MSPA_VERSION 130            /* 0.3.0: + mspa_pair_correspondences (compacted correspondence output), general homogeneous
+                                       points and depth scale in K1 / K6b */
 
 #define MSPA_OK 0
 #define MSPA_EINVAL (-1)            /* bad argument (null pointer, size out of range, ...) */
@@ -120,6 +121,41 @@ int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, const double 
                                              corr / dense / minimal */
 #define MSPA_KERNEL_PAIR_FAST_SCALED 5    /* colour grid over a smaller depth grid (ScanNet: 1296x968 over 640x480) */
 int mspa_pair_reproject_last_kernel(void);
+
+/*
+ * K3, compacted correspondence output -- "overlap + correspondence extraction" of the frame-pair pipe without the dense
+ * [P, 2] table, three quarters of which is (-1, -1) fill on overlap-sampled pairs: per pair the visibility bitset and, per
+ * 64 x 48-pixel tile of frame f1, the (xi, yi) of its VISIBLE pixels only.
+ *
+ *   Tiles: n_stripes = ceil(W / 64) across, ceil(H / 48) down, tile t = band * n_stripes + stripe (ragged at the right /
+ *   bottom edge); mspa_corr_tiles(H, W) returns their number.
+ *   out_vis_bits     [n_pairs, ceil(P/64)] uint64   as in mspa_pair_reproject
+ *   out_cpix_i16     [n_pairs, n_tiles, MSPA_CORR_TILE_CAP, 2] int16   tile t's segment holds, for its visible pixels in
+ *                    (row, column) order, the depth-pixel index (xi, yi) in f2 (IH:362-366) -- the k-th set bit of the
+ *                    tile's part of the bitset <-> entry k; entries beyond the tile's count are unspecified (never written
+ *                    by the fused kernel: HBM traffic is 4 bytes per VISIBLE pixel)
+ *   out_tile_counts  [n_pairs, n_tiles] int32       visible pixels per tile (= entries of its segment)
+ *   out_counts       [n_pairs, 2] int32 or NULL     (#valid, #visible); zeroed by the call
+ * With MSPA_PAIR_FAST on a whole-tile shape (W % 64 == 0, H % 48 == 0, colour grid == depth grid: BASELINE's 640x480)
+ * one fused kernel produces all of it; every other shape / mode runs mspa_pair_reproject into a dense table in
+ * `workspace` (caller-owned, 16-byte aligned, at least mspa_pair_correspondences_workspace_bytes(...) bytes; NULL / 0 when
+ * that returns 0) and compacts it with mspa_compact_correspondences.  Identical results either way (bit-exact integers).
+ * out_cpix_i16 must be 16-byte aligned.  MSPA_PAIR_STREAM as in mspa_pair_reproject.
+ */
+#define MSPA_CORR_TILE_W 64
+#define MSPA_CORR_TILE_H 48
+#define MSPA_CORR_TILE_CAP (MSPA_CORR_TILE_W * MSPA_CORR_TILE_H)
+int64_t mspa_corr_tiles(int32_t H, int32_t W);
+int64_t mspa_pair_correspondences_workspace_bytes(int64_t n_pairs, int32_t dh, int32_t dw, int32_t H, int32_t W,
+                                                  uint32_t flags);
+int mspa_pair_correspondences(const uint16_t *depth, const double *frame_mats, int32_t n_frames,
+                              const int32_t *pairs, int64_t n_pairs, int32_t dh, int32_t dw, int32_t H, int32_t W,
+                              uint64_t *out_vis_bits, int16_t *out_cpix_i16, int32_t *out_tile_counts,
+                              int32_t *out_counts, void *workspace, int64_t workspace_bytes, uint32_t flags,
+                              mspa_stream_t stream);
+/* The compaction step on its own: (vis_bits, dense pix_i16 [n_pairs, P, 2]) of mspa_pair_reproject -> segments + counts. */
+int mspa_compact_correspondences(const uint64_t *vis_bits, const int16_t *pix_i16, int64_t n_pairs, int32_t H, int32_t W,
+                                 int16_t *out_cpix_i16, int32_t *out_tile_counts, mspa_stream_t stream);
 
 /*
  * K1 -- vertex visibility, HOT LOOP 1 of CFR.process_scene (CFR:152-164) and

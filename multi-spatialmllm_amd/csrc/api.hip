@@ -21,6 +21,18 @@ int check_hip(hipError_t e, const char *what) {
     return MSPA_EHIP;
 }
 
+// Workgroups of a 1-D grid are dealt round-robin over the XCDs.  An MI355X in SPX mode exposes 256 CUs = 8 XCDs of 32; a
+// partitioned device (CPX: 32 CUs) or any other part gets 1, i.e. no XCD-aware regrouping (results never depend on it).
+int xcd_count() {
+    static thread_local int cached = 0;
+    if (cached) return cached;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
+    cached = (prop.multiProcessorCount == 256) ? 8 : 1;
+    return cached;
+}
+
 }  // namespace mspa
 
 using namespace mspa;

@@ -7,6 +7,10 @@
 
 #include "../../include/mspa.h"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libmspa is written for gfx950 (MI355X) only: 16-byte LDS-DMA, v_mfma_i32_32x32x32_i8, native f64 min/max atomics"
+#endif
+
 namespace mspa {
 
 constexpr int kWave = 64;
@@ -15,6 +19,17 @@ constexpr int kWave = 64;
 std::string &last_error();
 int fail(int code, const std::string &what);
 int check_hip(hipError_t e, const char *what);
+int xcd_count();               // XCDs a 1-D grid's workgroups are dealt over: 8 (MI355X, SPX mode) or 1
+
+// Lanes of one wave exchange data through LDS (every lane stores its slot, then loads another lane's).  The hardware executes a
+// wave's LDS operations in order, so no instruction is needed -- but the compiler must not move the loads above the stores
+// either, and under the HIP memory model nothing but a fence says so: a wavefront-scope release / acquire pair plus a wave
+// barrier (none of the three emits an instruction on gfx950).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // One row of an affine 4x4 (row-major, uniform address -> scalar loads) applied to (x, y, z, 1),
 // in the order NumPy/OpenBLAS evaluates a K=4 product: m0*x, fma(m1,y,.), fma(m2,z,.), then +m3

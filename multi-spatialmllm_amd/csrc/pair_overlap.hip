@@ -139,8 +139,9 @@ __device__ __forceinline__ void load_chunk(const TileArgs &a, int ta, int tb, in
 __device__ __forceinline__ void count_chunk(uint32_t *my, int lrow, int lcol, int ti, int tj, const u32x4 (&v)[kLoadsPerChunk],
                                             int (&acc)[4][4]) {
 #pragma unroll
-    for (int k = 0; k < kLoadsPerChunk; ++k)                             // the wave's own region: no barrier needed
+    for (int k = 0; k < kLoadsPerChunk; ++k)                             // the wave's own region: no workgroup barrier needed
         *reinterpret_cast<u32x4 *>(&my[(k * kRowsPerLoad + lrow) * kRowDw + lcol * 4]) = v[k];
+    wave_lds_fence();                                                    // other lanes' rows are read below
 #pragma unroll
     for (int s2 = 0; s2 < kChunkWords / 2; ++s2) {
         u32x4 va[4], vb[4];
@@ -155,6 +156,7 @@ __device__ __forceinline__ void count_chunk(uint32_t *my, int lrow, int lcol, in
                 acc[r][c] += __popc(va[r].x & vb[c].x) + __popc(va[r].y & vb[c].y) + __popc(va[r].z & vb[c].z) +
                              __popc(va[r].w & vb[c].w);
     }
+    wave_lds_fence();                                                    // the next chunk overwrites what was just read
 }
 
 // Occupancy is the point of the sizes above: a wave issues one VALU instruction every ~5.7 cycles on its own

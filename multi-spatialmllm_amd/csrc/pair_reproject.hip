@@ -47,6 +47,9 @@ struct PairArgs {
     double *uv_f64;
     double *depth_f64;
     int32_t *counts;
+    int16_t *cpix;            // compacted correspondences: [n_pairs][n_tiles][kTileCap][2] (fused tight kernel only)
+    int32_t *tile_counts;     // [n_pairs][n_tiles] entries per tile segment
+    uint32_t xcd_shift;       // log2 of the XCDs workgroups are dealt over (3 on an MI355X in SPX mode, 0 otherwise)
 };
 
 // Output sets.  A kernel instantiated with GENERIC = true tests every output pointer at run time
@@ -54,11 +57,13 @@ struct PairArgs {
 // ~20 SGPRs of pointers and removes the dead stores' address arithmetic.
 enum : uint32_t {
     O_VIS_BITS = 1u << 0, O_VIS_U8 = 1u << 1, O_VALID_U8 = 1u << 2, O_PIX = 1u << 3, O_XYZ32 = 1u << 4,
-    O_RGBA = 1u << 5, O_XYZ64 = 1u << 6, O_UV64 = 1u << 7, O_DEPTH64 = 1u << 8, O_COUNTS = 1u << 9,
+    O_RGBA = 1u << 5, O_XYZ64 = 1u << 6, O_UV64 = 1u << 7, O_DEPTH64 = 1u << 8, O_COUNTS = 1u << 9, O_CPIX = 1u << 10,
 };
 constexpr uint32_t kSetCorr = O_VIS_BITS | O_PIX | O_COUNTS;                         // correspondence
 constexpr uint32_t kSetDense = O_VIS_U8 | O_PIX | O_XYZ32 | O_RGBA | O_COUNTS;       // coloured point cloud
+constexpr uint32_t kSetDenseXyz = O_VIS_U8 | O_PIX | O_XYZ32 | O_COUNTS;              // point cloud without colour (rgb = 0)
 constexpr uint32_t kSetMinimal = O_VIS_BITS | O_COUNTS;                              // overlap only
+constexpr uint32_t kSetCompact = O_VIS_BITS | O_CPIX | O_COUNTS;                     // correspondences of the visible pixels only
 
 template <uint32_t SET, bool GENERIC>
 struct Outs {
@@ -227,13 +232,15 @@ __device__ __forceinline__ void flush_counts(const PairArgs &a, int64_t pair, in
     }
 }
 
-// XCD-aware decode: xcd = b % 8 picks the pair within a group of 8, the rest walks the strips.
+// XCD-aware decode: the hardware deals workgroup b to XCD b % n_xcd (n_xcd = 1 << xcd_shift: 8 on an MI355X in SPX mode; the
+// host passes shift 0 for partitioned devices and other parts, which is the plain linear decode).  xcd picks the pair within
+// a group of n_xcd pairs, the rest walks the strips: all workgroups of one pair share one L2.  Results never depend on it.
 __device__ __forceinline__ bool decode_block(const PairArgs &a, int64_t &pair, uint32_t &strip) {
     const uint32_t b = blockIdx.x;
-    const uint32_t xcd = b & 7u;
-    const uint32_t k = b >> 3;
+    const uint32_t xcd = b & ((1u << a.xcd_shift) - 1u);
+    const uint32_t k = b >> a.xcd_shift;
     strip = k % (uint32_t)a.strips;
-    pair = (int64_t)(k / (uint32_t)a.strips) * 8 + xcd;
+    pair = ((int64_t)(k / (uint32_t)a.strips) << a.xcd_shift) + xcd;
     return pair < a.n_pairs;
 }
 
@@ -734,6 +741,18 @@ __device__ __forceinline__ unsigned long long readlane64(uint32_t lo, uint32_t h
            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)hi, lane) << 32);
 }
 
+// lanes below this one whose bit is set in the wave-uniform mask m, plus base
+__device__ __forceinline__ uint32_t mbcnt64(unsigned long long m, uint32_t base) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
+}
+
+// Compacted correspondences (SET has O_CPIX, see include/mspa.h mspa_pair_correspondences): a tile writes the (xi, yi) of its
+// VISIBLE pixels only, in (row, column) order, into its own 3072-entry segment.  Rank of a lane = entries of the tile so far
+// (scalar) + set bits below the lane (v_mbcnt); entries collect in a 512-entry LDS ring and leave as whole 1 KB chunks (16
+// bytes per lane), so the tile issues n_visible / 256 stores instead of one per row group -- and nothing at all for culled
+// tiles and groups, which is where the dense table spends three quarters of its bytes on (-1, -1).
+constexpr int kCompactRing = 512;
+
 template <uint32_t SET, bool STREAM>
 __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
                                                                    const uint8_t *__restrict__ rgb,
@@ -741,6 +760,8 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
                                                                    const int32_t *__restrict__ pairs, PairArgs a) {
     using O = Outs<SET, false>;
     constexpr bool WANT_XYZ = (SET & O_XYZ32) != 0;
+    constexpr bool COMPACT = (SET & O_CPIX) != 0;
+    static_assert(!COMPACT || !(SET & (O_PIX | O_XYZ32 | O_RGBA | O_VIS_U8)), "the compacted set shares the transpose stage's LDS");
     int64_t pair;
     uint32_t tgroup;
     if (!decode_block(a, pair, tgroup)) return;
@@ -752,7 +773,7 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
     Ctx c;
     c.depth1 = depth + (int64_t)f1 * dpix;
     c.depth2 = depth + (int64_t)f2 * dpix;
-    c.rgb1 = rgb ? rgb + (int64_t)f1 * a.P * 3 : nullptr;
+    c.rgb1 = (rgb && (SET & O_RGBA)) ? rgb + (int64_t)f1 * a.P * 3 : nullptr;
     c.obase = pair * (int64_t)a.P;
     c.words_per_pair = (a.P + 63) >> 6;
     c.pair = pair;
@@ -815,9 +836,13 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
     }
 
     // transpose stage: the group's pixel indices, then (dense set) its rgba words, then its 4 x 64 x 3 point coordinates
-    __shared__ __attribute__((aligned(16))) uint32_t lds_px[kTightBW][kRowGroup * 64 * (WANT_XYZ ? 3 : 1)];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_px[kTightBW][COMPACT ? kCompactRing : kRowGroup * 64 * (WANT_XYZ ? 3 : 1)];
     static_assert(kTightRows <= 64, "one lane per tile row holds that row's visibility word");
-    __shared__ unsigned long long lds_rb[kTightBW][kTightRows];   // guarded-lane ballots of flagged rows (rare path)
+    static_assert(kTightRows * 64 == MSPA_CORR_TILE_CAP && kTightRows == MSPA_CORR_TILE_H, "tile segment of the compacted set");
+    // Guarded-lane ballots of flagged rows (rare path) and the wave's two counters live in the depth-1 tile itself: row r's
+    // 128 bytes are dead once the row group that holds r has loaded its samples (the cold loop re-reads from memory), and the
+    // wave's LDS operations execute in order.  Saves 1.5 KB per workgroup -- what lets the compacted set's 2 KB ring fit.
+    auto lds_rb = [&](int r) -> unsigned long long & { return *reinterpret_cast<unsigned long long *>(&lds_d1[wave][r * 64]); };
     int n_valid = 0, n_vis = 0;
     if (tile_ok) {
         const uint32_t Wb = (uint32_t)a.W;
@@ -845,6 +870,11 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
             (void *)(a.rgba ? a.rgba + c.obase : nullptr), 0, (SET & O_RGBA) ? (int)(a.P * 4) : 0, kRsrcFlags);
         __amdgpu_buffer_rsrc_t rs_xyz = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(a.xyz_f32 ? a.xyz_f32 + 3 * c.obase : nullptr), 0, (SET & O_XYZ32) ? (int)(a.P * 12) : 0, kRsrcFlags);
+        // compacted set: the tile's own segment of MSPA_CORR_TILE_CAP entries (4 bytes each)
+        __amdgpu_buffer_rsrc_t rs_cpix = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(COMPACT ? a.cpix + ((pair * (int64_t)a.n_tiles + (int64_t)tile) * MSPA_CORR_TILE_CAP) * 2 : nullptr), 0,
+            COMPACT ? MSPA_CORR_TILE_CAP * 4 : 0, kRsrcFlags);
+        uint32_t cfill = 0, cflushed = 0;            // wave-uniform: entries written to the ring, 256-entry chunks stored
         const int vis_voff = (int)(((uint32_t)c.lane >> 4) * Wb + stripe * 64u + ((uint32_t)c.lane & 15u) * 4u);
         const int rgb_voff = (int)(stripe * 192u + (c.lane == 0 ? 0u : (uint32_t)c.lane * 3u - 1u));
         int xyz_voff[3];
@@ -1021,18 +1051,32 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
                         vm[j] = ivm[j] & ballot64(sd < 0.0);
                         rbm[j] = ivm[j] & (rkc[j] | ballot64(!(__builtin_fabs(sd) > kGuardZmm)));
                         if (O::template has<O_PIX>(a.pix_i16)) lds_px[wave][j * 64 + c.lane] = (uint32_t)(inview ? pix[j] : -1);
+                        if (COMPACT) {
+                            const uint32_t rank = mbcnt64(vm[j], cfill);
+                            if (__builtin_amdgcn_inverse_ballot_w64(vm[j])) lds_px[wave][rank & (kCompactRing - 1)] = (uint32_t)pix[j];
+                            cfill += (uint32_t)__popcll(vm[j]);
+                        }
+                    }
+                    if (COMPACT && (cfill >> 8) != cflushed) {           // a 256-entry chunk is complete (at most one per group)
+                        wave_lds_fence();
+                        const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][((cflushed & 1u) << 8) + c.lane * 4]);
+                        buffer_store_b128_guarded(q, rs_cpix, c.lane * 16, (int)(cflushed << 10));
+                        wave_lds_fence();
+                        ++cflushed;
                     }
                     if (rbm[0] | rbm[1] | rbm[2] | rbm[3]) {             // wave-uniform, rare: one branch per group, not per row
 #pragma unroll
                         for (int j = 0; j < kRowGroup; ++j)
                             if (rbm[j]) {
-                                if (c.lane == 0) lds_rb[wave][r0 + j] = rbm[j];
+                                if (c.lane == 0) lds_rb(r0 + j) = rbm[j];
                                 risky_rows |= 1ull << (r0 + j);
                             }
                     }
                     if (O::template has<O_PIX>(a.pix_i16)) {
+                        wave_lds_fence();
                         const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][c.lane * 4]);
                         buffer_store_b128_guarded(q, rs_pix, pix_voff, (int)(rowg * Wb * 4u));
+                        wave_lds_fence();
                     }
                 }
                 // ---- common tail: counters (scalar) and the rows' visibility words (zero after an early-out) ----
@@ -1066,8 +1110,10 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
                         const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmk[j]);
                         lds_px[wave][j * 64 + c.lane] = colr | (valid ? 0xFF000000u : 0u);
                     }
+                    wave_lds_fence();
                     const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][c.lane * 4]);
                     buffer_store_b128_guarded(q, rs_rgba, pix_voff, (int)(rowg * Wb * 4u));
+                    wave_lds_fence();
                 }
                 if (SET & O_XYZ32) {
                     const uint32_t fnan = 0x7FC00000u;
@@ -1079,22 +1125,25 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
                         dst[1] = valid ? __float_as_uint(fy[j]) : fnan;
                         dst[2] = valid ? __float_as_uint(fz[j]) : fnan;
                     }
+                    wave_lds_fence();
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][(k * 64 + c.lane) * 4]);
                         buffer_store_b128_guarded(q, rs_xyz, xyz_voff[k], (int)(rowg * Wb * 12u));
                     }
+                    wave_lds_fence();
                 }
             }
         }
 
         // ---- cold loop: rows with guarded lanes are re-evaluated with the exact chain ---------------
+        const bool redo = COMPACT && risky_rows != 0;       // compacted set: see below
         if (risky_rows) {
             __builtin_amdgcn_s_waitcnt(0);                 // the fast path's stores are in L2, LDS writes landed
             while (risky_rows) {                            // wave-uniform
                 const int g = __builtin_amdgcn_readfirstlane(__builtin_ctzll(risky_rows));
                 risky_rows &= risky_rows - 1ull;
-                const unsigned long long rb = lds_rb[wave][g];
+                const unsigned long long rb = lds_rb(g);
                 const unsigned long long old = readlane64(bits_lo, bits_hi, g);
                 const uint32_t row = row0 + (uint32_t)g;
                 const uint32_t i = row * Wb + col;
@@ -1113,23 +1162,56 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
                 writelane64(fresh, g, bits_lo, bits_hi);
             }
         }
+        if (COMPACT) {
+            if (redo) {
+                // A guarded lane may have changed its visibility (every later rank of the tile shifts) or its pixel index:
+                // the tile's segment is rewritten from the patched visibility words with the reference chain for every
+                // visible pixel -- which yields the very indices the fast path wrote for unguarded lanes, that being the
+                // guard band's contract.  ~0.3 % of the tiles (identity pairs: all of them).
+                uint32_t base = 0;
+                for (int r = 0; r < kTightRows; ++r) {                    // wave-uniform
+                    const unsigned long long w = readlane64(bits_lo, bits_hi, r);
+                    if (w == 0) continue;
+                    if ((w >> c.lane) & 1ull) {
+                        const uint32_t row = row0 + (uint32_t)r;
+                        Pixel p;
+                        exact_unproject(m1, mxd, (double)row, (double)c.depth1[row * Wb + col] * 0.001, p.ax, p.ay, p.az);
+                        exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
+                        depth_test(false, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi);
+                        __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(uint16_t)p.xi | ((uint32_t)(uint16_t)p.yi << 16), rs_cpix,
+                                                              (int)(mbcnt64(w, base) * 4u), 0, 0);
+                    }
+                    base += (uint32_t)__popcll(w);
+                }
+            } else {
+                const uint32_t rem = cfill - (cflushed << 8);             // < 256 entries still in the ring
+                wave_lds_fence();
+                if ((uint32_t)c.lane * 4u < rem) {
+                    const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][((cflushed & 1u) << 8) + c.lane * 4]);
+                    buffer_store_b128_guarded(q, rs_cpix, c.lane * 16, (int)(cflushed << 10));
+                }
+            }
+            if (c.lane == 0) a.tile_counts[pair * (int64_t)a.n_tiles + (int64_t)tile] = n_vis;
+        }
         // the tile's visibility words: lane r stores the word of row row0 + r (8 bytes; rows are W/8 bytes apart)
         if (O::template has<O_VIS_BITS>(a.vis_bits) && c.lane < kTightRows)
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{bits_lo, bits_hi}, rs_bits, (int)((uint32_t)c.lane * wpr * 8u),
                                                   (int)((row0 * wpr + stripe) * 8u), 0);
     }
     if (O::template has<O_COUNTS>(a.counts)) {
-        __shared__ int red[2][kTightBW];
+        // the wave's totals go to bytes 16..23 of its own (finished) depth tile; thread 0 sums the four after the barrier
+        int *red = reinterpret_cast<int *>(&lds_d1[wave][8]);
         if (c.lane == 0) {
-            red[0][wave] = n_valid;
-            red[1][wave] = n_vis;
+            red[0] = n_valid;
+            red[1] = n_vis;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             int sv = 0, ss = 0;
             for (int j = 0; j < kTightBW; ++j) {
-                sv += red[0][j];
-                ss += red[1][j];
+                const int *rj = reinterpret_cast<const int *>(&lds_d1[j][8]);
+                sv += rj[0];
+                ss += rj[1];
             }
             atomicAdd(a.counts + 2 * pair + 0, sv);
             atomicAdd(a.counts + 2 * pair + 1, ss);
@@ -1395,10 +1477,12 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
                             }
                     }
                     if (O::template has<O_PIX>(a.pix_i16)) {
+                        wave_lds_fence();
                         const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][c.lane * 4]);
                         buffer_store_b128_guarded(q, rs_pix, pix_voff, (int)(wbase * 256u));
                         if (LAST) __builtin_amdgcn_raw_buffer_store_b32(lds_px[wave][4 * 64 + c.lane], rs_pix, (int)((uint32_t)c.lane * 4u),
                                                                         (int)((wbase + (uint32_t)S) * 256u), 0);
+                        wave_lds_fence();
                     }
                 }
     #pragma unroll
@@ -1474,6 +1558,39 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// compaction of a dense (vis_bits, pix_i16) result into the per-tile segments of mspa_pair_correspondences: the route for
+// shapes the fused tight kernel does not take (ragged tiles, colour grid != depth grid, reference-order mode).  One wave
+// per 64 x 48 tile, rows in order, rank = entries so far + visible lanes below (same order as the fused kernel).
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void compact_corr_kernel(const uint64_t *__restrict__ vis_bits,
+                                                                const uint32_t *__restrict__ pix, int64_t n_pairs, int H,
+                                                                int W, int n_stripes, int n_tiles, uint32_t *__restrict__ cpix,
+                                                                int32_t *__restrict__ tile_counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * (kThreads / kWave) + (threadIdx.x >> 6);
+    const int64_t pair = wid / n_tiles;
+    if (pair >= n_pairs) return;
+    const int tile = (int)(wid - pair * n_tiles);
+    const int band = tile / n_stripes, stripe = tile - band * n_stripes;
+    const int64_t P = (int64_t)H * W;
+    const int64_t wpp = (P + 63) >> 6;
+    const int col = stripe * 64 + lane;
+    uint32_t *seg = cpix + (pair * n_tiles + tile) * (int64_t)MSPA_CORR_TILE_CAP;
+    uint32_t base = 0;
+    for (int r = 0; r < MSPA_CORR_TILE_H; ++r) {
+        const int row = band * MSPA_CORR_TILE_H + r;
+        if (row >= H) break;                                              // wave-uniform
+        bool vis = false;
+        const int64_t i = (int64_t)row * W + col;
+        if (col < W) vis = (vis_bits[pair * wpp + (i >> 6)] >> (i & 63)) & 1ull;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(vis);
+        if (vis) seg[mbcnt64(m, base)] = pix[pair * P + i];
+        base += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) tile_counts[pair * n_tiles + tile] = (int32_t)base;
+}
+
 }  // namespace mspa
 
 using namespace mspa;
@@ -1482,13 +1599,18 @@ static thread_local int g_last_pair_kernel = MSPA_KERNEL_NONE;
 
 extern "C" int mspa_pair_reproject_last_kernel(void) { return g_last_pair_kernel; }
 
-extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, const double *frame_mats,
-                                   int32_t n_frames, const int32_t *pairs, int64_t n_pairs, int32_t dh,
-                                   int32_t dw, int32_t H, int32_t W, uint64_t *out_vis_bits,
-                                   uint8_t *out_vis_u8, uint8_t *out_valid_u8, int16_t *out_pix_i16,
-                                   float *out_xyz_f32, uint32_t *out_rgba, double *out_xyz_f64,
-                                   double *out_uv_f64, double *out_depth_f64, int32_t *out_counts,
-                                   uint32_t flags, mspa_stream_t stream) {
+// whole-tile shapes the tight kernel takes (W % 64 == 0, H % 48 == 0, colour grid == depth grid, 32-bit byte offsets)
+static bool tight_shape(int32_t dh, int32_t dw, int32_t H, int32_t W) {
+    return dh == H && dw == W && (W % 64 == 0) && (H % kTightRows == 0) && ((uint64_t)H * (uint64_t)W * 4 < (1ull << 31));
+}
+
+static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const double *frame_mats,
+                               int32_t n_frames, const int32_t *pairs, int64_t n_pairs, int32_t dh,
+                               int32_t dw, int32_t H, int32_t W, uint64_t *out_vis_bits,
+                               uint8_t *out_vis_u8, uint8_t *out_valid_u8, int16_t *out_pix_i16,
+                               float *out_xyz_f32, uint32_t *out_rgba, double *out_xyz_f64,
+                               double *out_uv_f64, double *out_depth_f64, int32_t *out_counts,
+                               int16_t *out_cpix, int32_t *out_tile_counts, uint32_t flags, mspa_stream_t stream) {
     if (n_frames <= 0 || n_pairs < 0) return fail(MSPA_EINVAL, "mspa_pair_reproject: bad frame/pair count");
     if (!depth || !frame_mats || (!pairs && n_pairs > 0))
         return fail(MSPA_EINVAL, "mspa_pair_reproject: null input pointer");
@@ -1511,6 +1633,9 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
     a.vis_bits = out_vis_bits; a.vis_u8 = out_vis_u8; a.valid_u8 = out_valid_u8; a.pix_i16 = out_pix_i16;
     a.xyz_f32 = out_xyz_f32; a.rgba = out_rgba; a.xyz_f64 = out_xyz_f64; a.uv_f64 = out_uv_f64;
     a.depth_f64 = out_depth_f64; a.counts = out_counts;
+    a.cpix = out_cpix; a.tile_counts = out_tile_counts;
+    const int n_xcd = xcd_count();
+    a.xcd_shift = n_xcd == 8 ? 3u : 0u;
 
     if (out_counts) {
         int rc = check_hip(hipMemsetAsync(out_counts, 0, sizeof(int32_t) * 2 * n_pairs, s), "hipMemsetAsync(counts)");
@@ -1526,12 +1651,16 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
     uint32_t set = 0;
     set |= out_vis_bits ? O_VIS_BITS : 0; set |= out_vis_u8 ? O_VIS_U8 : 0; set |= out_valid_u8 ? O_VALID_U8 : 0;
     set |= out_pix_i16 ? O_PIX : 0; set |= out_xyz_f32 ? O_XYZ32 : 0; set |= out_rgba ? O_RGBA : 0;
-    set |= out_counts ? O_COUNTS : 0;
+    set |= out_counts ? O_COUNTS : 0; set |= out_cpix ? O_CPIX : 0;
     // the tight kernel's LDS-DMA moves depth in 4-byte units and its 16-byte stores need aligned outputs
     const bool aligned = (((uintptr_t)depth & 3u) == 0) && (((uintptr_t)out_pix_i16 & 15u) == 0) &&
-                         (((uintptr_t)out_vis_bits & 7u) == 0);
-    const bool tight24 = fast && ident && aligned && (W % 64 == 0) && (H % kTightRows == 0) && (P * 4 < (1ull << 31)) &&
-                         (set == kSetCorr || set == kSetDense || set == kSetMinimal);
+                         (((uintptr_t)out_vis_bits & 7u) == 0) && (((uintptr_t)out_cpix & 15u) == 0) &&
+                         (((uintptr_t)out_xyz_f32 & 15u) == 0) && (((uintptr_t)out_rgba & 15u) == 0) &&
+                         (((uintptr_t)out_vis_u8 & 3u) == 0);
+    const bool tight24 = fast && aligned && tight_shape(dh, dw, H, W) &&
+                         (set == kSetCorr || set == kSetDense || set == kSetDenseXyz || set == kSetMinimal || set == kSetCompact);
+    if (out_cpix && !(tight24 && out_tile_counts))
+        return fail(MSPA_EINVAL, "pair_reproject_impl: the fused compacted set needs the tight kernel and a tile-count table");
     // ScanNet's own shape (1296 x 968 colour over 640 x 480 depth) has a kernel of its own
     const bool scaled = fast && !tight24 && aligned && W == 1296 && H == 968 && dw == 640 && dh == 480 &&
                         (set == kSetCorr || set == kSetMinimal);
@@ -1552,8 +1681,8 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
         a.n_stripes = a.n_tiles = 0;
         a.stripe_magic = 0;
     }
-    const int64_t groups = (n_pairs + 7) / 8;
-    const int64_t blocks = groups * 8 * a.strips;
+    const int64_t groups = (n_pairs + n_xcd - 1) / n_xcd;
+    const int64_t blocks = groups * n_xcd * a.strips;
     if (blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_pair_reproject: too many workgroups; split the batch");
     const dim3 grid((uint32_t)blocks), block(kThreads);
     g_last_pair_kernel = !fast ? MSPA_KERNEL_PAIR_EXACT
@@ -1580,6 +1709,8 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
     } while (0)
         if (set == kSetCorr) MSPA_LAUNCH_TIGHT(kSetCorr);
         else if (set == kSetDense) MSPA_LAUNCH_TIGHT(kSetDense);
+        else if (set == kSetDenseXyz) MSPA_LAUNCH_TIGHT(kSetDenseXyz);
+        else if (set == kSetCompact) MSPA_LAUNCH_TIGHT(kSetCompact);
         else MSPA_LAUNCH_TIGHT(kSetMinimal);
 #undef MSPA_LAUNCH_TIGHT
     } else {
@@ -1612,4 +1743,77 @@ extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, co
 #undef MSPA_LAUNCH_FAST
     }
     return check_hip(hipGetLastError(), "pair_reproject kernel launch");
+}
+
+extern "C" int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, const double *frame_mats,
+                                   int32_t n_frames, const int32_t *pairs, int64_t n_pairs, int32_t dh,
+                                   int32_t dw, int32_t H, int32_t W, uint64_t *out_vis_bits,
+                                   uint8_t *out_vis_u8, uint8_t *out_valid_u8, int16_t *out_pix_i16,
+                                   float *out_xyz_f32, uint32_t *out_rgba, double *out_xyz_f64,
+                                   double *out_uv_f64, double *out_depth_f64, int32_t *out_counts,
+                                   uint32_t flags, mspa_stream_t stream) {
+    return pair_reproject_impl(depth, rgb, frame_mats, n_frames, pairs, n_pairs, dh, dw, H, W, out_vis_bits, out_vis_u8,
+                               out_valid_u8, out_pix_i16, out_xyz_f32, out_rgba, out_xyz_f64, out_uv_f64, out_depth_f64,
+                               out_counts, nullptr, nullptr, flags, stream);
+}
+
+static bool corr_args_ok(int32_t H, int32_t W) { return H >= 2 && W >= 2 && H <= 32767 && W <= 32767; }
+
+extern "C" int64_t mspa_corr_tiles(int32_t H, int32_t W) {
+    if (!corr_args_ok(H, W)) return -1;
+    return (int64_t)((W + MSPA_CORR_TILE_W - 1) / MSPA_CORR_TILE_W) * ((H + MSPA_CORR_TILE_H - 1) / MSPA_CORR_TILE_H);
+}
+
+extern "C" int64_t mspa_pair_correspondences_workspace_bytes(int64_t n_pairs, int32_t dh, int32_t dw, int32_t H, int32_t W,
+                                                             uint32_t flags) {
+    if (n_pairs < 0 || !corr_args_ok(H, W)) return -1;
+    if ((flags & MSPA_PAIR_FAST) && tight_shape(dh, dw, H, W)) return 0;       // fused: no dense table in between
+    return n_pairs * (int64_t)H * W * 4;
+}
+
+extern "C" int mspa_compact_correspondences(const uint64_t *vis_bits, const int16_t *pix_i16, int64_t n_pairs, int32_t H,
+                                            int32_t W, int16_t *out_cpix_i16, int32_t *out_tile_counts,
+                                            mspa_stream_t stream) {
+    if (n_pairs < 0 || !corr_args_ok(H, W)) return fail(MSPA_EINVAL, "mspa_compact_correspondences: bad pair count / image size");
+    if (n_pairs == 0) return MSPA_OK;
+    if (!vis_bits || !pix_i16 || !out_cpix_i16 || !out_tile_counts)
+        return fail(MSPA_EINVAL, "mspa_compact_correspondences: null pointer");
+    if (((uintptr_t)pix_i16 & 3u) || ((uintptr_t)out_cpix_i16 & 3u))
+        return fail(MSPA_EINVAL, "mspa_compact_correspondences: pixel-index tables must be 4-byte aligned");
+    const int n_stripes = (W + MSPA_CORR_TILE_W - 1) / MSPA_CORR_TILE_W;
+    const int n_tiles = n_stripes * ((H + MSPA_CORR_TILE_H - 1) / MSPA_CORR_TILE_H);
+    const int64_t waves = n_pairs * n_tiles;
+    const int64_t blocks = (waves + (kThreads / kWave) - 1) / (kThreads / kWave);
+    if (blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_compact_correspondences: too many workgroups; split the batch");
+    hipLaunchKernelGGL(compact_corr_kernel, dim3((uint32_t)blocks), dim3(kThreads), 0, (hipStream_t)stream, vis_bits,
+                       reinterpret_cast<const uint32_t *>(pix_i16), n_pairs, H, W, n_stripes, n_tiles,
+                       reinterpret_cast<uint32_t *>(out_cpix_i16), out_tile_counts);
+    return check_hip(hipGetLastError(), "compact_corr_kernel launch");
+}
+
+extern "C" int mspa_pair_correspondences(const uint16_t *depth, const double *frame_mats, int32_t n_frames,
+                                         const int32_t *pairs, int64_t n_pairs, int32_t dh, int32_t dw, int32_t H, int32_t W,
+                                         uint64_t *out_vis_bits, int16_t *out_cpix_i16, int32_t *out_tile_counts,
+                                         int32_t *out_counts, void *workspace, int64_t workspace_bytes, uint32_t flags,
+                                         mspa_stream_t stream) {
+    if (!out_vis_bits || !out_cpix_i16 || !out_tile_counts)
+        return fail(MSPA_EINVAL, "mspa_pair_correspondences: vis_bits, cpix and tile_counts are all required");
+    if (((uintptr_t)out_cpix_i16 & 15u) || ((uintptr_t)out_vis_bits & 7u))
+        return fail(MSPA_EINVAL, "mspa_pair_correspondences: out_cpix_i16 must be 16-byte, out_vis_bits 8-byte aligned");
+    const int64_t need = mspa_pair_correspondences_workspace_bytes(n_pairs, dh, dw, H, W, flags);
+    if (need < 0) return fail(MSPA_EINVAL, "mspa_pair_correspondences: bad pair count / image size");
+    if (need == 0)
+        return pair_reproject_impl(depth, nullptr, frame_mats, n_frames, pairs, n_pairs, dh, dw, H, W, out_vis_bits, nullptr,
+                                   nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out_counts, out_cpix_i16,
+                                   out_tile_counts, flags, stream);
+    const int64_t dense = n_pairs * (int64_t)H * W * 4;
+    if (n_pairs > 0 && (!workspace || workspace_bytes < dense || ((uintptr_t)workspace & 15u)))
+        return fail(MSPA_EINVAL, "mspa_pair_correspondences: this shape / mode goes through the dense table: pass a 16-byte "
+                                 "aligned workspace of n_pairs * H * W * 4 bytes");
+    int rc = pair_reproject_impl(depth, nullptr, frame_mats, n_frames, pairs, n_pairs, dh, dw, H, W, out_vis_bits, nullptr,
+                                 nullptr, (int16_t *)workspace, nullptr, nullptr, nullptr, nullptr, nullptr, out_counts,
+                                 nullptr, nullptr, flags, stream);
+    if (rc) return rc;
+    return mspa_compact_correspondences(out_vis_bits, (const int16_t *)workspace, n_pairs, H, W, out_cpix_i16,
+                                        out_tile_counts, stream);
 }

@@ -496,18 +496,6 @@ __global__ __launch_bounds__(kVThreads) void check_visibility_kernel(const doubl
 
 using namespace mspa;
 
-// Workgroups of a 1-D grid are dealt round-robin over the XCDs.  An MI355X in SPX mode exposes 256 CUs = 8 XCDs of 32; a
-// partitioned device (CPX: 32 CUs) or any other part gets 1, i.e. no XCD-aware regrouping (results never depend on it).
-static int xcd_count() {
-    static thread_local int cached = 0;
-    if (cached) return cached;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
-    cached = (prop.multiProcessorCount == 256) ? 8 : 1;
-    return cached;
-}
-
 extern "C" int mspa_check_visibility(const double *uv, const double *point_depth, int64_t n,
                                      const uint16_t *depth_image, int32_t dh, int32_t dw, int32_t H, int32_t W,
                                      uint8_t *out_in_bounds, uint8_t *out_by_depth, uint8_t *out_visible,

@@ -12,6 +12,7 @@ MSPA_OK, MSPA_EINVAL, MSPA_EHIP, MSPA_EUNSUPPORTED = 0, -1, -2, -3
 MAT_KINV, MAT_E, MAT_A, MAT_EINV_ALIGNED, MAT_K, MAT_UNPROJ, MAT_REPROJ, FRAME_MATS = 0, 1, 2, 3, 4, 5, 6, 7
 PAIR_FAST = 1
 PAIR_STREAM = 2
+CORR_TILE_W, CORR_TILE_H, CORR_TILE_CAP = 64, 48, 64 * 48
 KERNEL_NONE, KERNEL_PAIR_EXACT, KERNEL_PAIR_FAST, KERNEL_PAIR_FAST_LINEAR, KERNEL_PAIR_FAST_TIGHT, KERNEL_PAIR_FAST_SCALED = range(6)
 
 
@@ -34,6 +35,11 @@ _SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
     "mspa_pair_reproject_last_kernel": (c_int, []),
+    "mspa_corr_tiles": (c_int64, [c_int32, c_int32]),
+    "mspa_pair_correspondences_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32, c_int32, c_int32, c_uint32]),
+    "mspa_pair_correspondences": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_uint32, c_void_p]),
+    "mspa_compact_correspondences": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "mspa_vertex_visibility": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p,
                                        c_int32, c_int32, c_int32, c_int32,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -129,6 +129,26 @@ def gather_blocks_host(blocks, dst: np.ndarray, n_threads: int = 4) -> None:
     _lib.check(_lib.load().mspa_gather_blocks_host(ptrs, n, block_bytes, dst.ctypes.data, int(n_threads)))
 
 
+_PINHOLE_CHECKED: Dict[Tuple[int, int, int], bool] = {}
+
+
+def _require_pinhole(mats: torch.Tensor):
+    """MSPA_PAIR_FAST reads the camera-2 depth off the third image row: K's third row must be 0 0 1 0 in EVERY frame record
+    (include/mspa.h).  The records live on the device, so the check is one read-back of all frames' rows the first time a
+    table is seen (keyed by storage address, size and in-place version counter); later launches on the same table enqueue
+    without touching the host -- a per-call read-back would synchronise the stream in the hot enqueue path."""
+    key = (mats.data_ptr(), mats.numel(), mats._version)
+    ok = _PINHOLE_CHECKED.get(key)
+    if ok is None:
+        rows = mats[:, _lib.MAT_K, 8:12]
+        want = torch.tensor([0.0, 0.0, 1.0, 0.0], dtype=torch.float64, device=mats.device)
+        ok = bool((rows == want).all().item()) if mats.shape[0] else True
+        if len(_PINHOLE_CHECKED) > 256:
+            _PINHOLE_CHECKED.clear()
+        _PINHOLE_CHECKED[key] = ok
+    _require(ok, "MSPA_PAIR_FAST needs a pinhole K (third row 0 0 1 0) in every frame record; use flags=0 for this camera")
+
+
 PAIR_OUTPUTS = ("vis_bits", "vis_u8", "valid_u8", "pix_i16", "xyz_f32", "rgba", "xyz_f64", "uv_f64",
                 "depth_f64", "counts")
 
@@ -170,11 +190,7 @@ def pair_reproject(depth: torch.Tensor, mats: torch.Tensor, pairs: torch.Tensor,
     F, DH, DW = depth.shape
     _require(mats.shape[0] == F, "mats.shape[0] == F")
     if flags & _lib.PAIR_FAST:
-        # MSPA_PAIR_FAST reads the camera-2 depth off the third image row: K's third row must be 0 0 1 0 (include/mspa.h).
-        # The frame records carry K (slot 4); one 32-byte read-back of the first frame's row per call.
-        k_row = mats[0, _lib.MAT_K, 8:12].cpu().numpy() if F else np.array([0.0, 0.0, 1.0, 0.0])
-        _require(bool(np.array_equal(k_row, np.array([0.0, 0.0, 1.0, 0.0]))),
-                 "MSPA_PAIR_FAST needs a pinhole K (third row 0 0 1 0); use flags=0 for this camera")
+        _require_pinhole(mats)
     H, W = image_hw
     if rgb is not None:
         _require(rgb.dtype == torch.uint8 and tuple(rgb.shape) == (F, H, W, 3), "rgb.dtype == torch.uint8 and tuple(rgb.shape) == (F, H, W, 3)")
@@ -184,6 +200,84 @@ def pair_reproject(depth: torch.Tensor, mats: torch.Tensor, pairs: torch.Tensor,
         g("vis_bits"), g("vis_u8"), g("valid_u8"), g("pix_i16"), g("xyz_f32"), g("rgba"),
         g("xyz_f64"), g("uv_f64"), g("depth_f64"), g("counts"), flags, _stream_ptr()))
     return out
+
+
+def corr_tiles(image_hw: Tuple[int, int]) -> Tuple[int, int]:
+    """(stripes across, bands down) of the 64 x 48-pixel tiles the compacted correspondence output is segmented by."""
+    H, W = image_hw
+    return (W + _lib.CORR_TILE_W - 1) // _lib.CORR_TILE_W, (H + _lib.CORR_TILE_H - 1) // _lib.CORR_TILE_H
+
+
+def alloc_pair_correspondences(n_pairs: int, image_hw: Tuple[int, int], device="cuda", counts: bool = True):
+    """Caller-owned outputs of ``pair_correspondences`` (include/mspa.h, mspa_pair_correspondences)."""
+    H, W = image_hw
+    ns, nb = corr_tiles(image_hw)
+    out = {"vis_bits": torch.empty((n_pairs, (H * W + 63) // 64), dtype=torch.int64, device=device),
+           "cpix": torch.empty((n_pairs, ns * nb, _lib.CORR_TILE_CAP, 2), dtype=torch.int16, device=device),
+           "tile_counts": torch.empty((n_pairs, ns * nb), dtype=torch.int32, device=device)}
+    if counts:
+        out["counts"] = torch.empty((n_pairs, 2), dtype=torch.int32, device=device)
+    return out
+
+
+def pair_correspondences(depth: torch.Tensor, mats: torch.Tensor, pairs: torch.Tensor, image_hw: Tuple[int, int],
+                         out: Optional[Dict[str, torch.Tensor]] = None, flags: int = _lib.PAIR_FAST,
+                         workspace: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """Enqueue K3 with the compacted correspondence output: the visibility bitset plus, per 64 x 48 tile of frame 1, the
+    frame-2 pixel (xi, yi) of its VISIBLE pixels in (row, column) order.  One fused kernel on whole-tile shapes with
+    MSPA_PAIR_FAST (640x480); other shapes / the reference-order mode go through a dense table in ``workspace`` (allocated
+    here when not given).  ``out`` from ``alloc_pair_correspondences``."""
+    _require_gpu()
+    lib = _lib.load()
+    _require(depth.dtype in (torch.int16, torch.uint16) and depth.dim() == 3, "depth: [F, DH, DW] int16 / uint16")
+    _require(mats.dtype == torch.float64 and mats.shape[1:] == (_lib.FRAME_MATS, 16), "mats: float64 [F, 7, 16]")
+    _require(pairs.dtype == torch.int32 and pairs.dim() == 2 and pairs.shape[1] == 2, "pairs: int32 [B, 2]")
+    F, DH, DW = depth.shape
+    _require(mats.shape[0] == F, "mats.shape[0] == F")
+    if flags & _lib.PAIR_FAST:
+        _require_pinhole(mats)
+    H, W = image_hw
+    n = pairs.shape[0]
+    if out is None:
+        out = alloc_pair_correspondences(n, image_hw, depth.device)
+    ns, nb = corr_tiles(image_hw)
+    _require(tuple(out["cpix"].shape) == (n, ns * nb, _lib.CORR_TILE_CAP, 2) and out["cpix"].dtype == torch.int16,
+             "out['cpix']: int16 [n_pairs, n_tiles, 3072, 2]")
+    _require(tuple(out["tile_counts"].shape) == (n, ns * nb) and out["tile_counts"].dtype == torch.int32,
+             "out['tile_counts']: int32 [n_pairs, n_tiles]")
+    _require(tuple(out["vis_bits"].shape) == (n, (H * W + 63) // 64) and out["vis_bits"].dtype == torch.int64,
+             "out['vis_bits']: int64 [n_pairs, ceil(P / 64)]")
+    need = int(lib.mspa_pair_correspondences_workspace_bytes(n, DH, DW, H, W, flags))
+    _require(need >= 0, "image size within [2, 32767]")
+    if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
+        workspace = torch.empty((need + 3) // 4, dtype=torch.int32, device=depth.device)
+    _lib.check(lib.mspa_pair_correspondences(
+        _ptr(depth), _ptr(mats), F, _ptr(pairs), n, DH, DW, H, W, _ptr(out["vis_bits"]), _ptr(out["cpix"]),
+        _ptr(out["tile_counts"]), _ptr(out.get("counts")), _ptr(workspace) if need else None,
+        workspace.numel() * workspace.element_size() if need else 0, flags, _stream_ptr()))
+    return out
+
+
+def correspondences_rowmajor(out: Dict[str, torch.Tensor], image_hw: Tuple[int, int], pair: int):
+    """One pair's compacted correspondences re-ordered to ``np.nonzero(visible)`` order (torch indexing as plumbing, for
+    consumers and tests that want the flat view): returns (pixel index i = y * W + x in frame 1 [n_vis] int64, xi [n_vis],
+    yi [n_vis] int16 in frame 2), all on the device."""
+    H, W = image_hw
+    ns, nb = corr_tiles(image_hw)
+    bits = out["vis_bits"][pair]
+    P = H * W
+    shifts = torch.arange(64, device=bits.device, dtype=torch.int64)
+    vis = ((bits.unsqueeze(1) >> shifts) & 1).reshape(-1)[:P].reshape(H, W).bool()
+    # rank of every visible pixel inside its tile, in (row, column) order of the tile
+    pad = torch.zeros((nb * _lib.CORR_TILE_H, ns * _lib.CORR_TILE_W), dtype=torch.bool, device=bits.device)
+    pad[:H, :W] = vis
+    tiles = pad.reshape(nb, _lib.CORR_TILE_H, ns, _lib.CORR_TILE_W).permute(0, 2, 1, 3).reshape(nb * ns, -1)
+    rank = torch.cumsum(tiles.to(torch.int32), dim=1) - 1
+    rank_img = rank.reshape(nb, ns, _lib.CORR_TILE_H, _lib.CORR_TILE_W).permute(0, 2, 1, 3).reshape(nb * _lib.CORR_TILE_H, -1)[:H, :W]
+    yy, xx = torch.nonzero(vis, as_tuple=True)
+    t = (yy // _lib.CORR_TILE_H) * ns + (xx // _lib.CORR_TILE_W)
+    e = out["cpix"][pair][t, rank_img[yy, xx].long()]
+    return yy * W + xx, e[:, 0], e[:, 1]
 
 
 def vertex_visibility(xyz: torch.Tensor, cam_mats: torch.Tensor, depth: torch.Tensor, image_hw: Tuple[int, int],

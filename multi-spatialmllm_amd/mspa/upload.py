@@ -40,8 +40,10 @@ class UploadSlot:
         self.ready = torch.cuda.Event()          # recorded on the copy stream when the scene's tensors are resident
         self.free = None                         # recorded on the consumer's stream when it is done with them
 
-    def _ensure(self, n_frames, depth_hw, n_points):
+    def _ensure(self, n_frames, depth_hw, n_points, copy_stream):
+        grown = False
         if n_frames > self.cap_frames or depth_hw != self.depth_hw:
+            grown = True
             self.cap_frames, self.depth_hw = max(n_frames, self.cap_frames), depth_hw
             shape = (self.cap_frames,) + tuple(depth_hw)
             self.h_depth = torch.empty(shape, dtype=torch.int16).pin_memory()
@@ -53,20 +55,27 @@ class UploadSlot:
             self.h_pose = torch.empty((self.cap_frames * 18,), dtype=torch.float64).pin_memory()   # A @ E, yaw, pitch (K4)
             self.d_pose = torch.empty_like(self.h_pose, device=self.device)
         if n_points > self.cap_points:
+            grown = True
             self.cap_points = n_points
             self.h_xyz = torch.empty((n_points, 3), dtype=torch.float64).pin_memory()
             self.d_xyz = torch.empty((n_points, 3), dtype=torch.float64, device=self.device)
+        if grown:
+            # The caching allocator hands out blocks on the ALLOCATING thread's current stream and may return one the
+            # consumer has just freed there while its last kernel (a K2 workspace, pair outputs) is still queued.  The
+            # copies below run on `copy_stream`: order them behind everything already enqueued on the allocation stream.
+            copy_stream.wait_stream(torch.cuda.current_stream(self.device))
 
     def stage_and_upload(self, sc, copy_stream) -> SceneOnDevice:
         """Fill the pinned buffers from ``sc`` (K, A, E, depth, color_hw, points) and enqueue the copies on ``copy_stream``."""
         ids = valid_image_ids(sc.E)
         F = len(ids)
-        first = next(iter(sc.depth.values()))
+        # a scene without depth frames is an empty scene (as SceneOnDevice treats it), not a StopIteration
+        first_shape = tuple(next(iter(sc.depth.values())).shape) if len(sc.depth) else (self.depth_hw or tuple(sc.color_hw))
         points = getattr(sc, "points", None)
         N = 0 if points is None else int(points.shape[0])
         if self.free is not None:
             self.free.synchronize()              # the previous user of this slot has finished (host-side wait: we overwrite
-        self._ensure(max(F, 1), tuple(first.shape), max(N, 1))       # pinned memory the earlier copy may still be reading)
+        self._ensure(max(F, 1), first_shape, max(N, 1), copy_stream)  # pinned memory the earlier copy may still be reading)
         # Depth frames: straight into pinned memory (no np.stack temporary), a chunk of frames at a time by native copy
         # threads, each chunk's H2D enqueued as soon as it is staged -- the link is busy while the next chunk is gathered
         # and while the matrices below are prepared.

@@ -19,6 +19,14 @@ int main(void) {
     if (!strstr(mspa_last_error_string(), "null pointer")) return 4;
     if (mspa_track_rigidity_loss(NULL, 3, 0, 0.01, NULL, NULL) != MSPA_OK) return 5;      /* empty input: nothing to do */
     if (mspa_object_extents(NULL, 0, 2, NULL, 100, NULL, NULL, 0, 2, NULL, NULL, NULL, NULL) != MSPA_OK) return 6;
+    if (mspa_corr_tiles(480, 640) != 100 || mspa_corr_tiles(968, 1296) != 21 * 21 || mspa_corr_tiles(1, 640) != -1) return 7;
+    if (mspa_pair_correspondences_workspace_bytes(10, 480, 640, 480, 640, MSPA_PAIR_FAST) != 0) return 8;   /* fused */
+    if (mspa_pair_correspondences_workspace_bytes(10, 480, 640, 480, 640, 0) != 10LL * 480 * 640 * 4) return 9;
+    if (mspa_pair_correspondences_workspace_bytes(2, 480, 640, 968, 1296, MSPA_PAIR_FAST) != 2LL * 968 * 1296 * 4) return 10;
+    if (mspa_pair_correspondences(NULL, NULL, 1, NULL, 1, 480, 640, 480, 640, NULL, NULL, NULL, NULL, NULL, 0, MSPA_PAIR_FAST,
+                                  NULL) != MSPA_EINVAL) return 11;
+    if (!strstr(mspa_last_error_string(), "required")) return 12;
+    if (mspa_compact_correspondences(NULL, NULL, 0, 480, 640, NULL, NULL, NULL) != MSPA_OK) return 13;   /* nothing to do */
     printf("ok %d\n", mspa_version());
     return 0;
 }

@@ -232,6 +232,16 @@ def test_fast_flag_needs_pinhole_and_bad_tensors_are_rejected():
     out = engine.alloc_pair_outputs(1, sc.color_hw, ("vis_bits", "counts"), DEV)
     with pytest.raises(ValueError, match="pinhole"):
         engine.pair_reproject(depth, mats, pairs, sc.color_hw, out, flags=_lib.PAIR_FAST)
+    # EVERY frame record is checked, once per table: a pinhole table passes (and is remembered), the same table with a LATER
+    # frame's K edited in place is re-checked (version counter) and refused
+    mats_ok = torch.from_numpy(engine.frame_matrices(sc.K, sc.A, [sc.E[i] for i in ids])).to(DEV)
+    engine.pair_reproject(depth, mats_ok, pairs, sc.color_hw, out, flags=_lib.PAIR_FAST)
+    engine.pair_reproject(depth, mats_ok, pairs, sc.color_hw, out, flags=_lib.PAIR_FAST)
+    mats_ok[1, _lib.MAT_K, 11] = 0.5
+    with pytest.raises(ValueError, match="pinhole"):
+        engine.pair_reproject(depth, mats_ok, pairs, sc.color_hw, out, flags=_lib.PAIR_FAST)
+    with pytest.raises(ValueError, match="pinhole"):
+        engine.pair_correspondences(depth, mats_ok, pairs, sc.color_hw)
     engine.pair_reproject(depth, mats, pairs, sc.color_hw, out, flags=0)              # the exact kernel takes any affine K
     ref = C.frame_pair(sc.depth[ids[0]], sc.depth[ids[1]], K2, sc.E[ids[0]], sc.E[ids[1]], sc.A, sc.color_hw)
     torch.cuda.synchronize()

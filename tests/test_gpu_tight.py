@@ -23,6 +23,7 @@ DEV = "cuda"
 SETS = {
     "corr": ("vis_bits", "pix_i16", "counts"),
     "dense": ("vis_u8", "pix_i16", "xyz_f32", "rgba", "counts"),
+    "dense_xyz": ("vis_u8", "pix_i16", "xyz_f32", "counts"),          # SURVEY 8d's dense with rgb = 0: no colour words
     "minimal": ("vis_bits", "counts"),
 }
 
