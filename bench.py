@@ -93,7 +93,7 @@ def parse_args():
                     help="which pairs of the scene (mspa/workload.py): vc = the reference's overlap-binned sample 6..35 %% "
                          "(headline), low = overlap < 6 %%, high = near-identical views")
     ap.add_argument("--variant", choices=sorted(VARIANTS), default="corr")
-    ap.add_argument("--mode", choices=("fast", "exact", "fulltile"), default="fast",
+    ap.add_argument("--mode", choices=("fast", "exact"), default="fast",
                     help="fast: MSPA_PAIR_FAST (bit-exact integers via guarded composed matrices); exact: the "
                          "reference's own operation order")
     ap.add_argument("--stream", choices=("auto", "on", "off"), default="auto",
@@ -221,9 +221,7 @@ def time_variant(variant, mode, depth, mats, rgb, pairs, steps, warmup, dist_ctx
 
     from mspa import _lib
     spec = VARIANTS[variant]
-    flags = 0
-    if mode in ("fast", "fulltile"):     # fulltile: round 2's full-tile kernel for the correspondence family (MSPA_PAIR_FULLTILE)
-        flags = _lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0) | (_lib.PAIR_FULLTILE if mode == "fulltile" else 0)
+    flags = (_lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0)) if mode == "fast" else 0
     # With N > 1 every step's per-pair records land in one job-level table [steps, pairs, 2] (the kernel writes its
     # slice directly) which is collated ONCE, inside the timed region, with a single RCCL all_gather -- the
     # pipeline's exchange step is per job (mspa/pipeline.py), not per launch.  (Collating after every launch was
@@ -661,8 +659,7 @@ def main():
                          if t else None,
                          "traffic_GBs": round(traffic / (kern_ms * 1e-3) / 1e9, 1) if traffic else None,
                          "traffic_frac": round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                         "kernel": ("mspa::pair_exact_kernel" if not tight else "mspa::pair_fast_tight_kernel"
-                                    if (args.mode == "fulltile" or args.variant.startswith("dense")) else "mspa::pair_fast_stream_kernel"),
+                         "kernel": "mspa::pair_fast_tight_kernel" if tight else "mspa::pair_exact_kernel",
                          "kernel_ms": round(kern_ms, 4), "bytes_per_pair": int(bytes_per_launch / args.pairs),
                          "bytes_per_launch": int(bytes_per_launch),
                          "measured_ceilings_GBs": ceilings},

@@ -70,10 +70,6 @@ typedef void *mspa_stream_t;        /* hipStream_t */
                                        displace frame-2 lines that ARE revisited (gathers).  Results are identical with or
                                        without it; measured +3 % with distinct frames, -10 % when 48 frames serve 1000 pairs */
 
-#define MSPA_PAIR_FULLTILE 4u       /* with MSPA_PAIR_FAST on a whole-tile shape: run the correspondence-family output sets on the
-                                       full-tile kernel (6 KB depth tile per wave in LDS, 4-row groups: round 2's kernel) instead of
-                                       the streaming one.  Identical results; for A/B timing and test coverage */
-
 int mspa_version(void);
 const char *mspa_last_error_string(void);
 
@@ -122,11 +118,8 @@ int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, const double 
 #define MSPA_KERNEL_PAIR_FAST 2           /* composed + guarded, any shape, stripe mapping */
 #define MSPA_KERNEL_PAIR_FAST_LINEAR 3    /* the same with the linear pixel mapping (bitset, W % 64 != 0) */
 #define MSPA_KERNEL_PAIR_FAST_TIGHT 4     /* whole-tile images (W % 64 == 0, H % 48 == 0, colour == depth grid), output set
-                                             dense / dense without colour (and corr / minimal / compact under MSPA_PAIR_FULLTILE) */
+                                             corr / dense / dense without colour / minimal / compact */
 #define MSPA_KERNEL_PAIR_FAST_SCALED 5    /* colour grid over a smaller depth grid (ScanNet: 1296x968 over 640x480) */
-#define MSPA_KERNEL_PAIR_FAST_STREAM 6    /* whole-tile images, output set corr / minimal / compact: the streaming form of the
-                                             tight kernel (2-row groups, depth-1 through a 3 KB LDS ring: 6-8 waves per SIMD).
-                                             the MSPA_PAIR_FULLTILE flag selects the full-tile kernel (4) instead */
 int mspa_pair_reproject_last_kernel(void);
 
 /*

@@ -702,6 +702,17 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 #ifndef MSPA_TIGHT_DMA16
 #define MSPA_TIGHT_DMA16 1
 #endif
+#ifndef MSPA_STAGE2_ROW_BARRIER
+#define MSPA_STAGE2_ROW_BARRIER 3      // 0 never, 1 after every row, 2 after the second row only, 3 every row for the compacted set
+#endif
+#ifndef MSPA_TIGHT_WAVES_PER_EU
+#define MSPA_TIGHT_WAVES_PER_EU 0      // > 0: ask the register allocator for that many waves per SIMD
+#endif
+#if MSPA_TIGHT_WAVES_PER_EU > 0
+#define MSPA_TIGHT_ATTR __attribute__((amdgpu_waves_per_eu(MSPA_TIGHT_WAVES_PER_EU, MSPA_TIGHT_WAVES_PER_EU)))
+#else
+#define MSPA_TIGHT_ATTR
+#endif
 constexpr int kTightRows = MSPA_TIGHT_ROWS;
 constexpr int kTightBW = MSPA_TIGHT_BLOCK_WAVES;      // waves (= tiles) per workgroup
 constexpr int kTightThreads = kTightBW * kWave;
@@ -747,30 +758,15 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m, uint32_t base)
 }
 
 // Compacted correspondences (SET has O_CPIX, see include/mspa.h mspa_pair_correspondences): a tile writes the (xi, yi) of its
-// VISIBLE pixels only, in (row, column) order, into its own 3072-entry segment.  Rank of a lane = entries of the tile so far
-// (scalar) + set bits below the lane (v_mbcnt); entries collect in a 512-entry LDS ring and leave as whole 1 KB chunks (16
-// bytes per lane), so the tile issues n_visible / 256 stores instead of one per row group -- and nothing at all for culled
-// tiles and groups, which is where the dense table spends three quarters of its bytes on (-1, -1).
-constexpr int kCompactRing = 512;
-// timing-only ablations of the compacted set (results wrong by construction; tools/build_variant.sh)
-#ifndef MSPA_CX_BRANCHLESS
-#define MSPA_CX_BRANCHLESS 0
-#endif
-#ifndef MSPA_CX_NORING
-#define MSPA_CX_NORING 0
-#endif
-#ifndef MSPA_CX_NOSTORE
-#define MSPA_CX_NOSTORE 0
-#endif
-#ifndef MSPA_CX_NOCOUNT
-#define MSPA_CX_NOCOUNT 0
-#endif
-#ifndef MSPA_DUMMY_LDS
-#define MSPA_DUMMY_LDS 0
-#endif
+// VISIBLE pixels only, in (row, column) order, into its own 3072-entry segment: rank of a lane = entries of the tile so far
+// (a scalar, the store's SGPR offset) + set bits below the lane (v_mbcnt), one exec-masked dword store per row with a visible
+// lane -- and nothing at all for culled tiles and groups, which is where the dense table spends three quarters of its bytes
+// on (-1, -1).  Two forms that staged the entries in LDS and stored 1 KB chunks (a 512-entry ring, a 320-entry buffer with
+// carry) were measured slower: their 1.25 - 2 KB per wave cost the kernel a workgroup per CU, and this kernel's time goes
+// with the waves in flight (profiles/r03a_k3_compact_fulltile_ring512_pmc.md).
 
 template <uint32_t SET, bool STREAM>
-__global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
+__global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
                                                                    const uint8_t *__restrict__ rgb,
                                                                    const double *__restrict__ mats,
                                                                    const int32_t *__restrict__ pairs, PairArgs a) {
@@ -809,7 +805,14 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
     // requests are in flight before any arithmetic and cost no VGPRs; their latency hides behind the
     // matrix composition below.  (A register prefetch one row group ahead left the kernel latency
     // bound once skipped groups made an iteration shorter than a memory round trip.)
-    __shared__ __attribute__((aligned(16))) uint16_t lds_d1[kTightBW][kTightRows * 64];
+    // The correspondence set's transpose stage (the 4 x 64 pixel indices of a row group, 1 KB) needs no LDS of its own: the
+    // depth-1 rows of a group are dead once the group has loaded its samples, so group g's stage is the 1 KB that ends with
+    // its own four rows -- bytes [512 g, 512 g + 1024) of a per-wave region that starts with a 512-byte pad (group 0 has no
+    // predecessor).  The wave's LDS operations execute in order; the next group reads ITS rows before its stage overwrites them.
+    constexpr bool PX_IN_TILE = (SET & O_PIX) && !(SET & (O_XYZ32 | O_RGBA));
+    constexpr int kPadPx = PX_IN_TILE ? 256 : 0;                        // uint16 units: 512 bytes
+    __shared__ __attribute__((aligned(16))) uint16_t lds_w[kTightBW][kPadPx + kTightRows * 64];
+    uint16_t *const lds_d1w = &lds_w[wave][kPadPx];                     // this wave's 48 x 64 depth-1 samples
     if (tile_ok) {
         typedef __attribute__((address_space(1))) const void gvoid_t;
         typedef __attribute__((address_space(3))) void lvoid_t;
@@ -822,14 +825,14 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
 #pragma unroll
         for (int k = 0; k < kTightRows / 8; ++k)
             __builtin_amdgcn_global_load_lds((gvoid_t *)(src + (int64_t)(8 * k) * a.W),
-                                             (lvoid_t *)&lds_d1[wave][k * 512], 16, 0, STREAM ? 2 : 0);  // aux 2 = nt
+                                             (lvoid_t *)&lds_d1w[k * 512], 16, 0, STREAM ? 2 : 0);  // aux 2 = nt
 #else
         const uint16_t *src = c.depth1 + (int64_t)(row0 + (uint32_t)(c.lane >> 5)) * a.W + stripe * 64u +
                               (uint32_t)(c.lane & 31) * 2u;
 #pragma unroll
         for (int k = 0; k < kTightRows / 2; ++k)
             __builtin_amdgcn_global_load_lds((gvoid_t *)(src + (int64_t)(2 * k) * a.W),
-                                             (lvoid_t *)&lds_d1[wave][k * 128], 4, 0, STREAM ? 2 : 0);   // aux 2 = nt
+                                             (lvoid_t *)&lds_d1w[k * 128], 4, 0, STREAM ? 2 : 0);   // aux 2 = nt
 #endif
     }
 
@@ -852,21 +855,12 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
     }
 
     // transpose stage: the group's pixel indices, then (dense set) its rgba words, then its 4 x 64 x 3 point coordinates
-    __shared__ __attribute__((aligned(16))) uint32_t lds_px[kTightBW][COMPACT ? kCompactRing : kRowGroup * 64 * (WANT_XYZ ? 3 : 1)];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_pxs[kTightBW][(PX_IN_TILE || !(SET & (O_PIX | O_XYZ32 | O_RGBA))) ? 4 : kRowGroup * 64 * (WANT_XYZ ? 3 : 1)];
     static_assert(kTightRows <= 64, "one lane per tile row holds that row's visibility word");
-    static_assert(kTightRows * 64 == MSPA_CORR_TILE_CAP && kTightRows == MSPA_CORR_TILE_H, "tile segment of the compacted set");
-    // Guarded-lane ballots of flagged rows (rare path) and the wave's two counters live in the depth-1 tile itself: row r's
-    // 128 bytes are dead once the row group that holds r has loaded its samples (the cold loop re-reads from memory), and the
-    // wave's LDS operations execute in order.  Saves 1.5 KB per workgroup -- what lets the compacted set's 2 KB ring fit.
-    auto lds_rb = [&](int r) -> unsigned long long & { return *reinterpret_cast<unsigned long long *>(&lds_d1[wave][r * 64]); };
-    int n_valid = 0, n_vis = 0;
-#if MSPA_DUMMY_LDS
-    __shared__ uint32_t lds_dummy[MSPA_DUMMY_LDS / 4];            // occupancy ablation: LDS that is never read
-    if (a.n_pairs < 0) {
-        lds_dummy[threadIdx.x] = threadIdx.x;
-        asm volatile("" ::"v"(lds_dummy[threadIdx.x ^ 1]));
-    }
+#ifndef MSPA_EXPERIMENT_ROWS   // timing-only builds with another tile height (tools/build_variant.sh): the compacted set is then wrong
+    static_assert(!COMPACT || (kTightRows * 64 == MSPA_CORR_TILE_CAP && kTightRows == MSPA_CORR_TILE_H), "tile segment of the compacted set");
 #endif
+    int n_valid = 0, n_vis = 0;
     if (tile_ok) {
         const uint32_t Wb = (uint32_t)a.W;
         // buffer resources: SGPR base + byte count; raw addressing = base + voffset (VGPR) + soffset (SGPR)
@@ -897,7 +891,13 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
         __amdgpu_buffer_rsrc_t rs_cpix = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(COMPACT ? a.cpix + ((pair * (int64_t)a.n_tiles + (int64_t)tile) * MSPA_CORR_TILE_CAP) * 2 : nullptr), 0,
             COMPACT ? MSPA_CORR_TILE_CAP * 4 : 0, kRsrcFlags);
-        uint32_t cfill = 0, cflushed = 0;            // wave-uniform: entries written to the ring, 256-entry chunks stored
+        uint32_t cfill = 0;                          // compacted set, wave-uniform: entries of the tile so far
+        // one row's visible lanes store their pixel index at their rank: entries so far (scalar offset) + set bits below the lane
+        auto compact_row = [&](unsigned long long vmask, int pixv) {
+            if (__builtin_amdgcn_inverse_ballot_w64(vmask))
+                __builtin_amdgcn_raw_buffer_store_b32((uint32_t)pixv, rs_cpix, (int)(mbcnt64(vmask, 0u) * 4u), (int)(cfill * 4u), 0);
+            cfill += (uint32_t)__popcll(vmask);
+        };
         const int vis_voff = (int)(((uint32_t)c.lane >> 4) * Wb + stripe * 64u + ((uint32_t)c.lane & 15u) * 4u);
         const int rgb_voff = (int)(stripe * 192u + (c.lane == 0 ? 0u : (uint32_t)c.lane * 3u - 1u));
         int xyz_voff[3];
@@ -926,6 +926,7 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
         // for 2 VALU issues per row; the tile's 48 words leave with ONE store at the end, after the cold loop has patched
         // them in registers.
         uint32_t bits_lo = 0, bits_hi = 0;
+        uint32_t rb_lo = 0, rb_hi = 0;               // lane r: guarded-lane ballot of tile row r (flagged rows only; rare path)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's depth-1 samples have landed in LDS
 
         // ---- tile-level culling -------------------------------------------------------------------
@@ -940,7 +941,7 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
         if (!WANT_XYZ && !O::template has<O_VALID_U8>(a.valid_u8) && !O::template has<O_RGBA>(a.rgba) &&
             !O::template has<O_VIS_U8>(a.vis_u8)) {
             typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-            const us2 *wds = reinterpret_cast<const us2 *>(&lds_d1[wave][0]);
+            const us2 *wds = reinterpret_cast<const us2 *>(lds_d1w);
             us2 mn = {0xFFFF, 0xFFFF}, mxv = {0, 0};
             const us2 one = {1, 1};
 #pragma unroll
@@ -994,7 +995,7 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
                 uint32_t d16[kRowGroup];
 #pragma unroll
                 for (int j = 0; j < kRowGroup; ++j) {
-                    d16[j] = lds_d1[wave][(r0 + j) * 64 + c.lane];
+                    d16[j] = lds_d1w[(r0 + j) * 64 + c.lane];
                     asm("" : "+v"(d16[j]));      // a plain 32-bit value from here on (ds_read_u16 zero-extends): otherwise the
                 }                                // compare below is narrowed to 16 bits and the conversion pays a v_and
                 // ---- stage 1: project; "in view" with the guard band folded into the comparison constants:
@@ -1037,6 +1038,8 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
                     any |= ivm[j];
                 }
                 const uint32_t rowg = row0 + (uint32_t)r0;
+                // transpose stage of this group (see the LDS layout above); the dense sets keep a stage of their own
+                uint32_t *const lds_px = PX_IN_TILE ? reinterpret_cast<uint32_t *>(&lds_w[wave][0]) + (r0 / kRowGroup) * 128 : &lds_pxs[wave][0];
                 unsigned long long vm[kRowGroup] = {0, 0, 0, 0};       // visibility words of the group's rows
                 if (any == 0) {
                     // ---- nothing of these 4 x 64 pixels can land in frame 2: no gather, no depth test ----
@@ -1064,6 +1067,13 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
                         const double wv = __builtin_fabs(v[j] - rv) - 0.25;
                         rkc[j] = ballot64(!(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx)) |
                                  ballot64(!(qz[j] > kGuardZmm));
+                        // Scheduling barrier between rows: left to itself the scheduler interleaves the four rows' rounding / guard
+                        // code and keeps all their temporaries live (86-88 VGPRs: 5 waves per SIMD); one row at a time needs 66-69
+                        // (6 waves).  Which is worth more depends on the set (tools/ab_k3.py, one box): the sixth wave for the
+                        // compacted set (0.493 -> 0.463 ms), the interleaving for the correspondence table (0.506 vs 0.552).
+                        if (MSPA_STAGE2_ROW_BARRIER == 1 || (MSPA_STAGE2_ROW_BARRIER == 2 && j == 1) ||
+                            (MSPA_STAGE2_ROW_BARRIER == 3 && COMPACT))
+                            __builtin_amdgcn_sched_barrier(0);
                     }
                     // ---- stage 3: depth test, outputs -------------------------------------------------------
                     unsigned long long rbm[kRowGroup];
@@ -1073,45 +1083,20 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
                         const double sd = qz[j] - (double)dv16[j];              // millimetres; IH:368-371 compares metres
                         vm[j] = ivm[j] & ballot64(sd < 0.0);
                         rbm[j] = ivm[j] & (rkc[j] | ballot64(!(__builtin_fabs(sd) > kGuardZmm)));
-                        if (O::template has<O_PIX>(a.pix_i16)) lds_px[wave][j * 64 + c.lane] = (uint32_t)(inview ? pix[j] : -1);
-                        if (COMPACT) {
-                            const uint32_t rank = mbcnt64(vm[j], cfill);
-#if MSPA_CX_BRANCHLESS
-                            // no exec-masked block per row: lanes that are not visible store to a dump slot -- dword `lane` of
-                            // the 256 bytes of this group's first two depth-1 rows, dead by now
-                            uint32_t *dump = reinterpret_cast<uint32_t *>(&lds_d1[wave][r0 * 64]) + c.lane;
-                            uint32_t *slot = &lds_px[wave][rank & (kCompactRing - 1)];
-                            *(__builtin_amdgcn_inverse_ballot_w64(vm[j]) ? slot : dump) = (uint32_t)pix[j];
-#elif !MSPA_CX_NORING
-                            if (__builtin_amdgcn_inverse_ballot_w64(vm[j])) lds_px[wave][rank & (kCompactRing - 1)] = (uint32_t)pix[j];
-#else
-                            asm volatile("" :: "v"(rank));
-#endif
-                            cfill += (uint32_t)__popcll(vm[j]);
-                        }
-                    }
-                    if (COMPACT && (cfill >> 8) != cflushed) {           // a 256-entry chunk is complete (at most one per group)
-                        wave_lds_fence();
-                        const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][((cflushed & 1u) << 8) + c.lane * 4]);
-#if !MSPA_CX_NOSTORE
-                        buffer_store_b128_guarded(q, rs_cpix, c.lane * 16, (int)(cflushed << 10));
-#else
-                        asm volatile("" :: "v"(q));
-#endif
-                        wave_lds_fence();
-                        ++cflushed;
+                        if (O::template has<O_PIX>(a.pix_i16)) lds_px[j * 64 + c.lane] = (uint32_t)(inview ? pix[j] : -1);
+                        if (COMPACT) compact_row(vm[j], pix[j]);
                     }
                     if (rbm[0] | rbm[1] | rbm[2] | rbm[3]) {             // wave-uniform, rare: one branch per group, not per row
 #pragma unroll
                         for (int j = 0; j < kRowGroup; ++j)
                             if (rbm[j]) {
-                                if (c.lane == 0) lds_rb(r0 + j) = rbm[j];
+                                writelane64(rbm[j], r0 + j, rb_lo, rb_hi);
                                 risky_rows |= 1ull << (r0 + j);
                             }
                     }
                     if (O::template has<O_PIX>(a.pix_i16)) {
                         wave_lds_fence();
-                        const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][c.lane * 4]);
+                        const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[c.lane * 4]);
                         buffer_store_b128_guarded(q, rs_pix, pix_voff, (int)(rowg * Wb * 4u));
                         wave_lds_fence();
                     }
@@ -1145,10 +1130,10 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
                         const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(rs_rgb, rgb_voff, (int)((rowg + (uint32_t)j) * Wb * 3u), 0);
                         const uint32_t colr = c.lane == 0 ? (w & 0xFFFFFFu) : (w >> 8);
                         const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmk[j]);
-                        lds_px[wave][j * 64 + c.lane] = colr | (valid ? 0xFF000000u : 0u);
+                        lds_px[j * 64 + c.lane] = colr | (valid ? 0xFF000000u : 0u);
                     }
                     wave_lds_fence();
-                    const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][c.lane * 4]);
+                    const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[c.lane * 4]);
                     buffer_store_b128_guarded(q, rs_rgba, pix_voff, (int)(rowg * Wb * 4u));
                     wave_lds_fence();
                 }
@@ -1157,7 +1142,7 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
 #pragma unroll
                     for (int j = 0; j < kRowGroup; ++j) {
                         const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmk[j]);
-                        uint32_t *dst = &lds_px[wave][(j * 64 + c.lane) * 3];
+                        uint32_t *dst = &lds_px[(j * 64 + c.lane) * 3];
                         dst[0] = valid ? __float_as_uint(fx[j]) : fnan;
                         dst[1] = valid ? __float_as_uint(fy[j]) : fnan;
                         dst[2] = valid ? __float_as_uint(fz[j]) : fnan;
@@ -1165,7 +1150,7 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
                     wave_lds_fence();
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][(k * 64 + c.lane) * 4]);
+                        const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[(k * 64 + c.lane) * 4]);
                         buffer_store_b128_guarded(q, rs_xyz, xyz_voff[k], (int)(rowg * Wb * 12u));
                     }
                     wave_lds_fence();
@@ -1180,7 +1165,7 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
             while (risky_rows) {                            // wave-uniform
                 const int g = __builtin_amdgcn_readfirstlane(__builtin_ctzll(risky_rows));
                 risky_rows &= risky_rows - 1ull;
-                const unsigned long long rb = lds_rb(g);
+                const unsigned long long rb = readlane64(rb_lo, rb_hi, g);
                 const unsigned long long old = readlane64(bits_lo, bits_hi, g);
                 const uint32_t row = row0 + (uint32_t)g;
                 const uint32_t i = row * Wb + col;
@@ -1220,17 +1205,8 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
                     }
                     base += (uint32_t)__popcll(w);
                 }
-            } else {
-                const uint32_t rem = cfill - (cflushed << 8);             // < 256 entries still in the ring
-                wave_lds_fence();
-                if ((uint32_t)c.lane * 4u < rem) {
-                    const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][((cflushed & 1u) << 8) + c.lane * 4]);
-                    buffer_store_b128_guarded(q, rs_cpix, c.lane * 16, (int)(cflushed << 10));
-                }
             }
-#if !MSPA_CX_NOCOUNT
             if (c.lane == 0) a.tile_counts[pair * (int64_t)a.n_tiles + (int64_t)tile] = n_vis;
-#endif
         }
         // the tile's visibility words: lane r stores the word of row row0 + r (8 bytes; rows are W/8 bytes apart)
         if (O::template has<O_VIS_BITS>(a.vis_bits) && c.lane < kTightRows)
@@ -1239,7 +1215,7 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
     }
     if (O::template has<O_COUNTS>(a.counts)) {
         // the wave's totals go to bytes 16..23 of its own (finished) depth tile; thread 0 sums the four after the barrier
-        int *red = reinterpret_cast<int *>(&lds_d1[wave][8]);
+        int *red = reinterpret_cast<int *>(&lds_w[wave][kPadPx + 8]);
         if (c.lane == 0) {
             red[0] = n_valid;
             red[1] = n_vis;
@@ -1248,400 +1224,9 @@ __global__ __launch_bounds__(kTightThreads) void pair_fast_tight_kernel(const ui
         if (threadIdx.x == 0) {
             int sv = 0, ss = 0;
             for (int j = 0; j < kTightBW; ++j) {
-                const int *rj = reinterpret_cast<const int *>(&lds_d1[j][8]);
+                const int *rj = reinterpret_cast<const int *>(&lds_w[j][kPadPx + 8]);
                 sv += rj[0];
                 ss += rj[1];
-            }
-            atomicAdd(a.counts + 2 * pair + 0, sv);
-            atomicAdd(a.counts + 2 * pair + 1, ss);
-        }
-    }
-}
-
-// --------------------------------------------------------------------------------------------
-// fast path, whole-tile images, STREAMING form (round 3) -- the correspondence family of output sets
-// (corr / minimal / compact) at the BASELINE shape
-// --------------------------------------------------------------------------------------------
-// Same arithmetic, guard band, culling and bookkeeping as pair_fast_tight_kernel; what changes is how many waves fit.
-// PMC on the tight kernel (profiles/r03_k3_occupancy.md): 3.2 - 5.1 waves resident per SIMD, waves parked on s_waitcnt
-// ~55 % of their cycles with VALU at 60 % and HBM at 50 % -- a latency-bound kernel whose occupancy is set by its 6 KB
-// depth-1 tile per wave (LDS) and its ~88 VGPRs (four rows of float64 state in flight).  Here:
-//   * rows are processed TWO at a time (kSRG): half the per-row float64 state, <= 64 VGPRs -> 8 waves / SIMD by registers;
-//   * the depth-1 samples stream through a ring of three 1 KB LDS slots (one 16-byte LDS-DMA request = 8 rows), the request
-//     for chunk c + 2 issued when chunk c starts: 3 KB per wave instead of 6;
-//   * the tile's depth range for the frustum test comes from a register pre-pass (the same 6 x 16-byte loads per lane,
-//     issued first so that the ring's requests hit L2): the whole tile is never resident in LDS;
-//   * guarded-row ballots live in VGPR lanes like the visibility words (no LDS);
-//   * the pixel-index table still leaves as 16-byte stores of 4-row blocks: two groups share the 1 KB transpose stage.
-#ifndef MSPA_STREAM_RG
-#define MSPA_STREAM_RG 2
-#endif
-constexpr int kSRG = MSPA_STREAM_RG;             // rows per group (gathers in flight together)
-constexpr int kChunkRows = 8;                    // rows per LDS-DMA request
-constexpr int kSlots = 3;                        // ring slots (1 KB each)
-static_assert(kSRG == 2 || kSRG == 4, "groups of 2 or 4 rows; a 4-row block is one 16-byte store per lane");
-static_assert(kTightRows % kChunkRows == 0 && kChunkRows % kSRG == 0, "whole chunks, whole groups");
-
-template <uint32_t SET, bool STREAM>
-__global__ __launch_bounds__(kTightThreads) void pair_fast_stream_kernel(const uint16_t *__restrict__ depth,
-                                                                    const double *__restrict__ mats,
-                                                                    const int32_t *__restrict__ pairs, PairArgs a) {
-    using O = Outs<SET, false>;
-    constexpr bool COMPACT = (SET & O_CPIX) != 0;
-    constexpr bool PIX = (SET & O_PIX) != 0;
-    static_assert((SET & ~(O_VIS_BITS | O_PIX | O_CPIX | O_COUNTS)) == 0 && !(COMPACT && PIX), "corr / minimal / compact");
-    int64_t pair;
-    uint32_t tgroup;
-    if (!decode_block(a, pair, tgroup)) return;
-    const int f1 = pairs[2 * pair + 0];
-    const int f2 = pairs[2 * pair + 1];
-    const double *m1 = mats + (int64_t)f1 * (MSPA_FRAME_MATS * 16);
-    const double *m2 = mats + (int64_t)f2 * (MSPA_FRAME_MATS * 16);
-    const int64_t dpix = (int64_t)a.dh * a.dw;
-    Ctx c;
-    c.depth1 = depth + (int64_t)f1 * dpix;
-    c.depth2 = depth + (int64_t)f2 * dpix;
-    c.rgb1 = nullptr;
-    c.obase = pair * (int64_t)a.P;
-    c.words_per_pair = (a.P + 63) >> 6;
-    c.pair = pair;
-    c.lane = threadIdx.x & 63;
-
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = tgroup * kTightBW + wave;
-    const uint32_t band = a.n_stripes == 1 ? tile : __umulhi(tile, a.stripe_magic);
-    const uint32_t stripe = tile - band * (uint32_t)a.n_stripes;
-    const bool tile_ok = tile < (uint32_t)a.n_tiles;
-    const uint32_t col = stripe * 64u + (uint32_t)c.lane;
-    const uint32_t row0 = band * (uint32_t)kTightRows;
-
-    __shared__ __attribute__((aligned(16))) uint16_t lds_d1[kTightBW][kSlots * kChunkRows * 64];
-    __shared__ __attribute__((aligned(16))) uint32_t lds_px[kTightBW][COMPACT ? kCompactRing : PIX ? 4 * 64 : 4];
-    typedef __attribute__((address_space(1))) const void gvoid_t;
-    typedef __attribute__((address_space(3))) void lvoid_t;
-    // lane L of a request: row L >> 3 of the chunk, 16-byte piece L & 7 of its 128 bytes
-    const uint16_t *src = c.depth1 + (int64_t)(row0 + (uint32_t)(c.lane >> 3)) * a.W + stripe * 64u + (uint32_t)(c.lane & 7) * 8u;
-    auto request_chunk = [&](int chunk, int slot) {
-        __builtin_amdgcn_global_load_lds((gvoid_t *)(src + (int64_t)(kChunkRows * chunk) * a.W),
-                                         (lvoid_t *)&lds_d1[wave][slot * (kChunkRows * 64)], 16, 0, STREAM ? 2 : 0);   // aux 2 = nt
-    };
-    // ---- pre-pass: the tile's samples once through registers (depth range for the frustum test, valid count) ----
-    constexpr int kChunks = kTightRows / kChunkRows;
-    u32x4_t pre[kChunks];
-    if (tile_ok) {
-#pragma unroll
-        for (int k = 0; k < kChunks; ++k)
-            pre[k] = *reinterpret_cast<const u32x4_t *>(src + (int64_t)(kChunkRows * k) * a.W);
-        request_chunk(0, 0);
-        request_chunk(1, 1);
-    }
-
-    const double *__restrict__ U = m1 + MSPA_MAT_UNPROJ * 16;
-    const double *__restrict__ N = m2 + MSPA_MAT_REPROJ * 16;
-    double M[3][4];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        double row[4];
-        compose_row(N, U, r, row);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) M[r][k] = uniform(k < 3 ? row[k] : row[k] * 1000.0);     // millimetre-scaled, see the tight kernel
-    }
-
-    int n_valid = 0, n_vis = 0;
-    if (tile_ok) {
-        const uint32_t Wb = (uint32_t)a.W;
-        const int kRsrcFlags = 0x00020000;
-        __amdgpu_buffer_rsrc_t rs_d2 = __builtin_amdgcn_make_buffer_rsrc((void *)c.depth2, 0, (int)(dpix * 2), kRsrcFlags);
-        __amdgpu_buffer_rsrc_t rs_pix = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(PIX ? a.pix_i16 + 2 * c.obase : nullptr), 0, PIX ? (int)(a.P * 4) : 0, kRsrcFlags);
-        __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(a.vis_bits ? a.vis_bits + pair * c.words_per_pair : nullptr), 0,
-            O::template has<O_VIS_BITS>(a.vis_bits) ? (int)(c.words_per_pair * 8) : 0, kRsrcFlags);
-        __amdgpu_buffer_rsrc_t rs_cpix = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(COMPACT ? a.cpix + ((pair * (int64_t)a.n_tiles + (int64_t)tile) * MSPA_CORR_TILE_CAP) * 2 : nullptr), 0,
-            COMPACT ? MSPA_CORR_TILE_CAP * 4 : 0, kRsrcFlags);
-        const int pix_voff = (int)((((uint32_t)c.lane >> 4) * Wb + stripe * 64u + ((uint32_t)c.lane & 15u) * 4u) * 4u);
-        const uint32_t wpr = Wb >> 6;
-        const int hi_x = a.dw - 1, hi_y = a.dh - 1;
-        const uint32_t dw2 = (uint32_t)a.dw * 2u;
-        const double mxd = (double)col;
-        const double myd0 = (double)row0;
-        double t0 = __builtin_fma(M[0][1], myd0, __builtin_fma(M[0][0], mxd, M[0][2]));
-        double t1 = __builtin_fma(M[1][1], myd0, __builtin_fma(M[1][0], mxd, M[1][2]));
-        double t2 = __builtin_fma(M[2][1], myd0, __builtin_fma(M[2][0], mxd, M[2][2]));
-        const double Wd = (double)a.W, Hd = (double)a.H;
-        unsigned long long risky_rows = 0;           // wave-uniform: rows with at least one guarded lane
-        uint32_t bits_lo = 0, bits_hi = 0;           // lane r: visibility word of tile row r
-        uint32_t rb_lo = 0, rb_hi = 0;               // lane r: guarded-lane ballot of tile row r (flagged rows only)
-        uint32_t cfill = 0, cflushed = 0;            // compacted set: entries written to the ring, 256-entry chunks stored
-
-        // ---- tile-level culling (see pair_fast_tight_kernel), from the pre-pass registers ----
-        bool culled = false;
-        {
-            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-            us2 mn = {0xFFFF, 0xFFFF}, mxv = {0, 0};
-            const us2 one = {1, 1};
-#pragma unroll
-            for (int k = 0; k < kChunks; ++k) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t w = pre[k][e];
-                    const us2 x = __builtin_bit_cast(us2, w);
-                    mn = __builtin_elementwise_min(mn, (us2)(x - one));      // 0 (invalid) wraps to 0xFFFF
-                    mxv = __builtin_elementwise_max(mxv, x);
-                }
-            }
-            int lo = min((int)mn.x, (int)mn.y), hi = max((int)mxv.x, (int)mxv.y);
-            for (int off = 32; off > 0; off >>= 1) {
-                lo = min(lo, __shfl_xor(lo, off));
-                hi = max(hi, __shfl_xor(hi, off));
-            }
-            if (hi == 0) {
-                culled = true;                                            // no valid depth sample at all
-            } else {
-                const int k = c.lane & 7;
-                const double cx = (double)(stripe * 64u + ((k & 1) ? 63u : 0u));
-                const double cy = (double)(row0 + ((k & 2) ? (uint32_t)(kTightRows - 1) : 0u));
-                const double cd = (double)((k & 4) ? hi : lo + 1);
-                const double hx = __builtin_fma(__builtin_fma(M[0][1], cy, __builtin_fma(M[0][0], cx, M[0][2])), cd, M[0][3]);
-                const double hy = __builtin_fma(__builtin_fma(M[1][1], cy, __builtin_fma(M[1][0], cx, M[1][2])), cd, M[1][3]);
-                const double hz = __builtin_fma(__builtin_fma(M[2][1], cy, __builtin_fma(M[2][0], cx, M[2][2])), cd, M[2][3]);
-                const double kMargin = 1.0;                               // homogeneous units (pixel * millimetre)
-                const bool all_behind = ballot64(hz <= -1e-3) == ~0ull;
-                const bool all_left = ballot64(hx < -kMargin) == ~0ull;
-                const bool all_right = ballot64(hx - (double)a.W * hz > kMargin) == ~0ull;
-                const bool all_above = ballot64(hy < -kMargin) == ~0ull;
-                const bool all_below = ballot64(hy - (double)a.H * hz > kMargin) == ~0ull;
-                culled = all_behind | all_left | all_right | all_above | all_below;
-            }
-            if (culled) {
-                us2 nz = {0, 0};
-#pragma unroll
-                for (int k = 0; k < kChunks; ++k) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const uint32_t w = pre[k][e];
-                        nz += __builtin_elementwise_min(__builtin_bit_cast(us2, w), one);
-                    }
-                }
-                int cnt = (int)nz.x + (int)nz.y;
-                for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-                n_valid = cnt;
-                if (PIX) {
-                    const u32x4_t none = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-#pragma unroll 4
-                    for (int r0 = 0; r0 < kTightRows; r0 += 4)
-                        buffer_store_b128_guarded(none, rs_pix, pix_voff, (int)((row0 + (uint32_t)r0) * Wb * 4u));
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the two ring requests land before the wave leaves its LDS
-            }
-        }
-
-        if (!culled) {
-            uint32_t slot = 0;                          // ring slot of the current chunk
-            bool blk_pending_none = false;              // PIX, kSRG == 2: the 4-row block's first half wrote nothing (all "none")
-#pragma unroll 1
-            for (int r0 = 0; r0 < kTightRows; r0 += kSRG) {
-                if ((r0 & (kChunkRows - 1)) == 0) {     // wave-uniform: a new chunk
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // its samples have landed (so has everything older)
-                    const int chunk = r0 / kChunkRows;
-                    if (r0) slot = slot + 1 == (uint32_t)kSlots ? 0u : slot + 1;
-                    if (chunk + 2 < kChunks) {
-                        const uint32_t s2 = slot + 2 >= (uint32_t)kSlots ? slot + 2 - (uint32_t)kSlots : slot + 2;
-                        request_chunk(chunk + 2, (int)s2);
-                    }
-                }
-                uint32_t d16[kSRG];
-#pragma unroll
-                for (int j = 0; j < kSRG; ++j) {
-                    d16[j] = lds_d1[wave][slot * (kChunkRows * 64) + ((r0 & (kChunkRows - 1)) + j) * 64 + c.lane];
-                    asm("" : "+v"(d16[j]));
-                }
-                double u[kSRG], v[kSRG], qz[kSRG];
-                unsigned long long vmk[kSRG], ivm[kSRG];
-                unsigned long long any = 0;
-#pragma unroll
-                for (int j = 0; j < kSRG; ++j) {
-                    const double dmm = (double)d16[j];
-                    const double ix = __builtin_fma(t0, dmm, M[0][3]);
-                    const double iy = __builtin_fma(t1, dmm, M[1][3]);
-                    const double iz = __builtin_fma(t2, dmm, M[2][3]);          // camera-2 depth, millimetres
-                    t0 += M[0][1];
-                    t1 += M[1][1];
-                    t2 += M[2][1];
-                    double rz = __builtin_amdgcn_rcp(iz);
-                    rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
-                    u[j] = ix * rz;
-                    v[j] = iy * rz;
-                    qz[j] = iz;
-                    vmk[j] = ballot64(d16[j] != 0u);                             // OPS:297
-                    ivm[j] = vmk[j] & ballot64(u[j] > -kGuardPx) & ballot64(u[j] < Wd + kGuardPx) & ballot64(v[j] > -kGuardPx) &
-                             ballot64(v[j] < Hd + kGuardPx) & ballot64(iz > -kGuardZmm);
-                    any |= ivm[j];
-                }
-                const uint32_t rowg = row0 + (uint32_t)r0;
-                const uint32_t blk = (uint32_t)r0 & 3u;                // first row of this group inside its 4-row block
-                unsigned long long vm[kSRG] = {};
-                if (any == 0) {
-                    // ---- nothing of these rows can land in frame 2: no gather, no depth test ----
-                    if (PIX) {
-                        const u32x4_t none = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-                        if (kSRG == 4) {
-                            buffer_store_b128_guarded(none, rs_pix, pix_voff, (int)(rowg * Wb * 4u));
-                        } else if (blk == 0) {
-                            blk_pending_none = true;                     // decided with the block's second half
-                        } else if (blk_pending_none) {
-                            buffer_store_b128_guarded(none, rs_pix, pix_voff, (int)((rowg - 2u) * Wb * 4u));
-                            blk_pending_none = false;
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < kSRG; ++j) lds_px[wave][(blk + j) * 64 + c.lane] = 0xFFFFFFFFu;
-                            wave_lds_fence();
-                            const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][c.lane * 4]);
-                            buffer_store_b128_guarded(q, rs_pix, pix_voff, (int)((rowg - 2u) * Wb * 4u));
-                            wave_lds_fence();
-                        }
-                    }
-                } else {
-                    int pix[kSRG];
-                    uint32_t dv16[kSRG];
-                    unsigned long long rkc[kSRG];
-#pragma unroll
-                    for (int j = 0; j < kSRG; ++j) {
-                        const double ru = __builtin_rint(u[j]), rv = __builtin_rint(v[j]);
-                        const int xi = med3_0((int)ru, hi_x);
-                        const int yi = med3_0((int)rv, hi_y);
-                        dv16[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, (int)(__umul24((uint32_t)yi, dw2) + ((uint32_t)xi << 1)), 0, 0);
-                        pix[j] = (int)((uint32_t)xi | ((uint32_t)yi << 16));
-                        const double wu = __builtin_fabs(u[j] - ru) - 0.25;
-                        const double wv = __builtin_fabs(v[j] - rv) - 0.25;
-                        rkc[j] = ballot64(!(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx)) |
-                                 ballot64(!(qz[j] > kGuardZmm));
-                    }
-                    if (PIX && kSRG == 2 && blk == 2 && blk_pending_none) {   // the first half of this block was all "none"
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) lds_px[wave][j * 64 + c.lane] = 0xFFFFFFFFu;
-                        blk_pending_none = false;
-                    }
-                    unsigned long long rbm[kSRG];
-#pragma unroll
-                    for (int j = 0; j < kSRG; ++j) {
-                        const bool inview = __builtin_amdgcn_inverse_ballot_w64(ivm[j]);
-                        const double sd = qz[j] - (double)dv16[j];              // millimetres; IH:368-371 compares metres
-                        vm[j] = ivm[j] & ballot64(sd < 0.0);
-                        rbm[j] = ivm[j] & (rkc[j] | ballot64(!(__builtin_fabs(sd) > kGuardZmm)));
-                        if (PIX) lds_px[wave][(blk + j) * 64 + c.lane] = (uint32_t)(inview ? pix[j] : -1);
-                        if (COMPACT) {
-                            const uint32_t rank = mbcnt64(vm[j], cfill);
-                            if (__builtin_amdgcn_inverse_ballot_w64(vm[j])) lds_px[wave][rank & (kCompactRing - 1)] = (uint32_t)pix[j];
-                            cfill += (uint32_t)__popcll(vm[j]);
-                        }
-                    }
-                    if (COMPACT && (cfill >> 8) != cflushed) {           // a 256-entry chunk is complete (at most one per group)
-                        wave_lds_fence();
-                        const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][((cflushed & 1u) << 8) + c.lane * 4]);
-                        buffer_store_b128_guarded(q, rs_cpix, c.lane * 16, (int)(cflushed << 10));
-                        wave_lds_fence();
-                        ++cflushed;
-                    }
-                    unsigned long long rb_any = 0;
-#pragma unroll
-                    for (int j = 0; j < kSRG; ++j) rb_any |= rbm[j];
-                    if (rb_any) {                                        // wave-uniform, rare
-#pragma unroll
-                        for (int j = 0; j < kSRG; ++j)
-                            if (rbm[j]) {
-                                writelane64(rbm[j], r0 + j, rb_lo, rb_hi);
-                                risky_rows |= 1ull << (r0 + j);
-                            }
-                    }
-                    if (PIX && (kSRG == 4 || blk == 2)) {                // the 4-row block is complete
-                        wave_lds_fence();
-                        const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][c.lane * 4]);
-                        buffer_store_b128_guarded(q, rs_pix, pix_voff, (int)((rowg - blk) * Wb * 4u));
-                        wave_lds_fence();
-                    } else if (PIX && kSRG == 2) {
-                        blk_pending_none = false;                        // first half written to the stage
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < kSRG; ++j) {
-                    n_valid += __popcll(vmk[j]);
-                    n_vis += __popcll(vm[j]);
-                    writelane64(vm[j], r0 + j, bits_lo, bits_hi);
-                }
-            }
-        }
-
-        // ---- cold loop: rows with guarded lanes are re-evaluated with the exact chain ---------------
-        const bool redo = COMPACT && risky_rows != 0;
-        if (risky_rows) {
-            __builtin_amdgcn_s_waitcnt(0);                 // the fast path's stores are in L2, LDS writes landed
-            while (risky_rows) {                            // wave-uniform
-                const int g = __builtin_amdgcn_readfirstlane(__builtin_ctzll(risky_rows));
-                risky_rows &= risky_rows - 1ull;
-                const unsigned long long rb = readlane64(rb_lo, rb_hi, g);
-                const unsigned long long old = readlane64(bits_lo, bits_hi, g);
-                const uint32_t row = row0 + (uint32_t)g;
-                const uint32_t i = row * Wb + col;
-                const bool mine = (rb >> c.lane) & 1ull;
-                bool vis = (old >> c.lane) & 1ull;
-                if (mine) {
-                    Pixel p;
-                    exact_unproject(m1, mxd, (double)row, (double)c.depth1[i] * 0.001, p.ax, p.ay, p.az);
-                    exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
-                    p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi, &p.inview);
-                    vis = p.vis;
-                    store_pixel<O, true>(a, c, i, true, true, p);
-                }
-                const unsigned long long fresh = ballot64(vis);
-                n_vis += __popcll(fresh) - __popcll(old);
-                writelane64(fresh, g, bits_lo, bits_hi);
-            }
-        }
-        if (COMPACT) {
-            if (redo) {   // see pair_fast_tight_kernel: the tile's segment rewritten from the patched words with the reference chain
-                uint32_t base = 0;
-                for (int r = 0; r < kTightRows; ++r) {                    // wave-uniform
-                    const unsigned long long w = readlane64(bits_lo, bits_hi, r);
-                    if (w == 0) continue;
-                    if ((w >> c.lane) & 1ull) {
-                        const uint32_t row = row0 + (uint32_t)r;
-                        Pixel p;
-                        exact_unproject(m1, mxd, (double)row, (double)c.depth1[row * Wb + col] * 0.001, p.ax, p.ay, p.az);
-                        exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
-                        depth_test(false, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi);
-                        __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(uint16_t)p.xi | ((uint32_t)(uint16_t)p.yi << 16), rs_cpix,
-                                                              (int)(mbcnt64(w, base) * 4u), 0, 0);
-                    }
-                    base += (uint32_t)__popcll(w);
-                }
-            } else {
-                const uint32_t rem = cfill - (cflushed << 8);             // < 256 entries still in the ring
-                wave_lds_fence();
-                if ((uint32_t)c.lane * 4u < rem) {
-                    const u32x4_t q = *reinterpret_cast<const u32x4_t *>(&lds_px[wave][((cflushed & 1u) << 8) + c.lane * 4]);
-                    buffer_store_b128_guarded(q, rs_cpix, c.lane * 16, (int)(cflushed << 10));
-                }
-            }
-            if (c.lane == 0) a.tile_counts[pair * (int64_t)a.n_tiles + (int64_t)tile] = n_vis;
-        }
-        if (O::template has<O_VIS_BITS>(a.vis_bits) && c.lane < kTightRows)
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{bits_lo, bits_hi}, rs_bits, (int)((uint32_t)c.lane * wpr * 8u),
-                                                  (int)((row0 * wpr + stripe) * 8u), 0);
-    }
-    if (O::template has<O_COUNTS>(a.counts)) {
-        __shared__ int red[2][kTightBW];
-        if (c.lane == 0) {
-            red[0][wave] = n_valid;
-            red[1][wave] = n_vis;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int sv = 0, ss = 0;
-            for (int j = 0; j < kTightBW; ++j) {
-                sv += red[0][j];
-                ss += red[1][j];
             }
             atomicAdd(a.counts + 2 * pair + 0, sv);
             atomicAdd(a.counts + 2 * pair + 1, ss);
@@ -2049,7 +1634,7 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
     const uint64_t P = (uint64_t)H * (uint64_t)W;
     if (P * (uint64_t)W >= (1ull << 32)) return fail(MSPA_EINVAL, "mspa_pair_reproject: H*W*W must be < 2^32");
     if (out_rgba && !rgb) return fail(MSPA_EINVAL, "mspa_pair_reproject: out_rgba needs rgb");
-    if (flags & ~(MSPA_PAIR_FAST | MSPA_PAIR_STREAM | MSPA_PAIR_FULLTILE)) return fail(MSPA_EINVAL, "mspa_pair_reproject: unknown flag");
+    if (flags & ~(MSPA_PAIR_FAST | MSPA_PAIR_STREAM)) return fail(MSPA_EINVAL, "mspa_pair_reproject: unknown flag");
     if (n_pairs == 0) return MSPA_OK;
     hipStream_t s = (hipStream_t)stream;
 
@@ -2111,16 +1696,12 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
         a.n_stripes = a.n_tiles = 0;
         a.stripe_magic = 0;
     }
-    // MSPA_PAIR_FULLTILE: the correspondence family on round 2's full-tile kernel instead of the streaming one -- same
-    // results; kept for A/B timing and so that the tests cover both
-    const bool legacy = (flags & MSPA_PAIR_FULLTILE) != 0;
     const int64_t groups = (n_pairs + n_xcd - 1) / n_xcd;
     const int64_t blocks = groups * n_xcd * a.strips;
     if (blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_pair_reproject: too many workgroups; split the batch");
     const dim3 grid((uint32_t)blocks), block(kThreads);
     g_last_pair_kernel = !fast ? MSPA_KERNEL_PAIR_EXACT
                          : scaled ? MSPA_KERNEL_PAIR_FAST_SCALED
-                         : (tight24 && !legacy && (set == kSetCorr || set == kSetMinimal || set == kSetCompact)) ? MSPA_KERNEL_PAIR_FAST_STREAM
                          : tight24 ? MSPA_KERNEL_PAIR_FAST_TIGHT
                          : linear ? MSPA_KERNEL_PAIR_FAST_LINEAR : MSPA_KERNEL_PAIR_FAST;
     if (!fast) {
@@ -2133,18 +1714,6 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
         if (set == kSetCorr) { if (st) MSPA_LAUNCH_SCALED(kSetCorr, true); else MSPA_LAUNCH_SCALED(kSetCorr, false); }
         else { if (st) MSPA_LAUNCH_SCALED(kSetMinimal, true); else MSPA_LAUNCH_SCALED(kSetMinimal, false); }
 #undef MSPA_LAUNCH_SCALED
-    } else if (tight24 && !legacy && (set == kSetCorr || set == kSetMinimal || set == kSetCompact)) {
-#define MSPA_LAUNCH_STREAM(SET_) \
-    do { \
-        if (flags & MSPA_PAIR_STREAM) \
-            hipLaunchKernelGGL((pair_fast_stream_kernel<SET_, true>), grid, dim3(kTightThreads), 0, s, depth, frame_mats, pairs, a); \
-        else \
-            hipLaunchKernelGGL((pair_fast_stream_kernel<SET_, false>), grid, dim3(kTightThreads), 0, s, depth, frame_mats, pairs, a); \
-    } while (0)
-        if (set == kSetCorr) MSPA_LAUNCH_STREAM(kSetCorr);
-        else if (set == kSetCompact) MSPA_LAUNCH_STREAM(kSetCompact);
-        else MSPA_LAUNCH_STREAM(kSetMinimal);
-#undef MSPA_LAUNCH_STREAM
     } else if (tight24) {
 #define MSPA_LAUNCH_TIGHT(SET_) \
     do { \
@@ -2243,6 +1812,9 @@ extern "C" int mspa_pair_correspondences(const uint16_t *depth, const double *fr
                                          int32_t *out_counts, void *workspace, int64_t workspace_bytes, uint32_t flags,
                                          mspa_stream_t stream) {
     if (n_pairs == 0) return MSPA_OK;
+#ifdef MSPA_EXPERIMENT_ROWS
+    return fail(MSPA_EUNSUPPORTED, "mspa_pair_correspondences: timing-only build with another tile height");
+#endif
     if (!out_vis_bits || !out_cpix_i16 || !out_tile_counts)
         return fail(MSPA_EINVAL, "mspa_pair_correspondences: vis_bits, cpix and tile_counts are all required");
     if (((uintptr_t)out_cpix_i16 & 15u) || ((uintptr_t)out_vis_bits & 7u))

@@ -12,10 +12,8 @@ MSPA_OK, MSPA_EINVAL, MSPA_EHIP, MSPA_EUNSUPPORTED = 0, -1, -2, -3
 MAT_KINV, MAT_E, MAT_A, MAT_EINV_ALIGNED, MAT_K, MAT_UNPROJ, MAT_REPROJ, FRAME_MATS = 0, 1, 2, 3, 4, 5, 6, 7
 PAIR_FAST = 1
 PAIR_STREAM = 2
-PAIR_FULLTILE = 4
 CORR_TILE_W, CORR_TILE_H, CORR_TILE_CAP = 64, 48, 64 * 48
-(KERNEL_NONE, KERNEL_PAIR_EXACT, KERNEL_PAIR_FAST, KERNEL_PAIR_FAST_LINEAR, KERNEL_PAIR_FAST_TIGHT, KERNEL_PAIR_FAST_SCALED,
- KERNEL_PAIR_FAST_STREAM) = range(7)
+KERNEL_NONE, KERNEL_PAIR_EXACT, KERNEL_PAIR_FAST, KERNEL_PAIR_FAST_LINEAR, KERNEL_PAIR_FAST_TIGHT, KERNEL_PAIR_FAST_SCALED = range(6)
 
 
 class MspaError(RuntimeError):

@@ -64,22 +64,16 @@ def scene_inputs(hw, seed=1010, frames=5):
     return sc, ids, depth, mats
 
 
-def fused_kernel(fulltile):
-    return _lib.KERNEL_PAIR_FAST_TIGHT if fulltile else _lib.KERNEL_PAIR_FAST_STREAM
-
-
 @pytest.mark.gpu
-@pytest.mark.parametrize("fulltile", [False, True], ids=["streaming", "fulltile"])
 @pytest.mark.parametrize("stream", [False, True], ids=["plain", "stream"])
 @pytest.mark.parametrize("hw", [(96, 128), (480, 640)], ids=["96x128", "640x480"])
-def test_fused_compact_vs_oracle(hw, stream, fulltile):
+def test_fused_compact_vs_oracle(hw, stream):
     sc, ids, depth, mats = scene_inputs(hw)
     pair_idx = [(0, 1), (1, 0), (0, 4), (3, 3), (4, 2)] if hw[0] < 200 else [(0, 1), (4, 0), (2, 2)]
     pairs = torch.tensor(pair_idx, dtype=torch.int32, device=DEV)
     out = poisoned_outputs(len(pair_idx), hw)
-    engine.pair_correspondences(depth, mats, pairs, hw, out, flags=_lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0) |
-                                (_lib.PAIR_FULLTILE if fulltile else 0))
-    assert _lib.load().mspa_pair_reproject_last_kernel() == fused_kernel(fulltile), "the fused kernel must be what ran"
+    engine.pair_correspondences(depth, mats, pairs, hw, out, flags=_lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0))
+    assert _lib.load().mspa_pair_reproject_last_kernel() == _lib.KERNEL_PAIR_FAST_TIGHT, "the fused kernel must be what ran"
     torch.cuda.synchronize()
     out_np = {k: v.cpu().numpy() for k, v in out.items()}
     seen = 0
@@ -104,9 +98,8 @@ def test_fused_compact_vs_oracle(hw, stream, fulltile):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fulltile", [False, True], ids=["streaming", "fulltile"])
 @pytest.mark.parametrize("stream", [False, True], ids=["plain", "stream"])
-def test_fused_compact_equals_exact_route_on_adversarial_poses(stream, fulltile):
+def test_fused_compact_equals_exact_route_on_adversarial_poses(stream):
     """240 adversarial pairs at 96x128: fused kernel == exact kernel + stand-alone compaction, every integer."""
     hw = (96, 128)
     rng = np.random.default_rng(77)
@@ -124,9 +117,8 @@ def test_fused_compact_equals_exact_route_on_adversarial_poses(stream, fulltile)
     pair_np[:24] = np.arange(24)[:, None]                 # identity pairs: everything lands on exact integers
     pairs = torch.from_numpy(pair_np).to(DEV)
     fused = poisoned_outputs(len(pair_np), hw)
-    engine.pair_correspondences(depth, mats, pairs, hw, fused, flags=_lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0) |
-                                (_lib.PAIR_FULLTILE if fulltile else 0))
-    assert _lib.load().mspa_pair_reproject_last_kernel() == fused_kernel(fulltile)
+    engine.pair_correspondences(depth, mats, pairs, hw, fused, flags=_lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0))
+    assert _lib.load().mspa_pair_reproject_last_kernel() == _lib.KERNEL_PAIR_FAST_TIGHT
     exact = poisoned_outputs(len(pair_np), hw)
     engine.pair_correspondences(depth, mats, pairs, hw, exact, flags=0)       # dense table in a workspace + compaction
     assert _lib.load().mspa_pair_reproject_last_kernel() == _lib.KERNEL_PAIR_EXACT
@@ -157,7 +149,7 @@ def test_dense_table_route_vs_oracle(case):
     pairs = torch.tensor(pair_idx, dtype=torch.int32, device=DEV)
     out = poisoned_outputs(len(pair_idx), hw)
     engine.pair_correspondences(depth, mats, pairs, hw, out, flags=0 if case == "ragged_exact" else _lib.PAIR_FAST)
-    assert _lib.load().mspa_pair_reproject_last_kernel() not in (_lib.KERNEL_PAIR_FAST_TIGHT, _lib.KERNEL_PAIR_FAST_STREAM)
+    assert _lib.load().mspa_pair_reproject_last_kernel() != _lib.KERNEL_PAIR_FAST_TIGHT
     torch.cuda.synchronize()
     out_np = {k: v.cpu().numpy() for k, v in out.items()}
     for n, (a, b) in enumerate(pair_idx):

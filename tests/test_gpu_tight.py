@@ -41,18 +41,6 @@ def unpack_bits(words, n):
     return np.unpackbits(words.view(np.uint8), bitorder="little")[:n].astype(bool)
 
 
-STREAM_SETS = ("corr", "minimal")                 # served by pair_fast_stream_kernel unless MSPA_PAIR_FULLTILE is set
-
-
-def expected_kernel(name, fulltile):
-    return _lib.KERNEL_PAIR_FAST_STREAM if (name in STREAM_SETS and not fulltile) else _lib.KERNEL_PAIR_FAST_TIGHT
-
-
-# (set, full-tile flag): every set on the kernel that serves it by default, the correspondence family also on the other one
-CASES = [(n, False) for n in SETS] + [(n, True) for n in STREAM_SETS]
-CASE_IDS = [n + ("-fulltile" if f else "") for n, f in CASES]
-
-
 def launch(depth, mats, rgb, pairs, hw, outputs, flags):
     out = engine.alloc_pair_outputs(pairs.shape[0], hw, outputs, DEV)
     for t in out.values():
@@ -92,9 +80,9 @@ def check_set(res, n, name, ref_np, ref_c, hw, color):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("stream", [False, True], ids=["plain", "stream"])
-@pytest.mark.parametrize("name,fulltile", CASES, ids=CASE_IDS)
+@pytest.mark.parametrize("name", list(SETS))
 @pytest.mark.parametrize("hw", [(96, 128), (480, 640)], ids=["96x128", "640x480"])
-def test_tight_instantiation_vs_oracle(hw, name, fulltile, stream):
+def test_tight_instantiation_vs_oracle(hw, name, stream):
     """Seeded scene, neighbouring + distant + identity pairs: the tight kernel of every output set, with and without the
     streaming hint, against the oracles, output by output."""
     sc = synth.make_scene(1010, n_points=64, n_frames=5, color_hw=hw, depth_hw=hw, invalid_pose_frac=0.0, with_color=True,
@@ -105,9 +93,9 @@ def test_tight_instantiation_vs_oracle(hw, name, fulltile, stream):
     rgb = torch.from_numpy(np.stack([sc.color[i] for i in ids])).to(DEV)
     pair_idx = [(0, 1), (1, 0), (0, 4), (3, 3), (4, 2)] if hw[0] < 200 else [(0, 1), (4, 0), (2, 2)]
     pairs = torch.tensor(pair_idx, dtype=torch.int32, device=DEV)
-    flags = _lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0) | (_lib.PAIR_FULLTILE if fulltile else 0)
+    flags = _lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0)
     res, kern = launch(depth, mats, rgb, pairs, hw, SETS[name], flags)
-    assert kern == expected_kernel(name, fulltile), "the specialised instantiation must be the kernel under test"
+    assert kern == _lib.KERNEL_PAIR_FAST_TIGHT, "the tight instantiation must be the kernel under test"
     seen_vis = 0
     for n, (a, b) in enumerate(pair_idx):
         ia, ib = ids[a], ids[b]
@@ -147,8 +135,8 @@ def adversarial_pairs(rng, n, hw):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("stream", [False, True], ids=["plain", "stream"])
-@pytest.mark.parametrize("name,fulltile", CASES, ids=CASE_IDS)
-def test_tight_equals_exact_on_adversarial_poses(name, fulltile, stream):
+@pytest.mark.parametrize("name", list(SETS))
+def test_tight_equals_exact_on_adversarial_poses(name, stream):
     """240 adversarial pairs at 96x128: every integer output of every tight instantiation equals the exact kernel's
     (which is bit-identical to the C oracle, test_gpu_parity.py), float32 points within 2e-7."""
     hw = (96, 128)
@@ -167,10 +155,10 @@ def test_tight_equals_exact_on_adversarial_poses(name, fulltile, stream):
     pair_np = np.stack([rng.integers(0, len(E), 240), rng.integers(0, len(E), 240)], 1).astype(np.int32)
     pair_np[:24] = np.arange(24)[:, None]                 # identity pairs: everything lands on exact integers
     pairs = torch.from_numpy(pair_np).to(DEV)
-    flags = _lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0) | (_lib.PAIR_FULLTILE if fulltile else 0)
+    flags = _lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0)
     fast, kf = launch(depth, mats, rgb, pairs, hw, SETS[name], flags)
     exact, ke = launch(depth, mats, rgb, pairs, hw, SETS[name], 0)
-    assert kf == expected_kernel(name, fulltile) and ke == _lib.KERNEL_PAIR_EXACT
+    assert kf == _lib.KERNEL_PAIR_FAST_TIGHT and ke == _lib.KERNEL_PAIR_EXACT
     for k in SETS[name]:
         if k == "xyz_f32":
             assert np.allclose(fast[k], exact[k], rtol=2e-7, atol=1e-7, equal_nan=True)
@@ -232,14 +220,12 @@ def test_kernels_reproduce_reference_at_640x480(g640):
         assert sha(cols) == str(g[f"pair{n}_sha_rgb"])
         assert np.array_equal(ex["vis_bits"][n].view(np.uint8)[:P // 8], g[f"pair{n}_vis_bits"])
         assert sha(ex["pix_i16"][n]) == str(g[f"pair{n}_sha_pix"])
-    for (name, fulltile), stream in [(cs, st) for cs in CASES for st in (False, True)]:
-        if True:
-            outs = SETS[name]
-            res, kern = launch(depth, mats, rgb, pairs, hw, outs, _lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0) |
-                               (_lib.PAIR_FULLTILE if fulltile else 0))
-            assert kern == expected_kernel(name, fulltile)
+    for name, outs in SETS.items():
+        for stream in (False, True):
+            res, kern = launch(depth, mats, rgb, pairs, hw, outs, _lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0))
+            assert kern == _lib.KERNEL_PAIR_FAST_TIGHT
             for n in range(len(pair_ids)):
-                tag = f"{name}{'/fulltile' if fulltile else ''}/{'stream' if stream else 'plain'} pair {n}"
+                tag = f"{name}/{'stream' if stream else 'plain'} pair {n}"
                 assert tuple(res["counts"][n]) == (int(g[f"pair{n}_rows"]), int(g[f"pair{n}_n_vis"])), tag
                 if "vis_bits" in res:
                     assert np.array_equal(res["vis_bits"][n].view(np.uint8)[:P // 8], g[f"pair{n}_vis_bits"]), tag
