@@ -652,7 +652,9 @@ def main():
                        "pairs_per_step_per_gpu": args.pairs, "distinct_frames_per_gpu": int(depth.shape[0]),
                        "image": "640x480 depth u16 (+rgb u8x3 for dense)", "parallelism": f"dp{world}",
                        "collation": ("one all_gather of the job's per-pair records inside the timed region ("
-                                     + ("gloo: ranks share GPUs" if share else "RCCL") + ")") if world > 1 else "none (1 GPU)"},
+                                     + ("gloo: ranks share GPUs" if share else "RCCL") + ")") if dist_ctx is not None
+                       else "none (1 GPU)",
+                       "collation_backend": dist_ctx.backend if dist_ctx is not None else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": (t["source"] + " -- committed PMC passes of this command, NOT measured in this run")

@@ -180,6 +180,21 @@ int mspa_vertex_visibility(const double *xyz, int64_t n_points, int64_t point_st
                            int32_t *out_count, mspa_stream_t stream);
 
 /*
+ * The same with the two parameters the reference's interface leaves open:
+ *   homogeneous != 0   the points are general homogeneous rows (x, y, z, w), the fourth coordinate at
+ *                      xyz[i*point_stride + 3*comp_stride] -- project_points (IH:46-72) takes any [N, 4] array; both 4x4
+ *                      products are then evaluated in full (w == 1 gives the bits of the affine form)
+ *   depth_value_scale  metres per depth-image unit (SceneInfoHandler(depth_value_scale=...), IH:76, applied at IH:368);
+ *                      0.001 in mspa_vertex_visibility.  Positive and finite.
+ * Either one selects the reference-order kernel (the composed kernels fold w == 1 and the millimetre in).
+ */
+int mspa_vertex_visibility_ex(const double *xyz, int64_t n_points, int64_t point_stride, int64_t comp_stride,
+                              int32_t homogeneous, const double *cam_mats, int32_t n_images, const uint16_t *depth,
+                              int32_t dh, int32_t dw, int32_t H, int32_t W, double depth_value_scale,
+                              uint64_t *out_bits, uint8_t *out_mask, double *out_uv, double *out_depth,
+                              int32_t *out_count, mspa_stream_t stream);
+
+/*
  * The three predicates of the reference on already-projected points, for callers that hold (uv, depth)
  * from an earlier projection: check_point_in_image_boundary (IH:337-344),
  * check_point_visibility_by_depth (IH:346-373), check_point_visibility (IH:375-386).
@@ -190,6 +205,11 @@ int mspa_check_visibility(const double *uv, const double *point_depth, int64_t n
                           const uint16_t *depth_image, int32_t dh, int32_t dw, int32_t H, int32_t W,
                           uint8_t *out_in_bounds, uint8_t *out_by_depth, uint8_t *out_visible,
                           mspa_stream_t stream);
+/* ... with the handler's depth_value_scale (IH:368) instead of the default 0.001 */
+int mspa_check_visibility_ex(const double *uv, const double *point_depth, int64_t n,
+                             const uint16_t *depth_image, int32_t dh, int32_t dw, int32_t H, int32_t W,
+                             double depth_value_scale, uint8_t *out_in_bounds, uint8_t *out_by_depth,
+                             uint8_t *out_visible, mspa_stream_t stream);
 
 /*
  * K2 -- pair overlap, HOT LOOP 2 of CFR.process_scene: calculate_camera_overlap (CFR:102-137)
@@ -383,6 +403,11 @@ int mspa_project_samples(const double *xyz, int64_t n_points, int64_t point_stri
                          const double *cam_mats, int32_t n_images, const uint16_t *depth, int32_t dh,
                          int32_t dw, int32_t H, int32_t W, const int32_t *samples, int64_t n,
                          double *out_uv, double *out_depth, uint8_t *out_visible, mspa_stream_t stream);
+/* ... with the handler's depth_value_scale (IH:368) instead of the default 0.001 */
+int mspa_project_samples_ex(const double *xyz, int64_t n_points, int64_t point_stride, int64_t comp_stride,
+                            const double *cam_mats, int32_t n_images, const uint16_t *depth, int32_t dh,
+                            int32_t dw, int32_t H, int32_t W, double depth_value_scale, const int32_t *samples, int64_t n,
+                            double *out_uv, double *out_depth, uint8_t *out_visible, mspa_stream_t stream);
 
 #ifdef __cplusplus
 }

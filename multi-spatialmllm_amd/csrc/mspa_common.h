@@ -42,6 +42,15 @@ __device__ __forceinline__ double affine_row(const double *__restrict__ m, doubl
     return acc + m[3];
 }
 
+// The same row applied to a general homogeneous point (x, y, z, w): the K = 4 chain ends with fma(m3, w, .) (IH:57-66 take
+// any [N, 4] input; with w == 1 this rounds exactly like affine_row).
+__device__ __forceinline__ double affine_row_w(const double *__restrict__ m, double x, double y, double z, double w) {
+    double acc = m[0] * x;
+    acc = __builtin_fma(m[1], y, acc);
+    acc = __builtin_fma(m[2], z, acc);
+    return __builtin_fma(m[3], w, acc);
+}
+
 // np.round(v).astype(int) then np.clip(.., 0, hi) (IH:362-366, OPS:285-290): half-to-even, the
 // x86-64 float64->int64 conversion (NaN / out of range -> INT64_MIN), clip.  hi < 32768.
 __device__ __forceinline__ int round_clip(double v, int hi) {
@@ -60,14 +69,15 @@ __device__ __forceinline__ int round_clip(double v, int hi) {
 // the camera): it is the condition under which (xi, yi) is a meaningful correspondence.
 __device__ __forceinline__ bool depth_test(bool enable, double u, double v, double d,
                                            const uint16_t *__restrict__ depth_img, int dh, int dw, int H, int W,
-                                           double sx, double sy, int &xi, int &yi, bool *inview = nullptr) {
+                                           double sx, double sy, int &xi, int &yi, bool *inview = nullptr,
+                                           double depth_value_scale = 0.001) {
     bool inb = (u >= 0.0) && (u < (double)W) && (v >= 0.0) && (v < (double)H);
     xi = round_clip(u * sx, dw - 1);
     yi = round_clip(v * sy, dh - 1);
     bool vis = false;
     if (inview) *inview = enable && inb && d > 0.0;
     if (enable && inb && d > 0.0) {
-        double dv = (double)depth_img[yi * dw + xi] * 0.001;
+        double dv = (double)depth_img[yi * dw + xi] * depth_value_scale;      // IH:368
         vis = d < dv;
     }
     return vis;

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void select_common_kernel(const uint64_t *__re
 __global__ __launch_bounds__(256) void project_samples_kernel(const double *__restrict__ xyz, int64_t point_stride,
                                                               int64_t comp_stride, const double *__restrict__ cam_mats,
                                                               const uint16_t *__restrict__ depth, int dh, int dw, int H,
-                                                              int W, double sx, double sy,
+                                                              int W, double sx, double sy, double dscale,
                                                               const int32_t *__restrict__ samples, int64_t n,
                                                               double *__restrict__ uv, double *__restrict__ pdepth,
                                                               uint8_t *__restrict__ vis) {
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void project_samples_kernel(const double *__re
     const double iz = affine_row(K + 8, qx, qy, qz);
     const double u = ix / iz, w = iy / iz;
     int xi, yi;
-    const bool ok = depth_test(true, u, w, qz, depth + (int64_t)img * dh * dw, dh, dw, H, W, sx, sy, xi, yi);
+    const bool ok = depth_test(true, u, w, qz, depth + (int64_t)img * dh * dw, dh, dw, H, W, sx, sy, xi, yi, nullptr, dscale);
     uv[2 * s] = u;
     uv[2 * s + 1] = w;
     pdepth[s] = qz;
@@ -98,10 +98,13 @@ extern "C" int mspa_select_common_point(const uint64_t *bits, int32_t n_images, 
     return check_hip(hipGetLastError(), "select_common_kernel launch");
 }
 
-extern "C" int mspa_project_samples(const double *xyz, int64_t n_points, int64_t point_stride, int64_t comp_stride,
-                                    const double *cam_mats, int32_t n_images, const uint16_t *depth, int32_t dh,
-                                    int32_t dw, int32_t H, int32_t W, const int32_t *samples, int64_t n,
-                                    double *out_uv, double *out_depth, uint8_t *out_visible, mspa_stream_t stream) {
+extern "C" int mspa_project_samples_ex(const double *xyz, int64_t n_points, int64_t point_stride, int64_t comp_stride,
+                                       const double *cam_mats, int32_t n_images, const uint16_t *depth, int32_t dh,
+                                       int32_t dw, int32_t H, int32_t W, double depth_value_scale, const int32_t *samples,
+                                       int64_t n, double *out_uv, double *out_depth, uint8_t *out_visible,
+                                       mspa_stream_t stream) {
+    if (!(depth_value_scale > 0.0 && depth_value_scale < 1e300))
+        return fail(MSPA_EINVAL, "mspa_project_samples: depth_value_scale must be positive and finite");
     if (n_points <= 0 || n_images <= 0 || n < 0 || point_stride <= 0 || comp_stride <= 0)
         return fail(MSPA_EINVAL, "mspa_project_samples: bad size");
     if (n == 0) return MSPA_OK;
@@ -113,6 +116,14 @@ extern "C" int mspa_project_samples(const double *xyz, int64_t n_points, int64_t
     if (blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_project_samples: too many samples; split the batch");
     hipLaunchKernelGGL(project_samples_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, xyz,
                        point_stride, comp_stride, cam_mats, depth, dh, dw, H, W, (double)dw / (double)W,
-                       (double)dh / (double)H, samples, n, out_uv, out_depth, out_visible);
+                       (double)dh / (double)H, depth_value_scale, samples, n, out_uv, out_depth, out_visible);
     return check_hip(hipGetLastError(), "project_samples_kernel launch");
+}
+
+extern "C" int mspa_project_samples(const double *xyz, int64_t n_points, int64_t point_stride, int64_t comp_stride,
+                                    const double *cam_mats, int32_t n_images, const uint16_t *depth, int32_t dh,
+                                    int32_t dw, int32_t H, int32_t W, const int32_t *samples, int64_t n,
+                                    double *out_uv, double *out_depth, uint8_t *out_visible, mspa_stream_t stream) {
+    return mspa_project_samples_ex(xyz, n_points, point_stride, comp_stride, cam_mats, n_images, depth, dh, dw, H, W, 0.001,
+                                   samples, n, out_uv, out_depth, out_visible, stream);
 }

@@ -25,6 +25,7 @@ struct VertexArgs {
     int32_t *count_atomic;
     uint32_t vblocks, igroups;     // vertex blocks, image groups of kImgPerBlock (grid decode)
     uint32_t n_xcd;                // XCDs the hardware deals workgroups over (1 = plain linear decode)
+    double dscale;                 // depth_value_scale (IH:76, IH:368): metres per depth unit, 0.001 for ScanNet
 };
 
 #ifndef MSPA_VTHREADS
@@ -37,6 +38,7 @@ static_assert(kVThreads % 64 == 0 && kVThreads <= 256, "the compacted kernel pac
 #endif
 constexpr int kImgPerBlock = MSPA_VIMG;
 
+template <bool HOMOG>
 __global__ __launch_bounds__(kVThreads) void vertex_visibility_kernel(const double *__restrict__ xyz,
                                                                       const double *__restrict__ cam_mats,
                                                                       const uint16_t *__restrict__ depth,
@@ -57,6 +59,7 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_kernel(const doub
     const double x = xyz[ic * a.point_stride];
     const double y = xyz[ic * a.point_stride + a.comp_stride];
     const double z = xyz[ic * a.point_stride + 2 * a.comp_stride];
+    const double w = HOMOG ? xyz[ic * a.point_stride + 3 * a.comp_stride] : 1.0;     // general [N, 4] input (IH:46-72)
     const int img0 = (int)group * kImgPerBlock;
     const int img1 = min(img0 + kImgPerBlock, a.n_images);
     const int64_t dpix = (int64_t)a.dh * a.dw;
@@ -66,15 +69,26 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_kernel(const doub
         const double *__restrict__ K = Einv + 16;
         const uint16_t *__restrict__ dimg = depth + (int64_t)img * dpix;
         // IH:57-69
-        const double qx = affine_row(Einv + 0, x, y, z);
-        const double qy = affine_row(Einv + 4, x, y, z);
-        const double qz = affine_row(Einv + 8, x, y, z);
-        const double ix = affine_row(K + 0, qx, qy, qz);
-        const double iy = affine_row(K + 4, qx, qy, qz);
-        const double iz = affine_row(K + 8, qx, qy, qz);
+        double qx, qy, qz, ix, iy, iz;
+        if (HOMOG) {                                       // all four rows of both products, as the reference's 4x4 @ 4xN
+            qx = affine_row_w(Einv + 0, x, y, z, w);
+            qy = affine_row_w(Einv + 4, x, y, z, w);
+            qz = affine_row_w(Einv + 8, x, y, z, w);
+            const double qw = affine_row_w(Einv + 12, x, y, z, w);
+            ix = affine_row_w(K + 0, qx, qy, qz, qw);
+            iy = affine_row_w(K + 4, qx, qy, qz, qw);
+            iz = affine_row_w(K + 8, qx, qy, qz, qw);
+        } else {
+            qx = affine_row(Einv + 0, x, y, z);
+            qy = affine_row(Einv + 4, x, y, z);
+            qz = affine_row(Einv + 8, x, y, z);
+            ix = affine_row(K + 0, qx, qy, qz);
+            iy = affine_row(K + 4, qx, qy, qz);
+            iz = affine_row(K + 8, qx, qy, qz);
+        }
         const double u = ix / iz, v = iy / iz;
         int xi, yi;
-        const bool vis = depth_test(live, u, v, qz, dimg, a.dh, a.dw, a.H, a.W, a.sx, a.sy, xi, yi);
+        const bool vis = depth_test(live, u, v, qz, dimg, a.dh, a.dw, a.H, a.W, a.sx, a.sy, xi, yi, nullptr, a.dscale);
 
         const unsigned long long word = __ballot(vis);
         if (lane == 0) {
@@ -473,7 +487,7 @@ __global__ __launch_bounds__(kVThreads) void bits_count_kernel(const uint64_t *_
 __global__ __launch_bounds__(kVThreads) void check_visibility_kernel(const double *__restrict__ uv,
                                                                      const double *__restrict__ pdepth, int64_t n,
                                                                      const uint16_t *__restrict__ dimg, int dh, int dw,
-                                                                     int H, int W, double sx, double sy,
+                                                                     int H, int W, double sx, double sy, double dscale,
                                                                      uint8_t *__restrict__ inb_out,
                                                                      uint8_t *__restrict__ byd_out,
                                                                      uint8_t *__restrict__ vis_out) {
@@ -484,7 +498,7 @@ __global__ __launch_bounds__(kVThreads) void check_visibility_kernel(const doubl
     bool byd = false;
     if (dimg) {                                                                         // IH:359-371
         const int xi = round_clip(u * sx, dw - 1), yi = round_clip(v * sy, dh - 1);
-        const double dv = (double)dimg[yi * dw + xi] * 0.001;
+        const double dv = (double)dimg[yi * dw + xi] * dscale;                          // IH:368
         byd = (d > 0.0) && (d < dv);
     }
     if (inb_out) inb_out[i] = inb ? 1 : 0;
@@ -496,10 +510,13 @@ __global__ __launch_bounds__(kVThreads) void check_visibility_kernel(const doubl
 
 using namespace mspa;
 
-extern "C" int mspa_check_visibility(const double *uv, const double *point_depth, int64_t n,
-                                     const uint16_t *depth_image, int32_t dh, int32_t dw, int32_t H, int32_t W,
-                                     uint8_t *out_in_bounds, uint8_t *out_by_depth, uint8_t *out_visible,
-                                     mspa_stream_t stream) {
+static bool scale_ok(double s) { return s > 0.0 && s < 1e300; }     // finite, positive (NaN fails both)
+
+extern "C" int mspa_check_visibility_ex(const double *uv, const double *point_depth, int64_t n,
+                                        const uint16_t *depth_image, int32_t dh, int32_t dw, int32_t H, int32_t W,
+                                        double depth_value_scale, uint8_t *out_in_bounds, uint8_t *out_by_depth,
+                                        uint8_t *out_visible, mspa_stream_t stream) {
+    if (!scale_ok(depth_value_scale)) return fail(MSPA_EINVAL, "mspa_check_visibility: depth_value_scale must be positive and finite");
     if (n < 0) return fail(MSPA_EINVAL, "mspa_check_visibility: bad count");
     if (n == 0) return MSPA_OK;
     if (!uv) return fail(MSPA_EINVAL, "mspa_check_visibility: null uv");
@@ -511,16 +528,26 @@ extern "C" int mspa_check_visibility(const double *uv, const double *point_depth
     if (blocks > 0x7fffffffLL) return fail(MSPA_EINVAL, "mspa_check_visibility: too many points; split the batch");
     const double sx = depth_image ? (double)dw / (double)W : 1.0, sy = depth_image ? (double)dh / (double)H : 1.0;
     hipLaunchKernelGGL(check_visibility_kernel, dim3((uint32_t)blocks), dim3(kVThreads), 0, (hipStream_t)stream, uv,
-                       point_depth, n, depth_image, dh, dw, H, W, sx, sy, out_in_bounds, out_by_depth, out_visible);
+                       point_depth, n, depth_image, dh, dw, H, W, sx, sy, depth_value_scale, out_in_bounds, out_by_depth,
+                       out_visible);
     return check_hip(hipGetLastError(), "check_visibility_kernel launch");
 }
 
+extern "C" int mspa_check_visibility(const double *uv, const double *point_depth, int64_t n,
+                                     const uint16_t *depth_image, int32_t dh, int32_t dw, int32_t H, int32_t W,
+                                     uint8_t *out_in_bounds, uint8_t *out_by_depth, uint8_t *out_visible,
+                                     mspa_stream_t stream) {
+    return mspa_check_visibility_ex(uv, point_depth, n, depth_image, dh, dw, H, W, 0.001, out_in_bounds, out_by_depth,
+                                    out_visible, stream);
+}
 
-extern "C" int mspa_vertex_visibility(const double *xyz, int64_t n_points, int64_t point_stride,
-                                      int64_t comp_stride, const double *cam_mats, int32_t n_images,
-                                      const uint16_t *depth, int32_t dh, int32_t dw, int32_t H, int32_t W,
-                                      uint64_t *out_bits, uint8_t *out_mask, double *out_uv,
-                                      double *out_depth, int32_t *out_count, mspa_stream_t stream) {
+
+extern "C" int mspa_vertex_visibility_ex(const double *xyz, int64_t n_points, int64_t point_stride,
+                                         int64_t comp_stride, int32_t homogeneous, const double *cam_mats, int32_t n_images,
+                                         const uint16_t *depth, int32_t dh, int32_t dw, int32_t H, int32_t W,
+                                         double depth_value_scale, uint64_t *out_bits, uint8_t *out_mask, double *out_uv,
+                                         double *out_depth, int32_t *out_count, mspa_stream_t stream) {
+    if (!scale_ok(depth_value_scale)) return fail(MSPA_EINVAL, "mspa_vertex_visibility: depth_value_scale must be positive and finite");
     if (n_points < 0 || n_images < 0 || point_stride <= 0 || comp_stride <= 0)
         return fail(MSPA_EINVAL, "mspa_vertex_visibility: bad count or stride");
     if ((!xyz && n_points > 0) || ((!cam_mats || !depth) && n_images > 0))
@@ -550,11 +577,15 @@ extern "C" int mspa_vertex_visibility(const double *xyz, int64_t n_points, int64
     a.vblocks = (uint32_t)bx;
     a.igroups = (uint32_t)by;
     a.n_xcd = (uint32_t)n_xcd;
+    a.dscale = depth_value_scale;
     // float64 outputs are DEFINED as the reference's operation order; everything else (bitset, byte mask, counts) takes the
     // composed + guarded kernel, which reproduces the same integers
     const bool compact = MSPA_VCOMPACT && (int64_t)kImgPerBlock * dh * dw * 2 < 0x7fffffffLL && kImgPerBlock * 12 <= kVThreads;
-    if (out_uv || out_depth)
-        hipLaunchKernelGGL(vertex_visibility_kernel, dim3((uint32_t)blocks), dim3(kVThreads), 0, s, xyz, cam_mats, depth, a);
+    // ... and so do a general homogeneous coordinate and a depth scale other than the millimetre the composed kernels fold in
+    if (homogeneous)
+        hipLaunchKernelGGL(vertex_visibility_kernel<true>, dim3((uint32_t)blocks), dim3(kVThreads), 0, s, xyz, cam_mats, depth, a);
+    else if (out_uv || out_depth || depth_value_scale != 0.001)
+        hipLaunchKernelGGL(vertex_visibility_kernel<false>, dim3((uint32_t)blocks), dim3(kVThreads), 0, s, xyz, cam_mats, depth, a);
     else if (compact && dh == H && dw == W)
         hipLaunchKernelGGL(vertex_visibility_compact_kernel<true>, dim3((uint32_t)blocks), dim3(kVThreads), 0, s, xyz, cam_mats, depth, a);
     else if (compact)
@@ -569,4 +600,13 @@ extern "C" int mspa_vertex_visibility(const double *xyz, int64_t n_points, int64
     hipLaunchKernelGGL(bits_count_kernel, dim3((uint32_t)((n_images + per_block - 1) / per_block)), dim3(kVThreads), 0, s,
                        out_bits, a.n_words, n_images, out_count);
     return check_hip(hipGetLastError(), "bits_count_kernel launch");
+}
+
+extern "C" int mspa_vertex_visibility(const double *xyz, int64_t n_points, int64_t point_stride,
+                                      int64_t comp_stride, const double *cam_mats, int32_t n_images,
+                                      const uint16_t *depth, int32_t dh, int32_t dw, int32_t H, int32_t W,
+                                      uint64_t *out_bits, uint8_t *out_mask, double *out_uv,
+                                      double *out_depth, int32_t *out_count, mspa_stream_t stream) {
+    return mspa_vertex_visibility_ex(xyz, n_points, point_stride, comp_stride, 0, cam_mats, n_images, depth, dh, dw, H, W,
+                                     0.001, out_bits, out_mask, out_uv, out_depth, out_count, stream);
 }

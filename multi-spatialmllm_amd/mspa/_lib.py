@@ -43,6 +43,14 @@ _SIGNATURES = {
     "mspa_vertex_visibility": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p,
                                        c_int32, c_int32, c_int32, c_int32,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mspa_vertex_visibility_ex": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p, c_int32, c_void_p,
+                                          c_int32, c_int32, c_int32, c_int32, c_double,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mspa_check_visibility_ex": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_double,
+                                         c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mspa_project_samples_ex": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_int32,
+                                        c_int32, c_int32, c_int32, c_double, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]),
     "mspa_pair_overlap": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
     "mspa_overlap_workspace_bytes": (c_int64, [c_int32, c_int32, c_int64]),

@@ -281,15 +281,18 @@ def correspondences_rowmajor(out: Dict[str, torch.Tensor], image_hw: Tuple[int, 
 
 
 def vertex_visibility(xyz: torch.Tensor, cam_mats: torch.Tensor, depth: torch.Tensor, image_hw: Tuple[int, int],
-                      want: Iterable[str] = ("bits", "count")) -> Dict[str, torch.Tensor]:
+                      want: Iterable[str] = ("bits", "count"), homogeneous: bool = False,
+                      depth_scale: float = 0.001) -> Dict[str, torch.Tensor]:
     """Enqueue K1.  xyz [N,3] or [N,C>=3] float64 rows (or a [3,N] SoA tensor with soa=True layout
-    given as xyz.t()); cam_mats [I,2,16]; depth [I,DH,DW].  Returns the requested outputs."""
+    given as xyz.t()); cam_mats [I,2,16]; depth [I,DH,DW].  Returns the requested outputs.
+    ``homogeneous``: the rows are general homogeneous points (x, y, z, w) (``project_points`` takes any [N, 4], IH:46-72);
+    ``depth_scale``: the handler's ``depth_value_scale`` (IH:76, IH:368)."""
     _require_gpu()
     lib = _lib.load()
     _require(xyz.dtype == torch.float64 and xyz.dim() == 2 and xyz.is_cuda, "xyz.dtype == torch.float64 and xyz.dim() == 2 and xyz.is_cuda")
     n = xyz.shape[0]
     ps, cs = xyz.stride(0), xyz.stride(1)
-    _require(xyz.shape[1] >= 3 and ps > 0 and cs > 0, "xyz.shape[1] >= 3 and ps > 0 and cs > 0")
+    _require(xyz.shape[1] >= (4 if homogeneous else 3) and ps > 0 and cs > 0, "xyz: [N, >= 3] rows ([N, >= 4] when homogeneous)")
     I, DH, DW = depth.shape
     _require(cam_mats.dtype == torch.float64 and tuple(cam_mats.shape) == (I, 2, 16), "cam_mats.dtype == torch.float64 and tuple(cam_mats.shape) == (I, 2, 16)")
     H, W = image_hw
@@ -307,8 +310,8 @@ def vertex_visibility(xyz: torch.Tensor, cam_mats: torch.Tensor, depth: torch.Te
     if "count" in want:
         out["count"] = torch.empty((I,), dtype=torch.int32, device=dev)
     _require(depth.dtype in (torch.int16, torch.uint16), "depth.dtype in (torch.int16, torch.uint16)")
-    _lib.check(lib.mspa_vertex_visibility(
-        xyz.data_ptr(), n, ps, cs, _ptr(cam_mats), I, _ptr(depth), DH, DW, H, W,
+    _lib.check(lib.mspa_vertex_visibility_ex(
+        xyz.data_ptr(), n, ps, cs, 1 if homogeneous else 0, _ptr(cam_mats), I, _ptr(depth), DH, DW, H, W, float(depth_scale),
         _ptr(out.get("bits")), _ptr(out.get("mask")), _ptr(out.get("uv")), _ptr(out.get("depth")),
         _ptr(out.get("count")), _stream_ptr()))
     return out
@@ -502,7 +505,7 @@ def track_displacement(world: torch.Tensor, w2c: torch.Tensor, c2w: torch.Tensor
 
 
 def check_visibility(uv: torch.Tensor, point_depth: Optional[torch.Tensor], depth_image: Optional[torch.Tensor],
-                     image_hw: Tuple[int, int], want=("visible",)) -> Dict[str, torch.Tensor]:
+                     image_hw: Tuple[int, int], want=("visible",), depth_scale: float = 0.001) -> Dict[str, torch.Tensor]:
     """The reference's three predicates on already-projected points (IH:337-386)."""
     _require_gpu()
     lib = _lib.load()
@@ -511,9 +514,9 @@ def check_visibility(uv: torch.Tensor, point_depth: Optional[torch.Tensor], dept
     out = {k: torch.empty((n,), dtype=torch.uint8, device=uv.device) for k in want}
     dh, dw = (depth_image.shape[-2], depth_image.shape[-1]) if depth_image is not None else (0, 0)
     H, W = image_hw
-    _lib.check(lib.mspa_check_visibility(_ptr(uv), _ptr(point_depth), n, _ptr(depth_image), dh, dw, H, W,
-                                         _ptr(out.get("in_bounds")), _ptr(out.get("by_depth")),
-                                         _ptr(out.get("visible")), _stream_ptr()))
+    _lib.check(lib.mspa_check_visibility_ex(_ptr(uv), _ptr(point_depth), n, _ptr(depth_image), dh, dw, H, W, float(depth_scale),
+                                            _ptr(out.get("in_bounds")), _ptr(out.get("by_depth")),
+                                            _ptr(out.get("visible")), _stream_ptr()))
     return out
 
 
@@ -531,7 +534,7 @@ def select_common_point(bits: torch.Tensor, selections: torch.Tensor) -> torch.T
 
 
 def project_samples(xyz: torch.Tensor, cam_mats: torch.Tensor, depth: torch.Tensor, image_hw: Tuple[int, int],
-                    samples: torch.Tensor):
+                    samples: torch.Tensor, depth_scale: float = 0.001):
     """Enqueue K6b.  samples [n, 2] int32 (vertex, image) -> (uv [n,2] f64, depth [n] f64, visible [n] u8)."""
     _require_gpu()
     lib = _lib.load()
@@ -547,9 +550,9 @@ def project_samples(xyz: torch.Tensor, cam_mats: torch.Tensor, depth: torch.Tens
     d = torch.empty((n,), dtype=torch.float64, device=dev)
     vis = torch.empty((n,), dtype=torch.uint8, device=dev)
     H, W = image_hw
-    _lib.check(lib.mspa_project_samples(xyz.data_ptr(), xyz.shape[0], xyz.stride(0), xyz.stride(1), _ptr(cam_mats), I,
-                                        _ptr(depth), DH, DW, H, W, _ptr(samples.contiguous()), n, _ptr(uv), _ptr(d),
-                                        _ptr(vis), _stream_ptr()))
+    _lib.check(lib.mspa_project_samples_ex(xyz.data_ptr(), xyz.shape[0], xyz.stride(0), xyz.stride(1), _ptr(cam_mats), I,
+                                           _ptr(depth), DH, DW, H, W, float(depth_scale), _ptr(samples.contiguous()), n,
+                                           _ptr(uv), _ptr(d), _ptr(vis), _stream_ptr()))
     return uv, d, vis
 
 

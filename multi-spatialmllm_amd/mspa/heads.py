@@ -259,7 +259,7 @@ def visual_correspondence_records(scene, rows: Sequence[dict], image_hw, start_i
         first = torch.tensor([idx[k, 1] if draws[k]["swap"] else idx[k, 0] for k in owner], dtype=torch.int32, device=dev)
         second = torch.tensor([idx[k, 0] if draws[k]["swap"] else idx[k, 1] for k in owner], dtype=torch.int32, device=dev)
         samples = torch.cat([torch.stack([vert, first], 1), torch.stack([vert, second], 1)], 0).contiguous()
-        uv, _, vis = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw, samples)
+        uv, _, vis = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw, samples, scene.depth_scale)
         uv, vis = uv.cpu().numpy(), vis.cpu().numpy().astype(bool)
         m = len(owner)
         if not vis.all():
@@ -448,7 +448,7 @@ class GpuCorrespondenceBackend:
         first = torch.tensor(a, dtype=torch.int32, device=dev)
         second = torch.tensor(b, dtype=torch.int32, device=dev)
         samples = torch.cat([torch.stack([vert, first], 1), torch.stack([vert, second], 1)], 0).contiguous()
-        uv, _, ok = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw, samples)
+        uv, _, ok = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw, samples, scene.depth_scale)
         uv, ok, vert_h = uv.cpu().numpy(), ok.cpu().numpy().astype(bool), vert.cpu().numpy()
         m = len(jobs)
         return [(int(vert_h[s]), uv[s], uv[s + m], bool(ok[s]), bool(ok[s + m])) for s in range(m)]
@@ -778,7 +778,7 @@ def gpu_point_numerics(scene):
         sel = torch.tensor([[scene.index[i], scene.index[i], j] for i, j in samples], dtype=torch.int32, device=scene.device)
         vert = engine.select_common_point(vis["bits"], sel)
         uv, d, ok = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw,
-                                           torch.stack([vert, sel[:, 0]], 1).contiguous())
+                                           torch.stack([vert, sel[:, 0]], 1).contiguous(), scene.depth_scale)
         uv, d, ok, vert = uv.cpu().numpy(), d.cpu().numpy(), ok.cpu().numpy().astype(bool), vert.cpu().numpy()
         return [(int(vert[s]), uv[s] if ok[s] else None, float(d[s])) for s in range(len(samples))]
     return fn
@@ -795,7 +795,7 @@ def list_point_numerics(scene, visible_points):
             return []
         vert = [int(visible_points(i)[j]) for i, j in samples]
         smp = torch.tensor([[v, scene.index[i]] for v, (i, _) in zip(vert, samples)], dtype=torch.int32, device=scene.device)
-        uv, d, ok = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw, smp)
+        uv, d, ok = engine.project_samples(scene.xyz, scene.cam_mats, scene.depth, scene.image_hw, smp, scene.depth_scale)
         uv, d, ok = uv.cpu().numpy(), d.cpu().numpy(), ok.cpu().numpy().astype(bool)
         return [(vert[s], uv[s] if ok[s] else None, float(d[s])) for s in range(len(samples))]
     return fn

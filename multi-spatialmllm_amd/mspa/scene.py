@@ -30,8 +30,9 @@ def valid_image_ids(E: Dict[str, np.ndarray]) -> List[str]:
 class SceneOnDevice:
     def __init__(self, K: np.ndarray, A: np.ndarray, E: Dict[str, np.ndarray], depth: Dict[str, np.ndarray],
                  image_hw: Tuple[int, int], points_xyz: Optional[np.ndarray] = None, device="cuda",
-                 color: Optional[Dict[str, np.ndarray]] = None):
+                 color: Optional[Dict[str, np.ndarray]] = None, depth_scale: float = 0.001):
         self.K, self.A = np.asarray(K, np.float64), np.asarray(A, np.float64)
+        self.depth_scale = float(depth_scale)       # the handler's depth_value_scale (IH:76): metres per depth-image unit
         self.ids = valid_image_ids(E)
         self.index = {k: n for n, k in enumerate(self.ids)}
         self.image_hw = tuple(int(v) for v in image_hw)
@@ -60,6 +61,7 @@ class SceneOnDevice:
         ``pose_tables`` = (E_aligned [F,16], yaw [F], pitch [F]) device tensors when the uploader staged them as well."""
         self = cls.__new__(cls)
         self.K, self.A = np.asarray(K, np.float64), np.asarray(A, np.float64)
+        self.depth_scale = 0.001
         self.ids = list(ids)
         self.index = {k: n for n, k in enumerate(self.ids)}
         self.image_hw = tuple(int(v) for v in image_hw)
@@ -88,7 +90,7 @@ class SceneOnDevice:
     def vertex_visibility(self, want=("bits", "count")) -> Dict[str, torch.Tensor]:
         if self.xyz is None:
             raise ValueError("scene uploaded without vertices")
-        return engine.vertex_visibility(self.xyz, self.cam_mats, self.depth, self.image_hw, want)
+        return engine.vertex_visibility(self.xyz, self.cam_mats, self.depth, self.image_hw, want, depth_scale=self.depth_scale)
 
     def _visibility(self):
         if self._vis is None:
@@ -156,7 +158,7 @@ class SceneOnDevice:
         k = self.index[image_id]
         sel = self.xyz[torch.as_tensor(list(point_ids), device=self.device, dtype=torch.long)].contiguous()
         out = engine.vertex_visibility(sel, self.cam_mats[k:k + 1].contiguous(), self.depth[k:k + 1].contiguous(),
-                                       self.image_hw, ("mask", "uv", "depth"))
+                                       self.image_hw, ("mask", "uv", "depth"), depth_scale=self.depth_scale)
         uv, d, m = out["uv"][0].cpu().numpy(), out["depth"][0].cpu().numpy(), out["mask"][0].cpu().numpy().astype(bool)
         if check_visible:
             return uv[m], d[m]

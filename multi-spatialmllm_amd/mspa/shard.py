@@ -54,6 +54,13 @@ def init_distributed(device: torch.device, backend: str = None, timeout_s: int =
     owns = False
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:      # a single process asking for a communicator
+            import socket                                                  # (MSPA_BENCH_FORCE_DIST, tests): world of one
+            os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         kwargs = {}
         if device.type == "cuda" and backend == "nccl":
             kwargs["device_id"] = device
@@ -123,6 +130,8 @@ def collate_records(local: torch.Tensor, ctx: DistContext) -> torch.Tensor:
     dist.all_gather(counts, n_local, group=ctx.group)
     counts = [int(c.item()) for c in counts]
     n_max = max(counts)
+    if n_max == 0:                                   # nobody has a record: no second collective
+        return local[:0]
     if n_max == local.shape[0]:
         padded = local.contiguous()
     else:

@@ -49,20 +49,19 @@ def _like(result: torch.Tensor, *inputs, as_bool=False):
 def project_points(points, K, E):
     """[N,4] homogeneous world points, 4x4 K, 4x4 camera->world E -> ([N,2] un-rounded pixel
     coordinates, [N] signed camera depth), float64 (reference: info_handler.py:46-72).
-    The homogeneous coordinate must be 1 (it is at every call site of the reference)."""
+    Any homogeneous coordinate is taken as it comes: E_inv @ points.T and K @ (.) are evaluated as the full 4x4 products the
+    reference forms (w = 1, the only value its own call sites pass, gives the same bits as the affine kernels)."""
     given = points
     if not isinstance(points, torch.Tensor):
         points = np.asarray(points, dtype=np.float64)
     if points.ndim != 2 or points.shape[1] != 4:
         raise ValueError("points must be [N, 4] homogeneous coordinates")
-    if not bool((points[:, 3] == 1.0).all()):
-        raise ValueError("libmspa projects affine points: the homogeneous coordinate must be exactly 1")
     K = K.cpu().numpy() if isinstance(K, torch.Tensor) else K
     E = E.cpu().numpy() if isinstance(E, torch.Tensor) else E
     cam = torch.from_numpy(engine.camera_matrices(np.asarray(K, np.float64), [np.asarray(E, np.float64)])).cuda()
-    xyz = _dev(points[:, :3])
+    xyzw = _dev(points)
     dummy = torch.zeros((1, 2, 2), dtype=torch.int16, device="cuda")
-    out = engine.vertex_visibility(xyz, cam, dummy, (2, 2), ("uv", "depth"))
+    out = engine.vertex_visibility(xyzw, cam, dummy, (2, 2), ("uv", "depth"), homogeneous=True)
     return _like(out["uv"][0], given), _like(out["depth"][0], given)
 
 
@@ -79,8 +78,8 @@ class SceneInfoHandler:
             except Exception as e:                       # same observable behaviour as upstream (IH:80-82)
                 print(f"Failed to load data from {info_path}: {e}")
                 raise SystemExit(1)
-        if depth_value_scale != 0.001:
-            raise ValueError("libmspa fixes the depth scale at 0.001 (millimetres), like the reference's data")
+        if not (isinstance(depth_value_scale, (int, float)) and 0.0 < float(depth_value_scale) < float("inf")):
+            raise ValueError("depth_value_scale must be a positive finite number (metres per depth-image unit)")
         self.posed_images_root = posed_images_root
         self.instance_data_root = instance_data_root
         self.mask_image_root = mask_image_root
@@ -238,12 +237,12 @@ class SceneInfoHandler:
 
     def check_point_visibility_by_depth(self, scene_id, image_id, points_2d, points_depth):
         out = engine.check_visibility(_dev(points_2d), _dev(points_depth), self._depth_dev(scene_id, image_id),
-                                      self.get_image_shape(scene_id, image_id), ("by_depth",))
+                                      self.get_image_shape(scene_id, image_id), ("by_depth",), depth_scale=self.depth_value_scale)
         return _like(out["by_depth"], points_2d, points_depth, as_bool=True)
 
     def check_point_visibility(self, scene_id, image_id, points_2d, points_depth):
         out = engine.check_visibility(_dev(points_2d), _dev(points_depth), self._depth_dev(scene_id, image_id),
-                                      self.get_image_shape(scene_id), ("visible",))
+                                      self.get_image_shape(scene_id), ("visible",), depth_scale=self.depth_value_scale)
         return _like(out["visible"], points_2d, points_depth, as_bool=True)
 
     def get_point_2d_coordinates_in_image(self, scene_id, image_id, point_id, align=True, check_visible=False,
@@ -281,7 +280,7 @@ class SceneInfoHandler:
         depth = {i: self.get_depth_image(scene_id, i) for i in valid}
         pts = self.get_scene_points_align(scene_id)[:, :3] if with_points else None
         return SceneOnDevice(self.get_intrinsic_matrix(scene_id), self.get_world_to_axis_align_matrix(scene_id),
-                             E, depth, self.get_image_shape(scene_id), pts)
+                             E, depth, self.get_image_shape(scene_id), pts, depth_scale=self.depth_value_scale)
 
 
 class VisibilityInfoHandler:

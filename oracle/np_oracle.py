@@ -94,16 +94,16 @@ def check_point_visibility_by_depth(uv, depth, depth_image, image_hw,
         return (depth > 0) & (depth < dv)
 
 
-def check_point_visibility(uv, depth, depth_image, image_hw) -> np.ndarray:
-    """IH:375-386."""
+def check_point_visibility(uv, depth, depth_image, image_hw, scale: float = DEPTH_VALUE_SCALE) -> np.ndarray:
+    """IH:375-386 (``scale`` = the handler's depth_value_scale, IH:76)."""
     return check_point_in_image_boundary(uv, image_hw) & \
-        check_point_visibility_by_depth(uv, depth, depth_image, image_hw)
+        check_point_visibility_by_depth(uv, depth, depth_image, image_hw, scale)
 
 
-def vertex_visibility(points_xyz, K, E_aligned, depth_image, image_hw):
+def vertex_visibility(points_xyz, K, E_aligned, depth_image, image_hw, scale: float = DEPTH_VALUE_SCALE):
     """HOT LOOP 1 body (CFR:152-157 == MVI:93-100): mask of vertices visible in one image."""
     uv, d = project_3d_point_to_image(points_xyz, K, E_aligned)
-    return check_point_visibility(uv, d, depth_image, image_hw), uv, d
+    return check_point_visibility(uv, d, depth_image, image_hw, scale), uv, d
 
 
 # --------------------------------------------------------------------------------------

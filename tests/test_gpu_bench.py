@@ -14,8 +14,15 @@ SMALL = ["--steps", "2", "--warmup", "1", "--pairs", "96", "--frames", "64", "--
          "--no-scene-legs", "--also", "none", "--cpu-seconds", "1"]
 
 
-def run(cmd):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def run(cmd, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -47,5 +54,46 @@ def test_bench_n2_self_launch_and_torchrun():
     import torch
     assert j["gpus_shared"] == (torch.cuda.device_count() < 2)
     j = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-             "--master-port", "29611", "bench.py", "--gpus", "2"] + SMALL)
+             "--master-port", str(free_port()), "bench.py", "--gpus", "2"] + SMALL)
     check_line(j, 2)
+
+
+def test_bench_n1_with_the_rccl_collation_forced():
+    """One rank, MSPA_BENCH_FORCE_DIST=1: the communicator is RCCL (backend "nccl"), the job's record table is collated by
+    all_gather_into_tensor on DEVICE tensors inside the timed region and the ranks meet at barrier(device_ids=...) -- the
+    branch every N > 1 run on real multi-GPU hardware takes, here with a world of one."""
+    j = run([sys.executable, "bench.py", "--gpus", "1"] + SMALL, MSPA_BENCH_FORCE_DIST="1")
+    check_line(j, 1)
+    assert j["config"]["collation_backend"] == "nccl" and "RCCL" in j["config"]["collation"]
+
+
+RCCL_WORLD1 = r"""
+import os, sys, torch
+sys.path[:0] = [os.path.join(os.getcwd(), "multi-spatialmllm_amd"), os.getcwd()]
+from mspa import shard
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+ctx = shard.init_distributed(dev)                       # backend None on a GPU -> "nccl" (= RCCL)
+assert ctx.backend == "nccl" and ctx.world == 1 and ctx.collective_device == dev
+local = torch.arange(21, dtype=torch.float64, device=dev).reshape(7, 3)
+full = shard.collate_records(local, ctx)                # counts all_gather + padded all_gather_into_tensor, on the device
+assert full.is_cuda and torch.equal(full, local)
+empty = shard.collate_records(local[:0], ctx)           # a rank without records
+assert tuple(empty.shape) == (0, 3)
+g, work = shard.collate_records_async(local.to(torch.int32).contiguous(), ctx)
+work.wait()
+torch.cuda.synchronize()
+assert torch.equal(g, local.to(torch.int32))
+ctx.barrier()                                           # dist.barrier(device_ids=[0])
+assert ctx.max_over_ranks(2.5) == 2.5
+ctx.close()
+print("rccl world-1 ok")
+"""
+
+
+def test_collate_records_on_device_tensors_over_rccl():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "MASTER_PORT", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", RCCL_WORLD1], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0 and "rccl world-1 ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

@@ -20,9 +20,12 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.fixture(scope="module")
-def world():
-    sc = synth.make_scene(3001, n_points=3000, n_frames=7, color_hw=(96, 128), depth_hw=(96, 128),
+# 96x128: the fast small case.  640x480: BASELINE.json configs[0]'s shape -- depth_perception QA (and the other heads' numeric
+# stages) on 16 frame pairs of 640x480 RGB-D frames, GPU heads vs oracle numerics.
+@pytest.fixture(scope="module", params=[(96, 128), (480, 640)], ids=["96x128", "640x480"])
+def world(request):
+    hw = request.param
+    sc = synth.make_scene(3001, n_points=3000, n_frames=7, color_hw=hw, depth_hw=hw,
                           invalid_pose_frac=0.15, with_color=False)
     scene = SceneOnDevice(sc.K, sc.A, sc.E, sc.depth, sc.color_hw, sc.points, DEV)
     table = O.frames_relations_scene(sc.points[:, :3], sc.K, sc.A, sc.E, sc.depth, sc.color_hw)
@@ -30,6 +33,9 @@ def world():
     rows = [{"scene_id": sc.scene_id, "image_id1": a, "image_id2": b, "overlap": max(float(v["overlap"]), 1.0),
              "distance": float(v["distance"]), "yaw": float(v["yaw"]), "pitch": float(v["pitch"])}
             for (a, b), v in table.items()]
+    if hw == (480, 640):
+        rows = rows[:16]                            # configs[0]: 16 frame pairs
+        assert len(rows) >= 10
     return sc, scene, rows, vis
 
 

@@ -167,6 +167,49 @@ def test_tight_equals_exact_on_adversarial_poses(name, stream):
     assert int(exact["counts"][:, 1].sum()) > 1000
 
 
+@pytest.mark.gpu
+def test_tight_equals_exact_on_adversarial_poses_at_640x480():
+    """The same at the BASELINE shape itself: 72 adversarial pairs of 640x480 frames (8 identity pairs among them), every
+    tight instantiation and the fused compacted set against the exact kernel, every integer output."""
+    hw = (480, 640)
+    rng = np.random.default_rng(4242)
+    K, A, E = adversarial_pairs(rng, 16, hw)
+    boxes = synth._make_boxes(rng)
+    depth_np = []
+    for e in E:
+        z = synth.render_depth(A @ e, K, hw, boxes)
+        mm = np.clip(np.rint(z * 1000.0 + rng.normal(0, 4.0, z.shape)), 0, 65535).astype(np.uint16)
+        mm[rng.random(mm.shape) < 0.07] = 0
+        depth_np.append(mm)
+    depth = engine.depth_to_device(np.stack(depth_np), DEV)
+    mats = torch.from_numpy(engine.frame_matrices(K, A, E)).to(DEV)
+    rgb = torch.from_numpy(rng.integers(0, 256, (len(E),) + hw + (3,), dtype=np.uint8)).to(DEV)
+    pair_np = np.stack([rng.integers(0, len(E), 72), rng.integers(0, len(E), 72)], 1).astype(np.int32)
+    pair_np[:8] = np.arange(8)[:, None]
+    pairs = torch.from_numpy(pair_np).to(DEV)
+    for name in SETS:
+        fast, kf = launch(depth, mats, rgb, pairs, hw, SETS[name], _lib.PAIR_FAST | _lib.PAIR_STREAM)
+        exact, ke = launch(depth, mats, rgb, pairs, hw, SETS[name], 0)
+        assert kf == _lib.KERNEL_PAIR_FAST_TIGHT and ke == _lib.KERNEL_PAIR_EXACT
+        for k in SETS[name]:
+            if k == "xyz_f32":
+                assert np.allclose(fast[k], exact[k], rtol=2e-7, atol=1e-7, equal_nan=True)
+            else:
+                assert np.array_equal(fast[k], exact[k]), f"{name}: {k} differs from the exact kernel at 640x480"
+        assert int(exact["counts"][:, 1].sum()) > 100000
+        del fast, exact
+    fused = engine.pair_correspondences(depth, mats, pairs, hw, flags=_lib.PAIR_FAST | _lib.PAIR_STREAM)
+    assert _lib.load().mspa_pair_reproject_last_kernel() == _lib.KERNEL_PAIR_FAST_TIGHT
+    route = engine.pair_correspondences(depth, mats, pairs, hw, flags=0)
+    torch.cuda.synchronize()
+    for k in ("vis_bits", "counts", "tile_counts"):
+        assert torch.equal(fused[k], route[k]), k
+    tc = route["tile_counts"].cpu().numpy()
+    f, e = fused["cpix"].cpu().numpy(), route["cpix"].cpu().numpy()
+    keep = np.arange(f.shape[2])[None, None, :] < tc[:, :, None]
+    assert np.array_equal(f[keep], e[keep])
+
+
 # ---- the reference's own outputs at the BASELINE shape -------------------------------------------------
 @pytest.fixture(scope="module")
 def g640():

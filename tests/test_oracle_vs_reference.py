@@ -166,3 +166,29 @@ def test_tracks(ref):
         assert r["point_moving"] == g["point_moving"] and r["cam_moving"] == g["cam_moving"]
     for pt in [np.array([0.1, 0.2, 2.0]), np.array([0.1, 0.2, -2.0]), np.array([9.0, 0.0, 1.0]), np.zeros(3)]:
         assert eng.project_point(pt, tr.fx_fy_cx_cy, H, W) == O.project_point(pt, tr.fx_fy_cx_cy, H, W)
+
+
+def test_general_homogeneous_points_and_depth_scale(ref, scene_and_handler):
+    """The two open parameters of the interface (missing 4): project_points on [N, 4] rows with w != 1
+    (IH:46-72) and a handler built with another depth_value_scale (IH:76 -> IH:368)."""
+    sc, h = scene_and_handler
+    sid = sc.scene_id
+    rng = np.random.default_rng(11)
+    i = sc.valid_image_ids[0]
+    E = O.aligned_extrinsic(sc.A, sc.E[i])
+    w = rng.uniform(0.25, 4.0, sc.points.shape[0])
+    w[::5] = 1.0
+    w[1::131] = 0.0
+    pts = np.hstack([sc.points[:, :3] * w[:, None], w[:, None]])
+    with np.errstate(all="ignore"):
+        uv_r, d_r = ref.IH.project_points(pts, sc.K, E)
+        uv_o, d_o = O.project_points(pts, sc.K, E)
+    assert same_f64(uv_r, uv_o) and same_f64(d_r, d_o)
+    h.depth_value_scale = 0.0005                                          # what SceneInfoHandler(depth_value_scale=...) stores
+    try:
+        uv, d = h.project_3d_point_to_image(sid, i, sc.points[:, :3])
+        m_r = h.check_point_visibility(sid, i, uv, d)
+        assert np.array_equal(m_r, O.check_point_visibility(uv, d, sc.depth[i], sc.color_hw, 0.0005))
+        assert not np.array_equal(m_r, O.check_point_visibility(uv, d, sc.depth[i], sc.color_hw))
+    finally:
+        h.depth_value_scale = 0.001
