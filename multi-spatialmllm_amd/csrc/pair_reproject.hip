@@ -244,17 +244,20 @@ __device__ __forceinline__ bool decode_block(const PairArgs &a, int64_t &pair, u
     return pair < a.n_pairs;
 }
 
-// 16-byte buffer store + guard.  Observed on gfx950 (a variant of the tight kernel that issued this store at the end
-// of a basic block whose successor began with a VALU write to the first data VGPR): lanes 12..15 of every 16 stored
-// the NEW value of that VGPR -- the store was still reading its data.  LLVM's hazard recognizer inserts the wait
-// state for > 64-bit stores only when soffset is an immediate; with an SGPR soffset it assumes none is needed.
-// One s_nop after the store keeps any following VALU write clear of the data registers.
+// 16-byte buffer store + guard.  Observed on gfx950: when a VALU instruction writes one of the store's four data VGPRs
+// right behind the store, lanes 12..15 of every 16 store the NEW value -- the store is still reading its data.  LLVM's
+// hazard recognizer inserts the wait state for > 64-bit stores only when soffset is an immediate; with an SGPR soffset it
+// assumes none is needed.  The guard is an s_nop that NAMES the data registers as an input: that keeps them live (nothing
+// else can be allocated to them) until the wait states have passed, and being a volatile asm with a memory clobber it
+// stays behind the store.  (Round 2's guard was a bare `s_nop 1`: the scheduler was free to slip a v_cndmask whose result
+// had been given one of the data registers between the store and the nop, and in round 3 it did -- the dense set's rgba
+// words came out as the next payload's float bits in exactly those lanes; tests/test_gpu_tight.py, 72 pairs at 640x480.)
 // The store carries the non-temporal hint (aux 2 = nt): the outputs are full 128-byte lines that this launch never reads
 // back; measured -2.5..-3 % on the headline kernel, with distinct as well as with heavily re-used input frames.
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void buffer_store_b128_guarded(u32x4_t q, __amdgpu_buffer_rsrc_t rs, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b128(q, rs, voff, soff, 2);
-    asm volatile("s_nop 1");
+    asm volatile("s_nop 1" ::"v"(q) : "memory");
 }
 
 // depth sample of frame 1 under colour pixel (mx, my): OPS:272-294

@@ -74,7 +74,7 @@ def test_depth_value_scale_through_k1_k6_and_the_predicates(scale, shape):
         assert np.array_equal(bits, ref) and int(out["count"][k]) == int(ref.sum())
         differs_from_mm |= not np.array_equal(ref, O.vertex_visibility(sc.points[:, :3], sc.K, Ea[k], sc.depth[i], hw)[0])
         # the predicates on already-projected points
-        got = engine.check_visibility(torch.from_numpy(uv).to(DEV), torch.from_numpy(d).to(DEV), depth[k], hw,
+        got = engine.check_visibility(torch.from_numpy(np.ascontiguousarray(uv)).to(DEV), torch.from_numpy(np.ascontiguousarray(d)).to(DEV), depth[k], hw,
                                       ("by_depth", "visible"), depth_scale=scale)
         with np.errstate(invalid="ignore"):
             assert np.array_equal(got["by_depth"].cpu().numpy().astype(bool), O.check_point_visibility_by_depth(uv, d, sc.depth[i], hw, scale))

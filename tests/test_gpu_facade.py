@@ -82,8 +82,12 @@ def test_handler_projection_and_visibility(setup):
     # free function
     uv, d = ns.IH.project_points(np.hstack([pts, np.ones((len(pts), 1))]), g.K, g.A @ g.E[image_id])
     assert f64_ok(uv, g["ref_uv"][0]) and f64_ok(d, g["ref_depth"][0])
+    # any homogeneous coordinate is accepted, as upstream (IH:46-72): (2x, 2y, 2z, 2) is the same Euclidean point,
+    # same pixel, twice the homogeneous depth (tests/test_gpu_boundary.py holds the general case against the oracle)
+    uv2, d2 = ns.IH.project_points(np.hstack([2.0 * pts, np.full((len(pts), 1), 2.0)]), g.K, g.A @ g.E[image_id])
+    assert np.allclose(uv2, uv, rtol=1e-12, equal_nan=True) and np.allclose(d2, 2.0 * d, rtol=1e-12, equal_nan=True)
     with pytest.raises(ValueError):
-        ns.IH.project_points(np.hstack([pts, np.full((len(pts), 1), 2.0)]), g.K, g.E[image_id])
+        ns.IH.project_points(pts, g.K, g.E[image_id])                    # [N, 3]: not homogeneous rows
 
 
 def test_project_mask_to_3d(setup):
@@ -256,8 +260,8 @@ def test_torch_tensors_stay_on_the_device(setup):
     hom = torch.cat([torch.from_numpy(pts).cuda(), torch.ones((len(pts), 1), dtype=torch.float64, device="cuda")], 1)
     uv2, _ = ns.IH.project_points(hom, g.K, h.get_extrinsic_matrix_align(sid, image_id))
     assert uv2.is_cuda and np.array_equal(uv2.cpu().numpy(), uv_np, equal_nan=True)
-    with pytest.raises(ValueError):
-        ns.IH.project_points(hom * 2.0, g.K, g.E[image_id])
+    uv3, _ = ns.IH.project_points(hom * 2.0, g.K, h.get_extrinsic_matrix_align(sid, image_id))   # w = 2: same pixels
+    assert uv3.is_cuda and torch.allclose(uv3, uv2, rtol=1e-12, atol=0, equal_nan=True)
 
 
 def test_object_visibility(setup):
