@@ -277,6 +277,9 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_fast_kernel(const
 #ifndef MSPA_VCOMPACT
 #define MSPA_VCOMPACT 1
 #endif
+#ifndef MSPA_V_NT
+#define MSPA_V_NT 0
+#endif
 #ifndef MSPA_VCOMPACT_ENTRIES
 #define MSPA_VCOMPACT_ENTRIES 1
 #endif
@@ -329,9 +332,19 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
     const int64_t i = (int64_t)vblock * kVThreads + tid;
     const bool live = i < a.n_points;
     const int64_t ic = live ? i : a.n_points - 1;
+    // MSPA_V_NT (off): the vertex array is streamed -- every block reads its 256 vertices once -- so non-temporal loads
+    // should keep its 3 MB per image group from displacing the eight depth frames the XCD's blocks gather from.  Measured
+    // (tools/ab_k1.py, round 3): 0.103 vs 0.092 ms on the shuffled cloud, 0.092 vs 0.077 in Morton order -- slower; so is
+    // 16 images per block (0.112 / 0.079).  The 200 MB working set lives in the 256 MB Infinity Cache either way.
+#if MSPA_V_NT
+    const double x = __builtin_nontemporal_load(&xyz[ic * a.point_stride]);
+    const double y = __builtin_nontemporal_load(&xyz[ic * a.point_stride + a.comp_stride]);
+    const double z = __builtin_nontemporal_load(&xyz[ic * a.point_stride + 2 * a.comp_stride]);
+#else
     const double x = xyz[ic * a.point_stride];
     const double y = xyz[ic * a.point_stride + a.comp_stride];
     const double z = xyz[ic * a.point_stride + 2 * a.comp_stride];
+#endif
     lds_xyz[tid][0] = x;
     lds_xyz[tid][1] = y;
     lds_xyz[tid][2] = z;

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""A/B timing of K1 (vertex visibility: bitset + counts) inside ONE process: every tools/ab/libmspa_*.so plus the in-tree
+library, on the bench's scene (320 images x 131 072 vertices), vertices shuffled and in Morton order.
+
+    python tools/ab_k1.py [--reps 20] [--rounds 3]
+"""
+import argparse
+import ctypes
+import glob
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "multi-spatialmllm_amd"), ROOT]
+
+
+def morton_order(pts):
+    q = ((pts - pts.min(0)) / np.maximum(np.ptp(pts, axis=0), 1e-9) * 1023).astype(np.uint64)
+
+    def part1by2(v):
+        v = (v | (v << 32)) & np.uint64(0x1F00000000FFFF)
+        v = (v | (v << 16)) & np.uint64(0x1F0000FF0000FF)
+        v = (v | (v << 8)) & np.uint64(0x100F00F00F00F00F)
+        v = (v | (v << 4)) & np.uint64(0x10C30C30C30C30C3)
+        return (v | (v << 2)) & np.uint64(0x1249249249249249)
+    return np.argsort(part1by2(q[:, 0]) | (part1by2(q[:, 1]) << np.uint64(1)) | (part1by2(q[:, 2]) << np.uint64(2)), kind="stable")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--points", type=int, default=131072)
+    ap.add_argument("--frames", type=int, default=320)
+    a = ap.parse_args()
+    import torch
+    from mspa import _lib, engine, synth
+    dev = torch.device("cuda", 0)
+    H, W = 480, 640
+    sc = synth.make_scene(4000, n_points=a.points, n_frames=8, color_hw=(H, W), depth_hw=(H, W), invalid_pose_frac=0.0, with_color=False)
+    ids = sc.valid_image_ids
+    rf = a.frames // len(ids)
+    Ea = [sc.A @ sc.E[i] for i in ids] * rf
+    cam = torch.from_numpy(engine.camera_matrices(sc.K, Ea)).to(dev)
+    depth = engine.depth_to_device(np.stack([sc.depth[i] for i in ids] * rf), dev)
+    pts = np.ascontiguousarray(sc.points[:, :3])
+    xyz = {"shuffled": torch.from_numpy(pts).to(dev), "morton": torch.from_numpy(np.ascontiguousarray(pts[morton_order(pts)])).to(dev)}
+    F, n = len(Ea), a.points
+    bits = torch.empty((F, (n + 63) // 64), dtype=torch.int64, device=dev)
+    count = torch.empty((F,), dtype=torch.int32, device=dev)
+    libs = sorted(glob.glob(os.path.join(ROOT, "tools/ab/libmspa_*.so"))) + [_lib.LIB_PATH]
+    stream = torch.cuda.current_stream().cuda_stream
+    handles = {}
+    for path in libs:
+        h = ctypes.CDLL(path)
+        h.mspa_vertex_visibility.restype, h.mspa_vertex_visibility.argtypes = _lib._SIGNATURES["mspa_vertex_visibility"]
+        handles[os.path.basename(path)] = h
+    res = {k: {o: [] for o in xyz} for k in handles}
+    ref_counts = {}
+    for r in range(a.rounds):
+        for o, x in xyz.items():
+            for k, h in handles.items():
+                def launch():
+                    rc = h.mspa_vertex_visibility(x.data_ptr(), n, 3, 1, cam.data_ptr(), F, depth.data_ptr(), H, W, H, W, bits.data_ptr(),
+                                                  None, None, None, count.data_ptr(), stream)
+                    assert rc == 0
+                for _ in range(3):
+                    launch()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(a.reps):
+                    launch()
+                e1.record()
+                torch.cuda.synchronize()
+                res[k][o].append(e0.elapsed_time(e1) / a.reps)
+                c = count.cpu().numpy().copy()
+                assert np.array_equal(ref_counts.setdefault(o, c), c), f"{k}: counts differ ({o})"
+    for k in handles:
+        print(f"{k:<28s} " + "  ".join(f"{o} {np.median(res[k][o]):.4f} (+-{(max(res[k][o]) - min(res[k][o])) / 2:.4f})" for o in xyz), flush=True)
+
+
+if __name__ == "__main__":
+    main()
