@@ -130,31 +130,50 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def _scene_cache_dir():
+    """A directory only this user can write (0700, ownership checked): the cached scene is plain arrays (np.load with
+    allow_pickle=False), and nobody else can plant a file under a name the bench will open."""
+    import tempfile
+    d = os.path.join(tempfile.gettempdir(), f"mspa_bench_{os.getuid()}")
+    try:
+        os.makedirs(d, mode=0o700, exist_ok=True)
+        st = os.stat(d)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            return None
+    except OSError:
+        return None
+    return d
+
+
 def make_base_scene(args, rank):
     """Host-only part of the inputs: the seeded synthetic scene (SURVEY.md 8d recipe; the camera follows a hand-held
     sweep so that one scene populates every overlap bin the reference samples from).  Rendering 64 frames on the host
-    takes ~20 s, so the finished scene is cached under the temp directory (profiling runs the same command six times)."""
-    import pickle
-    import tempfile
+    takes ~20 s, so the finished scene's arrays are cached (profiling runs the same command six times)."""
     from mspa import synth
-    key = f"mspa_bench_scene_{1000 + rank}_{args.scene_points}_{args.base_frames}_{args.walk_step}_{args.target_step}.pkl"
-    path = os.path.join(tempfile.gettempdir(), key)
-    if os.path.exists(path):
+    d = _scene_cache_dir()
+    key = f"scene_{1000 + rank}_{args.scene_points}_{args.base_frames}_{args.walk_step}_{args.target_step}.npz"
+    path = os.path.join(d, key) if d else None
+    if path and os.path.exists(path):
         try:
-            with open(path, "rb") as f:
-                return pickle.load(f)
+            z = np.load(path, allow_pickle=False)
+            ids = [str(i) for i in z["ids"]]
+            return synth.SynthScene(scene_id=str(z["scene_id"]), K=z["K"], A=z["A"], E={i: z["E"][k] for k, i in enumerate(ids)},
+                                    points=z["points"], depth={i: z["depth"][k] for k, i in enumerate(ids)}, color={},
+                                    color_hw=(H, W), depth_hw=(H, W), boxes=z["boxes"])
         except Exception:
             pass
     sc = synth.make_scene(1000 + rank, n_points=args.scene_points, n_frames=args.base_frames, color_hw=(H, W),
                           depth_hw=(H, W), invalid_pose_frac=0.0, with_color=False, trajectory="sweep",
                           walk_step=args.walk_step, target_step=args.target_step)
-    try:
-        tmp = path + f".{os.getpid()}"
-        with open(tmp, "wb") as f:
-            pickle.dump(sc, f, protocol=4)
-        os.replace(tmp, path)
-    except Exception:
-        pass
+    if path:
+        try:
+            ids = sc.image_ids
+            tmp = path + f".{os.getpid()}.npz"
+            np.savez(tmp, scene_id=np.str_(sc.scene_id), ids=np.array(ids), K=sc.K, A=sc.A, E=np.stack([sc.E[i] for i in ids]),
+                     points=sc.points, depth=np.stack([sc.depth[i] for i in ids]), boxes=sc.boxes)
+            os.replace(tmp, path)
+        except Exception:
+            pass
     return sc
 
 

@@ -38,8 +38,8 @@ def project_mask_to_3d(depth_image, intrinsic_matrix, extrinsic_matrix, mask=Non
     idx = torch.nonzero(keep_t).flatten()                         # row-major mask order, as np.where gives it (OPS:276-278)
     xyz = out["xyz_f64"][0].index_select(0, idx).cpu().numpy()
     keep = idx.cpu().numpy()
-    if world_to_axis_align_matrix is None:
-        pass    # A = identity: x*1 + 0*y + 0*z + 0 is exact, the result equals E @ cam
+    # (world_to_axis_align_matrix is None -> A = identity in the frame record: x*1 + 0*y + 0*z + 0 is exact, the result
+    # equals E @ cam as upstream computes it without the third product)
     if color_image is not None:
         rgb = np.asarray(color_image).reshape(-1, color_image.shape[-1])[keep]
         return np.hstack((xyz, rgb))

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Write / update profiles/traffic.json from the rocprofv3 PMC passes that tools/profile.sh left under gpurun_out/prof_<tag>/
+(fetch/ and write/ counter CSVs), so that the HBM bytes bench.py divides by its own kernel time are never hand-copied.
+
+    python tools/emit_traffic.py KEY=TAG[:committed-summary] ...     e.g.  corr:fast:vc=r03_corr_vc:profiles/r03_k3_corr_vc_pmc.md
+FETCH_SIZE is doubled (it reports half of the streamed bytes on gfx950: profiles/r01_counter_calibration.md,
+MI355X_MICROARCH.md HBM section); WRITE_SIZE is taken as reported.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATTERN = os.environ.get("MSPA_PROF_PATTERN", "pair_")
+
+
+def counter(prof_dir, sub, name):
+    vals, kernels = [], collections.Counter()
+    for f in glob.glob(os.path.join(prof_dir, sub, "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if PATTERN in r["Kernel_Name"] and r["Counter_Name"] == name:
+                vals.append(float(r["Counter_Value"]))
+                kernels[r["Kernel_Name"].split("(")[0].replace("void ", "")] += 1
+    if not vals:
+        raise SystemExit(f"{prof_dir}/{sub}: no {name} rows for kernels matching {PATTERN!r}")
+    return sum(vals) / len(vals), kernels.most_common(1)[0][0]
+
+
+def main():
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    table = json.load(open(path)) if os.path.exists(path) else {}
+    for spec in sys.argv[1:]:
+        key, rest = spec.split("=", 1)
+        tag, _, src = rest.partition(":")
+        d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+        fetch, kern = counter(d, "fetch", "FETCH_SIZE")
+        write, _ = counter(d, "write", "WRITE_SIZE")
+        table[key] = {"kernel": kern, "pairs": 1000, "fetch_kib_reported": round(fetch), "write_kib_reported": round(write),
+                      "hbm_bytes_per_launch": int(fetch * 2048 + write * 1024),
+                      "source": src or f"gpurun_out/prof_{tag}/summary.md"}
+        print(key, table[key])
+    table["_note"] = ("HBM bytes per launch of the benchmarked kernels, from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                      "passes of bench.py's own command (tools/profile.sh), written by tools/emit_traffic.py. FETCH_SIZE is doubled (it "
+                      "reports half of the streamed bytes on gfx950: profiles/r01_counter_calibration.md, MI355X_MICROARCH.md HBM "
+                      "section); WRITE_SIZE is exact. bench.py reads this file: the counters cannot be read from inside the run.")
+    with open(path, "w") as f:
+        json.dump(table, f, indent=1)
+        f.write("\n")
+
+
+if __name__ == "__main__":
+    main()
