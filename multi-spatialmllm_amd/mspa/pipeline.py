@@ -8,8 +8,10 @@ collations:
      are all-gathered (``shard.collate_records``) so that every rank sees the same global table and the
      overlap-binned sampling (``sampling.sample_dataframe``, seeded) picks the same rows everywhere --
      exactly what a single process would pick;
-  2. the finished QA records are gathered to rank 0 (``all_gather_object`` over RCCL), shuffled with the
-     head's seed and written as JSONL.
+  2. the heads' NUMERIC results -- not their text -- are collated: every rank records the arrays its K2 / K4 / K5 / K6 / K7 /
+     K8 launches return while it runs the heads of its scenes (``mspa/tape.py``), the tapes (float64 rows of width 8) go
+     through ``shard.collate_records``, and rank 0 replays the same heads on them to build the record text, shuffles with
+     the head's seed and writes the JSONL.  No pickled record ever crosses the fabric.
 This is BASELINE.json configs[4] in miniature: camera movement, visual correspondence, depth estimation / comparison and
 object perception from the posed RGB-D scenes, object movement from TAPVid-style track blocks (``tracks=``).  Scenes and
 tracks come in as arrays (``mspa.synth``, ``mspa.sens`` or the façade handler).
@@ -52,7 +54,7 @@ def pair_table_rows(scene_idx: int, scene) -> np.ndarray:
 def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None, device="cuda", seed: int = 0,
         n_camera: int = 64, n_correspondence: int = 64, depth_images_per_scene: int = 4,
         overlap_range=(6, 35), question_types: Sequence[str] = ("total_distance", "displacement_vector"),
-        object_perception: bool = True, tracks: Sequence = ()) -> Dict[str, int]:
+        object_perception: bool = True, tracks: Sequence = (), selftest_tape: bool = False) -> Dict[str, int]:
     """Run the ScanNet-side heads over ``scenes`` (objects with K, A, E, depth, points, color_hw, scene_id).
     Returns {jsonl name: record count} on rank 0 (empty dict elsewhere)."""
     import pandas as pd
@@ -62,7 +64,9 @@ def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None,
 
     rank, world = (ctx.rank, ctx.world) if ctx is not None else (0, 1)
     costs = [shard.scene_cost(len(sc.valid_image_ids), sc.points.shape[0]) for sc in scenes]
-    mine = shard.lpt_assign(costs, world)[rank]
+    scene_bins = shard.lpt_assign(costs, world)
+    scene_owner = {k: r for r, b in enumerate(scene_bins) for k in b}
+    mine = scene_bins[rank]
 
     # ---- geometry of my scenes; pair table collation --------------------------------------------
     resident = {k: SceneOnDevice(scenes[k].K, scenes[k].A, scenes[k].E, scenes[k].depth, scenes[k].color_hw,
@@ -82,117 +86,175 @@ def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None,
         "_scene": table[:, 0].astype(int),
     })
 
-    outputs: Dict[str, List[dict]] = {}
+    # ---- the heads as units of work: (collation name, unit key, fn(scene) -> records or {name: records}) ----------------
+    # A unit is one scene (or one track block) of one head; its generator is seeded per unit, so what it produces does not
+    # depend on which rank runs it -- nor on whether the numbers come from the kernels or from a tape (mspa/tape.py).
+    from . import engine, tape
+    units: Dict[str, List] = {}
 
-    def my_rows(sampled):
-        return [(k, sampled.iloc[k].to_dict()) for k in range(len(sampled)) if int(sampled.iloc[k]["_scene"]) in resident]
+    def rows_by_scene(sampled):
+        by: Dict[int, List] = {}
+        for k in range(len(sampled)):
+            row = sampled.iloc[k].to_dict()
+            by.setdefault(int(row["_scene"]), []).append((k, row))
+        return by
 
-    # ---- camera movement (seed as upstream: CME:17-18) -------------------------------------------
+    # camera movement (seed as upstream: CME:17-18)
     for qt in question_types:
         np.random.seed(seed)
         random.seed(seed)
         sampled = sampling.sample_dataframe(df, n_camera, 0, overlap_range[0], overlap_range[1], 1)
-        recs = []
-        by_scene: Dict[int, List] = {}
-        for k, row in my_rows(sampled):
-            by_scene.setdefault(int(row["_scene"]), []).append((k, row))
-        for s, items in by_scene.items():
-            rng = random.Random(f"{seed}:{qt}:{s}")             # per-scene stream: result independent of the sharding
-            t12, t21 = heads.camera_movement_numeric(resident[s], [r for _, r in items])
-            for n, (k, row) in enumerate(items):
-                recs.append(heads.camera_movement_record(row, k, qt, t12[n], t21[n], scenes[s].color_hw,
-                                                         T.CAMERA_MOVEMENT, rng))
-        outputs[f"camera_movement_{qt}"] = recs
+        for s, items in sorted(rows_by_scene(sampled).items()):
+            def cm_unit(scene, s=s, items=items, qt=qt):
+                rng = random.Random(f"{seed}:{qt}:{s}")             # per-scene stream: result independent of the sharding
+                t12, t21 = heads.camera_movement_numeric(scene, [r for _, r in items])
+                return [heads.camera_movement_record(row, k, qt, t12[n], t21[n], scenes[s].color_hw, T.CAMERA_MOVEMENT, rng)
+                        for n, (k, row) in enumerate(items)]
+            units.setdefault(f"camera_movement_{qt}", []).append((s, cm_unit))
 
-    # ---- visual correspondence (VC_C:11-12 seeds 1) ------------------------------------------------
+    # visual correspondence (VC_C:11-12 seeds 1)
     np.random.seed(seed + 1)
     sampled = sampling.sample_dataframe(df, n_correspondence, 0, overlap_range[0], overlap_range[1], 1)
-    recs = []
-    by_scene = {}
-    for k, row in my_rows(sampled):
-        by_scene.setdefault(int(row["_scene"]), []).append((k, row))
-    for s, items in by_scene.items():
-        rng = random.Random(f"{seed}:vc:{s}")
-        rows = [r for _, r in items]
-        got = heads.visual_correspondence_records(resident[s], rows, scenes[s].color_hw, 0, T.VISUAL_CORRESPONDENCE, rng)
-        recs.extend(got)
-    outputs["visual_correspondence_coor_2_coor"] = recs
+    units["visual_correspondence_coor_2_coor"] = []
+    for s, items in sorted(rows_by_scene(sampled).items()):
+        def vc_unit(scene, s=s, items=items):
+            rng = random.Random(f"{seed}:vc:{s}")
+            return heads.visual_correspondence_records(scene, [r for _, r in items], scenes[s].color_hw, 0,
+                                                       T.VISUAL_CORRESPONDENCE, rng)
+        units["visual_correspondence_coor_2_coor"].append((s, vc_unit))
 
-    # ---- depth estimation ------------------------------------------------------------------------
-    recs = []
-    for s in mine:
-        rng = random.Random(f"{seed}:depth:{s}")
-        recs.extend(heads.depth_estimation_records(resident[s], scenes[s].scene_id, scenes[s].color_hw,
-                                                   depth_images_per_scene, T.DEPTH_ESTIMATION, rng))
-    outputs["depth_estimation_coor"] = recs
-    recs = []
-    for s in mine:
-        rng = random.Random(f"{seed}:depthcmp:{s}")
-        recs.extend(heads.depth_comparison_records_gpu(resident[s], scenes[s].scene_id, scenes[s].color_hw,
-                                                       depth_images_per_scene, T.DEPTH_COMPARISON, rng))
-    outputs["depth_comparison_coor"] = recs
+    # depth estimation / comparison: every scene
+    units["depth_estimation_coor"], units["depth_comparison_coor"] = [], []
+    for s in range(len(scenes)):
+        def de_unit(scene, s=s):
+            return heads.depth_estimation_records(scene, scenes[s].scene_id, scenes[s].color_hw, depth_images_per_scene,
+                                                  T.DEPTH_ESTIMATION, random.Random(f"{seed}:depth:{s}"))
 
-    # ---- object perception: visibility + coverage + records, per scene (COVIS / COV / OPE) ----------
+        def dc_unit(scene, s=s):
+            return heads.depth_comparison_records_gpu(scene, scenes[s].scene_id, scenes[s].color_hw, depth_images_per_scene,
+                                                      T.DEPTH_COMPARISON, random.Random(f"{seed}:depthcmp:{s}"))
+        units["depth_estimation_coor"].append((s, de_unit))
+        units["depth_comparison_coor"].append((s, dc_unit))
+
+    # object perception: visibility + coverage + records, per scene (COVIS / COV / OPE); one unit yields several files
     if object_perception:
-        by_name: Dict[str, List[dict]] = {}
-        for s in mine:
+        units["object_perception"] = []
+        for s in range(len(scenes)):
             if not hasattr(scenes[s], "objects"):
                 continue
-            idx, bbox, cat = scenes[s].objects()
-            rng = random.Random(f"{seed}:op:{s}")
-            cov, _ = resident[s].object_coverage(idx, bbox, rng=rng)
-            for d, dim in enumerate(("height", "length", "width")):
-                table = {scenes[s].scene_id: {o: res[dim] for o, res in cov.items()}}
-                size = {"height": lambda o: bbox[o][5], "length": lambda o: max(bbox[o][3], bbox[o][4]),
-                        "width": lambda o: min(bbox[o][3], bbox[o][4])}[dim]
-                by_k = heads.object_perception_records(table, dim, lambda _s, o: size(o), lambda _s, o: cat[o],
-                                                       scenes[s].color_hw, 6, T.OBJECT_PERCEPTION, rng)
-                for k, recs in by_k.items():
-                    if recs:
-                        by_name.setdefault(f"object_perception_{dim}_k{k}", []).extend(recs)
-        if ctx is not None:                       # every rank must enter the same collations: agree on the names
-            names: List[Optional[list]] = [None] * world
-            dist.all_gather_object(names, sorted(by_name), group=ctx.group)
-            for n in sorted({x for part in names for x in part}):
-                by_name.setdefault(n, [])
-        outputs.update(by_name)
 
-    # ---- object movement on TAPVid-style track blocks (OM_C): blocks sharded like scenes -----------------------
+            def op_unit(scene, s=s):
+                idx, bbox, cat = scenes[s].objects()
+                rng = random.Random(f"{seed}:op:{s}")
+                cov, _ = scene.object_coverage(idx, bbox, rng=rng)
+                by_name: Dict[str, List[dict]] = {}
+                for dim in ("height", "length", "width"):
+                    table = {scenes[s].scene_id: {o: res[dim] for o, res in cov.items()}}
+                    size = {"height": lambda o: bbox[o][5], "length": lambda o: max(bbox[o][3], bbox[o][4]),
+                            "width": lambda o: min(bbox[o][3], bbox[o][4])}[dim]
+                    by_k = heads.object_perception_records(table, dim, lambda _s, o: size(o), lambda _s, o: cat[o],
+                                                           scenes[s].color_hw, 6, T.OBJECT_PERCEPTION, rng)
+                    for k, recs in by_k.items():
+                        if recs:
+                            by_name.setdefault(f"object_perception_{dim}_k{k}", []).extend(recs)
+                return by_name
+            units["object_perception"].append((s, op_unit))
+
+    # object movement on TAPVid-style track blocks (OM_C): blocks sharded like scenes; a block is its own "scene"
+    track_owner = {}
     if tracks:
         from scipy.cluster.hierarchy import fcluster, linkage
         from scipy.spatial.distance import squareform
-        from . import engine
-        mine_tr = shard.lpt_assign([float(t.tracks_XYZ.shape[0]) * t.tracks_XYZ.shape[1] ** 2 for t in tracks], world)[rank]
+        bins = shard.lpt_assign([float(t.tracks_XYZ.shape[0]) * t.tracks_XYZ.shape[1] ** 2 for t in tracks], world)
+        track_owner = {k: r for r, b in enumerate(bins) for k in b}
         for qt in T.OBJECT_MOVEMENT_TYPES:
-            recs = []
-            for k in mine_tr:
-                tr = tracks[k]
-                rng = random.Random(f"{seed}:om:{qt}:{k}")
-                xyz = np.ascontiguousarray(tr.tracks_XYZ, dtype=np.float64)
-                dev_tracks = torch.from_numpy(xyz).to(device)
-                loss = engine.track_rigidity_loss(dev_tracks).cpu().numpy()                       # K7
-                labels = fcluster(linkage(squareform(loss, checks=False), method="average"), 0.1, criterion="distance")
-                groups = [g for g in (np.where(labels == i)[0].tolist() for i in range(1, max(labels) + 1)) if len(g) > 5]
-                c2w = torch.from_numpy(np.linalg.inv(tr.extrinsics_w2c).reshape(-1, 16)).to(device)
-                world_xyz = engine.track_to_world(dev_tracks, c2w, tr.fx_fy_cx_cy, tr.image_hw, ("world",))["world"]   # K5a
-                pairs_k = heads.object_movement_mine_pairs(                                       # K5c
-                    tr.visibility, groups, lambda p, f: engine.track_pair_distances(world_xyz, p, f), 5, 3, True, 0.05, rng)
-                recs.extend(heads.object_movement_records(tr.scene_id, xyz, tr.extrinsics_w2c, tr.fx_fy_cx_cy, tr.image_hw,
-                                                          pairs_k, qt, T.OBJECT_MOVEMENT, rng, device))   # K5a + K5b
-            outputs[f"object_movement_{qt}"] = recs
+            units[f"object_movement_{qt}"] = []
+            for k in range(len(tracks)):
+                def om_unit(_scene, k=k, qt=qt):
+                    import torch
+                    from . import engine as E                      # the proxy while a tape is being recorded / replayed
+                    tr = tracks[k]
+                    rng = random.Random(f"{seed}:om:{qt}:{k}")
+                    xyz = np.ascontiguousarray(tr.tracks_XYZ, dtype=np.float64)
+                    dev_tracks = torch.from_numpy(xyz).to(device)
+                    loss = E.track_rigidity_loss(dev_tracks).cpu().numpy()                              # K7
+                    labels = fcluster(linkage(squareform(loss, checks=False), method="average"), 0.1, criterion="distance")
+                    groups = [g for g in (np.where(labels == i)[0].tolist() for i in range(1, max(labels) + 1)) if len(g) > 5]
+                    c2w = torch.from_numpy(np.linalg.inv(tr.extrinsics_w2c).reshape(-1, 16)).to(device)
+                    world_xyz = E.track_to_world(dev_tracks, c2w, tr.fx_fy_cx_cy, tr.image_hw, ("world",))["world"]   # K5a
+                    pairs_k = heads.object_movement_mine_pairs(                                       # K5c
+                        tr.visibility, groups, lambda p, f: E.track_pair_distances(world_xyz, p, f), 5, 3, True, 0.05, rng)
+                    return heads.object_movement_records(tr.scene_id, xyz, tr.extrinsics_w2c, tr.fx_fy_cx_cy, tr.image_hw,
+                                                         pairs_k, qt, T.OBJECT_MOVEMENT, rng, device)   # K5a + K5b
+                units[f"object_movement_{qt}"].append((k, om_unit))
 
-    # ---- collation of the finished records + JSONL --------------------------------------------------
+    def owner_of(name, key):
+        return track_owner[key] if name.startswith("object_movement_") else scene_owner[key]
+
+    def replay_scene(name, key, player):
+        if name.startswith("object_movement_"):
+            return None
+        sc = scenes[key]
+        return tape.ReplayScene(SceneOnDevice, sc.K, sc.A, sc.valid_image_ids, sc.color_hw, sc.points.shape[0], device,
+                                count=player.next())
+
+    def merge(outputs, name, produced):
+        if isinstance(produced, dict):
+            for n, recs in produced.items():
+                outputs.setdefault(n, []).extend(recs)
+        else:
+            outputs.setdefault(name, []).extend(produced)
+
+    # ---- run: directly with one process; record -> collate the numeric tapes -> replay on rank 0 with several ----------
+    outputs: Dict[str, List[dict]] = {}
+    for name in sorted(units):
+        if name != "object_perception":
+            outputs.setdefault(name, [])
+        if ctx is None and not selftest_tape:
+            for key, fn in units[name]:
+                merge(outputs, name, fn(resident.get(key)))
+            continue
+        local = []
+        for key, fn in units[name]:
+            if owner_of(name, key) != rank:
+                continue
+            rec = tape.Recorder(engine)
+            with tape.engine_as(rec):
+                if not name.startswith("object_movement_"):
+                    rec.note(resident[key]._visibility()["count"])
+                direct = fn(resident.get(key))
+            rows = rec.rows()
+            header = np.zeros((1, tape.WIDTH))
+            header[0, 0], header[0, 1] = key, len(rows)
+            local += [header, rows]
+            if selftest_tape:                                 # single-process self-check: the replay must reproduce the records
+                player = tape.Player(engine, rows, device)
+                with tape.engine_as(player):
+                    again = fn(replay_scene(name, key, player))
+                assert again == direct, f"tape replay of {name} / unit {key} differs from the direct run"
+                merge(outputs, name, direct)
+        if ctx is None:
+            continue
+        payload = torch.from_numpy(np.concatenate(local, 0) if local else np.zeros((0, tape.WIDTH))).to(ctx.collective_device)
+        table = shard.collate_records(payload, ctx).cpu().numpy()              # the exchange: float64 rows, nothing else
+        if rank != 0:
+            continue
+        tapes, pos = {}, 0
+        while pos < len(table):
+            key, n = int(table[pos, 0]), int(table[pos, 1])
+            tapes[key] = table[pos + 1:pos + 1 + n]
+            pos += 1 + n
+        for key, fn in units[name]:                            # unit order, whoever ran it
+            player = tape.Player(engine, tapes[key], device)
+            with tape.engine_as(player):
+                merge(outputs, name, fn(replay_scene(name, key, player)))
+
+    # ---- rank 0: canonical order, seeded shuffle, JSONL ------------------------------------------------------
     counts: Dict[str, int] = {}
     os.makedirs(out_dir, exist_ok=True)
-    for name in sorted(outputs):
-        local_recs = outputs[name]
-        if ctx is not None:
-            gathered: List[Optional[list]] = [None] * world
-            dist.all_gather_object(gathered, local_recs, group=ctx.group)      # RCCL (or gloo) under the hood
-            allrecs = [r for part in gathered for r in part]
-        else:
-            allrecs = list(local_recs)
-        if rank == 0:
+    if rank == 0:
+        for name in sorted(outputs):
+            allrecs = list(outputs[name])
             allrecs.sort(key=lambda r: str(r["id"]))            # canonical order first: shuffle is sharding-independent
             random.Random(f"{seed}:{name}").shuffle(allrecs)
             heads.write_jsonl(os.path.join(out_dir, f"{name}.jsonl"), allrecs)
