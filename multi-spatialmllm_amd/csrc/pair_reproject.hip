@@ -764,9 +764,10 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m, uint32_t base)
 // VISIBLE pixels only, in (row, column) order, into its own 3072-entry segment: rank of a lane = entries of the tile so far
 // (a scalar, the store's SGPR offset) + set bits below the lane (v_mbcnt), one exec-masked dword store per row with a visible
 // lane -- and nothing at all for culled tiles and groups, which is where the dense table spends three quarters of its bytes
-// on (-1, -1).  Two forms that staged the entries in LDS and stored 1 KB chunks (a 512-entry ring, a 320-entry buffer with
-// carry) were measured slower: their 1.25 - 2 KB per wave cost the kernel a workgroup per CU, and this kernel's time goes
-// with the waves in flight (profiles/r03a_k3_compact_fulltile_ring512_pmc.md).
+// on (-1, -1).  Three forms that staged the entries in LDS were measured slower (tools/ab_k3.py, one box): a 512-entry ring
+// and a 320-entry buffer with carry, storing 1 KB chunks -- their 1.25 - 2 KB per wave cost the kernel a workgroup per CU
+// (0.586 / 0.536 ms; profiles/r03a_k3_compact_fulltile_ring512_pmc.md) -- and a 128-entry buffer in the tile's pad storing
+// 64-entry chunks at the same occupancy as the direct form (0.483 vs 0.468 ms).
 
 template <uint32_t SET, bool STREAM>
 __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
