@@ -3,6 +3,7 @@
 (fetch/ and write/ counter CSVs), so that the HBM bytes bench.py divides by its own kernel time are never hand-copied.
 
     python tools/emit_traffic.py KEY=TAG[:committed-summary] ...     e.g.  corr:fast:vc=r03_corr_vc:profiles/r03_k3_corr_vc_pmc.md
+    python tools/emit_traffic.py --entry <prof_dir>                  (on the GPU box, by tools/profile.sh: one profile's two counters)
 FETCH_SIZE is doubled (it reports half of the streamed bytes on gfx950: profiles/r01_counter_calibration.md,
 MI355X_MICROARCH.md HBM section); WRITE_SIZE is taken as reported.
 """
@@ -29,18 +30,28 @@ def counter(prof_dir, sub, name):
     return sum(vals) / len(vals), kernels.most_common(1)[0][0]
 
 
+def entry(prof_dir):
+    """The two counters of one profile directory as a small JSON object (written on the GPU box by tools/profile.sh, where
+    the raw CSVs are; they are too big to bring back)."""
+    fetch, kern = counter(prof_dir, "fetch", "FETCH_SIZE")
+    write, _ = counter(prof_dir, "write", "WRITE_SIZE")
+    return {"kernel": kern, "pairs": 1000, "fetch_kib_reported": round(fetch), "write_kib_reported": round(write),
+            "hbm_bytes_per_launch": int(fetch * 2048 + write * 1024)}
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--entry":
+        print(json.dumps(entry(sys.argv[2])))
+        return
     path = os.path.join(ROOT, "profiles", "traffic.json")
     table = json.load(open(path)) if os.path.exists(path) else {}
     for spec in sys.argv[1:]:
         key, rest = spec.split("=", 1)
         tag, _, src = rest.partition(":")
         d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-        fetch, kern = counter(d, "fetch", "FETCH_SIZE")
-        write, _ = counter(d, "write", "WRITE_SIZE")
-        table[key] = {"kernel": kern, "pairs": 1000, "fetch_kib_reported": round(fetch), "write_kib_reported": round(write),
-                      "hbm_bytes_per_launch": int(fetch * 2048 + write * 1024),
-                      "source": src or f"gpurun_out/prof_{tag}/summary.md"}
+        small = os.path.join(d, "traffic_entry.json")
+        table[key] = dict(json.load(open(small)) if os.path.exists(small) else entry(d),
+                          source=src or f"gpurun_out/prof_{tag}/summary.md")
         print(key, table[key])
     table["_note"] = ("HBM bytes per launch of the benchmarked kernels, from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
                       "passes of bench.py's own command (tools/profile.sh), written by tools/emit_traffic.py. FETCH_SIZE is doubled (it "

@@ -37,3 +37,4 @@ for k in sorted(acc):
     v = acc[k]
     print(f"| {k} | {sum(v)/len(v):.4g} | {max(v):.4g} |")
 PY
+for d in sq sq2 ta ta2 tcp tcp2 tcc tcc2 fetch write grbm; do rm -rf $OUT/$d; done     # raw CSVs: too big to bring back

@@ -17,3 +17,7 @@ run fetch --pmc FETCH_SIZE
 run write --pmc WRITE_SIZE
 run tcc --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum
 python $ROOT/tools/rocprof_summary.py $OUT ${MSPA_PROF_PATTERN:-pair_} | tee $OUT/summary.md
+# the raw CSVs are tens of MB per pass and gpurun brings back 64 MiB in all: keep the summary and the two numbers
+# tools/emit_traffic.py needs, drop the rest
+MSPA_PROF_PATTERN=${MSPA_PROF_PATTERN:-pair_} python $ROOT/tools/emit_traffic.py --entry $OUT > $OUT/traffic_entry.json
+for d in stats sq sq2 fetch write tcc; do rm -rf $OUT/$d; done

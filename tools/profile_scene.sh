@@ -16,3 +16,4 @@ for f in glob.glob("$OUT/stats/*kernel_stats.csv"):
         if "mspa::" in r["Name"]:
             print(f"| \`{r['Name'].split('(')[0][-60:]}\` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} |")
 PY
+for d in stats sq fetch write; do rm -rf $OUT/$d; done     # raw CSVs: too big to bring back

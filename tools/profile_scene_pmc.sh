@@ -30,3 +30,4 @@ for name, c in acc.items():
     print(f"| \`{name[-40:]}\` | {sum(dur[name]) / max(1, len(dur[name])):.1f} | {m('SQ_WAVES'):.0f} | {m('SQ_INSTS_VALU') / m('SQ_WAVES'):.0f} | "
           f"{m('SQ_ACTIVE_INST_VALU') / m('SQ_WAVE_CYCLES'):.3f} | {m('FETCH_SIZE') * 2048 / 1e6:.1f} | {m('WRITE_SIZE') * 1024 / 1e6:.1f} |")
 PY
+for d in stats sq fetch write; do rm -rf $OUT/$d; done     # raw CSVs: too big to bring back
