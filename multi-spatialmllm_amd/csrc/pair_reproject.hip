@@ -708,6 +708,9 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 #ifndef MSPA_STAGE2_ROW_BARRIER
 #define MSPA_STAGE2_ROW_BARRIER 3      // 0 never, 1 after every row, 2 after the second row only, 3 every row for the compacted set
 #endif
+#ifndef MSPA_SCALED_ROW_BARRIER
+#define MSPA_SCALED_ROW_BARRIER 1      // ScanNet-shape kernel: 100 -> 73 VGPRs (4 -> 6 waves per SIMD), 2.30 -> 2.11 ms per 1 000 pairs
+#endif
 #ifndef MSPA_TIGHT_WAVES_PER_EU
 #define MSPA_TIGHT_WAVES_PER_EU 0      // > 0: ask the register allocator for that many waves per SIMD
 #endif
@@ -1474,6 +1477,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
                         const double wv = __builtin_fabs(v[e] - rv) - 0.25;
                         rkc[e] = ballot64(!(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx)) |
                                  ballot64(!(qz[e] > kGuardZmm));
+                        if (MSPA_SCALED_ROW_BARRIER) __builtin_amdgcn_sched_barrier(0);   // see the tight kernel: registers vs interleaving
                     }
                     unsigned long long rbm[NCH];
     #pragma unroll
