@@ -658,6 +658,10 @@ def main():
             d["bytes_per_pair_counting_rgba_out"] = int(bw / args.pairs)
         if "note" in VARIANTS[v]:
             d["note"] = VARIANTS[v]["note"]
+        if m == "exact":
+            d["note"] = ("pair_exact_kernel: the reference's own operation order (five 3x4 products + IEEE division per pixel), "
+                         "FP64-issue bound, not HBM bound -- the bit-exact path every float64-output call takes; the fast kernels "
+                         "reproduce its integers")
         return with_traffic(d, v, m, wl, k2)
 
     extra, sweep = {}, {}
