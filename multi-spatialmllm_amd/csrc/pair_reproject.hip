@@ -719,7 +719,14 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 #else
 #define MSPA_TIGHT_ATTR
 #endif
-constexpr int kTightRows = MSPA_TIGHT_ROWS;
+constexpr int kTightRows = MSPA_TIGHT_ROWS;            // tile height of the correspondence family (= MSPA_CORR_TILE_H)
+#ifndef MSPA_TIGHT_ROWS_DENSE
+#define MSPA_TIGHT_ROWS_DENSE 32
+#endif
+// The dense sets carry a 3 KB transpose stage per wave: with 48-row tiles that is 36 KB of LDS per workgroup (four per CU),
+// with 32-row tiles 28 KB (five): measured 1.22 -> 1.17 ms per 1 000 pairs (dense without colour words, tools/ab_k3.py)
+constexpr int kTightRowsDense = MSPA_TIGHT_ROWS_DENSE;
+constexpr int tight_rows_of(uint32_t set) { return (set & (O_XYZ32 | O_RGBA | O_VIS_U8)) ? kTightRowsDense : kTightRows; }
 constexpr int kTightBW = MSPA_TIGHT_BLOCK_WAVES;      // waves (= tiles) per workgroup
 constexpr int kTightThreads = kTightBW * kWave;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -772,7 +779,7 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m, uint32_t base)
 // (0.586 / 0.536 ms; profiles/r03a_k3_compact_fulltile_ring512_pmc.md) -- and a 128-entry buffer in the tile's pad storing
 // 64-entry chunks at the same occupancy as the direct form (0.483 vs 0.468 ms).
 
-template <uint32_t SET, bool STREAM>
+template <uint32_t SET, bool STREAM, int ROWS>
 __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
                                                                    const uint8_t *__restrict__ rgb,
                                                                    const double *__restrict__ mats,
@@ -805,7 +812,7 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
     const uint32_t stripe = tile - band * (uint32_t)a.n_stripes;
     const bool tile_ok = tile < (uint32_t)a.n_tiles;
     const uint32_t col = stripe * 64u + (uint32_t)c.lane;
-    const uint32_t row0 = band * (uint32_t)kTightRows;
+    const uint32_t row0 = band * (uint32_t)ROWS;
 
     // The tile's depth-1 samples (48 rows x 128 B) go HBM -> LDS by LDS-DMA, two rows per wave
     // instruction (lanes 0-31 fetch row 2k, lanes 32-63 row 2k+1, 4 bytes = 2 pixels each): all 24
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
     // predecessor).  The wave's LDS operations execute in order; the next group reads ITS rows before its stage overwrites them.
     constexpr bool PX_IN_TILE = (SET & O_PIX) && !(SET & (O_XYZ32 | O_RGBA));
     constexpr int kPadPx = PX_IN_TILE ? 256 : 0;                        // uint16 units: 512 bytes
-    __shared__ __attribute__((aligned(16))) uint16_t lds_w[kTightBW][kPadPx + kTightRows * 64];
+    __shared__ __attribute__((aligned(16))) uint16_t lds_w[kTightBW][kPadPx + ROWS * 64];
     uint16_t *const lds_d1w = &lds_w[wave][kPadPx];                     // this wave's 48 x 64 depth-1 samples
     if (tile_ok) {
         typedef __attribute__((address_space(1))) const void gvoid_t;
@@ -826,18 +833,18 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
 #if MSPA_TIGHT_DMA16
         // gfx950's 16-byte LDS-DMA: eight lanes fetch a row's 128 bytes, one wave instruction lands eight rows (1 KB,
         // contiguous in LDS: lane L writes bytes 16 L .. 16 L + 15 past the base) -- 6 requests per tile instead of 24
-        static_assert(kTightRows % 8 == 0, "eight rows per 16-byte LDS-DMA request");
+        static_assert(ROWS % 8 == 0, "eight rows per 16-byte LDS-DMA request");
         const uint16_t *src = c.depth1 + (int64_t)(row0 + (uint32_t)(c.lane >> 3)) * a.W + stripe * 64u +
                               (uint32_t)(c.lane & 7) * 8u;
 #pragma unroll
-        for (int k = 0; k < kTightRows / 8; ++k)
+        for (int k = 0; k < ROWS / 8; ++k)
             __builtin_amdgcn_global_load_lds((gvoid_t *)(src + (int64_t)(8 * k) * a.W),
                                              (lvoid_t *)&lds_d1w[k * 512], 16, 0, STREAM ? 2 : 0);  // aux 2 = nt
 #else
         const uint16_t *src = c.depth1 + (int64_t)(row0 + (uint32_t)(c.lane >> 5)) * a.W + stripe * 64u +
                               (uint32_t)(c.lane & 31) * 2u;
 #pragma unroll
-        for (int k = 0; k < kTightRows / 2; ++k)
+        for (int k = 0; k < ROWS / 2; ++k)
             __builtin_amdgcn_global_load_lds((gvoid_t *)(src + (int64_t)(2 * k) * a.W),
                                              (lvoid_t *)&lds_d1w[k * 128], 4, 0, STREAM ? 2 : 0);   // aux 2 = nt
 #endif
@@ -863,9 +870,9 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
 
     // transpose stage: the group's pixel indices, then (dense set) its rgba words, then its 4 x 64 x 3 point coordinates
     __shared__ __attribute__((aligned(16))) uint32_t lds_pxs[kTightBW][(PX_IN_TILE || !(SET & (O_PIX | O_XYZ32 | O_RGBA))) ? 4 : kRowGroup * 64 * (WANT_XYZ ? 3 : 1)];
-    static_assert(kTightRows <= 64, "one lane per tile row holds that row's visibility word");
+    static_assert(ROWS <= 64, "one lane per tile row holds that row's visibility word");
 #ifndef MSPA_EXPERIMENT_ROWS   // timing-only builds with another tile height (tools/build_variant.sh): the compacted set is then wrong
-    static_assert(!COMPACT || (kTightRows * 64 == MSPA_CORR_TILE_CAP && kTightRows == MSPA_CORR_TILE_H), "tile segment of the compacted set");
+    static_assert(!COMPACT || (ROWS * 64 == MSPA_CORR_TILE_CAP && ROWS == MSPA_CORR_TILE_H), "tile segment of the compacted set");
 #endif
     int n_valid = 0, n_vis = 0;
     if (tile_ok) {
@@ -952,7 +959,7 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
             us2 mn = {0xFFFF, 0xFFFF}, mxv = {0, 0};
             const us2 one = {1, 1};
 #pragma unroll
-            for (int k = 0; k < kTightRows / 2; ++k) {
+            for (int k = 0; k < ROWS / 2; ++k) {
                 const us2 x = wds[c.lane + 64 * k];
                 mn = __builtin_elementwise_min(mn, (us2)(x - one));      // 0 (invalid) wraps to 0xFFFF
                 mxv = __builtin_elementwise_max(mxv, x);
@@ -967,7 +974,7 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
             } else {
                 const int k = c.lane & 7;
                 const double cx = (double)(stripe * 64u + ((k & 1) ? 63u : 0u));
-                const double cy = (double)(row0 + ((k & 2) ? (uint32_t)(kTightRows - 1) : 0u));
+                const double cy = (double)(row0 + ((k & 2) ? (uint32_t)(ROWS - 1) : 0u));
                 const double cd = (double)((k & 4) ? hi : lo + 1);
                 const double hx = __builtin_fma(__builtin_fma(M[0][1], cy, __builtin_fma(M[0][0], cx, M[0][2])), cd, M[0][3]);
                 const double hy = __builtin_fma(__builtin_fma(M[1][1], cy, __builtin_fma(M[1][0], cx, M[1][2])), cd, M[1][3]);
@@ -983,14 +990,14 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
             if (culled) {
                 us2 nz = {0, 0};
 #pragma unroll
-                for (int k = 0; k < kTightRows / 2; ++k) nz += __builtin_elementwise_min(wds[c.lane + 64 * k], one);
+                for (int k = 0; k < ROWS / 2; ++k) nz += __builtin_elementwise_min(wds[c.lane + 64 * k], one);
                 int cnt = (int)nz.x + (int)nz.y;
                 for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
                 n_valid = cnt;
                 if (O::template has<O_PIX>(a.pix_i16)) {
                     const u32x4_t none = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 #pragma unroll 4
-                    for (int r0 = 0; r0 < kTightRows; r0 += kRowGroup)
+                    for (int r0 = 0; r0 < ROWS; r0 += kRowGroup)
                         buffer_store_b128_guarded(none, rs_pix, pix_voff, (int)((row0 + (uint32_t)r0) * Wb * 4u));
                 }
             }
@@ -998,7 +1005,7 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
 
         if (!culled) {
 #pragma unroll 1
-            for (int r0 = 0; r0 < kTightRows; r0 += kRowGroup) {
+            for (int r0 = 0; r0 < ROWS; r0 += kRowGroup) {
                 uint32_t d16[kRowGroup];
 #pragma unroll
                 for (int j = 0; j < kRowGroup; ++j) {
@@ -1198,7 +1205,7 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
                 // visible pixel -- which yields the very indices the fast path wrote for unguarded lanes, that being the
                 // guard band's contract.  ~0.3 % of the tiles (identity pairs: all of them).
                 uint32_t base = 0;
-                for (int r = 0; r < kTightRows; ++r) {                    // wave-uniform
+                for (int r = 0; r < ROWS; ++r) {                    // wave-uniform
                     const unsigned long long w = readlane64(bits_lo, bits_hi, r);
                     if (w == 0) continue;
                     if ((w >> c.lane) & 1ull) {
@@ -1216,7 +1223,7 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
             if (c.lane == 0) a.tile_counts[pair * (int64_t)a.n_tiles + (int64_t)tile] = n_vis;
         }
         // the tile's visibility words: lane r stores the word of row row0 + r (8 bytes; rows are W/8 bytes apart)
-        if (O::template has<O_VIS_BITS>(a.vis_bits) && c.lane < kTightRows)
+        if (O::template has<O_VIS_BITS>(a.vis_bits) && c.lane < ROWS)
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{bits_lo, bits_hi}, rs_bits, (int)((uint32_t)c.lane * wpr * 8u),
                                                   (int)((row0 * wpr + stripe) * 8u), 0);
     }
@@ -1623,8 +1630,8 @@ static thread_local int g_last_pair_kernel = MSPA_KERNEL_NONE;
 extern "C" int mspa_pair_reproject_last_kernel(void) { return g_last_pair_kernel; }
 
 // whole-tile shapes the tight kernel takes (W % 64 == 0, H % 48 == 0, colour grid == depth grid, 32-bit byte offsets)
-static bool tight_shape(int32_t dh, int32_t dw, int32_t H, int32_t W) {
-    return dh == H && dw == W && (W % 64 == 0) && (H % kTightRows == 0) && ((uint64_t)H * (uint64_t)W * 4 < (1ull << 31));
+static bool tight_shape(int32_t dh, int32_t dw, int32_t H, int32_t W, int rows = kTightRows) {
+    return dh == H && dw == W && (W % 64 == 0) && (H % rows == 0) && ((uint64_t)H * (uint64_t)W * 4 < (1ull << 31));
 }
 
 static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const double *frame_mats,
@@ -1680,7 +1687,7 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
                          (((uintptr_t)out_vis_bits & 7u) == 0) && (((uintptr_t)out_cpix & 15u) == 0) &&
                          (((uintptr_t)out_xyz_f32 & 15u) == 0) && (((uintptr_t)out_rgba & 15u) == 0) &&
                          (((uintptr_t)out_vis_u8 & 3u) == 0);
-    const bool tight24 = fast && aligned && tight_shape(dh, dw, H, W) &&
+    const bool tight24 = fast && aligned && tight_shape(dh, dw, H, W, tight_rows_of(set)) &&
                          (set == kSetCorr || set == kSetDense || set == kSetDenseXyz || set == kSetMinimal || set == kSetCompact);
     if (out_cpix && !(tight24 && out_tile_counts))
         return fail(MSPA_EINVAL, "pair_reproject_impl: the fused compacted set needs the tight kernel and a tile-count table");
@@ -1693,7 +1700,7 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
         a.stripe_magic = 0;
         a.strips = (a.n_tiles + (kThreads / kWave) - 1) / (kThreads / kWave);
     } else if (fast) {
-        const int tile_rows = tight24 ? kTightRows : kTileRows;
+        const int tile_rows = tight24 ? tight_rows_of(set) : kTileRows;
         a.n_stripes = (W + 63) / 64;
         a.n_tiles = linear ? (int)((P + (int64_t)kTileRows * 64 - 1) / ((int64_t)kTileRows * 64))
                            : a.n_stripes * ((H + tile_rows - 1) / tile_rows);
@@ -1726,9 +1733,9 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
 #define MSPA_LAUNCH_TIGHT(SET_) \
     do { \
         if (flags & MSPA_PAIR_STREAM) \
-            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, true>), grid, dim3(kTightThreads), 0, s, depth, rgb, frame_mats, pairs, a); \
+            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, true, tight_rows_of(SET_)>), grid, dim3(kTightThreads), 0, s, depth, rgb, frame_mats, pairs, a); \
         else \
-            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, false>), grid, dim3(kTightThreads), 0, s, depth, rgb, frame_mats, pairs, a); \
+            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, false, tight_rows_of(SET_)>), grid, dim3(kTightThreads), 0, s, depth, rgb, frame_mats, pairs, a); \
     } while (0)
         if (set == kSetCorr) MSPA_LAUNCH_TIGHT(kSetCorr);
         else if (set == kSetDense) MSPA_LAUNCH_TIGHT(kSetDense);
