@@ -726,6 +726,11 @@ constexpr int kTightRows = MSPA_TIGHT_ROWS;            // tile height of the cor
 // The dense sets carry a 3 KB transpose stage per wave: with 48-row tiles that is 36 KB of LDS per workgroup (four per CU),
 // with 32-row tiles 28 KB (five): measured 1.22 -> 1.17 ms per 1 000 pairs (dense without colour words, tools/ab_k3.py)
 constexpr int kTightRowsDense = MSPA_TIGHT_ROWS_DENSE;
+#ifndef MSPA_TIGHT_RG_LIGHT
+#define MSPA_TIGHT_RG_LIGHT 4
+#endif
+// rows whose depth-2 gathers are in flight together: the sets without a transpose stage (minimal, compact) may take more
+constexpr int tight_rg_of(uint32_t set) { return (set & (O_PIX | O_XYZ32 | O_RGBA | O_VIS_U8)) ? kRowGroup : MSPA_TIGHT_RG_LIGHT; }
 constexpr int tight_rows_of(uint32_t set) { return (set & (O_XYZ32 | O_RGBA | O_VIS_U8)) ? kTightRowsDense : kTightRows; }
 constexpr int kTightBW = MSPA_TIGHT_BLOCK_WAVES;      // waves (= tiles) per workgroup
 constexpr int kTightThreads = kTightBW * kWave;
@@ -779,7 +784,7 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m, uint32_t base)
 // (0.586 / 0.536 ms; profiles/r03a_k3_compact_fulltile_ring512_pmc.md) -- and a 128-entry buffer in the tile's pad storing
 // 64-entry chunks at the same occupancy as the direct form (0.483 vs 0.468 ms).
 
-template <uint32_t SET, bool STREAM, int ROWS>
+template <uint32_t SET, bool STREAM, int ROWS, int RG>
 __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
                                                                    const uint8_t *__restrict__ rgb,
                                                                    const double *__restrict__ mats,
@@ -787,6 +792,8 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
     using O = Outs<SET, false>;
     constexpr bool WANT_XYZ = (SET & O_XYZ32) != 0;
     constexpr bool COMPACT = (SET & O_CPIX) != 0;
+    static_assert(RG == 4 || !(SET & (O_PIX | O_XYZ32 | O_RGBA | O_VIS_U8)), "the transpose stages move 4-row blocks");
+    static_assert(ROWS % RG == 0, "whole row groups");
     static_assert(!COMPACT || !(SET & (O_PIX | O_XYZ32 | O_RGBA | O_VIS_U8)), "the compacted set shares the transpose stage's LDS");
     int64_t pair;
     uint32_t tgroup;
@@ -869,7 +876,7 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
     }
 
     // transpose stage: the group's pixel indices, then (dense set) its rgba words, then its 4 x 64 x 3 point coordinates
-    __shared__ __attribute__((aligned(16))) uint32_t lds_pxs[kTightBW][(PX_IN_TILE || !(SET & (O_PIX | O_XYZ32 | O_RGBA))) ? 4 : kRowGroup * 64 * (WANT_XYZ ? 3 : 1)];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_pxs[kTightBW][(PX_IN_TILE || !(SET & (O_PIX | O_XYZ32 | O_RGBA))) ? 4 : RG * 64 * (WANT_XYZ ? 3 : 1)];
     static_assert(ROWS <= 64, "one lane per tile row holds that row's visibility word");
 #ifndef MSPA_EXPERIMENT_ROWS   // timing-only builds with another tile height (tools/build_variant.sh): the compacted set is then wrong
     static_assert(!COMPACT || (ROWS * 64 == MSPA_CORR_TILE_CAP && ROWS == MSPA_CORR_TILE_H), "tile segment of the compacted set");
@@ -997,7 +1004,7 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
                 if (O::template has<O_PIX>(a.pix_i16)) {
                     const u32x4_t none = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 #pragma unroll 4
-                    for (int r0 = 0; r0 < ROWS; r0 += kRowGroup)
+                    for (int r0 = 0; r0 < ROWS; r0 += RG)
                         buffer_store_b128_guarded(none, rs_pix, pix_voff, (int)((row0 + (uint32_t)r0) * Wb * 4u));
                 }
             }
@@ -1005,10 +1012,10 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
 
         if (!culled) {
 #pragma unroll 1
-            for (int r0 = 0; r0 < ROWS; r0 += kRowGroup) {
-                uint32_t d16[kRowGroup];
+            for (int r0 = 0; r0 < ROWS; r0 += RG) {
+                uint32_t d16[RG];
 #pragma unroll
-                for (int j = 0; j < kRowGroup; ++j) {
+                for (int j = 0; j < RG; ++j) {
                     d16[j] = lds_d1w[(r0 + j) * 64 + c.lane];
                     asm("" : "+v"(d16[j]));      // a plain 32-bit value from here on (ds_read_u16 zero-extends): otherwise the
                 }                                // compare below is narrowed to 16 bits and the conversion pays a v_and
@@ -1018,12 +1025,12 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
                 // Lane predicates live as 64-bit ballots (SGPR pairs) from here on: carried as `bool` across the
                 // branch below the compiler parks them in 0/1 VGPRs and re-compares them (8 VALU issues per row);
                 // `opaque_mask` keeps it from folding inverse_ballot(ballot(x)) back into such a bool.
-                double u[kRowGroup], v[kRowGroup], qz[kRowGroup];
-                float fx[kRowGroup], fy[kRowGroup], fz[kRowGroup];
-                unsigned long long vmk[kRowGroup], ivm[kRowGroup];
+                double u[RG], v[RG], qz[RG];
+                float fx[RG], fy[RG], fz[RG];
+                unsigned long long vmk[RG], ivm[RG];
                 unsigned long long any = 0;
 #pragma unroll
-                for (int j = 0; j < kRowGroup; ++j) {
+                for (int j = 0; j < RG; ++j) {
                     const double dmm = (double)d16[j];
                     const double ix = __builtin_fma(t0, dmm, M[0][3]);
                     const double iy = __builtin_fma(t1, dmm, M[1][3]);
@@ -1053,8 +1060,8 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
                 }
                 const uint32_t rowg = row0 + (uint32_t)r0;
                 // transpose stage of this group (see the LDS layout above); the dense sets keep a stage of their own
-                uint32_t *const lds_px = PX_IN_TILE ? reinterpret_cast<uint32_t *>(&lds_w[wave][0]) + (r0 / kRowGroup) * 128 : &lds_pxs[wave][0];
-                unsigned long long vm[kRowGroup] = {0, 0, 0, 0};       // visibility words of the group's rows
+                uint32_t *const lds_px = PX_IN_TILE ? reinterpret_cast<uint32_t *>(&lds_w[wave][0]) + (r0 / RG) * 128 : &lds_pxs[wave][0];
+                unsigned long long vm[RG] = {};       // visibility words of the group's rows
                 if (any == 0) {
                     // ---- nothing of these 4 x 64 pixels can land in frame 2: no gather, no depth test ----
                     if (O::template has<O_PIX>(a.pix_i16)) {
@@ -1063,11 +1070,11 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
                     }
                 } else {
                     // ---- stage 2: pixel index, gather, guard ---------------------------------------------
-                    int pix[kRowGroup];
-                    uint32_t dv16[kRowGroup];
-                    unsigned long long rkc[kRowGroup];
+                    int pix[RG];
+                    uint32_t dv16[RG];
+                    unsigned long long rkc[RG];
 #pragma unroll
-                    for (int j = 0; j < kRowGroup; ++j) {
+                    for (int j = 0; j < RG; ++j) {
                         const double ru = __builtin_rint(u[j]), rv = __builtin_rint(v[j]);
                         const int xi = med3_0((int)ru, hi_x);
                         const int yi = med3_0((int)rv, hi_y);
@@ -1090,9 +1097,9 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
                             __builtin_amdgcn_sched_barrier(0);
                     }
                     // ---- stage 3: depth test, outputs -------------------------------------------------------
-                    unsigned long long rbm[kRowGroup];
+                    unsigned long long rbm[RG];
 #pragma unroll
-                    for (int j = 0; j < kRowGroup; ++j) {
+                    for (int j = 0; j < RG; ++j) {
                         const bool inview = __builtin_amdgcn_inverse_ballot_w64(ivm[j]);
                         const double sd = qz[j] - (double)dv16[j];              // millimetres; IH:368-371 compares metres
                         vm[j] = ivm[j] & ballot64(sd < 0.0);
@@ -1100,9 +1107,12 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
                         if (O::template has<O_PIX>(a.pix_i16)) lds_px[j * 64 + c.lane] = (uint32_t)(inview ? pix[j] : -1);
                         if (COMPACT) compact_row(vm[j], pix[j]);
                     }
-                    if (rbm[0] | rbm[1] | rbm[2] | rbm[3]) {             // wave-uniform, rare: one branch per group, not per row
+                    unsigned long long rb_any = 0;
 #pragma unroll
-                        for (int j = 0; j < kRowGroup; ++j)
+                    for (int j = 0; j < RG; ++j) rb_any |= rbm[j];
+                    if (rb_any) {             // wave-uniform, rare: one branch per group, not per row
+#pragma unroll
+                        for (int j = 0; j < RG; ++j)
                             if (rbm[j]) {
                                 writelane64(rbm[j], r0 + j, rb_lo, rb_hi);
                                 risky_rows |= 1ull << (r0 + j);
@@ -1117,7 +1127,7 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
                 }
                 // ---- common tail: counters (scalar) and the rows' visibility words (zero after an early-out) ----
 #pragma unroll
-                for (int j = 0; j < kRowGroup; ++j) {
+                for (int j = 0; j < RG; ++j) {
                     n_valid += __popcll(vmk[j]);
                     n_vis += __popcll(vm[j]);
                     writelane64(vm[j], r0 + j, bits_lo, bits_hi);      // also what the cold loop reads back
@@ -1138,7 +1148,7 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
                 }
                 if (SET & O_RGBA) {
 #pragma unroll
-                    for (int j = 0; j < kRowGroup; ++j) {
+                    for (int j = 0; j < RG; ++j) {
                         // the row's 192 colour bytes: one (unaligned) dword per lane at byte 3 L - 1 (lane 0: byte 0), never
                         // past the end of the row
                         const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(rs_rgb, rgb_voff, (int)((rowg + (uint32_t)j) * Wb * 3u), 0);
@@ -1154,7 +1164,7 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
                 if (SET & O_XYZ32) {
                     const uint32_t fnan = 0x7FC00000u;
 #pragma unroll
-                    for (int j = 0; j < kRowGroup; ++j) {
+                    for (int j = 0; j < RG; ++j) {
                         const bool valid = __builtin_amdgcn_inverse_ballot_w64(vmk[j]);
                         uint32_t *dst = &lds_px[(j * 64 + c.lane) * 3];
                         dst[0] = valid ? __float_as_uint(fx[j]) : fnan;
@@ -1733,9 +1743,9 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
 #define MSPA_LAUNCH_TIGHT(SET_) \
     do { \
         if (flags & MSPA_PAIR_STREAM) \
-            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, true, tight_rows_of(SET_)>), grid, dim3(kTightThreads), 0, s, depth, rgb, frame_mats, pairs, a); \
+            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, true, tight_rows_of(SET_), tight_rg_of(SET_)>), grid, dim3(kTightThreads), 0, s, depth, rgb, frame_mats, pairs, a); \
         else \
-            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, false, tight_rows_of(SET_)>), grid, dim3(kTightThreads), 0, s, depth, rgb, frame_mats, pairs, a); \
+            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, false, tight_rows_of(SET_), tight_rg_of(SET_)>), grid, dim3(kTightThreads), 0, s, depth, rgb, frame_mats, pairs, a); \
     } while (0)
         if (set == kSetCorr) MSPA_LAUNCH_TIGHT(kSetCorr);
         else if (set == kSetDense) MSPA_LAUNCH_TIGHT(kSetDense);
