@@ -180,8 +180,21 @@ def _worker(rank, world, port, q):
     work.wait()
     assert g.shape == (5 * world, 2) and all(int(g[5 * r, 0]) == r + 1 for r in range(world))
     t = ctx.max_over_ranks(float(rank + 1))
+    # numeric tapes of different length per rank, as mspa/pipeline.py collates them: [header, rows...] per unit, width 8
+    from mspa import tape as TP
+    rec = TP.Recorder(None)
+    rec.note(torch.arange(3 + 5 * rank, dtype=torch.float64) * 0.1 + rank)
+    rows = rec.rows()
+    header = np.zeros((1, TP.WIDTH))
+    header[0, 0], header[0, 1] = 10 + rank, len(rows)
+    table = S.collate_records(torch.from_numpy(np.concatenate([header, rows], 0)), ctx).numpy()
+    got, pos = {}, 0
+    while pos < len(table):
+        key, n = int(table[pos, 0]), int(table[pos, 1])
+        got[key] = TP.Player(None, table[pos + 1:pos + 1 + n], "cpu").next().numpy().tolist()
+        pos += 1 + n
     ctx.barrier()
-    q.put((rank, full.numpy().tolist(), t))
+    q.put((rank, full.numpy().tolist(), t, got))
     ctx.close()
 
 
@@ -207,9 +220,37 @@ def test_shard_and_collate_gloo_world2():
     for (i, j) in all_pairs:
         r = O.frame_pair(sc.depth[ids[i]], sc.depth[ids[j]], sc.K, sc.E[ids[i]], sc.E[ids[j]], sc.A, (24, 32), col)
         expect.append([i, j, r["n_valid"], r["n_vis"]])
-    for rank, full, t in results:
+    for rank, full, t, tapes in results:
         assert full == expect, f"rank {rank}: collated records differ from the single-process table"
         assert t == 2.0
+        assert tapes == {10 + r: (np.arange(3 + 5 * r) * 0.1 + r).tolist() for r in range(2)}, "every rank's tape, whole, on every rank"
+
+
+def test_correspondences_rowmajor_view_on_host_tensors():
+    """engine.correspondences_rowmajor is indexing only (torch as plumbing): exercised here on CPU tensors laid out the way
+    mspa_pair_correspondences lays them out, ragged tiles included."""
+    from mspa import engine, _lib
+    rng = np.random.default_rng(3)
+    H, W = 100, 150                                           # 3 stripes x 3 bands, ragged at both edges
+    ns, nb = engine.corr_tiles((H, W))
+    assert (ns, nb) == (3, 3)
+    vis = rng.random((H, W)) < 0.2
+    xi = rng.integers(0, W, (H, W)).astype(np.int16)
+    yi = rng.integers(0, H, (H, W)).astype(np.int16)
+    bits = np.packbits(np.concatenate([vis.reshape(-1), np.zeros((-H * W) % 64, bool)]), bitorder="little").view(np.int64)
+    cpix = np.full((1, ns * nb, _lib.CORR_TILE_CAP, 2), -7, dtype=np.int16)
+    counts = np.zeros((1, ns * nb), dtype=np.int32)
+    for b in range(nb):
+        for s_ in range(ns):
+            sl = (slice(b * 48, (b + 1) * 48), slice(s_ * 64, (s_ + 1) * 64))
+            m = vis[sl]
+            t = b * ns + s_
+            counts[0, t] = m.sum()
+            cpix[0, t, :m.sum(), 0], cpix[0, t, :m.sum(), 1] = xi[sl][m], yi[sl][m]
+    out = {"vis_bits": torch.from_numpy(bits[None]), "cpix": torch.from_numpy(cpix), "tile_counts": torch.from_numpy(counts)}
+    i, gx, gy = engine.correspondences_rowmajor(out, (H, W), 0)
+    nz = np.nonzero(vis.reshape(-1))[0]
+    assert np.array_equal(i.numpy(), nz) and np.array_equal(gx.numpy(), xi.reshape(-1)[nz]) and np.array_equal(gy.numpy(), yi.reshape(-1)[nz])
 
 
 def test_batched_matrix_preparation_is_bit_identical_to_per_frame_numpy():
