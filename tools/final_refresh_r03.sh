@@ -24,5 +24,7 @@ bash tools/profile_scene.sh > /dev/null 2>&1
 bash tools/profile_scene_pmc.sh > /dev/null 2>&1
 python tools/ab_k3.py --sets corr,compact,minimal,dense_xyz,dense --steps 30 --rounds 3 --libs multi-spatialmllm_amd/libmspa.so > $O/ab_k3.txt 2>&1
 python tools/ab_k1.py > $O/ab_k1.txt 2>&1
+python tools/heads_bench.py > $O/heads.md 2> $O/heads.err
+python tools/scaled_bench.py > $O/scaled.txt 2>&1
 cat $O/pytest_gpu.txt $O/smoke.txt $O/ab_k3.txt $O/ab_k1.txt
 tail -c 300 $O/bench_n1.json
