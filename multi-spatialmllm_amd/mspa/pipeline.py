@@ -59,7 +59,6 @@ def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None,
     Returns {jsonl name: record count} on rank 0 (empty dict elsewhere)."""
     import pandas as pd
     import torch
-    import torch.distributed as dist
     from .scene import SceneOnDevice
 
     rank, world = (ctx.rank, ctx.world) if ctx is not None else (0, 1)

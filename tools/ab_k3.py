@@ -30,7 +30,6 @@ def main():
     import torch
     from mspa import _lib, engine
     device = torch.device("cuda", 0)
-    args = bench.parse_args.__wrapped__() if hasattr(bench.parse_args, "__wrapped__") else None
     sys.argv = [sys.argv[0]]
     args = bench.parse_args()
     sc = bench.make_base_scene(args, 0)
