@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{bits_lo, bits_hi}, rs_bits, (int)((uint32_t)c.lane * wpr * 8u),
                                                   (int)((row0 * wpr + stripe) * 8u), 0);
     }
-    if (O::template has<O_COUNTS>(a.counts)) {
+    if (O::template has<O_COUNTS>(a.counts) && (!COMPACT || a.counts != nullptr)) {   // the compacted set's counters are optional
         // the wave's totals go to bytes 16..23 of its own (finished) depth tile; thread 0 sums the four after the barrier
         int *red = reinterpret_cast<int *>(&lds_w[wave][kPadPx + 8]);
         if (c.lane == 0) {
@@ -1691,7 +1691,7 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
     uint32_t set = 0;
     set |= out_vis_bits ? O_VIS_BITS : 0; set |= out_vis_u8 ? O_VIS_U8 : 0; set |= out_valid_u8 ? O_VALID_U8 : 0;
     set |= out_pix_i16 ? O_PIX : 0; set |= out_xyz_f32 ? O_XYZ32 : 0; set |= out_rgba ? O_RGBA : 0;
-    set |= out_counts ? O_COUNTS : 0; set |= out_cpix ? O_CPIX : 0;
+    set |= out_counts ? O_COUNTS : 0; set |= out_cpix ? (O_CPIX | O_COUNTS) : 0;   // compacted set: counters optional at run time
     // the tight kernel's LDS-DMA moves depth in 4-byte units and its 16-byte stores need aligned outputs
     const bool aligned = (((uintptr_t)depth & 3u) == 0) && (((uintptr_t)out_pix_i16 & 15u) == 0) &&
                          (((uintptr_t)out_vis_bits & 7u) == 0) && (((uintptr_t)out_cpix & 15u) == 0) &&

@@ -176,3 +176,30 @@ def test_compact_argument_checks():
     # zero pairs: nothing to do
     empty = engine.alloc_pair_correspondences(0, hw, DEV)
     engine.pair_correspondences(depth, mats, pairs[:0], hw, empty)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw,n_pairs", [((48, 64), 1), ((48, 64), 3), ((96, 64), 9), ((48, 192), 17)],
+                         ids=["one-tile-1", "one-tile-3", "two-bands-9", "three-stripes-17"])
+def test_fused_compact_small_shapes_and_odd_batch_sizes(hw, n_pairs):
+    """A single tile, batches that are not a multiple of the XCD count, and no counter output."""
+    sc, ids, depth, mats = scene_inputs(hw, seed=1717, frames=4)
+    rng = np.random.default_rng(n_pairs)
+    pair_idx = [(int(a), int(b)) for a, b in rng.integers(0, len(ids), (n_pairs, 2))]
+    pairs = torch.tensor(pair_idx, dtype=torch.int32, device=DEV)
+    out = engine.alloc_pair_correspondences(n_pairs, hw, DEV, counts=False)
+    for t in out.values():
+        t.fill_(-9)
+    engine.pair_correspondences(depth, mats, pairs, hw, out, flags=_lib.PAIR_FAST)
+    assert _lib.load().mspa_pair_reproject_last_kernel() == _lib.KERNEL_PAIR_FAST_TIGHT
+    assert "counts" not in out
+    torch.cuda.synchronize()
+    out_np = {k: v.cpu().numpy() for k, v in out.items()}
+    P = hw[0] * hw[1]
+    for n, (a, b) in enumerate(pair_idx):
+        ref = O.frame_pair(sc.depth[ids[a]], sc.depth[ids[b]], sc.K, sc.E[ids[a]], sc.E[ids[b]], sc.A, hw)
+        assert np.array_equal(unpack_bits(out_np["vis_bits"][n], P), ref["vis"])
+        segs, counts = expected_segments(ref["vis"], ref["xi"], ref["yi"], hw)
+        assert np.array_equal(out_np["tile_counts"][n], counts)
+        for t, seg in enumerate(segs):
+            assert np.array_equal(out_np["cpix"][n, t, :len(seg)], seg)
