@@ -79,6 +79,29 @@ def main():
                     xlo = min(max((xr - bw // 2) & ~7, 0), W - bw)
                     ylo = min(max(yr - bh // 2, 0), H - bh)
                     fit[(bw, bh)] += bool(((x[m] >= xlo) & (x[m] < xlo + bw) & (y[m] >= ylo) & (y[m] < ylo + bh)).all())
+    # the same pixels, other lane <-> pixel shapes per gather instruction (64 pixels each): distinct 64-byte lines touched
+    shapes = {"64 x 1 (as built)": (1, 64), "32 x 2": (2, 32), "16 x 4": (4, 16), "8 x 8": (8, 8)}
+    shape_lines = {k: [0, 0] for k in shapes}
+    for p in sel[:20]:
+        a, b = pairs[p]
+        M = (mats[b, REPROJ].reshape(4, 4) @ mats[a, UNPROJ].reshape(4, 4))[:3]
+        d = sc.depth[ids[a]].astype(np.float64)
+        q = np.stack([xx * d, yy * d, d, np.full_like(d, 1000.0)], -1) @ M.T
+        with np.errstate(all="ignore"):
+            u, v = q[..., 0] / q[..., 2], q[..., 1] / q[..., 2]
+        inv = (d > 0) & (u >= 0) & (u < W) & (v >= 0) & (v < H) & (q[..., 2] > 0)
+        xi = np.clip(np.rint(np.nan_to_num(u, nan=0, posinf=1e9, neginf=-1e9)), 0, W - 1).astype(np.int64)
+        yi = np.clip(np.rint(np.nan_to_num(v, nan=0, posinf=1e9, neginf=-1e9)), 0, H - 1).astype(np.int64)
+        for r0 in range(0, H, 8):
+            for c0 in range(0, W, 64):
+                if not inv[r0:r0 + 8, c0:c0 + 64].any():
+                    continue
+                for name, (bh, bw) in shapes.items():
+                    for rb in range(r0, r0 + 8, bh):
+                        for cb in range(c0, c0 + 64, bw):
+                            x, y = xi[rb:rb + bh, cb:cb + bw].reshape(-1), yi[rb:rb + bh, cb:cb + bw].reshape(-1)
+                            shape_lines[name][0] += len(np.unique(y * 64 + (x >> 5)))
+                            shape_lines[name][1] += 1
     ng = groups - culled
     pct = lambda a, q: np.percentile(a, q).round(1).tolist()
     print("# Depth-2 gather footprints of the tight kernel's row groups (tools/footprint_stats.py, CPU analysis)\n")
@@ -94,6 +117,11 @@ def main():
     print(f"| bounding box of a group's projections: height, 50 / 75 / 90 / 95 th pct | {pct(hs, [50, 75, 90, 95])} |")
     for (bw, bh), c in fit.items():
         print(f"| groups covered by a {bw} x {bh} box around the middle in-view lane ({bw * bh * 2} B of LDS, {bw * bh * 2 // 64} line requests) | {c / ng:.3f} |")
+    print("\nDistinct 64-byte lines per 64-lane gather for other lane <-> pixel shapes (8 x 64 blocks with a lane in view; the front end's")
+    print("cost of a gather is ~14 + 1.2 cycles per distinct line when everything hits: tools/ubench/gather_rates.hip, profiles/r03_gather_rates.txt):\n")
+    print("| pixels of one gather instruction | distinct lines | modelled front-end cycles |\n|---|---|---|")
+    for name, (l, n_) in shape_lines.items():
+        print(f"| {name} | {l / n_:.1f} | {14 + 1.2 * l / n_:.0f} |")
 
 
 if __name__ == "__main__":
