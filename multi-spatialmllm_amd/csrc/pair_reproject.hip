@@ -782,7 +782,10 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m, uint32_t base)
 // on (-1, -1).  Three forms that staged the entries in LDS were measured slower (tools/ab_k3.py, one box): a 512-entry ring
 // and a 320-entry buffer with carry, storing 1 KB chunks -- their 1.25 - 2 KB per wave cost the kernel a workgroup per CU
 // (0.586 / 0.536 ms; profiles/r03a_k3_compact_fulltile_ring512_pmc.md) -- and a 128-entry buffer in the tile's pad storing
-// 64-entry chunks at the same occupancy as the direct form (0.483 vs 0.468 ms).
+// 64-entry chunks at the same occupancy as the direct form (0.483 vs 0.468 ms); a fourth that ranks a whole row group into the
+// dead depth rows and stores it as one aligned 16-byte-per-lane piece (0.7 M store instructions instead of 2.2 M) came out
+// equal (0.3916 vs 0.3917 ms) -- the stores were never the problem.  What was: the rewrite of every tile with a guarded row
+// (see the cold loop), 0.07 of 0.46 ms.
 
 template <uint32_t SET, bool STREAM, int ROWS, int RG>
 __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
@@ -1079,7 +1082,13 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
                         const int xi = med3_0((int)ru, hi_x);
                         const int yi = med3_0((int)rv, hi_y);
                         // every lane gathers: the clamped index is always inside the image
+#if !defined(MSPA_EXPERIMENT_GATHER)
                         dv16[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, (int)(__umul24((uint32_t)yi, dw2) + ((uint32_t)xi << 1)), 0, 0);
+#elif MSPA_EXPERIMENT_GATHER == 1   // timing only (wrong results): every lane reads the first lane's row -- a coalesced gather
+                        dv16[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, (int)(__umul24((uint32_t)__builtin_amdgcn_readfirstlane(yi), dw2) + ((uint32_t)xi << 1)), 0, 0);
+#else                               // timing only (wrong results): no gather at all
+                        dv16[j] = (uint32_t)xi + 1000u;
+#endif
                         pix[j] = (int)((uint32_t)xi | ((uint32_t)yi << 16));
                         // With t = u - rint(u) in [-0.5, 0.5] a decision can flip only if |t| is within the guard of
                         // 0.5 (rounding tie) or of 0 (u at an integer: the image bounds are integers), i.e. unless
@@ -1183,9 +1192,25 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
         }
 
         // ---- cold loop: rows with guarded lanes are re-evaluated with the exact chain ---------------
-        const bool redo = COMPACT && risky_rows != 0;       // compacted set: see below
+        bool redo = false;                                  // compacted set: a guarded lane changed its visibility (wave-uniform)
+#ifdef MSPA_EXPERIMENT_NOCOLD   // timing only (wrong results on rows with guarded lanes)
+        risky_rows = 0;
+#endif
         if (risky_rows) {
             __builtin_amdgcn_s_waitcnt(0);                 // the fast path's stores are in L2, LDS writes landed
+            // compacted set: lane r <- entries of the tile's rows above r (exclusive prefix of the rows' popcounts), so that
+            // a guarded lane that stays visible can be patched at its rank
+            uint32_t cpref = 0;
+            if (COMPACT) {
+                const uint32_t cnt = (uint32_t)__popc(bits_lo) + (uint32_t)__popc(bits_hi);
+                uint32_t incl = cnt;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+                    if (c.lane >= off) incl += t;
+                }
+                cpref = incl - cnt;
+            }
             while (risky_rows) {                            // wave-uniform
                 const int g = __builtin_amdgcn_readfirstlane(__builtin_ctzll(risky_rows));
                 risky_rows &= risky_rows - 1ull;
@@ -1195,25 +1220,41 @@ __global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight
                 const uint32_t i = row * Wb + col;
                 const bool mine = (rb >> c.lane) & 1ull;
                 bool vis = (old >> c.lane) & 1ull;
+                int cxi = 0, cyi = 0;
                 if (mine) {
                     Pixel p;
                     exact_unproject(m1, mxd, (double)row, (double)c.depth1[i] * 0.001, p.ax, p.ay, p.az);
                     exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
                     p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi, &p.inview);
                     vis = p.vis;
+                    cxi = p.xi;
+                    cyi = p.yi;
                     store_pixel<O, true>(a, c, i, true, true, p);
                 }
                 const unsigned long long fresh = ballot64(vis);
                 n_vis += __popcll(fresh) - __popcll(old);
                 writelane64(fresh, g, bits_lo, bits_hi);
+                if (COMPACT) {
+                    // A guarded lane that stays visible keeps its rank: its entry is rewritten in place with the reference
+                    // chain's index (almost always the value the fast path wrote).  One that changes visibility shifts every
+                    // later rank of the tile: the segment is rebuilt below.
+                    if (fresh != old) {
+                        redo = true;
+                    } else if (mine && vis) {
+                        __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(uint16_t)cxi | ((uint32_t)(uint16_t)cyi << 16), rs_cpix,
+                                                              (int)(mbcnt64(old, (uint32_t)__builtin_amdgcn_readlane((int)cpref, g)) * 4u), 0, 0);
+                    }
+                }
             }
         }
         if (COMPACT) {
             if (redo) {
-                // A guarded lane may have changed its visibility (every later rank of the tile shifts) or its pixel index:
-                // the tile's segment is rewritten from the patched visibility words with the reference chain for every
-                // visible pixel -- which yields the very indices the fast path wrote for unguarded lanes, that being the
-                // guard band's contract.  ~0.3 % of the tiles (identity pairs: all of them).
+                // A guarded lane changed its visibility: the tile's segment is rewritten from the patched visibility words
+                // with the reference chain for every visible pixel -- which yields the very indices the fast path wrote for
+                // unguarded lanes, that being the guard band's contract.  Rebuilding the segment of EVERY tile with a
+                // guarded row (2.5 % of the tiles: 48 serialized row round trips each) cost the kernel 0.07 of 0.46 ms;
+                // a change of visibility needs fast and exact chain to disagree inside the band, which on real frames
+                // all but never happens (identity pairs, where every depth test is a tie: all tiles).
                 uint32_t base = 0;
                 for (int r = 0; r < ROWS; ++r) {                    // wave-uniform
                     const unsigned long long w = readlane64(bits_lo, bits_hi, r);
@@ -1677,7 +1718,7 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
     const int n_xcd = xcd_count();
     a.xcd_shift = n_xcd == 8 ? 3u : 0u;
 
-    if (out_counts) {
+    if (out_counts) {      // 2 us per launch (tools/ab_k3.py: 0.5044 vs 0.5062 ms without / with)
         int rc = check_hip(hipMemsetAsync(out_counts, 0, sizeof(int32_t) * 2 * n_pairs, s), "hipMemsetAsync(counts)");
         if (rc) return rc;
     }

@@ -203,3 +203,51 @@ def test_fused_compact_small_shapes_and_odd_batch_sizes(hw, n_pairs):
         assert np.array_equal(out_np["tile_counts"][n], counts)
         for t, seg in enumerate(segs):
             assert np.array_equal(out_np["cpix"][n, t, :len(seg)], seg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(96, 128), (480, 640)], ids=["96x128", "640x480"])
+def test_guarded_lanes_that_stay_visible_are_patched_in_place(hw):
+    """Fronto-parallel plane, camera 2 shifted sideways by a whole number of pixels: every projection sits on an integer
+    (the "u at an integer" guard), so EVERY lane is re-evaluated with the reference chain, while the depth test has a 5 mm
+    margin and no lane changes visibility -- each entry of each tile goes through the rewrite-at-its-rank path (a wrong
+    rank would clobber a neighbour).  The second pair adds holes so that ranks differ from columns."""
+    H, W = hw
+    K = np.array([[500.0, 0, W / 2 - 0.5, 0], [0, 500.0, H / 2 - 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    A = np.eye(4)
+    shift_px, d_mm = 8, 2000
+    E0 = np.eye(4)
+    E1 = np.eye(4)
+    E1[0, 3] = shift_px * (d_mm * 0.001) / 500.0            # camera-to-world: camera 2 sits to the right
+    d0 = np.full((H, W), d_mm, dtype=np.uint16)
+    d0_holes = d0.copy()
+    rng = np.random.default_rng(5)
+    d0_holes[rng.random((H, W)) < 0.3] = 0
+    d1 = np.full((H, W), d_mm + 5, dtype=np.uint16)
+    frames = [d0, d1, d0_holes]
+    Es = [E0, E1, E0]
+    depth = engine.depth_to_device(np.stack(frames), DEV)
+    mats = torch.from_numpy(engine.frame_matrices(K, A, Es)).to(DEV)
+    pair_idx = [(0, 1), (2, 1)]
+    pairs = torch.tensor(pair_idx, dtype=torch.int32, device=DEV)
+    out = poisoned_outputs(len(pair_idx), hw)
+    engine.pair_correspondences(depth, mats, pairs, hw, out, flags=_lib.PAIR_FAST)
+    assert _lib.load().mspa_pair_reproject_last_kernel() == _lib.KERNEL_PAIR_FAST_TIGHT
+    torch.cuda.synchronize()
+    out_np = {k: v.cpu().numpy() for k, v in out.items()}
+    for n, (a, b) in enumerate(pair_idx):
+        ref = O.frame_pair(frames[a], frames[b], K, Es[a], Es[b], A, hw)
+        assert ref["n_vis"] > 0.5 * (frames[a] > 0).sum()               # most of the plane lands in frame 2
+        check_pair(out_np, n, ref, hw)
+    # nothing past a tile's count was written.  (Not the first stripe and the first band: column 8 projects onto u = 0 and
+    # row 0 onto v = 0 up to rounding, where fast and exact chain may disagree about "in view" -- a change of visibility: the
+    # tile is rebuilt and may keep stale entries behind its count.)
+    cp, tc = out_np["cpix"], out_np["tile_counts"]
+    n_stripes = W // TW
+    checked = 0
+    for n in range(len(pair_idx)):
+        for t in range(n_stripes, cp.shape[1]):
+            if t % n_stripes:
+                assert (cp[n, t, int(tc[n, t]):] == -7).all()
+                checked += 1
+    assert checked > 0

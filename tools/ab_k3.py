@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--workload", default="vc")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per launch (default: the bench's 1 000); times are printed per 1 000 pairs")
     ap.add_argument("--libs", default="", help="comma list of library paths (default: tools/ab/libmspa_*.so + in-tree)")
     a = ap.parse_args()
     import torch
@@ -33,6 +34,8 @@ def main():
     sys.argv = [sys.argv[0]]
     args = bench.parse_args()
     sc = bench.make_base_scene(args, 0)
+    if a.pairs:
+        args.pairs = a.pairs
     args.also = "dense:fast"                                   # so that rgb frames exist
     depth, mats, rgb, nb, reps = bench.build_inputs(args, 0, device, sc)
     overlap = bench.scene_overlap_table(sc, device)
@@ -88,7 +91,7 @@ def main():
                         launch(h, s)
                     e1.record()
                     torch.cuda.synchronize()
-                    res[k][s].append(e0.elapsed_time(e1) / a.steps)       # includes the 2 us counter memset per launch
+                    res[k][s].append(e0.elapsed_time(e1) / a.steps * 1000.0 / n)   # per 1 000 pairs; includes the 2 us counter memset per launch
                 except Exception as ex:                                   # a timing-only build may refuse a set
                     res[k][s].append(float("nan"))
     for k in handles:
