@@ -711,6 +711,9 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 #ifndef MSPA_SCALED_ROW_BARRIER
 #define MSPA_SCALED_ROW_BARRIER 1      // ScanNet-shape kernel: 100 -> 73 VGPRs (4 -> 6 waves per SIMD), 2.30 -> 2.11 ms per 1 000 pairs
 #endif
+#ifndef MSPA_SCALED_TILE_CULL
+#define MSPA_SCALED_TILE_CULL 1        // ScanNet-shape kernel: frustum test of a tile's colour box against frame 2 before projecting it
+#endif
 #ifndef MSPA_TIGHT_WAVES_PER_EU
 #define MSPA_TIGHT_WAVES_PER_EU 0      // > 0: ask the register allocator for that many waves per SIMD
 #endif
@@ -1428,6 +1431,65 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
             E64[k] = uniform(64.0 * M[k][0]);
             Wr[k] = uniform(M[k][1] - (double)W_ * M[k][0]);
         }
+        // ---- tile-level culling (as in the tight kernel; not for the last stripe, whose words wrap into the next row) ----
+        // The tile's pixels lie in the colour box [cA, cB] x [rA, rB] (64 columns + the largest wobble), their depth-1 samples
+        // in the depth box the two tables map its corners to (both tables are monotone): the box's sample range comes from
+        // <= 7 eight-byte loads per lane (16 lanes per depth row, 4 rows per instruction), and if all 8 corners of the
+        // frustum {d (mx, my, 1)} violate ONE of the in-view half-spaces by a margin, no pixel of the tile can land in
+        // frame 2: its groups then only count their valid samples and write "nothing visible".
+        bool culled = false;
+#if MSPA_SCALED_TILE_CULL
+        if (!last) {
+            typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+            const uint32_t cA = stripe * 64u, cB = cA + 63u + (uint32_t)kOff[1];       // kOff[1] is the largest wobble
+            static_assert(kOff[1] >= kOff[2] && kOff[1] >= kOff[3] && (S - 2) * 64 + 63 + kOff[1] < W_, "colour box of a tile");
+            const uint32_t rA = row0, rB = row0 + 4u * (uint32_t)n_groups - 1u;
+            const uint32_t dxA = lds_dx[cA], dxB = lds_dx[cB];                          // byte offsets within a depth row
+            const uint32_t dyA = lds_dy[rA], dyB = lds_dy[rB];                          // byte offsets of the depth rows
+            const uint32_t xb0 = dxA & ~7u;
+            const uint32_t nxb = (dxB + 2u - xb0 + 7u) >> 3;                            // 8-byte pieces per depth row
+            const uint32_t nrow = (dyB - dyA) / (uint32_t)(DW_ * 2) + 1u;
+            static_assert((DW_ * 2) % 8 == 0, "8-byte pieces never straddle a depth row");
+            const uint32_t xoff = xb0 + min((uint32_t)c.lane & 15u, nxb - 1u) * 8u;
+            const uint32_t q = (uint32_t)c.lane >> 4;
+            us4 mn = {0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF}, mxv = {0, 0, 0, 0};
+            const us4 one = {1, 1, 1, 1};
+            const uint32_t nk = __builtin_amdgcn_readfirstlane((nrow + 3u) >> 2);
+            for (uint32_t k = 0; k < nk; ++k) {
+                const uint32_t r = min(4u * k + q, nrow - 1u);
+                const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs_d1, (int)(dyA + r * (uint32_t)(DW_ * 2) + xoff), 0, 0);
+                us4 x;
+                __builtin_memcpy(&x, &w, 8);
+                mn = __builtin_elementwise_min(mn, (us4)(x - one));                     // 0 (invalid) wraps to 0xFFFF
+                mxv = __builtin_elementwise_max(mxv, x);
+            }
+            int lo = min(min((int)mn.x, (int)mn.y), min((int)mn.z, (int)mn.w));
+            int hi = max(max((int)mxv.x, (int)mxv.y), max((int)mxv.z, (int)mxv.w));
+            for (int off = 32; off > 0; off >>= 1) {
+                lo = min(lo, __shfl_xor(lo, off));
+                hi = max(hi, __shfl_xor(hi, off));
+            }
+            if (hi == 0) {
+                culled = true;                                                          // no valid depth sample in the box
+            } else {
+                const int k = c.lane & 7;
+                const double cx = (double)((k & 1) ? cB : cA);
+                const double cy = (double)((k & 2) ? rB : rA);
+                const double cd = (double)((k & 4) ? hi : lo + 1);
+                const double hx = __builtin_fma(__builtin_fma(M[0][1], cy, __builtin_fma(M[0][0], cx, M[0][2])), cd, M[0][3]);
+                const double hy = __builtin_fma(__builtin_fma(M[1][1], cy, __builtin_fma(M[1][0], cx, M[1][2])), cd, M[1][3]);
+                const double hz = __builtin_fma(__builtin_fma(M[2][1], cy, __builtin_fma(M[2][0], cx, M[2][2])), cd, M[2][3]);
+                const double kMargin = 1.0;                                             // homogeneous units (depth pixel * millimetre)
+                const bool all_behind = ballot64(hz <= -1e-3) == ~0ull;
+                const bool all_left = ballot64(hx < -kMargin) == ~0ull;
+                const bool all_right = ballot64(hx - DWd * hz > kMargin) == ~0ull;
+                const bool all_above = ballot64(hy < -kMargin) == ~0ull;
+                const bool all_below = ballot64(hy - DHd * hz > kMargin) == ~0ull;
+                culled = all_behind | all_left | all_right | all_above | all_below;
+            }
+            culled = __builtin_amdgcn_readfirstlane((int)culled) != 0;                  // wave-uniform, and known to be
+        }
+#endif
         // The tile body once per kind of stripe (compile-time LAST): a run-time flag inside the row loop would keep both
         // variants' masks and corrections live at once (52 spilled SGPRs).
         auto run_tile = [&](auto last_c) {
@@ -1463,8 +1525,25 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
             };
             uint32_t d16n[NCH];
             load_group(0, d16n);
+            int g_first = 0;
+            if (!LAST && culled) {                           // wave-uniform: count the valid samples, write "nothing visible"
     #pragma unroll 1
-            for (int g = 0; g < n_groups; ++g) {
+                for (int g = 0; g < n_groups; ++g) {
+                    uint32_t d16[NCH];
+    #pragma unroll
+                    for (int e = 0; e < NCH; ++e) d16[e] = d16n[e];
+                    if (g + 1 < n_groups) load_group(g + 1, d16n);
+    #pragma unroll
+                    for (int e = 0; e < NCH; ++e) n_valid += __popcll(ballot64(d16[e] != 0u));
+                    if (O::template has<O_PIX>(a.pix_i16)) {
+                        const u32x4_t none = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                        buffer_store_b128_guarded(none, rs_pix, pix_voff, (int)((period0 + (uint32_t)g) * (uint32_t)kPeriodWords * 256u));
+                    }
+                }
+                g_first = n_groups;
+            }
+    #pragma unroll 1
+            for (int g = g_first; g < n_groups; ++g) {
                 uint32_t d16[NCH];
     #pragma unroll
                 for (int e = 0; e < NCH; ++e) {

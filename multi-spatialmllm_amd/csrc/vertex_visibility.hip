@@ -442,7 +442,11 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
             const double sd = izs[k] - (double)d[k];
             bool vis = sd < 0.0;
             const bool rk = active[k] & (risky[k] | !(__builtin_fabs(sd) > kVGuardZmm));
+#ifdef MSPA_EXPERIMENT_NOCOLD   // timing only (wrong results for guarded lanes)
+            if (false) {
+#else
             if (__builtin_amdgcn_ballot_w64(rk) != 0ull) {            // rare: the reference chain (IH:57-69, 337-386)
+#endif
                 if (rk) {
                     const int img = img0 + (int)qq[k];
                     const double *__restrict__ Einv = cam_mats + (int64_t)img * 32;

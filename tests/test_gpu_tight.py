@@ -341,3 +341,57 @@ def test_scaled_kernel_reproduces_reference_digest():
         assert sha(vis[valid]) == str(g["pair_sha_vis"]) and int(vis.sum()) == int(g["pair_n_vis"]) == int(res["counts"][0, 1])
         for k in ("vis_bits", "pix_i16", "counts"):
             assert np.array_equal(res[k], ex[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw,dhw,kernel", [((480, 640), (480, 640), "tight"), (SCANNET_HW, SCANNET_DHW, "scaled")], ids=["640x480", "scannet"])
+def test_tile_culling_with_large_holes_and_distant_views(hw, dhw, kernel):
+    """Tile-level culling: tiles whose depth box holds no valid sample at all (a quarter of frame 0 is a hole), tiles
+    that cannot land in the other view (cameras back to back, side by side looking apart) and tiles that straddle the edge
+    of the other view -- every integer output of the fast kernel equals the exact kernel's."""
+    rng = np.random.default_rng(17)
+    H, W = hw
+    K = np.array([[1.1 * W / 1.3, 0, W / 2 - 0.5, 0], [0, 1.1 * W / 1.3, H / 2 - 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    Kd = K.copy()
+    Kd[0] *= dhw[1] / W
+    Kd[1] *= dhw[0] / H
+    A = np.eye(4)
+
+    def pose(yaw_deg, tx):
+        c, s = np.cos(np.radians(yaw_deg)), np.sin(np.radians(yaw_deg))
+        E = np.eye(4)
+        E[:3, :3] = [[c, 0, s], [0, 1, 0], [-s, 0, c]]
+        E[0, 3] = tx
+        return E
+    E = [pose(0, 0), pose(35, 0.3), pose(180, 0), pose(-70, -0.5), pose(8, 0.05)]
+    boxes = synth._make_boxes(rng)
+    depth_np = []
+    for k, e in enumerate(E):
+        z = synth.render_depth(A @ e, Kd, dhw, boxes)
+        mm = np.clip(np.rint(z * 1000.0), 0, 65535).astype(np.uint16)
+        if k == 0:
+            mm[:dhw[0] // 2, :dhw[1] // 2] = 0                      # a hole of whole tiles
+        if k == 4:
+            mm[rng.random(mm.shape) < 0.5] = 0
+        depth_np.append(mm)
+    depth = engine.depth_to_device(np.stack(depth_np), DEV)
+    mats = torch.from_numpy(engine.frame_matrices(K, A, E)).to(DEV)
+    pair_np = np.array([(a, b) for a in range(5) for b in range(5)], dtype=np.int32)
+    pairs = torch.from_numpy(pair_np).to(DEV)
+    outs = SETS["corr"]
+    for stream in (False, True):
+        fast = engine.alloc_pair_outputs(len(pair_np), hw, outs, DEV)
+        exact = engine.alloc_pair_outputs(len(pair_np), hw, outs, DEV)
+        for t in fast.values():
+            t.fill_(23)
+        engine.pair_reproject(depth, mats, pairs, hw, fast, flags=_lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0))
+        assert _lib.load().mspa_pair_reproject_last_kernel() == (_lib.KERNEL_PAIR_FAST_TIGHT if kernel == "tight" else _lib.KERNEL_PAIR_FAST_SCALED)
+        engine.pair_reproject(depth, mats, pairs, hw, exact, flags=0)
+        torch.cuda.synchronize()
+        for k in outs:
+            if not torch.equal(fast[k], exact[k]):
+                bad = (fast[k] != exact[k]).reshape(len(pair_np), -1).any(dim=1).nonzero().flatten().tolist()
+                raise AssertionError(f"{k} differs from the exact kernel in pairs {[tuple(pair_np[i]) for i in bad[:8]]}")
+        c = exact["counts"].cpu().numpy()
+        assert c[5 * 0 + 2, 1] == 0 and c[5 * 2 + 0, 1] == 0          # back to back: nothing visible
+        assert c[:, 1].sum() > 100000
