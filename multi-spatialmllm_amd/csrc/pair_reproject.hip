@@ -1608,7 +1608,13 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
                         const double ru = __builtin_rint(u[e]), rv = __builtin_rint(v[e]);
                         const int xi = med3_0((int)ru, hi_x);
                         const int yi = med3_0((int)rv, hi_y);
+#if !defined(MSPA_EXPERIMENT_GATHER)
                         dv16[e] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, (int)(__umul24((uint32_t)yi, (uint32_t)(DW_ * 2)) + ((uint32_t)xi << 1)), 0, 0);
+#elif MSPA_EXPERIMENT_GATHER == 1   // timing only, as in the tight kernel
+                        dv16[e] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, (int)(__umul24((uint32_t)__builtin_amdgcn_readfirstlane(yi), (uint32_t)(DW_ * 2)) + ((uint32_t)xi << 1)), 0, 0);
+#else
+                        dv16[e] = (uint32_t)xi + 1000u;
+#endif
                         pix[e] = (int)((uint32_t)xi | ((uint32_t)yi << 16));
                         const double wu = __builtin_fabs(u[e] - ru) - 0.25;
                         const double wv = __builtin_fabs(v[e] - rv) - 0.25;
