@@ -25,7 +25,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--workload", default="vc")
-    ap.add_argument("--pairs", type=int, default=0, help="pairs per launch (default: the bench's 1 000); times are printed per 1 000 pairs")
+    ap.add_argument("--repeat", type=int, default=1, help="the bench's 1 000 pairs this many times over in one launch (same mix of "
+                    "overlaps: drawing MORE pairs from the sampler changes the mix); times are printed per 1 000 pairs")
     ap.add_argument("--libs", default="", help="comma list of library paths (default: tools/ab/libmspa_*.so + in-tree)")
     a = ap.parse_args()
     import torch
@@ -34,13 +35,11 @@ def main():
     sys.argv = [sys.argv[0]]
     args = bench.parse_args()
     sc = bench.make_base_scene(args, 0)
-    if a.pairs:
-        args.pairs = a.pairs
     args.also = "dense:fast"                                   # so that rgb frames exist
     depth, mats, rgb, nb, reps = bench.build_inputs(args, 0, device, sc)
     overlap = bench.scene_overlap_table(sc, device)
     pairs_np, _, _ = bench.workload_pairs(overlap, nb, reps, args.pairs, a.workload, 0)
-    pairs = torch.from_numpy(pairs_np).to(device)
+    pairs = torch.from_numpy(pairs_np).to(device).repeat(a.repeat, 1)
     n = pairs.shape[0]
     H, W = bench.H, bench.W
     sets = [s for s in a.sets.split(",") if s]
