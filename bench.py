@@ -709,7 +709,7 @@ def main():
             extra[lg] = leg(v, m, pairs, short, args.workload)
         if not args.no_sweep:
             # the same pairs four times over in ONE launch (same mix of overlaps): does a launch of configs[1]'s size pay for the
-            # ramp and the tail of its grid?  Measured: no -- the larger launch is ~4 % slower per pair.
+            # ramp and the tail of its grid?  Measured: no -- within +-4 % of the 1 000-pair launch, either way.
             _, k4, _ = time_variant(args.variant, args.mode, depth, mats, rgb, pairs.repeat(4, 1), max(short, 5), 3, None, stream)
             extra["launch_size"] = {"variant": f"{args.variant}:{args.mode}", "pairs_per_launch": 4 * args.pairs,
                                     "kernel_ms_per_1000_pairs": round(k4 / 4 * 1000.0 / args.pairs, 4),
