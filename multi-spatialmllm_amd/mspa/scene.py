@@ -206,6 +206,17 @@ class SceneOnDevice:
         engine.pair_reproject(self.depth, self.frame_mats, pairs, self.image_hw, out, rgb=self.rgb, flags=flags)
         return out
 
+    def pair_correspondences(self, pairs_ids: Sequence[Tuple[str, str]], fast: bool = True):
+        """K3 with the compacted output (include/mspa.h, mspa_pair_correspondences): per pair the visibility bitset and, per
+        64 x 48 tile of the first image, the second image's depth pixel (xi, yi) of the VISIBLE pixels only.
+        ``engine.correspondences_rowmajor(out, self.image_hw, k)`` gives pair k's flat (pixel, xi, yi) in np.nonzero order."""
+        pairs = torch.tensor([[self.index[a], self.index[b]] for a, b in pairs_ids], dtype=torch.int32,
+                             device=self.device).reshape(-1, 2)
+        out = engine.alloc_pair_correspondences(pairs.shape[0], self.image_hw, self.device)
+        flags = engine._lib.PAIR_FAST if (fast and engine.fast_path_ok(self.K)) else 0
+        engine.pair_correspondences(self.depth, self.frame_mats, pairs, self.image_hw, out, flags=flags)
+        return out
+
 
 def pack_index_lists(index_lists: Sequence[Sequence[int]], n_points: int) -> np.ndarray:
     """Vertex-index lists -> [len, ceil(n_points/64)] int64 bitset rows (bit i of word w = vertex 64w+i)."""

@@ -251,3 +251,27 @@ def test_guarded_lanes_that_stay_visible_are_patched_in_place(hw):
                 assert (cp[n, t, int(tc[n, t]):] == -7).all()
                 checked += 1
     assert checked > 0
+
+
+@pytest.mark.gpu
+def test_scene_on_device_pair_correspondences():
+    """The resident-scene entry point (mspa/scene.py): image-id pairs in, compacted correspondences out, flat view in
+    np.nonzero order -- against the oracle."""
+    from mspa.scene import SceneOnDevice
+    hw = (96, 128)
+    sc = synth.make_scene(1011, n_points=64, n_frames=4, color_hw=hw, depth_hw=hw, invalid_pose_frac=0.0, with_color=False,
+                          trajectory="sweep", walk_step=0.08)
+    scene = SceneOnDevice(sc.K, sc.A, sc.E, sc.depth, sc.color_hw, sc.points, DEV)
+    ids = sc.valid_image_ids
+    pair_ids = [(ids[0], ids[1]), (ids[2], ids[0]), (ids[3], ids[3])]
+    out = scene.pair_correspondences(pair_ids)
+    torch.cuda.synchronize()
+    out_np = {k: v.cpu().numpy() for k, v in out.items()}
+    for n, (a, b) in enumerate(pair_ids):
+        ref = O.frame_pair(sc.depth[a], sc.depth[b], sc.K, sc.E[a], sc.E[b], sc.A, hw)
+        check_pair(out_np, n, ref, hw)
+        i, xi, yi = engine.correspondences_rowmajor(out, hw, n)
+        nz = np.nonzero(ref["vis"])[0]
+        assert np.array_equal(i.cpu().numpy(), nz) and np.array_equal(xi.cpu().numpy(), ref["xi"][nz])
+        assert np.array_equal(yi.cpu().numpy(), ref["yi"][nz])
+    assert scene.pair_correspondences([])["tile_counts"].shape[0] == 0
