@@ -1,12 +1,12 @@
 // K3: frame-pair back-projection -> reprojection -> depth-buffer visibility (see include/mspa.h).
 //
-// Common to all three kernels.  Blocks of one pair are numbered so that they land on one XCD (the
+// Common to all four kernels.  Blocks of one pair are numbered so that they land on one XCD (the
 // hardware dispatches block b to XCD b % 8): the frame-2 depth image the pair gathers from (600 KB)
 // then stays in that XCD's 4 MB L2.  Camera matrices are read through wave-uniform addresses, i.e.
 // as scalar loads into SGPRs -- the one operand v_fma_f64 takes for free -- while the per-pixel
 // chain lives in VGPRs.  No MFMA: this is point geometry, bound by HBM and VALU issue.
 //
-// Three kernels behind one entry point:
+// Four kernels behind one entry point (mspa_pair_correspondences adds the compacted output set of the third):
 //   * pair_exact_kernel -- the reference's own operation order (five sequential 3x4 products, IEEE
 //     division); a workgroup owns a strip of 4096 consecutive pixels, lanes take consecutive pixels.
 //     Float64 outputs are bit-identical to the C oracle.  ~100 FP64 VALU ops / pixel: issue bound.
@@ -19,6 +19,8 @@
 //   * pair_fast_tight_kernel (MSPA_PAIR_FAST, whole-tile images such as 640x480) -- the benchmarked
 //     one: same arithmetic, plus LDS-DMA depth tiles, tile- and group-level culling, buffer-resource
 //     addressing and 16-byte stores (see the comment above it).
+//   * pair_fast_scaled_kernel (MSPA_PAIR_FAST, ScanNet's 1296 x 968 colour grid over 640 x 480 depth) -- the same machinery
+//     on stripes that follow the bitset's word boundaries, both grid scalings off the per-pixel path.
 #include "mspa_common.h"
 
 #include <type_traits>
