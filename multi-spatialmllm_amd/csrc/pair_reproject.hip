@@ -716,6 +716,9 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 #ifndef MSPA_SCALED_TILE_CULL
 #define MSPA_SCALED_TILE_CULL 1        // ScanNet-shape kernel: frustum test of a tile's colour box against frame 2 before projecting it
 #endif
+#ifndef MSPA_SCALED_FULL_WAIT
+#define MSPA_SCALED_FULL_WAIT 1        // ScanNet-shape kernel: one vmcnt(0) for a group's gathers instead of a counted wait per row (-1..4 %)
+#endif
 #ifndef MSPA_TIGHT_WAVES_PER_EU
 #define MSPA_TIGHT_WAVES_PER_EU 0      // > 0: ask the register allocator for that many waves per SIMD
 #endif
@@ -1625,6 +1628,9 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
                         if (MSPA_SCALED_ROW_BARRIER) __builtin_amdgcn_sched_barrier(0);   // see the tight kernel: registers vs interleaving
                     }
                     unsigned long long rbm[NCH];
+#if MSPA_SCALED_FULL_WAIT
+                    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): ONE wait for the group's gathers instead of one per row
+#endif
     #pragma unroll
                     for (int e = 0; e < NCH; ++e) {
                         const bool inview = __builtin_amdgcn_inverse_ballot_w64(ivm[e]);
