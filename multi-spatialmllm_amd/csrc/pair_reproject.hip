@@ -702,7 +702,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 #define MSPA_TIGHT_ROWS 48
 #endif
 #ifndef MSPA_TIGHT_BLOCK_WAVES
-#define MSPA_TIGHT_BLOCK_WAVES 4
+#define MSPA_TIGHT_BLOCK_WAVES 0       // 0 = per output set (tight_bw_of)
 #endif
 #ifndef MSPA_TIGHT_DMA16
 #define MSPA_TIGHT_DMA16 1
@@ -740,8 +740,17 @@ constexpr int kTightRowsDense = MSPA_TIGHT_ROWS_DENSE;
 // rows whose depth-2 gathers are in flight together: the sets without a transpose stage (minimal, compact) may take more
 constexpr int tight_rg_of(uint32_t set) { return (set & (O_PIX | O_XYZ32 | O_RGBA | O_VIS_U8)) ? kRowGroup : MSPA_TIGHT_RG_LIGHT; }
 constexpr int tight_rows_of(uint32_t set) { return (set & (O_XYZ32 | O_RGBA | O_VIS_U8)) ? kTightRowsDense : kTightRows; }
-constexpr int kTightBW = MSPA_TIGHT_BLOCK_WAVES;      // waves (= tiles) per workgroup
-constexpr int kTightThreads = kTightBW * kWave;
+// waves (= tiles) per workgroup, per output set (tools/ab_k3.py, one box, ms per 1 000 pairs at 1 / 2 / 4 / 8 waves): the sets
+// without an index table like small workgroups -- a workgroup's LDS is released only when its slowest tile is done --
+// minimal 0.325 / 0.309 / 0.319 / 0.351, compact 0.388 / 0.377 / 0.388 / 0.424; corr 0.525 / 0.505 / 0.503 / 0.558; the dense
+// point set without colour a large one, dense_xyz 1.303 / 1.200 / 1.149 / 1.132 (with colour words 4 stay better than 8:
+// 1.572 vs 1.587).  MSPA_TIGHT_BLOCK_WAVES > 0 forces one size for all (A/B builds).
+constexpr int tight_bw_of(uint32_t set) {
+    return MSPA_TIGHT_BLOCK_WAVES > 0 ? MSPA_TIGHT_BLOCK_WAVES
+           : (set & O_RGBA) ? 4
+           : (set & (O_XYZ32 | O_VIS_U8)) ? 8
+           : (set & O_PIX) ? 4 : 2;
+}
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int med3_0(int x, int hi) {   // clamp(x, 0, hi), hi wave-uniform
@@ -796,11 +805,12 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m, uint32_t base)
 // (see the cold loop), 0.07 of 0.46 ms.
 
 template <uint32_t SET, bool STREAM, int ROWS, int RG>
-__global__ __launch_bounds__(kTightThreads) MSPA_TIGHT_ATTR void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
+__global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
                                                                    const uint8_t *__restrict__ rgb,
                                                                    const double *__restrict__ mats,
                                                                    const int32_t *__restrict__ pairs, PairArgs a) {
     using O = Outs<SET, false>;
+    constexpr int kTightBW = tight_bw_of(SET);
     constexpr bool WANT_XYZ = (SET & O_XYZ32) != 0;
     constexpr bool COMPACT = (SET & O_CPIX) != 0;
     static_assert(RG == 4 || !(SET & (O_PIX | O_XYZ32 | O_RGBA | O_VIS_U8)), "the transpose stages move 4-row blocks");
@@ -1849,7 +1859,7 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
         a.n_tiles = linear ? (int)((P + (int64_t)kTileRows * 64 - 1) / ((int64_t)kTileRows * 64))
                            : a.n_stripes * ((H + tile_rows - 1) / tile_rows);
         a.stripe_magic = (uint32_t)((1ull << 32) / (uint64_t)a.n_stripes) + 1u;
-        const int bw = tight24 ? kTightBW : (kThreads / kWave);
+        const int bw = tight24 ? tight_bw_of(set) : (kThreads / kWave);
         a.strips = (a.n_tiles + bw - 1) / bw;
     } else {
         a.n_stripes = a.n_tiles = 0;
@@ -1877,9 +1887,9 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
 #define MSPA_LAUNCH_TIGHT(SET_) \
     do { \
         if (flags & MSPA_PAIR_STREAM) \
-            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, true, tight_rows_of(SET_), tight_rg_of(SET_)>), grid, dim3(kTightThreads), 0, s, depth, rgb, frame_mats, pairs, a); \
+            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, true, tight_rows_of(SET_), tight_rg_of(SET_)>), grid, dim3(tight_bw_of(SET_) * kWave), 0, s, depth, rgb, frame_mats, pairs, a); \
         else \
-            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, false, tight_rows_of(SET_), tight_rg_of(SET_)>), grid, dim3(kTightThreads), 0, s, depth, rgb, frame_mats, pairs, a); \
+            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, false, tight_rows_of(SET_), tight_rg_of(SET_)>), grid, dim3(tight_bw_of(SET_) * kWave), 0, s, depth, rgb, frame_mats, pairs, a); \
     } while (0)
         if (set == kSetCorr) MSPA_LAUNCH_TIGHT(kSetCorr);
         else if (set == kSetDense) MSPA_LAUNCH_TIGHT(kSetDense);
