@@ -223,9 +223,7 @@ def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None,
                     rec.note(resident[key]._visibility()["count"])
                 direct = fn(resident.get(key))
             rows = rec.rows()
-            header = np.zeros((1, tape.WIDTH))
-            header[0, 0], header[0, 1] = key, len(rows)
-            local += [header, rows]
+            local += tape.frame(key, rows)
             if selftest_tape:                                 # single-process self-check: the replay must reproduce the records
                 player = tape.Player(engine, rows, device)
                 with tape.engine_as(player):
@@ -238,11 +236,7 @@ def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None,
         table = shard.collate_records(payload, ctx).cpu().numpy()              # the exchange: float64 rows, nothing else
         if rank != 0:
             continue
-        tapes, pos = {}, 0
-        while pos < len(table):
-            key, n = int(table[pos, 0]), int(table[pos, 1])
-            tapes[key] = table[pos + 1:pos + 1 + n]
-            pos += 1 + n
+        tapes = tape.unframe(table)
         for key, fn in units[name]:                            # unit order, whoever ran it
             player = tape.Player(engine, tapes[key], device)
             with tape.engine_as(player):

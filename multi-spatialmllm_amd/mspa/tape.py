@@ -124,6 +124,23 @@ class Player:
         return self._reader.decode()
 
 
+def frame(key: int, rows: np.ndarray) -> List[np.ndarray]:
+    """One unit's tape as it travels through ``shard.collate_records``: a header row (unit key, number of rows) + the rows."""
+    header = np.zeros((1, WIDTH))
+    header[0, 0], header[0, 1] = key, len(rows)
+    return [header, rows]
+
+
+def unframe(table: np.ndarray) -> Dict[int, np.ndarray]:
+    """The collated table (every rank's framed tapes, rank order) -> {unit key: tape rows}."""
+    tapes, pos = {}, 0
+    while pos < len(table):
+        key, n = int(table[pos, 0]), int(table[pos, 1])
+        tapes[key] = table[pos + 1:pos + 1 + n]
+        pos += 1 + n
+    return tapes
+
+
 @contextlib.contextmanager
 def engine_as(proxy):
     """Route ``engine.<kernel>`` calls of the head code (mspa.heads, mspa.scene, mspa.coverage, mspa.pipeline) through

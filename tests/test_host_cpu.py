@@ -184,15 +184,13 @@ def _worker(rank, world, port, q):
     from mspa import tape as TP
     rec = TP.Recorder(None)
     rec.note(torch.arange(3 + 5 * rank, dtype=torch.float64) * 0.1 + rank)
-    rows = rec.rows()
-    header = np.zeros((1, TP.WIDTH))
-    header[0, 0], header[0, 1] = 10 + rank, len(rows)
-    table = S.collate_records(torch.from_numpy(np.concatenate([header, rows], 0)), ctx).numpy()
-    got, pos = {}, 0
-    while pos < len(table):
-        key, n = int(table[pos, 0]), int(table[pos, 1])
-        got[key] = TP.Player(None, table[pos + 1:pos + 1 + n], "cpu").next().numpy().tolist()
-        pos += 1 + n
+    local = TP.frame(10 + rank, rec.rows())
+    if rank == 1:                                  # a second unit on one rank, with an empty tape
+        local += TP.frame(99, TP.Recorder(None).rows())
+    table = S.collate_records(torch.from_numpy(np.concatenate(local, 0)), ctx).numpy()
+    tapes = TP.unframe(table)
+    assert sorted(tapes) == [10, 11, 99] and len(tapes[99]) == 0
+    got = {key: TP.Player(None, tapes[key], "cpu").next().numpy().tolist() for key in (10, 11)}
     ctx.barrier()
     q.put((rank, full.numpy().tolist(), t, got))
     ctx.close()
