@@ -708,7 +708,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 #define MSPA_TIGHT_DMA16 1
 #endif
 #ifndef MSPA_STAGE2_ROW_BARRIER
-#define MSPA_STAGE2_ROW_BARRIER 3      // 0 never, 1 after every row, 2 after the second row only, 3 every row for the compacted set
+#define MSPA_STAGE2_ROW_BARRIER 3      // 0 never, 1 after every row, 2 after the second row only, 3 after the second row for the compacted set only
 #endif
 #ifndef MSPA_SCALED_ROW_BARRIER
 #define MSPA_SCALED_ROW_BARRIER 1      // ScanNet-shape kernel: 100 -> 73 VGPRs (4 -> 6 waves per SIMD), 2.30 -> 2.11 ms per 1 000 pairs
@@ -1119,8 +1119,10 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                         // code and keeps all their temporaries live (86-88 VGPRs: 5 waves per SIMD); one row at a time needs 66-69
                         // (6 waves).  Which is worth more depends on the set (tools/ab_k3.py, one box): the sixth wave for the
                         // compacted set (0.493 -> 0.463 ms), the interleaving for the correspondence table (0.506 vs 0.552).
+                        // One barrier, after the second row, gives the compacted set the same 73 VGPRs and the better time
+                        // (0.381 vs 0.388 with four; 0.387 +- 0.026 with none).
                         if (MSPA_STAGE2_ROW_BARRIER == 1 || (MSPA_STAGE2_ROW_BARRIER == 2 && j == 1) ||
-                            (MSPA_STAGE2_ROW_BARRIER == 3 && COMPACT))
+                            (MSPA_STAGE2_ROW_BARRIER == 3 && COMPACT && j == 1))
                             __builtin_amdgcn_sched_barrier(0);
                     }
                     // ---- stage 3: depth test, outputs -------------------------------------------------------
