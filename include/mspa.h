@@ -132,8 +132,9 @@ int mspa_pair_reproject_last_kernel(void);
  *   out_vis_bits     [n_pairs, ceil(P/64)] uint64   as in mspa_pair_reproject
  *   out_cpix_i16     [n_pairs, n_tiles, MSPA_CORR_TILE_CAP, 2] int16   tile t's segment holds, for its visible pixels in
  *                    (row, column) order, the depth-pixel index (xi, yi) in f2 (IH:362-366) -- the k-th set bit of the
- *                    tile's part of the bitset <-> entry k; entries beyond the tile's count are unspecified (never written
- *                    by the fused kernel: HBM traffic is 4 bytes per VISIBLE pixel)
+ *                    tile's part of the bitset <-> entry k; entries beyond the tile's count are unspecified (the fused
+ *                    kernel writes 4 bytes per VISIBLE pixel and nothing else; only a tile in which the exact re-evaluation
+ *                    of a guarded pixel took a pixel OUT of the visible set may keep stale entries behind its count)
  *   out_tile_counts  [n_pairs, n_tiles] int32       visible pixels per tile (= entries of its segment)
  *   out_counts       [n_pairs, 2] int32 or NULL     (#valid, #visible); zeroed by the call
  * With MSPA_PAIR_FAST on a whole-tile shape (W % 64 == 0, H % 48 == 0, colour grid == depth grid: BASELINE's 640x480)
