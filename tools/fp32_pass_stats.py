@@ -67,3 +67,62 @@ print('* fp32 |du| px: median %.2e  99%% %.2e  99.99%% %.2e  max %.2e'%(np.media
 print('* fp32 |dz| mm: median %.2e  99%% %.2e  99.99%% %.2e  max %.2e'%(np.median(ez),np.percentile(ez,99),np.percentile(ez,99.99),ez.max()))
 for g in guards:
     print('* guard px %.0e / mm %.2f: guarded lanes %.3f %% of in-view, 64-lane rows with a guarded lane %.1f %%'%(g[0],g[1],100*cnt[g]/tot,100*rows_any[g]/nrows))
+
+# ---- a guard that is a BOUND, not an observation: per tile B_k = c eps (Tmax_k dhi + |M_k3|) with Tmax_k = sum of the absolute
+# terms of the affine row at the tile's far corner (no credit for cancellation), per lane g_u = (B_0 + |u| B_2) / |q_2|, likewise
+# g_v; g_z = B_2.  c = 4 covers the rounded matrix entries, the two FMAs per row, the reciprocal (1 ulp) and the product.
+eps = 2.0 ** -24
+c = 4.0
+viol = 0
+lanes = 0
+guarded = 0
+rows_g = 0
+rows_n = 0
+gmax = 0.0
+for p in sel:
+    a, b = pairs[p]
+    M = (mats[b, 6].reshape(4, 4) @ mats[a, 5].reshape(4, 4))[:3].copy()
+    M[:, 3] *= 1000.0
+    d = sc.depth[ids[a]].astype(np.float64)
+    t = M[:, 0][None, None, :] * xx[..., None] + M[:, 1][None, None, :] * yy[..., None] + M[:, 2][None, None, :]
+    q = t * d[..., None] + M[:, 3]
+    with np.errstate(all='ignore'):
+        u = q[..., 0] / q[..., 2]
+        v = q[..., 1] / q[..., 2]
+    iz = q[..., 2]
+    M32 = M.astype(f32); x32 = xx.astype(f32); y32 = yy.astype(f32); d32 = d.astype(f32)
+    t32 = [fma32(np.full_like(x32, M32[k, 1]), y32, fma32(np.full_like(x32, M32[k, 0]), x32, np.full_like(x32, M32[k, 2]))) for k in range(3)]
+    q32 = [fma32(t32[k], d32, np.full_like(d32, M32[k, 3])) for k in range(3)]
+    with np.errstate(all='ignore'):
+        r = (f32(1) / q32[2]).astype(f32)
+        u32 = (q32[0] * r).astype(f32).astype(np.float64)
+        v32 = (q32[1] * r).astype(f32).astype(np.float64)
+    z32 = q32[2].astype(np.float64)
+    xi = np.clip(np.rint(np.nan_to_num(u)), 0, W - 1).astype(int)
+    yi = np.clip(np.rint(np.nan_to_num(v)), 0, H - 1).astype(int)
+    dv = sc.depth[ids[b]].astype(np.float64)[yi, xi]
+    for R0 in range(0, H, 48):
+        for c0 in range(0, W, 64):
+            sl = (slice(R0, R0 + 48), slice(c0, c0 + 64))
+            dt = d[sl]
+            if not (dt > 0).any():
+                continue
+            dhi = dt.max()
+            Tmax = np.abs(M[:, 0]) * (c0 + 63) + np.abs(M[:, 1]) * (R0 + 47) + np.abs(M[:, 2])
+            B = c * eps * (Tmax * dhi + np.abs(M[:, 3]))
+            inv = (dt > 0) & (u[sl] > -1) & (u[sl] < W + 1) & (v[sl] > -1) & (v[sl] < H + 1) & (iz[sl] > 1)
+            if not inv.any():
+                continue
+            with np.errstate(all='ignore'):
+                gu = (B[0] + np.abs(u32[sl]) * B[2]) / np.abs(z32[sl])
+                gv = (B[1] + np.abs(v32[sl]) * B[2]) / np.abs(z32[sl])
+            gz = B[2]
+            viol += int((inv & ((np.abs(u32[sl] - u[sl]) > gu) | (np.abs(v32[sl] - v[sl]) > gv) | (np.abs(z32[sl] - iz[sl]) > gz))).sum())
+            fu = np.abs(u32[sl] - np.rint(u32[sl])); fv = np.abs(v32[sl] - np.rint(v32[sl]))
+            risky = inv & ((fu < gu) | (fu > 0.5 - gu) | (fv < gv) | (fv > 0.5 - gv) | (np.abs(z32[sl] - dv[sl]) < gz))
+            guarded += int(risky.sum()); lanes += int(inv.sum())
+            rows_g += int(risky.any(1).sum()); rows_n += int(inv.any(1).sum())
+            gmax = max(gmax, float(np.max(gu[inv])), float(np.max(gv[inv])))
+print('\n* bound-derived guard (per tile B_k = 4 eps (Tmax_k dhi + |M_k3|), per lane (B_0 + |u| B_2) / |q_2|): lanes whose float32 result '
+      'is off by MORE than their guard: %d of %d; guarded lanes %.3f %%; 64-lane rows with a guarded lane %.1f %%; largest guard %.2e px'
+      % (viol, lanes, 100 * guarded / lanes, 100 * rows_g / rows_n, gmax))
