@@ -70,9 +70,9 @@ for g in guards:
 
 # ---- a guard that is a BOUND, not an observation: per tile B_k = c eps (Tmax_k dhi + |M_k3|) with Tmax_k = sum of the absolute
 # terms of the affine row at the tile's far corner (no credit for cancellation), per lane g_u = (B_0 + |u| B_2) / |q_2|, likewise
-# g_v; g_z = B_2.  c = 4 covers the rounded matrix entries, the two FMAs per row, the reciprocal (1 ulp) and the product.
+# g_v; g_z = B_2 -- exactly the form of DESIGN.md section 8.1 (constants 4.02, 1.25, 3.01, + the float64 level's 1e-6).
 eps = 2.0 ** -24
-c = 4.0
+c = 4.02
 viol = 0
 lanes = 0
 guarded = 0
@@ -114,15 +114,15 @@ for p in sel:
             if not inv.any():
                 continue
             with np.errstate(all='ignore'):
-                gu = (B[0] + np.abs(u32[sl]) * B[2]) / np.abs(z32[sl])
-                gv = (B[1] + np.abs(v32[sl]) * B[2]) / np.abs(z32[sl])
-            gz = B[2]
+                gu = 1.25 * ((B[0] + np.abs(u32[sl]) * B[2]) / np.abs(z32[sl]) + 3.01 * eps * np.abs(u32[sl])) + 1e-6
+                gv = 1.25 * ((B[1] + np.abs(v32[sl]) * B[2]) / np.abs(z32[sl]) + 3.01 * eps * np.abs(v32[sl])) + 1e-6
+            gz = B[2] + 1e-6
             viol += int((inv & ((np.abs(u32[sl] - u[sl]) > gu) | (np.abs(v32[sl] - v[sl]) > gv) | (np.abs(z32[sl] - iz[sl]) > gz))).sum())
             fu = np.abs(u32[sl] - np.rint(u32[sl])); fv = np.abs(v32[sl] - np.rint(v32[sl]))
-            risky = inv & ((fu < gu) | (fu > 0.5 - gu) | (fv < gv) | (fv > 0.5 - gv) | (np.abs(z32[sl] - dv[sl]) < gz))
+            risky = inv & ((fu < gu) | (fu > 0.5 - gu) | (fv < gv) | (fv > 0.5 - gv) | (np.abs(z32[sl] - dv[sl]) < gz) | (np.abs(z32[sl]) <= 2 * B[2]))
             guarded += int(risky.sum()); lanes += int(inv.sum())
             rows_g += int(risky.any(1).sum()); rows_n += int(inv.any(1).sum())
             gmax = max(gmax, float(np.max(gu[inv])), float(np.max(gv[inv])))
-print('\n* bound-derived guard (per tile B_k = 4 eps (Tmax_k dhi + |M_k3|), per lane (B_0 + |u| B_2) / |q_2|): lanes whose float32 result '
+print('\n* bound-derived guard (DESIGN.md 8.1: per tile B_k = 4.02 eps (Tmax_k dhi + |M_k3|), per lane 1.25 ((B_0 + |u| B_2) / |q_2| + 3.01 eps |u|) + 1e-6): lanes whose float32 result '
       'is off by MORE than their guard: %d of %d; guarded lanes %.3f %%; 64-lane rows with a guarded lane %.1f %%; largest guard %.2e px'
       % (viol, lanes, 100 * guarded / lanes, 100 * rows_g / rows_n, gmax))
