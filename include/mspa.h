@@ -37,8 +37,8 @@
 extern "C" {
 #endif
 
-#define MSPA_VERSION 130            /* 0.3.0: + mspa_pair_correspondences (compacted correspondence output), general homogeneous
-                                       points and depth scale in K1 / K6b */
+#define MSPA_VERSION 140            /* 0.4.0: frame records carry guard-bound coefficients (slot MSPA_MAT_BOUNDS, MSPA_FRAME_MATS
+                                       7 -> 8): the fast kernels' guard band is a bound, not a constant */
 
 #define MSPA_OK 0
 #define MSPA_EINVAL (-1)            /* bad argument (null pointer, size out of range, ...) */
@@ -55,13 +55,26 @@ typedef void *mspa_stream_t;        /* hipStream_t */
 #define MSPA_MAT_K 4                /* K                 IH:66 */
 #define MSPA_MAT_UNPROJ 5           /* A @ E @ inv(K)    composed on the host (fast path only) */
 #define MSPA_MAT_REPROJ 6           /* K @ inv(A @ E)    composed on the host (fast path only) */
-#define MSPA_FRAME_MATS 7
+#define MSPA_MAT_BOUNDS 7           /* not a matrix: the frame's guard-bound coefficients (fast path only), filled by
+                                       mspa_frame_bounds_host from slots 0-4.  With |.| entrywise, Uabs = |A| |E| |inv(K)|,
+                                       Nabs = |K| |inv(A @ E)| and c = MSPA_GUARD_C * 2^-53:
+                                         [0..2]  max over rows r < 3 of Uabs[r][j], j = 0, 1, 2      [3]  1000 * max_r Uabs[r][3]
+                                         [4..6]  c * (Nabs[k][0] + Nabs[k][1] + Nabs[k][2]), k = 0, 1, 2
+                                         [8..10] c * 1000 * Nabs[k][3]                              (other entries 0)
+                                       For a pixel block with columns <= X, rows <= Y and depth samples <= D millimetres,
+                                       w = D * ([0] X + [1] Y + [2]) + [3] bounds the aligned-world coordinates (mm) and
+                                       B_k = [4 + k] * w + [8 + k] bounds the difference between ANY two float64 evaluation
+                                       orders of the k-th homogeneous image coordinate (pixel * millimetre; k = 2: the
+                                       camera-2 depth in mm) -- the reference's five products vs the composed 3x4 of the
+                                       fast kernels.  The guard band of MSPA_PAIR_FAST is derived from B_k per tile. */
+#define MSPA_FRAME_MATS 8
+#define MSPA_GUARD_C 256.0          /* >= the roundings of either evaluation order (89 counted) */
 
 /* flags of mspa_pair_reproject */
 #define MSPA_PAIR_FAST 1u           /* composed-matrix evaluation with exact re-evaluation of every
                                        lane near a decision boundary: masks, pixel indices and counters
                                        stay bit-exact, float32 points agree to ~1e-12 relative.  Needs
-                                       slots 5/6 filled and K's third row == 0 0 1 0 (pinhole); ignored
+                                       slots 5-7 filled and K's third row == 0 0 1 0 (pinhole); ignored
                                        (the exact kernel runs) when any float64 output is requested.  A bitset
                                        output on a width that is not a multiple of 64 takes a linear pixel mapping
                                        (64 consecutive pixel indices per wave) so that ballots stay whole words. */
@@ -72,6 +85,13 @@ typedef void *mspa_stream_t;        /* hipStream_t */
 
 int mspa_version(void);
 const char *mspa_last_error_string(void);
+
+/*
+ * Host-side: fills slot MSPA_MAT_BOUNDS of n_frames frame records from their slots 0-4 (HOST pointer to the
+ * [n_frames, MSPA_FRAME_MATS, 16] table, before it is uploaded).  The shipped host layer computes the same numbers in NumPy
+ * (mspa.engine.frame_bounds); a C caller that builds its own table calls this once per table.
+ */
+int mspa_frame_bounds_host(double *frame_mats_host, int32_t n_frames);
 
 /* Device facts the host layer reports next to measurements.  Any out pointer may be NULL. */
 int mspa_device_info(int device, int *n_cu, int *wave_size, int64_t *hbm_bytes, int *clock_khz,
@@ -141,7 +161,11 @@ int mspa_pair_reproject_last_kernel(void);
  * one fused kernel produces all of it; every other shape / mode runs mspa_pair_reproject into a dense table in
  * `workspace` (caller-owned, 16-byte aligned, at least mspa_pair_correspondences_workspace_bytes(...) bytes; NULL / 0 when
  * that returns 0) and compacts it with mspa_compact_correspondences.  Identical results either way (bit-exact integers).
- * out_cpix_i16 must be 16-byte aligned.  MSPA_PAIR_STREAM as in mspa_pair_reproject.
+ * out_cpix_i16 must be 16-byte aligned.  MSPA_PAIR_STREAM as in mspa_pair_reproject.  The fused kernel additionally needs
+ * `depth` 4-byte aligned (any allocator's base address is): a table at an odd 2-byte offset takes the dense route as well,
+ * i.e. needs the workspace although mspa_pair_correspondences_workspace_bytes, which cannot see the pointer, returned 0
+ * (the error string says so).  Depth samples are millimetres here and in mspa_pair_reproject (project_mask_to_3d's literal
+ * 0.001, OPS:292-294): a handler's depth_value_scale applies to K1 / K6b / the predicates only.
  */
 #define MSPA_CORR_TILE_W 64
 #define MSPA_CORR_TILE_H 48

@@ -1,6 +1,7 @@
 // Library-level entry points of libmspa.so: version, error string, device facts.
 #include "mspa_common.h"
 
+#include <cmath>
 #include <cstring>
 
 namespace mspa {
@@ -53,6 +54,41 @@ extern "C" int mspa_device_info(int device, int *n_cu, int *wave_size, int64_t *
     if (name_host && name_len > 0) {
         std::strncpy(name_host, prop.gcnArchName, (size_t)name_len - 1);
         name_host[name_len - 1] = 0;
+    }
+    return MSPA_OK;
+}
+
+// Slot MSPA_MAT_BOUNDS of the frame records (include/mspa.h): magnitudes of the two halves of the pair pipe's matrix chain,
+// from which the fast kernels derive their guard band per tile.  Products of non-negative numbers: no cancellation, the few
+// roundings of this function itself are covered by MSPA_GUARD_C's slack.
+static void abs_mul(const double *X, const double *Y, double *out) {       // out = |X| |Y|, 4x4 row-major
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) acc += std::fabs(X[4 * r + k]) * std::fabs(Y[4 * k + c]);
+            out[4 * r + c] = acc;
+        }
+}
+
+extern "C" int mspa_frame_bounds_host(double *frame_mats_host, int32_t n_frames) {
+    if (n_frames < 0 || (!frame_mats_host && n_frames > 0)) return fail(MSPA_EINVAL, "mspa_frame_bounds_host: bad table");
+    const double c = MSPA_GUARD_C * 0x1p-53;
+    for (int32_t f = 0; f < n_frames; ++f) {
+        double *rec = frame_mats_host + (int64_t)f * (MSPA_FRAME_MATS * 16);
+        double AE[16], Ua[16], Na[16];
+        abs_mul(rec + MSPA_MAT_A * 16, rec + MSPA_MAT_E * 16, AE);
+        abs_mul(AE, rec + MSPA_MAT_KINV * 16, Ua);
+        abs_mul(rec + MSPA_MAT_K * 16, rec + MSPA_MAT_EINV_ALIGNED * 16, Na);
+        double *b = rec + MSPA_MAT_BOUNDS * 16;
+        for (int k = 0; k < 16; ++k) b[k] = 0.0;
+        for (int j = 0; j < 4; ++j) {
+            const double m = std::fmax(Ua[j], std::fmax(Ua[4 + j], Ua[8 + j]));
+            b[j] = j < 3 ? m : 1000.0 * m;
+        }
+        for (int k = 0; k < 3; ++k) {
+            b[4 + k] = c * ((Na[4 * k + 0] + Na[4 * k + 1]) + Na[4 * k + 2]);
+            b[8 + k] = c * 1000.0 * Na[4 * k + 3];
+        }
     }
     return MSPA_OK;
 }

@@ -51,6 +51,58 @@ __device__ __forceinline__ double affine_row_w(const double *__restrict__ m, dou
     return __builtin_fma(m[3], w, acc);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Guard band of the composed ("fast") kernels, as a BOUND.  The fast kernels evaluate K2 inv(A E2) A E1 inv(K1) p through one
+// composed 3x4 matrix; the reference multiplies the five matrices one after the other.  Both are float64 evaluations of the
+// same real number, and both stay within c 2^-53 (|K2| |inv(A E2)| |A| |E1| |inv(K1)| |p|) of it (c counts the roundings of the
+// longer chain; MSPA_GUARD_C in include/mspa.h).  Slot MSPA_MAT_BOUNDS of the two frame records carries that product of
+// magnitudes in factored form; for a block of pixels (columns <= xmax, rows <= ymax, depth samples <= dmax millimetres) it
+// gives B_k >= |q_k(fast) - q_k(reference)| for the homogeneous image coordinates q (pixel * millimetre; k = 2: the camera-2
+// depth in millimetres).  From B:
+//   zmin   a lane with |q_2| <= zmin is never trusted: above it |u(fast) - u(reference)| <= (B_0 + |u| B_2) / q_2 <= guard / 2
+//          for every |u| <= max(W, H) + 1, so rounding ties / integer bounds within the pixel guard catch every other flip;
+//   zsafe  a FAST-evaluated q_2 above zsafe means every evaluation order is above zmin (and positive);
+//   gz     depth-test guard: |q_2 - sample| <= gz may flip the strict comparison.
+// (Sums stand in for maxima -- B_0 + B_1 >= max(B_0, B_1) -- which only widens the band: v_max_f64 drags a canonicalising
+// instruction per operand along.)  The frustum culling keeps its constant margins (1 pixel * mm, 1e-3 mm) and checks, only
+// when it is about to cull, that they are at least four times the evaluation error anywhere in the image (cull_margins_hold).
+// Round 3 used constants (1e-6 px, 1e-6 mm) for all of these: wrong when camera 2 sits within micrometres of a frame-1
+// surface point (the error grows like 1 / q_2) or when world coordinates are huge (tools/guard_bound_emulation.py).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr double kGuardPx = 1e-6;                // distance to a rounding tie / an integer bound (pixels)
+constexpr double kGuardZmmFloor = 1e-6;          // smallest depth-test guard (mm): covers the rounding of sample * 0.001 itself
+constexpr double kCullMarginXY = 1.0;            // frustum culling: homogeneous x / y (pixel * millimetre)
+constexpr double kCullMarginZ = 1e-3;            // frustum culling: homogeneous depth (millimetres)
+
+struct Guard {
+    double zmin, zsafe, gz;
+};
+
+// b1 = slot MSPA_MAT_BOUNDS of frame 1, b2 = of frame 2 (wave-uniform addresses: scalar loads); all arguments wave-uniform.
+__device__ __forceinline__ Guard guard_from_bounds(const double *__restrict__ b1, const double *__restrict__ b2, double xmax,
+                                                   double ymax, double dmax_mm, double wh_max) {
+    const double w = __builtin_fma(__builtin_fma(b1[0], xmax, __builtin_fma(b1[1], ymax, b1[2])), dmax_mm, b1[3]);
+    const double B0 = __builtin_fma(b2[4], w, b2[8]);
+    const double B1 = __builtin_fma(b2[5], w, b2[9]);
+    const double B2 = __builtin_fma(b2[6], w, b2[10]);
+    Guard g;
+    g.zmin = __builtin_fma(wh_max + 1.0, B2, B0 + B1) * (2.0 / kGuardPx);
+    g.zsafe = __builtin_fma(2.0, B2, g.zmin);
+    g.gz = __builtin_fma(2.0, B2, kGuardZmmFloor);
+    return g;
+}
+
+// The culling margins against the pair's bound over the whole image (columns <= xmax, rows <= ymax) and the full sample range.
+// NaN coefficients compare false: nothing is culled.
+__device__ __forceinline__ bool cull_margins_hold(const double *__restrict__ b1, const double *__restrict__ b2, double xmax,
+                                                  double ymax, double wh_max) {
+    const double w = __builtin_fma(__builtin_fma(b1[0], xmax, __builtin_fma(b1[1], ymax, b1[2])), 65535.0, b1[3]);
+    const double B0 = __builtin_fma(b2[4], w, b2[8]);
+    const double B1 = __builtin_fma(b2[5], w, b2[9]);
+    const double B2 = __builtin_fma(b2[6], w, b2[10]);
+    return (__builtin_fma(wh_max, B2, B0 + B1) < 0.25 * kCullMarginXY) & (B2 < 0.25 * kCullMarginZ);
+}
+
 // np.round(v).astype(int) then np.clip(.., 0, hi) (IH:362-366, OPS:285-290): half-to-even, the
 // x86-64 float64->int64 conversion (NaN / out of range -> INT64_MIN), clip.  hi < 32768.
 __device__ __forceinline__ int round_clip(double v, int hi) {

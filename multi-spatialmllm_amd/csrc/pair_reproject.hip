@@ -14,8 +14,8 @@
 //     lane <-> image column, a wave walks down a 64 x 16 tile.  Every lane whose integer decisions
 //     (half-to-even rounding of the pixel index, the image bounds, the strict depth comparison) sit
 //     within a guard band of a decision boundary is re-evaluated with the exact chain, so masks, pixel
-//     indices and counters stay bit-exact; the guard (1e-6 px / 1e-9 m) is ~5 orders of magnitude wider
-//     than the worst rounding difference between the two evaluation orders.
+//     indices and counters stay bit-exact; the band is derived per tile from a BOUND on the difference between
+//     the two evaluation orders (mspa_common.h guard_from_bounds, slot MSPA_MAT_BOUNDS).
 //   * pair_fast_tight_kernel (MSPA_PAIR_FAST, whole-tile images such as 640x480) -- the benchmarked
 //     one: same arithmetic, plus LDS-DMA depth tiles, tile- and group-level culling, buffer-resource
 //     addressing and 16-byte stores (see the comment above it).
@@ -52,6 +52,7 @@ struct PairArgs {
     int16_t *cpix;            // compacted correspondences: [n_pairs][n_tiles][kTileCap][2] (fused tight kernel only)
     int32_t *tile_counts;     // [n_pairs][n_tiles] entries per tile segment
     uint32_t xcd_shift;       // log2 of the XCDs workgroups are dealt over (3 on an MI355X in SPX mode, 0 otherwise)
+    double wm1, hm1, wh_max;  // W - 1, H - 1, max(W, H) as float64 (guard band: mspa_common.h guard_from_bounds)
 };
 
 // Output sets.  A kernel instantiated with GENERIC = true tests every output pointer at run time
@@ -80,9 +81,7 @@ constexpr int kIters = 16;                       // 4096 pixels per workgroup
 constexpr int kStrip = kThreads * kIters;
 constexpr int kGroup = 4;                        // pixels per lane processed between matrix reloads
 
-constexpr double kGuardPx = 1e-6;                // fast path: distance to a rounding/bounds boundary
-constexpr double kGuardZ = 1e-9;                 // fast path: distance to a depth-test boundary (m)
-constexpr double kGuardZmm = 1e-6;               // the same in millimetres (tight kernel: millimetre-scaled composed matrix)
+// guard band of the fast kernels: kGuardPx and guard_from_bounds in mspa_common.h
 
 // Makes a wave-uniform pointer opaque to LICM: loads through the result cannot be hoisted out of
 // the pixel loop, so at most one stage's matrices are live in SGPRs at a time (all five would
@@ -423,6 +422,11 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
         }
     }
 
+    // guard band from the pair's bound coefficients, over the whole image and the full sample range (this kernel serves the
+    // shapes without a tile pre-pass); its composed matrix works in metres
+    const Guard gd = guard_from_bounds(m1 + MSPA_MAT_BOUNDS * 16, m2 + MSPA_MAT_BOUNDS * 16, a.wm1, a.hm1, 65535.0, a.wh_max);
+    const double zmin_m = uniform(gd.zmin * 0.001), gz_m = uniform(gd.gz * 0.001);
+
     // wave tile -> (row band, column stripe); both wave-uniform
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t tile = tgroup * (kThreads / kWave) + wave;
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
                 const double wu = __builtin_fabs(us - ru) - 0.25;
                 const double wv = __builtin_fabs(vs - rv) - 0.25;
                 bool rk = !(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx);
-                rk = rk | !(__builtin_fabs(iz) > kGuardZ);
+                rk = rk | !(__builtin_fabs(iz) > zmin_m);         // below zmin the projection itself is not trusted
                 if (!IDENT) {   // bounds live in colour-pixel units here, not at integers of the depth grid
                     const double bu = __builtin_fmin(__builtin_fabs(u), __builtin_fabs(u - Wd));
                     const double bv = __builtin_fmin(__builtin_fabs(v), __builtin_fabs(v - Hd));
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
                 }
                 const double dv = (double)dv16[j] * 0.001;
                 const bool vis = test[j] & (qz[j] < dv);
-                const bool rk = valid[j] & (risky[j] | (test[j] & !(__builtin_fabs(qz[j] - dv) > kGuardZ)));
+                const bool rk = valid[j] & (risky[j] | (test[j] & !(__builtin_fabs(qz[j] - dv) > gz_m)));
                 risky_rows |= (uint32_t)rk << g;
                 vis_rows |= (uint32_t)vis << g;
                 const unsigned long long vmask = __ballot(vis);
@@ -979,7 +983,16 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
         // rounding differences between evaluation orders), no pixel of the tile can land in frame 2:
         // the wave writes "nothing visible" for 48 x 64 pixels without projecting any of them.
         // (Homogeneous coordinates are in pixel * millimetre here: M maps the raw millimetre sample.)
+        // The same pass yields the tile's guard band (guard_from_bounds with the tile's far corner and largest sample) and
+        // whether the camera-2 plane can be near any of its pixels: if all 8 corners lie in front of it by more than zsafe,
+        // every pixel of the tile does (the depth coordinate is affine too), no lane can be "near the plane", and the row
+        // loop runs without its two depth-sign compares (`all_front`; the other tiles take the careful instantiation).
         bool culled = false;
+        bool all_front = false;
+        const double *__restrict__ bnd1 = m1 + MSPA_MAT_BOUNDS * 16;
+        const double *__restrict__ bnd2 = m2 + MSPA_MAT_BOUNDS * 16;
+        const double tile_xmax = (double)(stripe * 64u + 63u), tile_ymax = (double)(row0 + (uint32_t)(ROWS - 1));
+        double zmin = 0.0, gz = kGuardZmmFloor;            // wave-uniform (SGPR pairs) once set below
         if (!WANT_XYZ && !O::template has<O_VALID_U8>(a.valid_u8) && !O::template has<O_RGBA>(a.rgba) &&
             !O::template has<O_VIS_U8>(a.vis_u8)) {
             typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -1007,13 +1020,23 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                 const double hx = __builtin_fma(__builtin_fma(M[0][1], cy, __builtin_fma(M[0][0], cx, M[0][2])), cd, M[0][3]);
                 const double hy = __builtin_fma(__builtin_fma(M[1][1], cy, __builtin_fma(M[1][0], cx, M[1][2])), cd, M[1][3]);
                 const double hz = __builtin_fma(__builtin_fma(M[2][1], cy, __builtin_fma(M[2][0], cx, M[2][2])), cd, M[2][3]);
-                const double kMargin = 1.0;                               // homogeneous units (pixel * millimetre)
-                const bool all_behind = ballot64(hz <= -1e-3) == ~0ull;
-                const bool all_left = ballot64(hx < -kMargin) == ~0ull;
-                const bool all_right = ballot64(hx - (double)a.W * hz > kMargin) == ~0ull;
-                const bool all_above = ballot64(hy < -kMargin) == ~0ull;
-                const bool all_below = ballot64(hy - (double)a.H * hz > kMargin) == ~0ull;
+                // margins in homogeneous units (pixel * millimetre; millimetres for the depth); a tile about to be culled
+                // checks that they are at least four times what two evaluation orders can differ by (mspa_common.h)
+                const bool all_behind = ballot64(hz <= -kCullMarginZ) == ~0ull;
+                const bool all_left = ballot64(hx < -kCullMarginXY) == ~0ull;
+                const bool all_right = ballot64(hx - (double)a.W * hz > kCullMarginXY) == ~0ull;
+                const bool all_above = ballot64(hy < -kCullMarginXY) == ~0ull;
+                const bool all_below = ballot64(hy - (double)a.H * hz > kCullMarginXY) == ~0ull;
                 culled = all_behind | all_left | all_right | all_above | all_below;
+                if (culled) {
+                    culled = ballot64(cull_margins_hold(bnd1, bnd2, a.wm1, a.hm1, a.wh_max)) == ~0ull;
+                }
+                if (!culled) {
+                    const Guard gd = guard_from_bounds(bnd1, bnd2, tile_xmax, tile_ymax, (double)hi, a.wh_max);
+                    all_front = ballot64(hz > gd.zsafe) == ~0ull;
+                    zmin = uniform(gd.zmin);
+                    gz = uniform(gd.gz);
+                }
             }
             if (culled) {
                 us2 nz = {0, 0};
@@ -1031,7 +1054,17 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
             }
         }
 
-        if (!culled) {
+        else {
+            // sets without the pre-pass (dense payloads: every pixel is written anyway): the bound over the full sample range
+            const Guard gd = guard_from_bounds(bnd1, bnd2, tile_xmax, tile_ymax, 65535.0, a.wh_max);
+            zmin = uniform(gd.zmin);
+            gz = uniform(gd.gz);
+        }
+
+        // The row loop once per kind of tile (compile-time CAREFUL, as the ScanNet-shape kernel does for its last stripe): a
+        // run-time flag inside the loop would be if-converted -- the compares executed regardless.
+        auto run_rows = [&](auto careful_c) {
+            constexpr bool CAREFUL = decltype(careful_c)::value;
 #pragma unroll 1
             for (int r0 = 0; r0 < ROWS; r0 += RG) {
                 uint32_t d16[RG];
@@ -1076,7 +1109,11 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                     // (a ballot of an AND of predicates is lowered to v_cndmask 0/1 + v_cmp again)
                     vmk[j] = ballot64(d16[j] != 0u);                             // OPS:297
                     ivm[j] = vmk[j] & ballot64(u[j] > -kGuardPx) & ballot64(u[j] < Wd + kGuardPx) & ballot64(v[j] > -kGuardPx) &
-                             ballot64(v[j] < Hd + kGuardPx) & ballot64(iz > -kGuardZmm);
+                             ballot64(v[j] < Hd + kGuardPx);
+                    // CAREFUL tiles (the camera-2 plane may cut the tile's frustum): in front of the plane by more than zmin,
+                    // or within zmin of it -- there u and v mean nothing, the lane is a candidate whatever they say and stage 2
+                    // hands it to the reference chain.  (NaN depth lands in the second set.)
+                    if (CAREFUL) ivm[j] = vmk[j] & ((ivm[j] & ballot64(iz > zmin)) | ballot64(!(__builtin_fabs(iz) > zmin)));
                     any |= ivm[j];
                 }
                 const uint32_t rowg = row0 + (uint32_t)r0;
@@ -1113,8 +1150,8 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                         // guard < |t| < 0.5 - guard  <=>  ||t| - 0.25| < 0.25 - guard.  NaN fails the ordered compare.
                         const double wu = __builtin_fabs(u[j] - ru) - 0.25;
                         const double wv = __builtin_fabs(v[j] - rv) - 0.25;
-                        rkc[j] = ballot64(!(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx)) |
-                                 ballot64(!(qz[j] > kGuardZmm));
+                        rkc[j] = ballot64(!(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx));
+                        if (CAREFUL) rkc[j] |= ballot64(!(qz[j] > zmin));        // lanes behind the plane are not in ivm
                         // Scheduling barrier between rows: left to itself the scheduler interleaves the four rows' rounding / guard
                         // code and keeps all their temporaries live (86-88 VGPRs: 5 waves per SIMD); one row at a time needs 66-69
                         // (6 waves).  Which is worth more depends on the set (tools/ab_k3.py, one box): the sixth wave for the
@@ -1132,7 +1169,7 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                         const bool inview = __builtin_amdgcn_inverse_ballot_w64(ivm[j]);
                         const double sd = qz[j] - (double)dv16[j];              // millimetres; IH:368-371 compares metres
                         vm[j] = ivm[j] & ballot64(sd < 0.0);
-                        rbm[j] = ivm[j] & (rkc[j] | ballot64(!(__builtin_fabs(sd) > kGuardZmm)));
+                        rbm[j] = ivm[j] & (rkc[j] | ballot64(!(__builtin_fabs(sd) > gz)));
                         if (O::template has<O_PIX>(a.pix_i16)) lds_px[j * 64 + c.lane] = (uint32_t)(inview ? pix[j] : -1);
                         if (COMPACT) compact_row(vm[j], pix[j]);
                     }
@@ -1209,6 +1246,10 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                     wave_lds_fence();
                 }
             }
+        };
+        if (!culled) {
+            if (all_front) run_rows(std::false_type{});
+            else run_rows(std::true_type{});
         }
 
         // ---- cold loop: rows with guarded lanes are re-evaluated with the exact chain ---------------
@@ -1454,7 +1495,19 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
         // <= 7 eight-byte loads per lane (16 lanes per depth row, 4 rows per instruction), and if all 8 corners of the
         // frustum {d (mx, my, 1)} violate ONE of the in-view half-spaces by a margin, no pixel of the tile can land in
         // frame 2: its groups then only count their valid samples and write "nothing visible".
+        // Guard band and `all_front` as in the tight kernel (bounds taken over the colour grid, which only widens them: the
+        // kernel's u, v are in depth-grid units, sx, sy <= 1).
         bool culled = false;
+        bool all_front = false;
+        const double *__restrict__ bnd1 = m1 + MSPA_MAT_BOUNDS * 16;
+        const double *__restrict__ bnd2 = m2 + MSPA_MAT_BOUNDS * 16;
+        constexpr double wh_max = (double)(W_ > H_ ? W_ : H_);
+        double zmin = 0.0, gz = kGuardZmmFloor;
+        if (last || !MSPA_SCALED_TILE_CULL) {             // no pre-pass for the last stripe: the bound over the full sample range
+            const Guard gd = guard_from_bounds(bnd1, bnd2, (double)(W_ - 1), (double)(row0 + (uint32_t)(kRows - 1)), 65535.0, wh_max);
+            zmin = uniform(gd.zmin);
+            gz = uniform(gd.gz);
+        }
 #if MSPA_SCALED_TILE_CULL
         if (!last) {
             typedef unsigned short us4 __attribute__((ext_vector_type(4)));
@@ -1496,21 +1549,28 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
                 const double hx = __builtin_fma(__builtin_fma(M[0][1], cy, __builtin_fma(M[0][0], cx, M[0][2])), cd, M[0][3]);
                 const double hy = __builtin_fma(__builtin_fma(M[1][1], cy, __builtin_fma(M[1][0], cx, M[1][2])), cd, M[1][3]);
                 const double hz = __builtin_fma(__builtin_fma(M[2][1], cy, __builtin_fma(M[2][0], cx, M[2][2])), cd, M[2][3]);
-                const double kMargin = 1.0;                                             // homogeneous units (depth pixel * millimetre)
-                const bool all_behind = ballot64(hz <= -1e-3) == ~0ull;
-                const bool all_left = ballot64(hx < -kMargin) == ~0ull;
-                const bool all_right = ballot64(hx - DWd * hz > kMargin) == ~0ull;
-                const bool all_above = ballot64(hy < -kMargin) == ~0ull;
-                const bool all_below = ballot64(hy - DHd * hz > kMargin) == ~0ull;
+                const bool all_behind = ballot64(hz <= -kCullMarginZ) == ~0ull;        // margins: see the tight kernel
+                const bool all_left = ballot64(hx < -kCullMarginXY) == ~0ull;
+                const bool all_right = ballot64(hx - DWd * hz > kCullMarginXY) == ~0ull;
+                const bool all_above = ballot64(hy < -kCullMarginXY) == ~0ull;
+                const bool all_below = ballot64(hy - DHd * hz > kCullMarginXY) == ~0ull;
                 culled = all_behind | all_left | all_right | all_above | all_below;
+                if (culled) culled = ballot64(cull_margins_hold(bnd1, bnd2, (double)(W_ - 1), (double)(H_ - 1), wh_max)) == ~0ull;
+                if (!culled) {
+                    const Guard gd = guard_from_bounds(bnd1, bnd2, (double)cB, (double)rB, (double)hi, wh_max);
+                    all_front = ballot64(hz > gd.zsafe) == ~0ull;
+                    zmin = uniform(gd.zmin);
+                    gz = uniform(gd.gz);
+                }
             }
             culled = __builtin_amdgcn_readfirstlane((int)culled) != 0;                  // wave-uniform, and known to be
         }
 #endif
         // The tile body once per kind of stripe (compile-time LAST): a run-time flag inside the row loop would keep both
         // variants' masks and corrections live at once (52 spilled SGPRs).
-        auto run_tile = [&](auto last_c) {
+        auto run_tile = [&](auto last_c, auto careful_c) {
             constexpr bool LAST = decltype(last_c)::value;
+            constexpr bool CAREFUL = decltype(careful_c)::value;   // the camera-2 plane may cut the tile's frustum (tight kernel)
             unsigned long long risky_chunks = 0;         // wave-uniform: chunk slots with at least one guarded lane
             uint32_t bits_lo = 0, bits_hi = 0, rb_lo = 0, rb_hi = 0;   // lane = chunk slot (5 per group in the last stripe, else 4)
             constexpr int NCH = LAST ? 5 : 4;               // words per row group: the last stripe also owns the 21st word of row 0
@@ -1603,7 +1663,8 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
                     qz[e] = iz;
                     vmk[e] = ballot64(d16[e] != 0u);
                     ivm[e] = vmk[e] & ballot64(u[e] > -kGuardPx) & ballot64(u[e] < DWd + kGuardPx) & ballot64(v[e] > -kGuardPx) &
-                             ballot64(v[e] < DHd + kGuardPx) & ballot64(iz > -kGuardZmm);
+                             ballot64(v[e] < DHd + kGuardPx);
+                    if (CAREFUL) ivm[e] = vmk[e] & ((ivm[e] & ballot64(iz > zmin)) | ballot64(!(__builtin_fabs(iz) > zmin)));
                     any |= ivm[e];
                 }
                 unsigned long long vm[NCH] = {};
@@ -1635,8 +1696,8 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
                         pix[e] = (int)((uint32_t)xi | ((uint32_t)yi << 16));
                         const double wu = __builtin_fabs(u[e] - ru) - 0.25;
                         const double wv = __builtin_fabs(v[e] - rv) - 0.25;
-                        rkc[e] = ballot64(!(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx)) |
-                                 ballot64(!(qz[e] > kGuardZmm));
+                        rkc[e] = ballot64(!(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx));
+                        if (CAREFUL) rkc[e] |= ballot64(!(qz[e] > zmin));
                         if (MSPA_SCALED_ROW_BARRIER) __builtin_amdgcn_sched_barrier(0);   // see the tight kernel: registers vs interleaving
                     }
                     unsigned long long rbm[NCH];
@@ -1648,7 +1709,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
                         const bool inview = __builtin_amdgcn_inverse_ballot_w64(ivm[e]);
                         const double sd = qz[e] - (double)dv16[e];
                         vm[e] = ivm[e] & ballot64(sd < 0.0);
-                        rbm[e] = ivm[e] & (rkc[e] | ballot64(!(__builtin_fabs(sd) > kGuardZmm)));
+                        rbm[e] = ivm[e] & (rkc[e] | ballot64(!(__builtin_fabs(sd) > gz)));
                         if (O::template has<O_PIX>(a.pix_i16)) lds_px[wave][e * 64 + c.lane] = (uint32_t)(inview ? pix[e] : -1);
                     }
                     unsigned long long rb_any = 0;
@@ -1723,8 +1784,9 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
                 __builtin_amdgcn_raw_buffer_store_b64(u32x2{bits_lo, bits_hi}, rs_bits, (int)(w * 8u), 0, 0);
             }
         };
-        if (last) run_tile(std::true_type{});
-        else run_tile(std::false_type{});
+        if (last) run_tile(std::true_type{}, std::true_type{});
+        else if (all_front) run_tile(std::false_type{}, std::false_type{});
+        else run_tile(std::false_type{}, std::true_type{});
     }
     if (O::template has<O_COUNTS>(a.counts)) {
         if (c.lane == 0) {
@@ -1822,6 +1884,7 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
     a.cpix = out_cpix; a.tile_counts = out_tile_counts;
     const int n_xcd = xcd_count();
     a.xcd_shift = n_xcd == 8 ? 3u : 0u;
+    a.wm1 = (double)(W - 1); a.hm1 = (double)(H - 1); a.wh_max = (double)(W > H ? W : H);
 
     if (out_counts) {      // 2 us per launch (tools/ab_k3.py: 0.5044 vs 0.5062 ms without / with)
         int rc = check_hip(hipMemsetAsync(out_counts, 0, sizeof(int32_t) * 2 * n_pairs, s), "hipMemsetAsync(counts)");
@@ -1992,14 +2055,18 @@ extern "C" int mspa_pair_correspondences(const uint16_t *depth, const double *fr
         return fail(MSPA_EINVAL, "mspa_pair_correspondences: out_cpix_i16 must be 16-byte, out_vis_bits 8-byte aligned");
     const int64_t need = mspa_pair_correspondences_workspace_bytes(n_pairs, dh, dw, H, W, flags);
     if (need < 0) return fail(MSPA_EINVAL, "mspa_pair_correspondences: bad pair count / image size");
-    if (need == 0)
+    // the fused kernel's LDS-DMA moves depth in 4-byte units: a depth table that is only 2-byte aligned takes the dense route
+    const bool depth_aligned = ((uintptr_t)depth & 3u) == 0;
+    if (need == 0 && depth_aligned)
         return pair_reproject_impl(depth, nullptr, frame_mats, n_frames, pairs, n_pairs, dh, dw, H, W, out_vis_bits, nullptr,
                                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, out_counts, out_cpix_i16,
                                    out_tile_counts, flags, stream);
     const int64_t dense = n_pairs * (int64_t)H * W * 4;
     if (n_pairs > 0 && (!workspace || workspace_bytes < dense || ((uintptr_t)workspace & 15u)))
-        return fail(MSPA_EINVAL, "mspa_pair_correspondences: this shape / mode goes through the dense table: pass a 16-byte "
-                                 "aligned workspace of n_pairs * H * W * 4 bytes");
+        return fail(MSPA_EINVAL, need == 0 ? "mspa_pair_correspondences: the fused kernel needs a 4-byte aligned depth table; this one "
+                                             "goes through the dense table: pass a 16-byte aligned workspace of n_pairs * H * W * 4 bytes"
+                                           : "mspa_pair_correspondences: this shape / mode goes through the dense table: pass a 16-byte "
+                                             "aligned workspace of n_pairs * H * W * 4 bytes");
     int rc = pair_reproject_impl(depth, nullptr, frame_mats, n_frames, pairs, n_pairs, dh, dw, H, W, out_vis_bits, nullptr,
                                  nullptr, (int16_t *)workspace, nullptr, nullptr, nullptr, nullptr, nullptr, out_counts,
                                  nullptr, nullptr, flags, stream);

@@ -118,14 +118,43 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_kernel(const doub
 // M = K * inv(A E), twelve entries, one per thread of the block, parked in LDS -- and a vertex costs 9 FMAs, a
 // reciprocal with one Newton step and two multiplies instead of 24 FP64 operations and two IEEE divisions.  Bit-exactness
 // is kept exactly as in K3's fast path: a lane whose decisions (half-to-even rounding of the pixel index, the image bounds,
-// the strict depth comparison) sit within a guard band of a decision boundary (1e-6 px, 1e-9 m: five orders of magnitude
-// above the rounding differences between the two evaluation orders) is re-evaluated with the reference chain.
+// the strict depth comparison) sit within a guard band of a decision boundary is re-evaluated with the reference chain.
+// The band is a BOUND (round 4; mspa_common.h): two float64 evaluation orders of K inv(A E) p differ by at most
+// B_k = c 2^-53 (Nabs[k][:3] . |p| + Nabs[k][3]), Nabs = |K| |inv(A E)|, in the k-th homogeneous coordinate; one thread per
+// image forms Nabs and leaves four numbers in LDS from which every lane takes, with s = |x| + |y| + |z| of its vertex,
+//   zmin = za s + zb   (camera depth, mm, at or below which the projection is not trusted: the error of u grows like 1 / depth)
+//   gz   = ga s + gb   (depth-test guard, mm).
 // Needs a pinhole K (third row 0 0 1 0: the third homogeneous coordinate IS the camera depth); any other image takes
 // the reference chain for all its lanes.  The composed matrix is scaled by 1000: u and v are unchanged and the third
 // coordinate is the camera depth in millimetres, directly comparable with the raw depth sample.
 // ---------------------------------------------------------------------------------------------------------
-constexpr double kVGuardPx = 1e-6;
-constexpr double kVGuardZmm = 1e-6;
+constexpr double kVGuardPx = kGuardPx;
+
+// Per-image guard coefficients (za, zb, ga, gb), by ONE thread per image: 36 multiply-adds of magnitudes, once per block, while
+// the other threads fetch their vertices.  The composed matrix is millimetre-scaled, hence the factor 1000.
+__device__ __forceinline__ void image_guard_coefficients(const double *__restrict__ Einv, const double *__restrict__ K, double wh_max,
+                                                         double *out4) {
+    double nr[3], nt[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double row[4];
+#pragma unroll
+        for (int cidx = 0; cidx < 4; ++cidx) {
+            double acc = __builtin_fabs(K[4 * r + 0]) * __builtin_fabs(Einv[0 + cidx]);
+            acc = __builtin_fma(__builtin_fabs(K[4 * r + 1]), __builtin_fabs(Einv[4 + cidx]), acc);
+            acc = __builtin_fma(__builtin_fabs(K[4 * r + 2]), __builtin_fabs(Einv[8 + cidx]), acc);
+            if (cidx == 3) acc += __builtin_fabs(K[4 * r + 3]);
+            row[cidx] = acc;
+        }
+        nr[r] = (row[0] + row[1]) + row[2];
+        nt[r] = row[3];
+    }
+    const double c = MSPA_GUARD_C * 0x1p-53 * 1000.0;
+    out4[0] = (2.0 / kGuardPx) * c * __builtin_fma(wh_max + 1.0, nr[2], nr[0] + nr[1]);
+    out4[1] = (2.0 / kGuardPx) * c * __builtin_fma(wh_max + 1.0, nt[2], nt[0] + nt[1]);
+    out4[2] = 2.0 * c * nr[2];
+    out4[3] = __builtin_fma(2.0 * c, nt[2], kGuardZmmFloor);
+}
 #ifndef MSPA_VBATCH
 #define MSPA_VBATCH 8
 #endif
@@ -145,6 +174,7 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_fast_kernel(const
     const int img1 = min(img0 + kImgPerBlock, a.n_images);
 
     __shared__ double lds_m[kImgPerBlock][12];
+    __shared__ __attribute__((aligned(16))) double lds_g[kImgPerBlock][4];
     __shared__ int lds_pinhole[kImgPerBlock];
     if (threadIdx.x < kImgPerBlock * 12) {
         const int im = threadIdx.x / 12, e = threadIdx.x % 12, r = e / 4, cidx = e % 4;
@@ -158,6 +188,9 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_fast_kernel(const
             lds_m[im][e] = acc * 1000.0;
             if (e == 0) lds_pinhole[im] = (K[8] == 0.0 && K[9] == 0.0 && K[10] == 1.0 && K[11] == 0.0) ? 1 : 0;
         }
+    } else if (threadIdx.x >= 128 && threadIdx.x < 128 + kImgPerBlock && img0 + (int)(threadIdx.x - 128) < img1) {
+        const double *__restrict__ Einv = cam_mats + (int64_t)(img0 + (int)(threadIdx.x - 128)) * 32;
+        image_guard_coefficients(Einv, Einv + 16, (double)max(a.W, a.H), lds_g[threadIdx.x - 128]);
     }
     const int64_t i = (int64_t)vblock * kVThreads + threadIdx.x;
     const bool live = i < a.n_points;
@@ -166,6 +199,7 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_fast_kernel(const
     const double x = xyz[ic * a.point_stride];
     const double y = xyz[ic * a.point_stride + a.comp_stride];
     const double z = xyz[ic * a.point_stride + 2 * a.comp_stride];
+    const double psum = (__builtin_fabs(x) + __builtin_fabs(y)) + __builtin_fabs(z);
     const int64_t dpix = (int64_t)a.dh * a.dw;
     const double Wd = (double)a.W, Hd = (double)a.H;
     const int hi_x = a.dw - 1, hi_y = a.dh - 1;
@@ -193,6 +227,7 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_fast_kernel(const
             const double u = ix * rz, v = iy * rz;
             const double us = IDENT ? u : u * a.sx, vs = IDENT ? v : v * a.sy;
             const double ru = __builtin_rint(us), rv = __builtin_rint(vs);
+            const double zmin = __builtin_fma(lds_g[im][0], psum, lds_g[im][1]);      // this vertex, this image (see the top)
             // saturating conversion (NaN -> 0), clamp by v_med3; the gather goes through a buffer resource of the frame with a
             // 32-bit byte offset (64-bit address arithmetic cost five more instructions per image in an instruction-bound
             // kernel).  The `cand ? offset : 0` below compiles to an exec-masked load: non-candidates (three lanes in four)
@@ -201,13 +236,15 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_fast_kernel(const
             int xi, yi;
             asm("v_med3_i32 %0, %1, 0, %2" : "=v"(xi) : "v"((int)ru), "s"(hi_x));
             asm("v_med3_i32 %0, %1, 0, %2" : "=v"(yi) : "v"((int)rv), "s"(hi_y));
-            // candidate = what the reference would accept, widened by the guard (a lane inside the widening is risky)
-            const bool cand = live & (u > -kVGuardPx) & (u < Wd + kVGuardPx) & (v > -kVGuardPx) & (v < Hd + kVGuardPx) &
-                              (iz > -kVGuardZmm);
+            // candidate = what the reference would accept, widened by the guard (a lane inside the widening is risky); within
+            // zmin of the camera plane u and v mean nothing: candidate whatever they say, and risky below
+            const bool nearz = !(__builtin_fabs(iz) > zmin);
+            const bool cand = live & (((u > -kVGuardPx) & (u < Wd + kVGuardPx) & (v > -kVGuardPx) & (v < Hd + kVGuardPx) &
+                                       (iz > zmin)) | nearz);
             // guard < |t| < 0.5 - guard for both coordinates  <=>  max(||tu| - .25|, ||tv| - .25|) < .25 - guard
             const double wu = __builtin_fabs(us - ru) - 0.25, wv = __builtin_fabs(vs - rv) - 0.25;
             unsigned long long rk = __builtin_amdgcn_ballot_w64(!(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kVGuardPx)) |
-                                    __builtin_amdgcn_ballot_w64(!(iz > kVGuardZmm));
+                                    __builtin_amdgcn_ballot_w64(nearz);
             if (!IDENT) {   // the bounds are integers of the COLOUR grid, the rounding ties belong to the depth grid
                 const double bu = __builtin_fmin(__builtin_fabs(u), __builtin_fabs(u - Wd));
                 const double bv = __builtin_fmin(__builtin_fabs(v), __builtin_fabs(v - Hd));
@@ -226,7 +263,8 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_fast_kernel(const
             const int im = img - img0;
             const double sd = izs[q] - (double)dv[q];
             unsigned long long word = cand_m[q] & __builtin_amdgcn_ballot_w64(sd < 0.0);
-            const unsigned long long rk = cand_m[q] & (risky_m[q] | __builtin_amdgcn_ballot_w64(!(__builtin_fabs(sd) > kVGuardZmm)));
+            const double gz = __builtin_fma(lds_g[im][2], psum, lds_g[im][3]);
+            const unsigned long long rk = cand_m[q] & (risky_m[q] | __builtin_amdgcn_ballot_w64(!(__builtin_fabs(sd) > gz)));
             const bool pin = lds_pinhole[im] != 0;               // block-uniform
             if (rk != 0 || !pin) {                               // rare: the reference chain (IH:57-69, 337-386) for those lanes
                 const double *__restrict__ Einv = cam_mats + (int64_t)img * 32;
@@ -309,6 +347,7 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
     const int tid = threadIdx.x, lane = tid & 63;
 
     __shared__ __attribute__((aligned(16))) double lds_m[kImgPerBlock][12];
+    __shared__ __attribute__((aligned(16))) double lds_g[kImgPerBlock][4];
     __shared__ int lds_pinhole[kImgPerBlock];
     __shared__ __attribute__((aligned(16))) double lds_xyz[kVThreads][3];
     __shared__ uint16_t lds_list[kVThreads * kImgPerBlock];
@@ -326,6 +365,9 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
             lds_m[im][e] = acc * 1000.0;
             if (e == 0) lds_pinhole[im] = (K[8] == 0.0 && K[9] == 0.0 && K[10] == 1.0 && K[11] == 0.0) ? 1 : 0;
         }
+    } else if (tid >= 128 && tid < 128 + kImgPerBlock && tid - 128 < nimg) {
+        const double *__restrict__ Einv = cam_mats + (int64_t)(img0 + tid - 128) * 32;
+        image_guard_coefficients(Einv, Einv + 16, (double)max(a.W, a.H), lds_g[tid - 128]);
     }
     if (tid < kImgPerBlock * (kVThreads / 32)) (&lds_bits[0][0])[tid] = 0u;
     if (tid == 0) lds_n = 0u;
@@ -348,6 +390,7 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
     lds_xyz[tid][0] = x;
     lds_xyz[tid][1] = y;
     lds_xyz[tid][2] = z;
+    const double psum = (__builtin_fabs(x) + __builtin_fabs(y)) + __builtin_fabs(z);
     const unsigned long long live_m = __builtin_amdgcn_ballot_w64(live);
     const double Wd = (double)a.W, Hd = (double)a.H;
     __syncthreads();
@@ -363,12 +406,13 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
             const double ix = __builtin_fma(m[0], x, __builtin_fma(m[1], y, __builtin_fma(m[2], z, m[3])));
             const double iy = __builtin_fma(m[4], x, __builtin_fma(m[5], y, __builtin_fma(m[6], z, m[7])));
             const double iz = __builtin_fma(m[8], x, __builtin_fma(m[9], y, __builtin_fma(m[10], z, m[11])));   // mm
-            const double gz = kVBandPx * iz;
-            const unsigned long long near0 = __builtin_amdgcn_ballot_w64(!(iz > kVGuardZmm));   // NaN lands here too
+            const double gb = kVBandPx * iz;
+            const double zmin = __builtin_fma(lds_g[q][0], psum, lds_g[q][1]);                  // this vertex, this image
+            const unsigned long long near0 = __builtin_amdgcn_ballot_w64(!(iz > zmin));         // NaN lands here too
             const unsigned long long inside =
-                __builtin_amdgcn_ballot_w64(ix > -gz) & __builtin_amdgcn_ballot_w64(ix < (Wd + kVBandPx) * iz) &
-                __builtin_amdgcn_ballot_w64(iy > -gz) & __builtin_amdgcn_ballot_w64(iy < (Hd + kVBandPx) * iz);
-            c = lds_pinhole[q] ? (live_m & __builtin_amdgcn_ballot_w64(!(iz <= -kVGuardZmm)) & (near0 | inside)) : live_m;
+                __builtin_amdgcn_ballot_w64(ix > -gb) & __builtin_amdgcn_ballot_w64(ix < (Wd + kVBandPx) * iz) &
+                __builtin_amdgcn_ballot_w64(iy > -gb) & __builtin_amdgcn_ballot_w64(iy < (Hd + kVBandPx) * iz);
+            c = lds_pinhole[q] ? (live_m & __builtin_amdgcn_ballot_w64(!(iz <= -zmin)) & (near0 | inside)) : live_m;
         }
         cm[q] = c;
         total += __popcll(c);
@@ -398,7 +442,7 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
     for (uint32_t e0 = 0; e0 < n; e0 += kVThreads * kEnt) {           // block-uniform trip count
         bool active[kEnt], risky[kEnt];
         uint32_t vv[kEnt], qq[kEnt], d[kEnt];
-        double pxs[kEnt], pys[kEnt], pzs[kEnt], izs[kEnt];
+        double pxs[kEnt], pys[kEnt], pzs[kEnt], izs[kEnt], gzs[kEnt];
 #pragma unroll
         for (int k = 0; k < kEnt; ++k) {
             const uint32_t e = e0 + (uint32_t)(k * kVThreads + tid);
@@ -425,7 +469,10 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
             asm("v_med3_i32 %0, %1, 0, %2" : "=v"(xi) : "v"((int)ru), "s"(hi_x));
             asm("v_med3_i32 %0, %1, 0, %2" : "=v"(yi) : "v"((int)rv), "s"(hi_y));
             const double wu = __builtin_fabs(us - ru) - 0.25, wv = __builtin_fabs(vs - rv) - 0.25;
-            bool rk = !(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kVTiePx) | !(iz > kVGuardZmm) |
+            const double es = (__builtin_fabs(px) + __builtin_fabs(py)) + __builtin_fabs(pz);
+            const double zmin = __builtin_fma(lds_g[q][0], es, lds_g[q][1]);
+            gzs[k] = __builtin_fma(lds_g[q][2], es, lds_g[q][3]);
+            bool rk = !(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kVTiePx) | !(iz > zmin) |
                       (lds_pinhole[q] == 0);
             if (!IDENT) {   // the bounds are integers of the COLOUR grid, the rounding ties belong to the depth grid
                 const double bu = __builtin_fmin(__builtin_fabs(u), __builtin_fabs(u - Wd));
@@ -441,7 +488,7 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
         for (int k = 0; k < kEnt; ++k) {
             const double sd = izs[k] - (double)d[k];
             bool vis = sd < 0.0;
-            const bool rk = active[k] & (risky[k] | !(__builtin_fabs(sd) > kVGuardZmm));
+            const bool rk = active[k] & (risky[k] | !(__builtin_fabs(sd) > gzs[k]));
 #ifdef MSPA_EXPERIMENT_NOCOLD   // timing only (wrong results for guarded lanes)
             if (false) {
 #else

@@ -24,6 +24,7 @@ from __future__ import annotations
 import argparse
 import os
 import random
+import time
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -51,6 +52,9 @@ def pair_table_rows(scene_idx: int, scene) -> np.ndarray:
     return out
 
 
+LAST_TIMINGS: Dict[str, float] = {}      # of the most recent run() in this process: rank 0's serial replay of the other ranks' tapes
+
+
 def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None, device="cuda", seed: int = 0,
         n_camera: int = 64, n_correspondence: int = 64, depth_images_per_scene: int = 4,
         overlap_range=(6, 35), question_types: Sequence[str] = ("total_distance", "displacement_vector"),
@@ -62,6 +66,7 @@ def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None,
     from .scene import SceneOnDevice
 
     rank, world = (ctx.rank, ctx.world) if ctx is not None else (0, 1)
+    LAST_TIMINGS.clear()
     costs = [shard.scene_cost(len(sc.valid_image_ids), sc.points.shape[0]) for sc in scenes]
     scene_bins = shard.lpt_assign(costs, world)
     scene_owner = {k: r for r, b in enumerate(scene_bins) for k in b}
@@ -214,6 +219,7 @@ def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None,
                 merge(outputs, name, fn(resident.get(key)))
             continue
         local = []
+        own = {}                                               # records of the units this rank ran itself
         for key, fn in units[name]:
             if owner_of(name, key) != rank:
                 continue
@@ -223,24 +229,32 @@ def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None,
                     rec.note(resident[key]._visibility()["count"])
                 direct = fn(resident.get(key))
             rows = rec.rows()
-            local += tape.frame(key, rows)
-            if selftest_tape:                                 # single-process self-check: the replay must reproduce the records
+            if rank != 0:                                      # rank 0 keeps its own records: nothing of its units crosses the fabric
+                local += tape.frame(key, rows)
+            own[key] = direct
+            if selftest_tape:                                 # self-check: the replay must reproduce the records
                 player = tape.Player(engine, rows, device)
                 with tape.engine_as(player):
                     again = fn(replay_scene(name, key, player))
                 assert again == direct, f"tape replay of {name} / unit {key} differs from the direct run"
-                merge(outputs, name, direct)
         if ctx is None:
+            for key, fn in units[name]:                        # selftest without a communicator: every unit is this rank's
+                merge(outputs, name, own[key])
             continue
         payload = torch.from_numpy(np.concatenate(local, 0) if local else np.zeros((0, tape.WIDTH))).to(ctx.collective_device)
-        table = shard.collate_records(payload, ctx).cpu().numpy()              # the exchange: float64 rows, nothing else
+        table = shard.collate_records(payload, ctx, dst=0)                    # the exchange: float64 rows, to rank 0 only
         if rank != 0:
             continue
-        tapes = tape.unframe(table)
+        tapes = tape.unframe(table.cpu().numpy())
+        t_replay = time.perf_counter()
         for key, fn in units[name]:                            # unit order, whoever ran it
+            if key in own:                                     # rank 0's own units: the records it already has
+                merge(outputs, name, own[key])
+                continue
             player = tape.Player(engine, tapes[key], device)
             with tape.engine_as(player):
                 merge(outputs, name, fn(replay_scene(name, key, player)))
+        LAST_TIMINGS["rank0_replay_s"] = LAST_TIMINGS.get("rank0_replay_s", 0.0) + (time.perf_counter() - t_replay)
 
     # ---- rank 0: canonical order, seeded shuffle, JSONL ------------------------------------------------------
     counts: Dict[str, int] = {}
@@ -278,7 +292,7 @@ def main():
     tracks = [synth.make_tracks(300 + k, T=120, P=96, n_groups=4) for k in range(args.tracks)]
     counts = run(scenes, args.out, ctx, device, args.seed, tracks=tracks)
     if ctx is None or ctx.rank == 0:
-        print({"out": args.out, "records": counts})
+        print({"out": args.out, "records": counts, "timings": dict(LAST_TIMINGS)})
     if ctx is not None:
         ctx.close()
 

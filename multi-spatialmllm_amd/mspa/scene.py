@@ -198,7 +198,15 @@ class SceneOnDevice:
         return out, visibility
 
     # ---- K3 ---------------------------------------------------------------------------------
+    def _require_millimetres(self, what: str):
+        """K3 folds the reference's 0.001 m per depth unit (OPS:292-294, a literal there) into its matrices; a handler built
+        with another ``depth_value_scale`` (IH:76) would get vertex visibility at one scale and pair visibility at another."""
+        if self.depth_scale != 0.001:
+            raise ValueError(f"SceneOnDevice.{what}: the frame-pair kernels work in millimetres (project_mask_to_3d's literal "
+                             f"0.001, OPS:292-294); this scene was built with depth_scale={self.depth_scale!r}")
+
     def pair_reproject(self, pairs_ids: Sequence[Tuple[str, str]], outputs: Sequence[str], fast: bool = True):
+        self._require_millimetres("pair_reproject")
         pairs = torch.tensor([[self.index[a], self.index[b]] for a, b in pairs_ids], dtype=torch.int32,
                              device=self.device).reshape(-1, 2)
         out = engine.alloc_pair_outputs(pairs.shape[0], self.image_hw, outputs, self.device)
@@ -210,6 +218,7 @@ class SceneOnDevice:
         """K3 with the compacted output (include/mspa.h, mspa_pair_correspondences): per pair the visibility bitset and, per
         64 x 48 tile of the first image, the second image's depth pixel (xi, yi) of the VISIBLE pixels only.
         ``engine.correspondences_rowmajor(out, self.image_hw, k)`` gives pair k's flat (pixel, xi, yi) in np.nonzero order."""
+        self._require_millimetres("pair_correspondences")
         pairs = torch.tensor([[self.index[a], self.index[b]] for a, b in pairs_ids], dtype=torch.int32,
                              device=self.device).reshape(-1, 2)
         out = engine.alloc_pair_correspondences(pairs.shape[0], self.image_hw, self.device)

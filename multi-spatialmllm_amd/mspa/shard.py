@@ -116,11 +116,12 @@ def collate_records_async(local: torch.Tensor, ctx: DistContext, out: torch.Tens
     return out, work
 
 
-def collate_records(local: torch.Tensor, ctx: DistContext) -> torch.Tensor:
-    """all_gather a [n_local, k] record tensor whose n_local may differ per rank.
+def collate_records(local: torch.Tensor, ctx: DistContext, dst: int = None) -> torch.Tensor:
+    """Collate a [n_local, k] record tensor whose n_local may differ per rank.
 
-    Two collectives: counts (one int64 per rank), then the records padded to the largest count.
-    Returns the concatenation in rank order, identical on every rank."""
+    Two collectives: counts (one int64 per rank), then the records padded to the largest count.  ``dst=None``: all_gather,
+    the concatenation in rank order comes back identical on every rank.  ``dst=r``: gather to rank r only (the pipeline's
+    tapes, which only rank 0 reads: fabric traffic world x less); the other ranks get an empty [0, k] tensor."""
     if local.dim() != 2:
         raise ValueError("collate_records: a [n, k] record tensor is required")
     if local.device != ctx.collective_device:
@@ -137,6 +138,12 @@ def collate_records(local: torch.Tensor, ctx: DistContext) -> torch.Tensor:
     else:
         padded = torch.zeros((n_max, local.shape[1]), dtype=local.dtype, device=local.device)
         padded[:local.shape[0]] = local
+    if dst is not None:
+        parts = [torch.empty_like(padded) for _ in range(ctx.world)] if ctx.rank == dst else None
+        dist.gather(padded, parts, dst=dst, group=ctx.group)
+        if ctx.rank != dst:
+            return local[:0]
+        return torch.cat([parts[r][:c] for r, c in enumerate(counts)], dim=0)
     gathered = torch.empty((ctx.world * n_max, local.shape[1]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(gathered, padded, group=ctx.group)
     if all(c == n_max for c in counts):

@@ -173,6 +173,28 @@ def test_compact_argument_checks():
                                        out["vis_bits"].data_ptr(), out["cpix"].data_ptr(), out["tile_counts"].data_ptr(), None,
                                        None, 0, 0, None)
     assert rc == _lib.MSPA_EINVAL and b"workspace" in lib.mspa_last_error_string()
+    # a depth table at an odd 2-byte offset cannot feed the fused kernel's 4-byte LDS-DMA: dense route, i.e. a workspace is
+    # needed although workspace_bytes (which cannot see the pointer) said 0 -- the error says so; with one, same results
+    F = depth.shape[0]
+    buf = torch.zeros(F * 96 * 128 + 1, dtype=depth.dtype, device=DEV)
+    odd = buf[1:].view(F, 96, 128)
+    odd.copy_(depth)
+    assert odd.data_ptr() % 4 == 2
+    fused = engine.pair_correspondences(depth, mats, pairs, hw, flags=_lib.PAIR_FAST)
+    assert lib.mspa_pair_correspondences_workspace_bytes(1, 96, 128, 96, 128, _lib.PAIR_FAST) == 0
+    args = (mats.data_ptr(), 2, pairs.data_ptr(), 1, 96, 128, 96, 128, out["vis_bits"].data_ptr(), out["cpix"].data_ptr(),
+            out["tile_counts"].data_ptr(), out["counts"].data_ptr())
+    rc = lib.mspa_pair_correspondences(odd.data_ptr(), *args, None, 0, _lib.PAIR_FAST, None)
+    assert rc == _lib.MSPA_EINVAL and b"4-byte aligned" in lib.mspa_last_error_string()
+    ws = torch.empty(96 * 128, dtype=torch.int32, device=DEV)
+    rc = lib.mspa_pair_correspondences(odd.data_ptr(), *args, ws.data_ptr(), ws.numel() * 4, _lib.PAIR_FAST, None)
+    assert rc == 0 and lib.mspa_pair_reproject_last_kernel() != _lib.KERNEL_PAIR_FAST_TIGHT
+    torch.cuda.synchronize()
+    for k in ("vis_bits", "tile_counts", "counts"):
+        assert torch.equal(out[k], fused[k]), k
+    n0 = fused["tile_counts"][0].cpu().numpy()
+    for t in range(n0.size):
+        assert torch.equal(out["cpix"][0, t, :n0[t]], fused["cpix"][0, t, :n0[t]])
     # zero pairs: nothing to do
     empty = engine.alloc_pair_correspondences(0, hw, DEV)
     engine.pair_correspondences(depth, mats, pairs[:0], hw, empty)

@@ -118,6 +118,22 @@ def test_matrix_preparation_matches_numpy():
         assert np.array_equal(m[f, _lib.MAT_EINV_ALIGNED].reshape(4, 4), np.linalg.inv(sc.A @ E[f]))
         assert np.allclose(m[f, _lib.MAT_UNPROJ].reshape(4, 4), sc.A @ E[f] @ np.linalg.inv(sc.K), rtol=1e-15)
         assert np.allclose(m[f, _lib.MAT_REPROJ].reshape(4, 4), sc.K @ np.linalg.inv(sc.A @ E[f]), rtol=1e-15)
+    # slot MSPA_MAT_BOUNDS: the guard-bound coefficients, NumPy form == the library's host helper (up to the summation order
+    # of the magnitudes), and what they claim -- magnitudes of the chain's two halves -- holds
+    m2 = m.copy()
+    m2[:, _lib.MAT_BOUNDS] = -1.0
+    _lib.check(_lib.load().mspa_frame_bounds_host(m2.ctypes.data, m2.shape[0]))
+    assert np.allclose(m2[:, _lib.MAT_BOUNDS], m[:, _lib.MAT_BOUNDS], rtol=1e-14, atol=0)
+    assert np.array_equal(m2[:, :_lib.MAT_BOUNDS], m[:, :_lib.MAT_BOUNDS])
+    c = _lib.GUARD_C * 2.0 ** -53
+    for f in range(3):
+        b = m[f, _lib.MAT_BOUNDS]
+        Ua = np.abs(sc.A) @ np.abs(E[f]) @ np.abs(np.linalg.inv(sc.K))
+        Na = np.abs(sc.K) @ np.abs(np.linalg.inv(sc.A @ E[f]))
+        assert np.allclose(b[:3], Ua[:3, :3].max(axis=0), rtol=1e-14) and np.isclose(b[3], 1000.0 * Ua[:3, 3].max(), rtol=1e-14)
+        assert np.allclose(b[4:7], c * Na[:3, :3].sum(axis=1), rtol=1e-14) and np.allclose(b[8:11], c * 1000.0 * Na[:3, 3], rtol=1e-14)
+        assert b[7] == 0 and (b[11:] == 0).all()
+    assert _lib.load().mspa_frame_bounds_host(None, 3) == _lib.MSPA_EINVAL
     assert engine.fast_path_ok(sc.K)
     bad_K = sc.K.copy()
     bad_K[2, 3] = 0.5
@@ -191,6 +207,9 @@ def _worker(rank, world, port, q):
     tapes = TP.unframe(table)
     assert sorted(tapes) == [10, 11, 99] and len(tapes[99]) == 0
     got = {key: TP.Player(None, tapes[key], "cpu").next().numpy().tolist() for key in (10, 11)}
+    # the same exchange towards rank 0 only (what the pipeline does since round 4: rank 0 is the only reader)
+    to0 = S.collate_records(torch.from_numpy(np.concatenate(local, 0)), ctx, dst=0).numpy()
+    assert np.array_equal(to0, table) if rank == 0 else to0.shape == (0, TP.WIDTH)
     ctx.barrier()
     q.put((rank, full.numpy().tolist(), t, got))
     ctx.close()

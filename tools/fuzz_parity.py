@@ -23,30 +23,13 @@ SETS = {"corr": ("vis_bits", "pix_i16", "counts"), "minimal": ("vis_bits", "coun
 
 
 def _poses(seed, n, hw):
-    from mspa import synth
-    from test_gpu_tight import adversarial_pairs
-    rng = np.random.default_rng(seed)
-    K, A, E = adversarial_pairs(rng, n // 2, hw)
-    eye = rng.uniform([1.5, 1.5, 1.3], [4.5, 4.5, 1.8])
-    tgt = synth.ROOM / 2 + rng.normal(0, 0.8, 3) * [1, 1, 0.3]
-    for _ in range(n - len(E)):                       # a hand-held walk: neighbouring views with 10-90 % overlap
-        eye = np.clip(eye + rng.normal(0, 0.25, 3) * [1, 1, 0.2], [0.4, 0.4, 0.8], [5.6, 5.6, 2.4])
-        tgt = tgt + rng.normal(0, 0.4, 3) * [1, 1, 0.3]
-        E.append(synth._roundtrip_f(synth._look_at(eye, tgt)))
-    return K, A, E, synth._make_boxes(rng)
+    import adversarial
+    return adversarial.fuzz_poses(seed, n, hw)
 
 
 def _render(job):
-    from mspa import synth
-    seed, k, Ae, Kd, dhw, boxes = job
-    rng = np.random.default_rng(seed * 1000 + k)
-    z = synth.render_depth(Ae, Kd, dhw, boxes)
-    mm = np.clip(np.rint(z * 1000.0 + rng.normal(0, 4.0, z.shape)), 0, 65535).astype(np.uint16)
-    mm[rng.random(mm.shape) < 0.07] = 0
-    if k % 5 == 0:                                    # a large hole: tiles without a single valid sample
-        y0, x0 = rng.integers(0, dhw[0] // 2), rng.integers(0, dhw[1] // 2)
-        mm[y0:y0 + dhw[0] // 3, x0:x0 + dhw[1] // 3] = 0
-    return mm
+    import adversarial
+    return adversarial.fuzz_depth(job)
 
 
 def main():
