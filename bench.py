@@ -238,8 +238,10 @@ def stream_hint(args, n_frames):
 SPINUP = {"steps": 0}
 
 
-def time_variant(variant, mode, depth, mats, rgb, pairs, steps, warmup, dist_ctx, stream=False, spinup_ms=0.0):
-    """Returns (wall seconds for `steps` steps, mean kernel ms from HIP events, outputs)."""
+def time_variant(variant, mode, depth, mats, rgb, pairs, steps, warmup, dist_ctx, stream=False, spinup_ms=0.0,
+                 per_step_events=False):
+    """Returns (wall seconds for `steps` steps, mean kernel ms from HIP events, outputs).  ``per_step_events``: round 2's
+    method -- an event pair around EVERY launch, mean of the per-step times (the `cold_ms_per_step` leg)."""
     import torch
     from mspa import engine, shard
 
@@ -301,16 +303,23 @@ def time_variant(variant, mode, depth, mats, rgb, pairs, steps, warmup, dist_ctx
         dist_ctx.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev_start.record()
-    for k in range(steps):
-        step(k)
-    ev_end.record()
+    if per_step_events:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for k in range(steps):
+            evs[k][0].record()
+            step(k)
+            evs[k][1].record()
+    else:
+        ev_start.record()
+        for k in range(steps):
+            step(k)
+        ev_end.record()
     table = collate(steps)
     torch.cuda.synchronize()
     if dist_ctx is not None:
         dist_ctx.barrier()
     wall = time.perf_counter() - t0
-    kern_ms = float(ev_start.elapsed_time(ev_end)) / steps
+    kern_ms = (sum(float(a.elapsed_time(b)) for a, b in evs) / steps) if per_step_events else float(ev_start.elapsed_time(ev_end)) / steps
     if spinup_ms > 0:
         SPINUP["steps"] = spun
     if table is not None and dist_ctx.rank == 0:         # the collated table really holds every rank's records
@@ -645,9 +654,26 @@ def main():
     dist_ctx = (shard.init_distributed(device, backend="gloo" if share else None)
                 if (world > 1 or os.environ.get("MSPA_BENCH_FORCE_DIST")) else None)
     stream = stream_hint(args, int(depth.shape[0]))
+    # `cold_ms_per_step`: rounds 1-2's method, kept beside the steady-state number so that rounds stay comparable -- no clock
+    # spin-up (the part comes straight from the host-side input preparation), an event pair around every step, W warm-up steps.
+    # Rank 0 of a single-GPU run only; it runs BEFORE the headline (afterwards the clock would be warm).
+    cold_ms = None
+    if world == 1 and not os.environ.get("MSPA_BENCH_FORCE_DIST"):
+        _, cold_ms, _cold_out = time_variant(args.variant, args.mode, depth, mats, rgb, pairs, args.steps, args.warmup, None, stream,
+                                             spinup_ms=0.0, per_step_events=True)
+        del _cold_out
     wall, kern_ms, out = time_variant(args.variant, args.mode, depth, mats, rgb, pairs, args.steps, args.warmup,
                                       dist_ctx, stream, spinup_ms=args.spinup_ms)
+    rank_walls = None
     if dist_ctx is not None:
+        # every rank's own wall time of the timed region (they all include the same final barrier; what differs is how long a
+        # rank waited there): per-rank rates in the line make a scaling record self-validating
+        import torch.distributed as dist
+        w_t = torch.tensor([wall], dtype=torch.float64, device=dist_ctx.collective_device)
+        w_all = [torch.zeros_like(w_t) for _ in range(dist_ctx.world)]
+        dist.all_gather(w_all, w_t, group=dist_ctx.group)
+        rank_walls = [float(x.item()) for x in w_all]
+        rccl_world = dist.get_world_size()
         wall = dist_ctx.max_over_ranks(wall)
     pairs_per_step = args.pairs * world
     value = pairs_per_step * args.steps / wall
@@ -660,12 +686,22 @@ def main():
         return round(float(c[:, 1].sum() / max(1, c[:, 0].sum())), 4)
 
     def with_traffic(d, v, m, wl, k_ms):
-        """`traffic_frac` = PMC-measured HBM bytes (committed profile of this leg) / this run's kernel time / peak."""
+        """`traffic_frac` = PMC-measured HBM bytes (committed profile of this leg) / this run's kernel time / peak, printed
+        beside `frac` (the SURVEY 8d formula) for every point; a point whose formula exceeds the measured traffic by more than
+        10 % is flagged: there the formula counts bytes the kernel never moves (depth-2 of culled tiles) and `traffic_frac`
+        is the reading to use."""
         t = committed_traffic(f"{v}:{m}:{wl}") if args.pairs == 1000 else None
         if t:
             d["traffic"] = t["hbm_bytes_per_launch"]
             d["traffic_frac"] = round(t["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             d["traffic_source"] = t["source"]
+            over = d["bytes_per_pair"] * args.pairs / t["hbm_bytes_per_launch"]
+            d["formula_over_traffic"] = round(over, 3)
+            if over > 1.10:
+                d["frac_flag"] = ("formula bytes exceed the measured HBM traffic by more than 10 % (depth-2 is counted at 2 B per "
+                                  "pixel although culled tiles never read it): read traffic_frac, not frac")
+        else:
+            d["traffic_frac"] = None
         return d
 
     def leg(v, m, prs, steps, wl):
@@ -707,6 +743,16 @@ def main():
         for lg in [v for v in _legs(args.also) if v != f"{args.variant}:{args.mode}"]:
             v, m = lg.split(":")
             extra[lg] = leg(v, m, pairs, short, args.workload)
+        if not args.no_sweep and "compact:fast" in _legs(args.also) and args.variant != "compact":
+            # the compacted set is what the correspondence head consumes: its own three-point sweep
+            sweep_compact = {}
+            for kind in WORKLOADS:
+                if kind == args.workload:
+                    sweep_compact[kind] = extra["compact:fast"]
+                    continue
+                p2, _, i2 = workload_pairs(overlap, nb, reps, args.pairs, kind, rank)
+                sweep_compact[kind] = dict(leg("compact", "fast", torch.from_numpy(p2).to(device), max(short, 5), kind), pairs=i2)
+            extra["sweep_compact"] = sweep_compact
         if not args.no_sweep:
             # the same pairs four times over in ONE launch (same mix of overlaps): does a launch of configs[1]'s size pay for the
             # ramp and the tail of its grid?  Measured: no -- within +-4 % of the 1 000-pair launch, either way.
@@ -748,6 +794,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
+            "cold_ms_per_step": None if cold_ms is None else round(cold_ms, 4),
+            "cold_method": "no clock spin-up, HIP event pair around every step, mean of the K per-step times after W warm-up "
+                           "steps (rounds 1-2's method); `ms_per_step` / `roofline.kernel_ms` are the steady-state reading",
             "config": {"workload": "visual_correspondence unproject+reproject+occlusion kernel (K3) on "
                                    f"{args.pairs} 640x480 frame pairs per GPU per step (BASELINE.json configs[1]); pairs = "
                                    f"'{args.workload}' sample of the scene's overlap table: {winfo['rule']}",
@@ -785,6 +834,12 @@ def main():
         if world > 1:
             line["gpus_shared"] = bool(share)
             line["physical_gpus"] = n_dev
+        if rank_walls is not None:
+            rates = [args.pairs * args.steps / w for w in rank_walls]
+            line["rccl_world"] = rccl_world               # torch.distributed.get_world_size() of the communicator that collated
+            line["per_rank_pairs_per_s"] = {"min": round(min(rates), 1), "max": round(max(rates), 1),
+                                            "note": "each rank's own pairs / its own wall time of the timed region; `value` = all "
+                                                    "ranks' pairs / the slowest rank's wall time"}
     if dist_ctx is not None:
         dist_ctx.barrier()          # leave together: no rank tears the communicator down under another one's feet
         dist_ctx.close()

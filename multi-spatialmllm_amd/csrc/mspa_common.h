@@ -69,7 +69,10 @@ __device__ __forceinline__ double affine_row_w(const double *__restrict__ m, dou
 // Round 3 used constants (1e-6 px, 1e-6 mm) for all of these: wrong when camera 2 sits within micrometres of a frame-1
 // surface point (the error grows like 1 / q_2) or when world coordinates are huge (tools/guard_bound_emulation.py).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr double kGuardPx = 1e-6;                // distance to a rounding tie / an integer bound (pixels)
+#ifndef MSPA_GUARD_PX
+#define MSPA_GUARD_PX 1e-6
+#endif
+constexpr double kGuardPx = MSPA_GUARD_PX;       // distance to a rounding tie / an integer bound (pixels); zmin scales with 1 / it
 constexpr double kGuardZmmFloor = 1e-6;          // smallest depth-test guard (mm): covers the rounding of sample * 0.001 itself
 constexpr double kCullMarginXY = 1.0;            // frustum culling: homogeneous x / y (pixel * millimetre)
 constexpr double kCullMarginZ = 1e-3;            // frustum culling: homogeneous depth (millimetres)

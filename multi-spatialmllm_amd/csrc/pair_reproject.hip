@@ -993,8 +993,11 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
         const double *__restrict__ bnd2 = m2 + MSPA_MAT_BOUNDS * 16;
         const double tile_xmax = (double)(stripe * 64u + 63u), tile_ymax = (double)(row0 + (uint32_t)(ROWS - 1));
         double zmin = 0.0, gz = kGuardZmmFloor;            // wave-uniform (SGPR pairs) once set below
-        if (!WANT_XYZ && !O::template has<O_VALID_U8>(a.valid_u8) && !O::template has<O_RGBA>(a.rgba) &&
-            !O::template has<O_VIS_U8>(a.vis_u8)) {
+        // the dense payload sets write every pixel, so their tiles are never culled -- but they take the pass all the same: the
+        // band comes from the tile's own largest sample (with the format's 65 535 mm it is ~13 x wider, and on distant views
+        // whole rows of lanes "near the camera-2 plane" went to the reference chain: dense_xyz 0.98 -> 1.38 ms on `low`)
+        constexpr bool CAN_CULL = !WANT_XYZ && !(SET & (O_VALID_U8 | O_RGBA | O_VIS_U8));
+        {
             typedef unsigned short us2 __attribute__((ext_vector_type(2)));
             const us2 *wds = reinterpret_cast<const us2 *>(lds_d1w);
             us2 mn = {0xFFFF, 0xFFFF}, mxv = {0, 0};
@@ -1011,7 +1014,8 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                 hi = max(hi, __shfl_xor(hi, off));
             }
             if (hi == 0) {
-                culled = true;                                            // no valid depth sample at all
+                culled = CAN_CULL;                                        // no valid depth sample at all
+                all_front = true;                                         // (and nothing the row loop could get wrong)
             } else {
                 const int k = c.lane & 7;
                 const double cx = (double)(stripe * 64u + ((k & 1) ? 63u : 0u));
@@ -1027,7 +1031,7 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                 const bool all_right = ballot64(hx - (double)a.W * hz > kCullMarginXY) == ~0ull;
                 const bool all_above = ballot64(hy < -kCullMarginXY) == ~0ull;
                 const bool all_below = ballot64(hy - (double)a.H * hz > kCullMarginXY) == ~0ull;
-                culled = all_behind | all_left | all_right | all_above | all_below;
+                culled = CAN_CULL && (all_behind | all_left | all_right | all_above | all_below);
                 if (culled) {
                     culled = ballot64(cull_margins_hold(bnd1, bnd2, a.wm1, a.hm1, a.wh_max)) == ~0ull;
                 }
@@ -1052,13 +1056,6 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                         buffer_store_b128_guarded(none, rs_pix, pix_voff, (int)((row0 + (uint32_t)r0) * Wb * 4u));
                 }
             }
-        }
-
-        else {
-            // sets without the pre-pass (dense payloads: every pixel is written anyway): the bound over the full sample range
-            const Guard gd = guard_from_bounds(bnd1, bnd2, tile_xmax, tile_ymax, 65535.0, a.wh_max);
-            zmin = uniform(gd.zmin);
-            gz = uniform(gd.gz);
         }
 
         // The row loop once per kind of tile (compile-time CAREFUL, as the ScanNet-shape kernel does for its last stripe): a

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_kernel(const doub
 // the reference chain for all its lanes.  The composed matrix is scaled by 1000: u and v are unchanged and the third
 // coordinate is the camera depth in millimetres, directly comparable with the raw depth sample.
 // ---------------------------------------------------------------------------------------------------------
-constexpr double kVGuardPx = kGuardPx;
+constexpr double kVGuardPx = 1e-6;              // K1's own pixel guard (K3's is tunable: mspa_common.h MSPA_GUARD_PX)
 
 // Per-image guard coefficients (za, zb, ga, gb), by ONE thread per image: 36 multiply-adds of magnitudes, once per block, while
 // the other threads fetch their vertices.  The composed matrix is millimetre-scaled, hence the factor 1000.
@@ -150,8 +150,8 @@ __device__ __forceinline__ void image_guard_coefficients(const double *__restric
         nt[r] = row[3];
     }
     const double c = MSPA_GUARD_C * 0x1p-53 * 1000.0;
-    out4[0] = (2.0 / kGuardPx) * c * __builtin_fma(wh_max + 1.0, nr[2], nr[0] + nr[1]);
-    out4[1] = (2.0 / kGuardPx) * c * __builtin_fma(wh_max + 1.0, nt[2], nt[0] + nt[1]);
+    out4[0] = (2.0 / kVGuardPx) * c * __builtin_fma(wh_max + 1.0, nr[2], nr[0] + nr[1]);
+    out4[1] = (2.0 / kVGuardPx) * c * __builtin_fma(wh_max + 1.0, nt[2], nt[0] + nt[1]);
     out4[2] = 2.0 * c * nr[2];
     out4[3] = __builtin_fma(2.0 * c, nt[2], kGuardZmmFloor);
 }
@@ -321,8 +321,8 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_fast_kernel(const
 #ifndef MSPA_VCOMPACT_ENTRIES
 #define MSPA_VCOMPACT_ENTRIES 1
 #endif
-constexpr double kVBandPx = 1e-6;            // phase A: candidate band around the image, on the homogeneous coordinates
-constexpr double kVTiePx = 2e-6;             // phase B: tie / bound guard on the divided coordinates
+constexpr double kVBandPx = kVGuardPx;       // phase A: candidate band around the image, on the homogeneous coordinates
+constexpr double kVTiePx = 2.0 * kVGuardPx;  // phase B: tie / bound guard on the divided coordinates
 
 #ifndef MSPA_VCOMPACT_WAVES
 #define MSPA_VCOMPACT_WAVES 8
@@ -347,7 +347,7 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
     const int tid = threadIdx.x, lane = tid & 63;
 
     __shared__ __attribute__((aligned(16))) double lds_m[kImgPerBlock][12];
-    __shared__ __attribute__((aligned(16))) double lds_g[kImgPerBlock][4];
+    __shared__ __attribute__((aligned(16))) double lds_g[4];         // guard coefficients: the LARGEST over the block's images
     __shared__ int lds_pinhole[kImgPerBlock];
     __shared__ __attribute__((aligned(16))) double lds_xyz[kVThreads][3];
     __shared__ uint16_t lds_list[kVThreads * kImgPerBlock];
@@ -365,9 +365,27 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
             lds_m[im][e] = acc * 1000.0;
             if (e == 0) lds_pinhole[im] = (K[8] == 0.0 && K[9] == 0.0 && K[10] == 1.0 && K[11] == 0.0) ? 1 : 0;
         }
-    } else if (tid >= 128 && tid < 128 + kImgPerBlock && tid - 128 < nimg) {
-        const double *__restrict__ Einv = cam_mats + (int64_t)(img0 + tid - 128) * 32;
-        image_guard_coefficients(Einv, Einv + 16, (double)max(a.W, a.H), lds_g[tid - 128]);
+    }
+    // Guard coefficients: lane q of the block's LAST wave forms image q's four numbers, the wave takes the maximum over its
+    // images (they are non-negative: 0 is neutral) and leaves ONE set per block -- a lane's zmin then costs one FMA per
+    // block instead of one per image, at the price of the widest image's band for all eight.
+    static_assert(kImgPerBlock <= 8, "three xor-shuffle steps cover eight lanes");
+    if (tid >= kVThreads - 64) {
+        const int q = tid - (kVThreads - 64);
+        double g4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (q < nimg) {
+            const double *__restrict__ Einv = cam_mats + (int64_t)(img0 + q) * 32;
+            image_guard_coefficients(Einv, Einv + 16, (double)max(a.W, a.H), g4);
+        }
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g4[k] = __builtin_fmax(g4[k], __shfl_xor(g4[k], off));
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lds_g[k] = g4[k];
+        }
     }
     if (tid < kImgPerBlock * (kVThreads / 32)) (&lds_bits[0][0])[tid] = 0u;
     if (tid == 0) lds_n = 0u;
@@ -394,6 +412,15 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
     const unsigned long long live_m = __builtin_amdgcn_ballot_w64(live);
     const double Wd = (double)a.W, Hd = (double)a.H;
     __syncthreads();
+    // block-uniform coefficients -> scalar registers; this lane's camera-depth threshold for all of the block's images
+    double gc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long b = __double_as_longlong(lds_g[k]);
+        gc[k] = __longlong_as_double(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)b));
+    }
+    const double zmin_l = __builtin_fma(gc[0], psum, gc[1]);
 
     // ---- phase A: candidates of this wave's 64 vertices for the block's images ----
     unsigned long long cm[kImgPerBlock];
@@ -407,7 +434,7 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
             const double iy = __builtin_fma(m[4], x, __builtin_fma(m[5], y, __builtin_fma(m[6], z, m[7])));
             const double iz = __builtin_fma(m[8], x, __builtin_fma(m[9], y, __builtin_fma(m[10], z, m[11])));   // mm
             const double gb = kVBandPx * iz;
-            const double zmin = __builtin_fma(lds_g[q][0], psum, lds_g[q][1]);                  // this vertex, this image
+            const double zmin = zmin_l;                                                         // this vertex, any image of the block
             const unsigned long long near0 = __builtin_amdgcn_ballot_w64(!(iz > zmin));         // NaN lands here too
             const unsigned long long inside =
                 __builtin_amdgcn_ballot_w64(ix > -gb) & __builtin_amdgcn_ballot_w64(ix < (Wd + kVBandPx) * iz) &
@@ -470,8 +497,8 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
             asm("v_med3_i32 %0, %1, 0, %2" : "=v"(yi) : "v"((int)rv), "s"(hi_y));
             const double wu = __builtin_fabs(us - ru) - 0.25, wv = __builtin_fabs(vs - rv) - 0.25;
             const double es = (__builtin_fabs(px) + __builtin_fabs(py)) + __builtin_fabs(pz);
-            const double zmin = __builtin_fma(lds_g[q][0], es, lds_g[q][1]);
-            gzs[k] = __builtin_fma(lds_g[q][2], es, lds_g[q][3]);
+            const double zmin = __builtin_fma(gc[0], es, gc[1]);
+            gzs[k] = __builtin_fma(gc[2], es, gc[3]);
             bool rk = !(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kVTiePx) | !(iz > zmin) |
                       (lds_pinhole[q] == 0);
             if (!IDENT) {   // the bounds are integers of the COLOUR grid, the rounding ties belong to the depth grid

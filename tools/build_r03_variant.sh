@@ -1,0 +1,22 @@
+#!/bin/bash
+# A/B baseline for round 4: round 3's kernels (constant guard band) compiled against round 4's frame-record stride (8 slots),
+# so that tools/ab_k3.py can time them in the same process, on the same inputs, as the in-tree library.
+# -> tools/ab/libmspa_r03guard.so
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+REV=${1:-7182b9d}
+B=/tmp/mspa_r03src
+rm -rf $B && mkdir -p $B/multi-spatialmllm_amd/csrc $B/include $ROOT/tools/ab
+cd $ROOT
+for f in api pair_reproject vertex_visibility pair_overlap pose_tracks samples object_extents bitset_index; do
+  git show $REV:multi-spatialmllm_amd/csrc/$f.hip > $B/multi-spatialmllm_amd/csrc/$f.hip
+done
+git show $REV:multi-spatialmllm_amd/csrc/mspa_common.h > $B/multi-spatialmllm_amd/csrc/mspa_common.h
+git show $REV:include/mspa.h | sed 's/#define MSPA_FRAME_MATS 7/#define MSPA_FRAME_MATS 8/' > $B/include/mspa.h
+cd $B/multi-spatialmllm_amd/csrc
+for f in api pair_reproject vertex_visibility pair_overlap pose_tracks samples object_extents bitset_index; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-result -c $f.hip -o $f.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/ab/libmspa_r03guard.so *.o -lz
+echo built tools/ab/libmspa_r03guard.so
