@@ -533,7 +533,39 @@ def time_scannet_shape(device, n_pairs=200, base_frames=16, steps=5):
     ms = e0.elapsed_time(e1) / steps
     bpp = 2 * 2 * DH * DW + (4 + 1 / 8) * CH * CW
     c = out["counts"].cpu().numpy()
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        for _ in range(steps):
+            fn()
+        a1.record()
+        torch.cuda.synchronize()
+        return a0.elapsed_time(a1) / steps
+
+    # the same set through the rectangular-tile kernel (what the compacted set runs on at this shape), and the fused
+    # compacted set itself: bitset + 4 B per VISIBLE pixel + a count per tile, no dense table
+    ms_rect = timed(lambda: engine.pair_reproject(depth, mats, pairs, (CH, CW), out, flags=flags | _lib.PAIR_RECT_TILES))
+    kern_rect = _lib.load().mspa_pair_reproject_last_kernel()
+    comp = engine.alloc_pair_correspondences(n_pairs, (CH, CW), device)
+    ms_comp = timed(lambda: engine.pair_correspondences(depth, mats, pairs, (CH, CW), comp, flags=flags))
+    kern_comp = _lib.load().mspa_pair_reproject_last_kernel()
+    n_vis = float(comp["counts"][:, 1].sum().item())
+    bcomp = (2 * 2 * DH * DW + CH * CW / 8) * n_pairs + 4.0 * n_vis + 4.0 * comp["tile_counts"].numel()
+    ws = int(_lib.load().mspa_pair_correspondences_workspace_bytes(n_pairs, DH, DW, CH, CW, flags))
+    compact = {"shape": "colour 1296x968 over depth 640x480", "pairs": n_pairs, "kernel_ms": round(ms_comp, 4),
+               "kernel": "mspa::pair_fast_tight_kernel<compact, SCALED> (rectangular tiles)" if kern_comp == _lib.KERNEL_PAIR_FAST_RECT
+               else f"kernel id {kern_comp}", "workspace_bytes": ws,
+               "ms_per_1000_pairs": round(ms_comp / n_pairs * 1000, 4), "pairs_per_s_1gpu": round(n_pairs / (ms_comp * 1e-3), 1),
+               "bytes_per_pair": int(bcomp / n_pairs),
+               "bytes_formula": "2 x 2 B x 307 200 + 1 254 528 / 8 (bitset) + 4 B x n_visible + 4 B x 441 tiles (n_visible from this launch's counters)",
+               "achieved_GBs": round(bcomp / (ms_comp * 1e-3) / 1e9, 1), "frac": round(bcomp / (ms_comp * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "visible_fraction": round(float(c[:, 1].sum() / max(1, c[:, 0].sum())), 4)}
     return {"shape": "colour 1296x968 over depth 640x480", "pairs": n_pairs, "kernel_ms": round(ms, 4),
+            "rect_tiles_ms_per_1000_pairs": round(ms_rect / n_pairs * 1000, 4) if kern_rect == _lib.KERNEL_PAIR_FAST_RECT else None,
+            "compact": compact,
             "kernel": "mspa::pair_fast_scaled_kernel" if kern == _lib.KERNEL_PAIR_FAST_SCALED else f"kernel id {kern}",
             "ms_per_1000_pairs": round(ms / n_pairs * 1000, 4), "pairs_per_s_1gpu": round(n_pairs / (ms * 1e-3), 1),
             "colour_pixels_per_s": round(n_pairs * CH * CW / (ms * 1e-3), 1),
@@ -763,6 +795,7 @@ def main():
                                     "note": "informational: the timed step stays one launch of configs[1]'s batch"}
         if not args.no_scene_legs:
             extra["scannet_shape:fast"] = time_scannet_shape(device)
+            extra["scannet_shape:compact"] = extra["scannet_shape:fast"].pop("compact")
             extra["scene"] = time_scene_kernels(device)
             extra["pipeline"] = time_scene_pipeline(device)
             t1 = committed_traffic("K1_vertex_visibility")

@@ -83,6 +83,10 @@ typedef void *mspa_stream_t;        /* hipStream_t */
                                        displace frame-2 lines that ARE revisited (gathers).  Results are identical with or
                                        without it; measured +3 % with distinct frames, -10 % when 48 frames serve 1000 pairs */
 
+#define MSPA_PAIR_RECT_TILES 0x100u  /* diagnostic / A-B: take the rectangular-tile kernel (MSPA_KERNEL_PAIR_FAST_RECT) also where a
+                                       shape has a kernel of its own (ScanNet's 1296x968 over 640x480, correspondence / minimal
+                                       sets).  Results are identical. */
+
 int mspa_version(void);
 const char *mspa_last_error_string(void);
 
@@ -139,7 +143,10 @@ int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, const double 
 #define MSPA_KERNEL_PAIR_FAST_LINEAR 3    /* the same with the linear pixel mapping (bitset, W % 64 != 0) */
 #define MSPA_KERNEL_PAIR_FAST_TIGHT 4     /* whole-tile images (W % 64 == 0, H % 48 == 0, colour == depth grid), output set
                                              corr / dense / dense without colour / minimal / compact */
-#define MSPA_KERNEL_PAIR_FAST_SCALED 5    /* colour grid over a smaller depth grid (ScanNet: 1296x968 over 640x480) */
+#define MSPA_KERNEL_PAIR_FAST_SCALED 5    /* colour grid over a smaller depth grid (ScanNet: 1296x968 over 640x480), word-aligned stripes */
+#define MSPA_KERNEL_PAIR_FAST_RECT 6      /* the tight kernel on rectangular tiles of ANY colour / depth grid pair with W % 16 == 0,
+                                             H % 4 == 0, dw % 4 == 0 (ScanNet's shape: the compacted set; other shapes: corr /
+                                             minimal / compact) */
 int mspa_pair_reproject_last_kernel(void);
 
 /*
@@ -157,8 +164,9 @@ int mspa_pair_reproject_last_kernel(void);
  *                    of a guarded pixel took a pixel OUT of the visible set may keep stale entries behind its count)
  *   out_tile_counts  [n_pairs, n_tiles] int32       visible pixels per tile (= entries of its segment)
  *   out_counts       [n_pairs, 2] int32 or NULL     (#valid, #visible); zeroed by the call
- * With MSPA_PAIR_FAST on a whole-tile shape (W % 64 == 0, H % 48 == 0, colour grid == depth grid: BASELINE's 640x480)
- * one fused kernel produces all of it; every other shape / mode runs mspa_pair_reproject into a dense table in
+ * With MSPA_PAIR_FAST on a whole-tile shape (W % 64 == 0, H % 48 == 0, colour grid == depth grid: BASELINE's 640x480) and on
+ * every shape with W % 16 == 0, H % 4 == 0, dw % 4 == 0 (ScanNet's own 1296x968 colour over 640x480 depth; ragged tiles hold
+ * fewer pixels, same indexing) one fused kernel produces all of it; every other shape / mode runs mspa_pair_reproject into a dense table in
  * `workspace` (caller-owned, 16-byte aligned, at least mspa_pair_correspondences_workspace_bytes(...) bytes; NULL / 0 when
  * that returns 0) and compacts it with mspa_compact_correspondences.  Identical results either way (bit-exact integers).
  * out_cpix_i16 must be 16-byte aligned.  MSPA_PAIR_STREAM as in mspa_pair_reproject.  The fused kernel additionally needs

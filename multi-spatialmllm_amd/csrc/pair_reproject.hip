@@ -808,7 +808,21 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m, uint32_t base)
 // equal (0.3916 vs 0.3917 ms) -- the stores were never the problem.  What was: the rewrite of every tile with a guarded row
 // (see the cold loop), 0.07 of 0.46 ms.
 
-template <uint32_t SET, bool STREAM, int ROWS, int RG>
+// SCALED (round 4): the same kernel on a colour grid that differs from the depth grid, or whose width is not a multiple of 64
+// -- ScanNet's 1296 x 968 colour over 640 x 480 depth -- with the SAME rectangular 64 x ROWS tiles (so the compacted output
+// needs no dense table at that shape either; the wobbling-stripe kernel below cannot rank a rectangular tile's entries, its
+// waves own word-aligned stripes).  What changes, all of it off the per-pixel path:
+//   * no LDS depth tile: a row's depth-1 samples come through the reference's colour -> depth pixel map (OPS:285-290) as one
+//     2-byte gather per lane and row, requested one row group ahead (byte offsets: the lane's column once per tile, the rows'
+//     offsets in a VGPR read lane by lane into the load's scalar offset); the tile's sample range comes from the depth BOX
+//     its corners map to (a superset of its samples: the culling and the guard band only get more cautious);
+//   * the composed matrix's rows 0 / 1 carry sx / sy (IH:359-366 folded in): u, v are depth-grid coordinates, as in the
+//     wobbling-stripe kernel;
+//   * ragged right edge (W = 1296: 16 live columns in the 21st stripe): dead lanes load through an out-of-range offset (the
+//     buffer returns 0 = "no sample") and store through one (dropped); ragged bottom band: a run-time row count;
+//   * the bitset: W % 16 == 0 makes a tile row's 64 bits four ALIGNED 16-bit pieces of the row-major bitset whatever the
+//     row -- four 2-byte stores per tile (lane = row) instead of one 8-byte store, no atomics, no wobble.
+template <uint32_t SET, bool STREAM, int ROWS, int RG, bool SCALED = false>
 __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
                                                                    const uint8_t *__restrict__ rgb,
                                                                    const double *__restrict__ mats,
@@ -820,6 +834,7 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
     static_assert(RG == 4 || !(SET & (O_PIX | O_XYZ32 | O_RGBA | O_VIS_U8)), "the transpose stages move 4-row blocks");
     static_assert(ROWS % RG == 0, "whole row groups");
     static_assert(!COMPACT || !(SET & (O_PIX | O_XYZ32 | O_RGBA | O_VIS_U8)), "the compacted set shares the transpose stage's LDS");
+    static_assert(!SCALED || !(SET & (O_XYZ32 | O_RGBA | O_VIS_U8 | O_VALID_U8)), "SCALED: correspondence / minimal / compacted sets");
     int64_t pair;
     uint32_t tgroup;
     if (!decode_block(a, pair, tgroup)) return;
@@ -855,11 +870,11 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
     // depth-1 rows of a group are dead once the group has loaded its samples, so group g's stage is the 1 KB that ends with
     // its own four rows -- bytes [512 g, 512 g + 1024) of a per-wave region that starts with a 512-byte pad (group 0 has no
     // predecessor).  The wave's LDS operations execute in order; the next group reads ITS rows before its stage overwrites them.
-    constexpr bool PX_IN_TILE = (SET & O_PIX) && !(SET & (O_XYZ32 | O_RGBA));
+    constexpr bool PX_IN_TILE = !SCALED && (SET & O_PIX) && !(SET & (O_XYZ32 | O_RGBA));
     constexpr int kPadPx = PX_IN_TILE ? 256 : 0;                        // uint16 units: 512 bytes
-    __shared__ __attribute__((aligned(16))) uint16_t lds_w[kTightBW][kPadPx + ROWS * 64];
+    __shared__ __attribute__((aligned(16))) uint16_t lds_w[kTightBW][SCALED ? 16 : kPadPx + ROWS * 64];   // SCALED: counter slots only
     uint16_t *const lds_d1w = &lds_w[wave][kPadPx];                     // this wave's 48 x 64 depth-1 samples
-    if (tile_ok) {
+    if (tile_ok && !SCALED) {
         typedef __attribute__((address_space(1))) const void gvoid_t;
         typedef __attribute__((address_space(3))) void lvoid_t;
 #if MSPA_TIGHT_DMA16
@@ -893,7 +908,10 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
         // millimetre-scaled homogeneous coordinates: M maps (mx*d, my*d, d) with d the RAW millimetre sample to 1000 x the
         // image-space triple, so u and v are unchanged and the third coordinate is the camera-2 depth in millimetres --
         // directly comparable with the raw depth-2 sample (no 0.001 multiply per pixel)
-        for (int k = 0; k < 4; ++k) M[r][k] = uniform(k < 3 ? row[k] : row[k] * 1000.0);
+        for (int k = 0; k < 4; ++k) {
+            if (SCALED) M[r][k] = uniform((k < 3 ? row[k] : row[k] * 1000.0) * (r == 0 ? a.sx : r == 1 ? a.sy : 1.0));
+            else M[r][k] = uniform(k < 3 ? row[k] : row[k] * 1000.0);
+        }
         if (WANT_XYZ) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) Us[r][k] = k < 3 ? U[4 * r + k] * 0.001 : U[4 * r + k];
@@ -921,8 +939,27 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
         // Pixel indices are stored per ROW GROUP, 16 bytes per lane: four dword-per-lane stores per group left the
         // kernel store-issue bound (~3.6 B/clk/CU).  The 4 x 64 pixel indices of a group are transposed
         // through 1 KB of LDS so that lane L owns 4 consecutive pixels of row L / 16.
-        const int pix_voff = (int)((((uint32_t)c.lane >> 4) * Wb + stripe * 64u + ((uint32_t)c.lane & 15u) * 4u) * 4u);
+        // (SCALED: the 4-pixel groups to the right of the image's last column store through an offset the range check drops)
+        constexpr int kDropOffset = 0x7FFFFFF0;
+        const bool px4_ok = !SCALED || (stripe * 64u + ((uint32_t)c.lane & 15u) * 4u) < Wb;
+        const int pix_voff = px4_ok ? (int)((((uint32_t)c.lane >> 4) * Wb + stripe * 64u + ((uint32_t)c.lane & 15u) * 4u) * 4u) : kDropOffset;
         const uint32_t wpr = Wb >> 6;                                   // bitset words per image row
+        // SCALED: rows of this tile (ragged bottom band), depth-1 addressing through the colour -> depth pixel map (OPS:285-290)
+        const int n_rows = SCALED ? (int)min((uint32_t)ROWS, (uint32_t)a.H - row0) : ROWS;
+        __amdgpu_buffer_rsrc_t rs_d1 = __builtin_amdgcn_make_buffer_rsrc((void *)c.depth1, 0, SCALED ? (int)(dpix * 2) : 0, kRsrcFlags);
+        int dxb = 0, dyb = 0;                          // byte offsets: this lane's column; lane r: tile row r
+        if (SCALED) {
+            dxb = col < Wb ? 2 * round_clip((double)col * a.sx, a.dw - 1) : kDropOffset;            // dead lanes read 0
+            dyb = round_clip((double)min(row0 + (uint32_t)c.lane, (uint32_t)a.H - 1u) * a.sy, a.dh - 1) * (a.dw * 2);
+        }
+        auto load_d1_row = [&](int r) -> uint32_t {     // SCALED: depth-1 sample of (tile row r, this lane's column)
+            return __builtin_amdgcn_raw_buffer_load_b16(rs_d1, dxb, __builtin_amdgcn_readlane(dyb, r), STREAM ? 2 : 0);
+        };
+        // the reference's sample of colour pixel (row, col) for the cold paths
+        auto sample1 = [&](uint32_t row, uint32_t colx) -> uint32_t {
+            if (!SCALED) return c.depth1[row * Wb + colx];
+            return c.depth1[round_clip((double)row * a.sy, a.dh - 1) * a.dw + round_clip((double)colx * a.sx, a.dw - 1)];
+        };
         // dense payload: byte mask (lane L: 4 pixels of row L >> 4), colour in / rgba out, points (16-byte pieces of the
         // group's 4 x 768 bytes: piece 64 k + L lies in row (16 (64 k + L)) / 768)
         __amdgpu_buffer_rsrc_t rs_vis = __builtin_amdgcn_make_buffer_rsrc(
@@ -966,14 +1003,14 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
             s1 = __builtin_fma(Us[1][1], myd0, __builtin_fma(Us[1][0], mxd, Us[1][2]));
             s2 = __builtin_fma(Us[2][1], myd0, __builtin_fma(Us[2][0], mxd, Us[2][2]));
         }
-        const double Wd = (double)a.W, Hd = (double)a.H;
+        const double Wd = SCALED ? (double)a.dw : (double)a.W, Hd = SCALED ? (double)a.dh : (double)a.H;   // bounds in u, v's units
         unsigned long long risky_rows = 0;           // wave-uniform: rows with at least one guarded lane
         // Lane r keeps the visibility word of tile row r: ballots are SGPR pairs and v_writelane drops them into one lane
         // for 2 VALU issues per row; the tile's 48 words leave with ONE store at the end, after the cold loop has patched
         // them in registers.
         uint32_t bits_lo = 0, bits_hi = 0;
         uint32_t rb_lo = 0, rb_hi = 0;               // lane r: guarded-lane ballot of tile row r (flagged rows only; rare path)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's depth-1 samples have landed in LDS
+        if (!SCALED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's depth-1 samples have landed in LDS
 
         // ---- tile-level culling -------------------------------------------------------------------
         // The tile's pixels with depths in [dlo, dhi] span a frustum {d*(mx, my, 1)}, the convex hull of 8
@@ -1000,15 +1037,48 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
         {
             typedef unsigned short us2 __attribute__((ext_vector_type(2)));
             const us2 *wds = reinterpret_cast<const us2 *>(lds_d1w);
-            us2 mn = {0xFFFF, 0xFFFF}, mxv = {0, 0};
             const us2 one = {1, 1};
+            int lo, hi;
+            const uint32_t cB = SCALED ? min(stripe * 64u + 63u, Wb - 1u) : stripe * 64u + 63u;     // the tile's last live column / row
+            const uint32_t rB = row0 + (uint32_t)n_rows - 1u;
+            if (!SCALED) {
+                us2 mn = {0xFFFF, 0xFFFF}, mxv = {0, 0};
 #pragma unroll
-            for (int k = 0; k < ROWS / 2; ++k) {
-                const us2 x = wds[c.lane + 64 * k];
-                mn = __builtin_elementwise_min(mn, (us2)(x - one));      // 0 (invalid) wraps to 0xFFFF
-                mxv = __builtin_elementwise_max(mxv, x);
+                for (int k = 0; k < ROWS / 2; ++k) {
+                    const us2 x = wds[c.lane + 64 * k];
+                    mn = __builtin_elementwise_min(mn, (us2)(x - one));      // 0 (invalid) wraps to 0xFFFF
+                    mxv = __builtin_elementwise_max(mxv, x);
+                }
+                lo = min((int)mn.x, (int)mn.y);
+                hi = max((int)mxv.x, (int)mxv.y);
+            } else {
+                // the depth BOX the tile's corners map to (both maps are monotone): 8-byte pieces, 16 lanes across a depth row,
+                // 4 rows per pass; needs dw % 4 == 0 (pieces never straddle a row; the host checks)
+                typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+                const uint32_t dxA = 2u * (uint32_t)round_clip((double)(stripe * 64u) * a.sx, a.dw - 1);
+                const uint32_t dxB = 2u * (uint32_t)round_clip((double)cB * a.sx, a.dw - 1);
+                const uint32_t dyA = (uint32_t)round_clip((double)row0 * a.sy, a.dh - 1) * dw2;
+                const uint32_t dyB = (uint32_t)round_clip((double)rB * a.sy, a.dh - 1) * dw2;
+                const uint32_t xb0 = dxA & ~7u;
+                const uint32_t nxb = __builtin_amdgcn_readfirstlane((dxB + 2u - xb0 + 7u) >> 3);
+                const uint32_t nrow = __builtin_amdgcn_readfirstlane((dyB - dyA) / dw2 + 1u);
+                const uint32_t q = (uint32_t)c.lane >> 4;
+                us4 mn = {0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF}, mxv = {0, 0, 0, 0};
+                const us4 one4 = {1, 1, 1, 1};
+                for (uint32_t k = 0; k < (nrow + 3u) >> 2; ++k) {
+                    const uint32_t r = min(4u * k + q, nrow - 1u);
+                    for (uint32_t j = 0; j < (nxb + 15u) >> 4; ++j) {
+                        const uint32_t piece = min(16u * j + ((uint32_t)c.lane & 15u), nxb - 1u);
+                        const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs_d1, (int)(dyA + r * dw2 + xb0 + piece * 8u), 0, 0);
+                        us4 x;
+                        __builtin_memcpy(&x, &w, 8);
+                        mn = __builtin_elementwise_min(mn, (us4)(x - one4));
+                        mxv = __builtin_elementwise_max(mxv, x);
+                    }
+                }
+                lo = min(min((int)mn.x, (int)mn.y), min((int)mn.z, (int)mn.w));
+                hi = max(max((int)mxv.x, (int)mxv.y), max((int)mxv.z, (int)mxv.w));
             }
-            int lo = min((int)mn.x, (int)mn.y), hi = max((int)mxv.x, (int)mxv.y);
             for (int off = 32; off > 0; off >>= 1) {
                 lo = min(lo, __shfl_xor(lo, off));
                 hi = max(hi, __shfl_xor(hi, off));
@@ -1018,8 +1088,8 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                 all_front = true;                                         // (and nothing the row loop could get wrong)
             } else {
                 const int k = c.lane & 7;
-                const double cx = (double)(stripe * 64u + ((k & 1) ? 63u : 0u));
-                const double cy = (double)(row0 + ((k & 2) ? (uint32_t)(ROWS - 1) : 0u));
+                const double cx = (double)((k & 1) ? cB : stripe * 64u);
+                const double cy = (double)((k & 2) ? rB : row0);
                 const double cd = (double)((k & 4) ? hi : lo + 1);
                 const double hx = __builtin_fma(__builtin_fma(M[0][1], cy, __builtin_fma(M[0][0], cx, M[0][2])), cd, M[0][3]);
                 const double hy = __builtin_fma(__builtin_fma(M[1][1], cy, __builtin_fma(M[1][0], cx, M[1][2])), cd, M[1][3]);
@@ -1028,9 +1098,9 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                 // checks that they are at least four times what two evaluation orders can differ by (mspa_common.h)
                 const bool all_behind = ballot64(hz <= -kCullMarginZ) == ~0ull;
                 const bool all_left = ballot64(hx < -kCullMarginXY) == ~0ull;
-                const bool all_right = ballot64(hx - (double)a.W * hz > kCullMarginXY) == ~0ull;
+                const bool all_right = ballot64(hx - Wd * hz > kCullMarginXY) == ~0ull;
                 const bool all_above = ballot64(hy < -kCullMarginXY) == ~0ull;
-                const bool all_below = ballot64(hy - (double)a.H * hz > kCullMarginXY) == ~0ull;
+                const bool all_below = ballot64(hy - Hd * hz > kCullMarginXY) == ~0ull;
                 culled = CAN_CULL && (all_behind | all_left | all_right | all_above | all_below);
                 if (culled) {
                     culled = ballot64(cull_margins_hold(bnd1, bnd2, a.wm1, a.hm1, a.wh_max)) == ~0ull;
@@ -1043,16 +1113,26 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                 }
             }
             if (culled) {
-                us2 nz = {0, 0};
+                if (!SCALED) {
+                    us2 nz = {0, 0};
 #pragma unroll
-                for (int k = 0; k < ROWS / 2; ++k) nz += __builtin_elementwise_min(wds[c.lane + 64 * k], one);
-                int cnt = (int)nz.x + (int)nz.y;
-                for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-                n_valid = cnt;
+                    for (int k = 0; k < ROWS / 2; ++k) nz += __builtin_elementwise_min(wds[c.lane + 64 * k], one);
+                    int cnt = (int)nz.x + (int)nz.y;
+                    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+                    n_valid = cnt;
+                } else {                                   // the tile's own samples (the box only bounded their range)
+#pragma unroll 1
+                    for (int r0 = 0; r0 < n_rows; r0 += RG) {
+                        uint32_t d[RG];
+#pragma unroll
+                        for (int j = 0; j < RG; ++j) d[j] = load_d1_row(r0 + j);
+#pragma unroll
+                        for (int j = 0; j < RG; ++j) n_valid += __popcll(ballot64(d[j] != 0u));
+                    }
+                }
                 if (O::template has<O_PIX>(a.pix_i16)) {
                     const u32x4_t none = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-#pragma unroll 4
-                    for (int r0 = 0; r0 < ROWS; r0 += RG)
+                    for (int r0 = 0; r0 < n_rows; r0 += RG)
                         buffer_store_b128_guarded(none, rs_pix, pix_voff, (int)((row0 + (uint32_t)r0) * Wb * 4u));
                 }
             }
@@ -1062,14 +1142,23 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
         // run-time flag inside the loop would be if-converted -- the compares executed regardless.
         auto run_rows = [&](auto careful_c) {
             constexpr bool CAREFUL = decltype(careful_c)::value;
+            uint32_t d16n[RG] = {};                  // SCALED: the next row group's samples, requested one group ahead
+            if (SCALED) {
+#pragma unroll
+                for (int j = 0; j < RG; ++j) d16n[j] = load_d1_row(j);
+            }
 #pragma unroll 1
-            for (int r0 = 0; r0 < ROWS; r0 += RG) {
+            for (int r0 = 0; r0 < n_rows; r0 += RG) {
                 uint32_t d16[RG];
 #pragma unroll
                 for (int j = 0; j < RG; ++j) {
-                    d16[j] = lds_d1w[(r0 + j) * 64 + c.lane];
+                    d16[j] = SCALED ? d16n[j] : (uint32_t)lds_d1w[(r0 + j) * 64 + c.lane];
                     asm("" : "+v"(d16[j]));      // a plain 32-bit value from here on (ds_read_u16 zero-extends): otherwise the
                 }                                // compare below is narrowed to 16 bits and the conversion pays a v_and
+                if (SCALED && r0 + RG < n_rows) {    // wave-uniform
+#pragma unroll
+                    for (int j = 0; j < RG; ++j) d16n[j] = load_d1_row(r0 + RG + j);
+                }
                 // ---- stage 1: project; "in view" with the guard band folded into the comparison constants:
                 // a lane the reference would accept (0 <= u < W, 0 <= v < H, depth > 0) always passes, and a lane
                 // that passes without being accepted sits inside a guard band and is re-evaluated exactly.
@@ -1281,7 +1370,7 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                 int cxi = 0, cyi = 0;
                 if (mine) {
                     Pixel p;
-                    exact_unproject(m1, mxd, (double)row, (double)c.depth1[i] * 0.001, p.ax, p.ay, p.az);
+                    exact_unproject(m1, mxd, (double)row, (double)sample1(row, col) * 0.001, p.ax, p.ay, p.az);
                     exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
                     p.vis = depth_test(true, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi, &p.inview);
                     vis = p.vis;
@@ -1314,13 +1403,13 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                 // a change of visibility needs fast and exact chain to disagree inside the band, which on real frames
                 // all but never happens (identity pairs, where every depth test is a tie: all tiles).
                 uint32_t base = 0;
-                for (int r = 0; r < ROWS; ++r) {                    // wave-uniform
+                for (int r = 0; r < n_rows; ++r) {                  // wave-uniform
                     const unsigned long long w = readlane64(bits_lo, bits_hi, r);
                     if (w == 0) continue;
                     if ((w >> c.lane) & 1ull) {
                         const uint32_t row = row0 + (uint32_t)r;
                         Pixel p;
-                        exact_unproject(m1, mxd, (double)row, (double)c.depth1[row * Wb + col] * 0.001, p.ax, p.ay, p.az);
+                        exact_unproject(m1, mxd, (double)row, (double)sample1(row, col) * 0.001, p.ax, p.ay, p.az);
                         exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
                         depth_test(false, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi);
                         __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(uint16_t)p.xi | ((uint32_t)(uint16_t)p.yi << 16), rs_cpix,
@@ -1332,7 +1421,19 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
             if (c.lane == 0) a.tile_counts[pair * (int64_t)a.n_tiles + (int64_t)tile] = n_vis;
         }
         // the tile's visibility words: lane r stores the word of row row0 + r (8 bytes; rows are W/8 bytes apart)
-        if (O::template has<O_VIS_BITS>(a.vis_bits) && c.lane < ROWS)
+        if (SCALED && (Wb & 63u)) {
+            // rows are not whole words: the row's 64 bits are four 16-bit pieces at bit (row W + 64 stripe), a multiple of 16 --
+            // aligned 2-byte stores, lane = row; pieces past the image's last column (ragged stripe) are dropped
+            if (O::template has<O_VIS_BITS>(a.vis_bits) && c.lane < n_rows) {
+                const uint32_t byte0 = ((row0 + (uint32_t)c.lane) * Wb + stripe * 64u) >> 3;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t piece = (k & 1) ? ((k & 2) ? bits_hi : bits_lo) >> 16 : ((k & 2) ? bits_hi : bits_lo);
+                    const int off = (stripe * 64u + 16u * (uint32_t)k) < Wb ? (int)(byte0 + 2u * (uint32_t)k) : kDropOffset;
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)piece, rs_bits, off, 0, 0);
+                }
+            }
+        } else if (O::template has<O_VIS_BITS>(a.vis_bits) && c.lane < n_rows)
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{bits_lo, bits_hi}, rs_bits, (int)((uint32_t)c.lane * wpr * 8u),
                                                   (int)((row0 * wpr + stripe) * 8u), 0);
     }
@@ -1849,6 +1950,13 @@ static bool tight_shape(int32_t dh, int32_t dw, int32_t H, int32_t W, int rows =
     return dh == H && dw == W && (W % 64 == 0) && (H % rows == 0) && ((uint64_t)H * (uint64_t)W * 4 < (1ull << 31));
 }
 
+// shapes the tight kernel takes in its SCALED form (rectangular tiles on any colour / depth grid combination): bitset rows in
+// whole 16-bit pieces, whole 4-row groups, depth rows in whole 8-byte pieces, 32-bit byte offsets
+static bool rect_shape(int32_t dh, int32_t dw, int32_t H, int32_t W) {
+    return !tight_shape(dh, dw, H, W) && (W % 16 == 0) && (H % 4 == 0) && (dw % 4 == 0) &&
+           ((uint64_t)H * (uint64_t)W * 4 < (1ull << 31)) && ((uint64_t)dh * (uint64_t)dw * 2 < (1ull << 31));
+}
+
 static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const double *frame_mats,
                                int32_t n_frames, const int32_t *pairs, int64_t n_pairs, int32_t dh,
                                int32_t dw, int32_t H, int32_t W, uint64_t *out_vis_bits,
@@ -1864,7 +1972,7 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
     const uint64_t P = (uint64_t)H * (uint64_t)W;
     if (P * (uint64_t)W >= (1ull << 32)) return fail(MSPA_EINVAL, "mspa_pair_reproject: H*W*W must be < 2^32");
     if (out_rgba && !rgb) return fail(MSPA_EINVAL, "mspa_pair_reproject: out_rgba needs rgb");
-    if (flags & ~(MSPA_PAIR_FAST | MSPA_PAIR_STREAM)) return fail(MSPA_EINVAL, "mspa_pair_reproject: unknown flag");
+    if (flags & ~(MSPA_PAIR_FAST | MSPA_PAIR_STREAM | MSPA_PAIR_RECT_TILES)) return fail(MSPA_EINVAL, "mspa_pair_reproject: unknown flag");
     if (n_pairs == 0) return MSPA_OK;
     hipStream_t s = (hipStream_t)stream;
 
@@ -1905,23 +2013,27 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
                          (((uintptr_t)out_vis_u8 & 3u) == 0);
     const bool tight24 = fast && aligned && tight_shape(dh, dw, H, W, tight_rows_of(set)) &&
                          (set == kSetCorr || set == kSetDense || set == kSetDenseXyz || set == kSetMinimal || set == kSetCompact);
-    if (out_cpix && !(tight24 && out_tile_counts))
+    // ScanNet's own shape (1296 x 968 colour over 640 x 480 depth) has a wobbling-stripe kernel of its own for the
+    // correspondence / minimal sets; the tight kernel's SCALED form (rectangular tiles) takes the compacted set there, all
+    // three sets on every other such shape, and all three under MSPA_PAIR_RECT_TILES
+    const bool scannet = W == 1296 && H == 968 && dw == 640 && dh == 480;
+    const bool rect = fast && !tight24 && aligned && rect_shape(dh, dw, H, W) &&
+                      (set == kSetCompact || ((set == kSetCorr || set == kSetMinimal) && (!scannet || (flags & MSPA_PAIR_RECT_TILES))));
+    if (out_cpix && !((tight24 || rect) && out_tile_counts))
         return fail(MSPA_EINVAL, "pair_reproject_impl: the fused compacted set needs the tight kernel and a tile-count table");
-    // ScanNet's own shape (1296 x 968 colour over 640 x 480 depth) has a kernel of its own
-    const bool scaled = fast && !tight24 && aligned && W == 1296 && H == 968 && dw == 640 && dh == 480 &&
-                        (set == kSetCorr || set == kSetMinimal);
+    const bool scaled = fast && !tight24 && !rect && aligned && scannet && (set == kSetCorr || set == kSetMinimal);
     if (scaled) {
         a.n_stripes = 1296 / 64;
         a.n_tiles = a.n_stripes * ((968 + 47) / 48);
         a.stripe_magic = 0;
         a.strips = (a.n_tiles + (kThreads / kWave) - 1) / (kThreads / kWave);
     } else if (fast) {
-        const int tile_rows = tight24 ? tight_rows_of(set) : kTileRows;
+        const int tile_rows = (tight24 || rect) ? tight_rows_of(set) : kTileRows;
         a.n_stripes = (W + 63) / 64;
-        a.n_tiles = linear ? (int)((P + (int64_t)kTileRows * 64 - 1) / ((int64_t)kTileRows * 64))
-                           : a.n_stripes * ((H + tile_rows - 1) / tile_rows);
+        a.n_tiles = (linear && !rect) ? (int)((P + (int64_t)kTileRows * 64 - 1) / ((int64_t)kTileRows * 64))
+                                      : a.n_stripes * ((H + tile_rows - 1) / tile_rows);
         a.stripe_magic = (uint32_t)((1ull << 32) / (uint64_t)a.n_stripes) + 1u;
-        const int bw = tight24 ? tight_bw_of(set) : (kThreads / kWave);
+        const int bw = (tight24 || rect) ? tight_bw_of(set) : (kThreads / kWave);
         a.strips = (a.n_tiles + bw - 1) / bw;
     } else {
         a.n_stripes = a.n_tiles = 0;
@@ -1933,6 +2045,7 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
     const dim3 grid((uint32_t)blocks), block(kThreads);
     g_last_pair_kernel = !fast ? MSPA_KERNEL_PAIR_EXACT
                          : scaled ? MSPA_KERNEL_PAIR_FAST_SCALED
+                         : rect ? MSPA_KERNEL_PAIR_FAST_RECT
                          : tight24 ? MSPA_KERNEL_PAIR_FAST_TIGHT
                          : linear ? MSPA_KERNEL_PAIR_FAST_LINEAR : MSPA_KERNEL_PAIR_FAST;
     if (!fast) {
@@ -1945,6 +2058,18 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
         if (set == kSetCorr) { if (st) MSPA_LAUNCH_SCALED(kSetCorr, true); else MSPA_LAUNCH_SCALED(kSetCorr, false); }
         else { if (st) MSPA_LAUNCH_SCALED(kSetMinimal, true); else MSPA_LAUNCH_SCALED(kSetMinimal, false); }
 #undef MSPA_LAUNCH_SCALED
+    } else if (rect) {
+#define MSPA_LAUNCH_RECT(SET_) \
+    do { \
+        if (flags & MSPA_PAIR_STREAM) \
+            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, true, tight_rows_of(SET_), tight_rg_of(SET_), true>), grid, dim3(tight_bw_of(SET_) * kWave), 0, s, depth, rgb, frame_mats, pairs, a); \
+        else \
+            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, false, tight_rows_of(SET_), tight_rg_of(SET_), true>), grid, dim3(tight_bw_of(SET_) * kWave), 0, s, depth, rgb, frame_mats, pairs, a); \
+    } while (0)
+        if (set == kSetCorr) MSPA_LAUNCH_RECT(kSetCorr);
+        else if (set == kSetCompact) MSPA_LAUNCH_RECT(kSetCompact);
+        else MSPA_LAUNCH_RECT(kSetMinimal);
+#undef MSPA_LAUNCH_RECT
     } else if (tight24) {
 #define MSPA_LAUNCH_TIGHT(SET_) \
     do { \
@@ -2013,7 +2138,7 @@ extern "C" int64_t mspa_corr_tiles(int32_t H, int32_t W) {
 extern "C" int64_t mspa_pair_correspondences_workspace_bytes(int64_t n_pairs, int32_t dh, int32_t dw, int32_t H, int32_t W,
                                                              uint32_t flags) {
     if (n_pairs < 0 || !corr_args_ok(H, W)) return -1;
-    if ((flags & MSPA_PAIR_FAST) && tight_shape(dh, dw, H, W)) return 0;       // fused: no dense table in between
+    if ((flags & MSPA_PAIR_FAST) && (tight_shape(dh, dw, H, W) || rect_shape(dh, dw, H, W))) return 0;   // fused: no dense table
     return n_pairs * (int64_t)H * W * 4;
 }
 

@@ -13,8 +13,9 @@ MAT_KINV, MAT_E, MAT_A, MAT_EINV_ALIGNED, MAT_K, MAT_UNPROJ, MAT_REPROJ, MAT_BOU
 GUARD_C = 256.0
 PAIR_FAST = 1
 PAIR_STREAM = 2
+PAIR_RECT_TILES = 0x100
 CORR_TILE_W, CORR_TILE_H, CORR_TILE_CAP = 64, 48, 64 * 48
-KERNEL_NONE, KERNEL_PAIR_EXACT, KERNEL_PAIR_FAST, KERNEL_PAIR_FAST_LINEAR, KERNEL_PAIR_FAST_TIGHT, KERNEL_PAIR_FAST_SCALED = range(6)
+KERNEL_NONE, KERNEL_PAIR_EXACT, KERNEL_PAIR_FAST, KERNEL_PAIR_FAST_LINEAR, KERNEL_PAIR_FAST_TIGHT, KERNEL_PAIR_FAST_SCALED, KERNEL_PAIR_FAST_RECT = range(7)
 
 
 class MspaError(RuntimeError):

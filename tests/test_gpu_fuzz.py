@@ -67,15 +67,16 @@ def one_seed(seed, hw, dhw, n_frames, n_oracle):
                 check_integers(res, j, refs[k], hw)
             del fast
         del exact
-    if tight:
-        out = engine.alloc_pair_correspondences(n, hw, DEV)
-        out["cpix"].fill_(-7)
-        engine.pair_correspondences(depth, mats, pairs, hw, out, flags=_lib.PAIR_FAST | _lib.PAIR_STREAM)
-        assert _lib.load().mspa_pair_reproject_last_kernel() == _lib.KERNEL_PAIR_FAST_TIGHT
-        torch.cuda.synchronize()
-        out_np = {k: v[pick].cpu().numpy() for k, v in out.items()}
-        for j, k in enumerate(pick):
-            check_compact_pair(out_np, j, refs[k], hw)
+    # the fused compacted set: the tight kernel at 640x480, its rectangular-tile form at ScanNet's shape (no dense table)
+    out = engine.alloc_pair_correspondences(n, hw, DEV)
+    out["cpix"].fill_(-7)
+    engine.pair_correspondences(depth, mats, pairs, hw, out, flags=_lib.PAIR_FAST | _lib.PAIR_STREAM)
+    assert _lib.load().mspa_pair_reproject_last_kernel() == (_lib.KERNEL_PAIR_FAST_TIGHT if tight else _lib.KERNEL_PAIR_FAST_RECT)
+    torch.cuda.synchronize()
+    out_np = {k: v[pick].cpu().numpy() for k, v in out.items()}
+    for j, k in enumerate(pick):
+        check_compact_pair(out_np, j, refs[k], hw)
+    del out
     torch.cuda.synchronize()
     return n, len(pick)
 
