@@ -1,11 +1,12 @@
 #!/bin/bash
-# A/B baseline for round 4: round 3's kernels (constant guard band) compiled against round 4's frame-record stride (8 slots),
-# so that tools/ab_k3.py can time them in the same process, on the same inputs, as the in-tree library.
-# -> tools/ab/libmspa_r03guard.so
+# A/B baselines: the kernels of an earlier revision compiled against round 4's frame-record stride (8 slots), so that
+# tools/ab_k3.py / ab_k1.py can time them in the same process, on the same inputs, as the in-tree library.
+#   tools/build_rev_variant.sh [REV [NAME]]   -> tools/ab/libmspa_NAME.so   (default: round 3's final kernels, "r03guard")
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 REV=${1:-7182b9d}
-B=/tmp/mspa_r03src
+NAME=${2:-r03guard}
+B=/tmp/mspa_src_$NAME
 rm -rf $B && mkdir -p $B/multi-spatialmllm_amd/csrc $B/include $ROOT/tools/ab
 cd $ROOT
 for f in api pair_reproject vertex_visibility pair_overlap pose_tracks samples object_extents bitset_index; do
@@ -18,5 +19,5 @@ for f in api pair_reproject vertex_visibility pair_overlap pose_tracks samples o
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-result -c $f.hip -o $f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/ab/libmspa_r03guard.so *.o -lz
-echo built tools/ab/libmspa_r03guard.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/ab/libmspa_$NAME.so *.o -lz
+echo built tools/ab/libmspa_$NAME.so

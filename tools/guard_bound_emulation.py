@@ -56,11 +56,21 @@ def emulate_pair(depth1, depth2, K, E1, E2, A, hw, m1, m2, stats, constant_guard
     M[:, 3] *= 1000.0
     d = depth1.astype(np.float64)
     valid = d > 0
-    t = M[:, 0] * xx[..., None] + M[:, 1] * yy[..., None] + M[:, 2]
-    q = t * d[..., None] + M[:, 3]
+    # the tight kernel's form since round 4: rows 0 / 1 centred on the image and scaled by its half extent (+ guard); "in view"
+    # is |xn| < z on the homogeneous coordinates, the division happens only for candidates
+    khw, khh = W / 2 + G_PX, H / 2 + G_PX
+    Mc = M.copy()
+    Mc[0] = (M[0] - (W / 2) * M[2]) * (1.0 / khw)
+    Mc[1] = (M[1] - (H / 2) * M[2]) * (1.0 / khh)
+    t = Mc[:, 0] * xx[..., None] + Mc[:, 1] * yy[..., None] + Mc[:, 2]
+    qc = t * d[..., None] + Mc[:, 3]
+    z = qc[..., 2]
     with np.errstate(all="ignore"):
-        u, v = q[..., 0] / q[..., 2], q[..., 1] / q[..., 2]
-    z = q[..., 2]
+        rz = 1.0 / z
+        u = qc[..., 0] * (rz * khw) + W / 2          # un-centred only for the comparison with the oracle below
+        v = qc[..., 1] * (rz * khh) + H / 2
+        homog_in = (np.abs(qc[..., 0]) < z) & (np.abs(qc[..., 1]) < z)
+    q = np.stack([qc[..., 0] * khw + (W / 2) * z, qc[..., 1] * khh + (H / 2) * z, z], -1)     # for the bound check
     b1, b2 = m1[_lib.MAT_BOUNDS], m2[_lib.MAT_BOUNDS]
     dv_of = depth2.astype(np.float64)
     guard = np.zeros((H, W), dtype=bool)
@@ -90,7 +100,7 @@ def emulate_pair(depth1, depth2, K, E1, E2, A, hw, m1, m2, stats, constant_guard
                 fu, fv = np.abs(us - np.rint(us)), np.abs(vs - np.rint(vs))
                 tie = ~((fu > G_PX) & (fu < 0.5 - G_PX) & (fv > G_PX) & (fv < 0.5 - G_PX))
                 nearz = ~(np.abs(zs) > zmin)
-                cand = ((us > -G_PX) & (us < W + G_PX) & (vs > -G_PX) & (vs < H + G_PX) & (zs > zmin)) | nearz
+                cand = (homog_in[sl] & (zs > zmin)) | nearz
                 xi = np.clip(np.rint(np.nan_to_num(us, nan=0, posinf=1e9, neginf=-1e9)), 0, W - 1).astype(np.int64)
                 yi = np.clip(np.rint(np.nan_to_num(vs, nan=0, posinf=1e9, neginf=-1e9)), 0, H - 1).astype(np.int64)
                 dtie = ~(np.abs(zs - dv_of[yi, xi]) > gz)

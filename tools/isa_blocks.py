@@ -22,6 +22,9 @@ for l in lines[start + 1:end]:
     if not t or t.startswith(";") or t.startswith("."):
         continue
     cur[1].append(t)
+    if t.startswith(("s_cbranch", "s_branch")):            # a branch ends a block even without a label behind it
+        blocks.append(cur)
+        cur = [cur[0] + "+", []]
 blocks.append(cur)
 print("%-14s %5s %5s %5s %5s %5s  %s" % ("block", "valu", "salu", "vmem", "lds", "lane", "notes"))
 for name, ins in blocks:
