@@ -433,16 +433,20 @@ def time_scene_kernels(device, n_points=131072, n_frames=320, reps=5):
     # it gave "fractions" above 1 and is no longer printed)
     b1 = 24 * n_points + F * (2 * H * W + n_points // 8)
     b2 = pairs.shape[0] * (2 * n_points // 8 + 8)
-    return {"K1_vertex_visibility": {"images": F, "vertices": n_points, "kernel_ms": round(t1, 4),
-                                     "images_per_s": round(F / (t1 * 1e-3), 1),
+    # The PRIMARY K1 reading is the spatially coherent vertex order (a Morton curve over the same vertices): mesh files list
+    # vertices patch by patch, which is what ScanNet's aligned_points are; the shuffled synthetic cloud -- every wave's 64
+    # vertices scattered over the whole room -- is kept beside it as the worst case.
+    return {"K1_vertex_visibility": {"images": F, "vertices": n_points, "kernel_ms": round(t1s, 4),
+                                     "images_per_s": round(F / (t1s * 1e-3), 1),
                                      "compulsory_bytes": int(b1),
-                                     "compulsory_GBs": round(b1 / (t1 * 1e-3) / 1e9, 1),
-                                     "compulsory_frac": round(b1 / (t1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "compulsory_GBs": round(b1 / (t1s * 1e-3) / 1e9, 1),
+                                     "compulsory_frac": round(b1 / (t1s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                      "includes": "vertex_visibility_compact_kernel + bits_count_kernel",
-                                     "vertex_order": "shuffled (synthetic cloud)",
-                                     "mesh_ordered": {"kernel_ms": round(t1s, 4), "images_per_s": round(F / (t1s * 1e-3), 1),
-                                                      "order": "Morton curve over the same vertices",
-                                                      "same_counts_as_shuffled": same_counts}},
+                                     "vertex_order": "spatially coherent (Morton curve over the synthetic cloud: mesh-like)",
+                                     "same_counts_as_shuffled": same_counts,
+                                     "shuffled_worst_case": {"kernel_ms": round(t1, 4), "images_per_s": round(F / (t1 * 1e-3), 1),
+                                                             "compulsory_frac": round(b1 / (t1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                             "order": "the synthetic cloud as generated (shuffled)"}},
             "K2_pair_overlap": {"pairs": int(pairs.shape[0]), "kernel_ms": round(t2, 4), "form": "tiled (mspa_scene_overlap)",
                                 "pairs_per_s": round(pairs.shape[0] / (t2 * 1e-3), 1),
                                 "streaming_GBs": round(b2 / (t2 * 1e-3) / 1e9, 1)},
@@ -451,7 +455,7 @@ def time_scene_kernels(device, n_points=131072, n_frames=320, reps=5):
                                   "kernel_ms": round(t8, 4),
                                   "bit_tests_per_s": round(float(offsets[-1]) * F / (t8 * 1e-3), 1)},
             "K7_track_rigidity": {"frames": 300, "points": 256, "kernel_ms": round(t7, 4)},
-            "scene_total": {"frames": F, "vertices": n_points, "ms": round(t1 + t2 + t3, 4),
+            "scene_total": {"frames": F, "vertices": n_points, "ms": round(t1s + t2 + t3, 4),
                             "note": "CFR.process_scene for one ScanNet-sized scene (every-5th-frame average)"}}
 
 
@@ -800,7 +804,7 @@ def main():
             extra["pipeline"] = time_scene_pipeline(device)
             t1 = committed_traffic("K1_vertex_visibility")
             if t1:
-                k1 = extra["scene"]["K1_vertex_visibility"]
+                k1 = extra["scene"]["K1_vertex_visibility"]["shuffled_worst_case"]   # the PMC passes ran on the shuffled cloud
                 k1["frac_note"] = ("`compulsory_frac` = (24 N once + per image 2 DW DH + N/8) / time / peak: the bytes any K1 must "
                                    "move; `traffic_frac` = PMC-measured L2-miss traffic / time / peak (the vertex array is re-read "
                                    "by each of the 40 image groups, and 8 depth frames + 3 MB of vertices overflow a 4 MB L2)")

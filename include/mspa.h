@@ -70,6 +70,18 @@ typedef void *mspa_stream_t;        /* hipStream_t */
 #define MSPA_FRAME_MATS 8
 #define MSPA_GUARD_C 256.0          /* >= the roundings of either evaluation order (89 counted) */
 
+/* Slots of one image record in `cam_mats` ([n_images][MSPA_CAM_MATS][16] float64) of K1 / K6b. */
+#define MSPA_CAM_EINV 0             /* inv(A @ E)        IH:57 */
+#define MSPA_CAM_K 1                /* K                 IH:66 */
+#define MSPA_CAM_BOUNDS 2           /* not a matrix: guard-bound coefficients of the composed K1 kernels, filled by
+                                       mspa_camera_bounds_host from slots 0-1.  Nabs = |K| |inv(A @ E)|, c = MSPA_GUARD_C * 2^-53 * 1000:
+                                         [0] c (nr_0 + nr_1)   [1] c nr_2   [2] c (Nabs[0][3] + Nabs[1][3])   [3] c Nabs[2][3]
+                                       with nr_k = Nabs[k][0] + Nabs[k][1] + Nabs[k][2] (other entries 0).  For a vertex with
+                                       s = |x| + |y| + |z| (metres), [0] s + [2] bounds the difference between any two float64
+                                       evaluation orders of the homogeneous image x and y (summed; pixel * millimetre) and
+                                       [1] s + [3] that of the camera depth (millimetres). */
+#define MSPA_CAM_MATS 3
+
 /* flags of mspa_pair_reproject */
 #define MSPA_PAIR_FAST 1u           /* composed-matrix evaluation with exact re-evaluation of every
                                        lane near a decision boundary: masks, pixel indices and counters
@@ -96,6 +108,8 @@ const char *mspa_last_error_string(void);
  * (mspa.engine.frame_bounds); a C caller that builds its own table calls this once per table.
  */
 int mspa_frame_bounds_host(double *frame_mats_host, int32_t n_frames);
+/* The same for K1's image records: fills slot MSPA_CAM_BOUNDS of [n_images, MSPA_CAM_MATS, 16] from slots 0-1 (HOST pointer). */
+int mspa_camera_bounds_host(double *cam_mats_host, int32_t n_images);
 
 /* Device facts the host layer reports next to measurements.  Any out pointer may be NULL. */
 int mspa_device_info(int device, int *n_cu, int *wave_size, int64_t *hbm_bytes, int *clock_khz,
@@ -197,7 +211,7 @@ int mspa_compact_correspondences(const uint64_t *vis_bits, const int16_t *pix_i1
  *
  *   xyz         vertex coordinates, element (i, c) at xyz[i*point_stride + c*comp_stride]
  *               ([N,3] rows: 3,1;  aligned_points.npy [N,6] rows: 6,1;  SoA [3,N]: 1,N)
- *   cam_mats    [n_images, 2, 16] float64: inv(A @ E) then K, per image
+ *   cam_mats    [n_images, MSPA_CAM_MATS, 16] float64: inv(A @ E), K, guard-bound coefficients (mspa_camera_bounds_host), per image
  *   depth       [n_images, dh, dw] uint16
  * Outputs, each optional:
  *   out_bits    [n_images, ceil(n_points/64)] uint64  visibility bitset (tail bits zero)
@@ -429,7 +443,7 @@ int mspa_select_common_point(const uint64_t *bits, int32_t n_images, int64_t n_w
 /*
  * K6b -- SceneInfoHandler.get_point_2d_coordinates_in_image (IH:291-305) for a batch of
  * (vertex, image) samples: un-rounded (u, v), camera depth and the check_point_visibility flag.
- *   xyz as in mspa_vertex_visibility; cam_mats [n_images, 2, 16]; depth [n_images, dh, dw]
+ *   xyz as in mspa_vertex_visibility; cam_mats [n_images, MSPA_CAM_MATS, 16]; depth [n_images, dh, dw]
  *   samples [n, 2] int32 (vertex, image);  out_uv [n, 2] f64, out_depth [n] f64, out_visible [n] u8
  */
 int mspa_project_samples(const double *xyz, int64_t n_points, int64_t point_stride, int64_t comp_stride,

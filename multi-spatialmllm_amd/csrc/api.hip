@@ -92,3 +92,22 @@ extern "C" int mspa_frame_bounds_host(double *frame_mats_host, int32_t n_frames)
     }
     return MSPA_OK;
 }
+
+extern "C" int mspa_camera_bounds_host(double *cam_mats_host, int32_t n_images) {
+    if (n_images < 0 || (!cam_mats_host && n_images > 0)) return fail(MSPA_EINVAL, "mspa_camera_bounds_host: bad table");
+    const double c = MSPA_GUARD_C * 0x1p-53 * 1000.0;
+    for (int32_t i = 0; i < n_images; ++i) {
+        double *rec = cam_mats_host + (int64_t)i * (MSPA_CAM_MATS * 16);
+        double Na[16];
+        abs_mul(rec + MSPA_CAM_K * 16, rec + MSPA_CAM_EINV * 16, Na);
+        double *b = rec + MSPA_CAM_BOUNDS * 16;
+        for (int k = 0; k < 16; ++k) b[k] = 0.0;
+        double nr[3];
+        for (int k = 0; k < 3; ++k) nr[k] = (Na[4 * k + 0] + Na[4 * k + 1]) + Na[4 * k + 2];
+        b[0] = c * (nr[0] + nr[1]);
+        b[1] = c * nr[2];
+        b[2] = c * (Na[3] + Na[7]);
+        b[3] = c * Na[11];
+    }
+    return MSPA_OK;
+}

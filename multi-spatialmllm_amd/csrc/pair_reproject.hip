@@ -53,10 +53,6 @@ struct PairArgs {
     int32_t *tile_counts;     // [n_pairs][n_tiles] entries per tile segment
     uint32_t xcd_shift;       // log2 of the XCDs workgroups are dealt over (3 on an MI355X in SPX mode, 0 otherwise)
     double wm1, hm1, wh_max;  // W - 1, H - 1, max(W, H) as float64 (guard band: mspa_common.h guard_from_bounds)
-    // tight kernel, "in view" on the homogeneous coordinates: half extents of the grid u, v live on (the depth grid) plus the
-    // pixel guard, and their reciprocals
-    double khw, khh, ikhw, ikhh;
-    int hwi, hhi;             // dw / 2, dh / 2
 };
 
 // Output sets.  A kernel instantiated with GENERIC = true tests every output pointer at run time
@@ -430,6 +426,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
     // shapes without a tile pre-pass); its composed matrix works in metres
     const Guard gd = guard_from_bounds(m1 + MSPA_MAT_BOUNDS * 16, m2 + MSPA_MAT_BOUNDS * 16, a.wm1, a.hm1, 65535.0, a.wh_max);
     const double zmin_m = uniform(gd.zmin * 0.001), gz_m = uniform(gd.gz * 0.001);
+    const double tnear_m = uniform(2.0 * a.wh_max * gd.zmin * 0.001);   // near the plane AND near the optical axis (tight kernel)
 
     // wave tile -> (row band, column stripe); both wave-uniform
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -564,7 +561,9 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
                 const double wu = __builtin_fabs(us - ru) - 0.25;
                 const double wv = __builtin_fabs(vs - rv) - 0.25;
                 bool rk = !(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx);
-                rk = rk | !(__builtin_fabs(iz) > zmin_m);         // below zmin the projection itself is not trusted
+                // below zmin the projection itself is not trusted; only a lane that is also within tnear of the optical axis
+                // (homogeneous x, y) can be accepted by any evaluation order
+                rk = rk | (!(__builtin_fabs(iz) > zmin_m) & (__builtin_fabs(ix) < tnear_m) & (__builtin_fabs(iy) < tnear_m));
                 if (!IDENT) {   // bounds live in colour-pixel units here, not at integers of the depth grid
                     const double bu = __builtin_fmin(__builtin_fabs(u), __builtin_fabs(u - Wd));
                     const double bv = __builtin_fmin(__builtin_fabs(v), __builtin_fabs(v - Hd));
@@ -913,27 +912,13 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
         // image-space triple, so u and v are unchanged and the third coordinate is the camera-2 depth in millimetres --
         // directly comparable with the raw depth-2 sample (no 0.001 multiply per pixel)
         for (int k = 0; k < 4; ++k) {
-            if (SCALED) M[r][k] = (k < 3 ? row[k] : row[k] * 1000.0) * (r == 0 ? a.sx : r == 1 ? a.sy : 1.0);
-            else M[r][k] = k < 3 ? row[k] : row[k] * 1000.0;
+            if (SCALED) M[r][k] = uniform((k < 3 ? row[k] : row[k] * 1000.0) * (r == 0 ? a.sx : r == 1 ? a.sy : 1.0));
+            else M[r][k] = uniform(k < 3 ? row[k] : row[k] * 1000.0);
         }
         if (WANT_XYZ) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) Us[r][k] = k < 3 ? U[4 * r + k] * 0.001 : U[4 * r + k];
         }
-    }
-    // Rows 0 / 1 are CENTRED on the image and scaled by its half extent (+ guard): with xn = (x - (W/2) z) / (W/2 + g) the
-    // test "0 <= u < W up to the guard" is |xn| < z -- one compare per axis on the homogeneous coordinates, BEFORE any
-    // division (round 4: a row group none of whose pixels passes skips the reciprocal, its Newton step and the two
-    // multiplies: 8 of its ~22 issue slots per row), and u - W/2 = xn (W/2 + g) / z for the groups that go on.  W/2 and H/2 are
-    // integers (whole tiles; the SCALED form requires even depth-grid sizes), so rounding ties and integer bounds sit at the
-    // same fractional parts as before.  The two extra roundings per entry are inside MSPA_GUARD_C's slack.
-    const double hw2 = (double)a.hwi, hh2 = (double)a.hhi;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double m2 = M[2][k];
-        M[0][k] = uniform(__builtin_fma(-hw2, m2, M[0][k]) * a.ikhw);
-        M[1][k] = uniform(__builtin_fma(-hh2, m2, M[1][k]) * a.ikhh);
-        M[2][k] = uniform(m2);
     }
 
     // transpose stage: the group's pixel indices, then (dense set) its rgba words, then its 4 x 64 x 3 point coordinates
@@ -1047,7 +1032,7 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
         const double *__restrict__ bnd1 = m1 + MSPA_MAT_BOUNDS * 16;
         const double *__restrict__ bnd2 = m2 + MSPA_MAT_BOUNDS * 16;
         const double tile_xmax = (double)(stripe * 64u + 63u), tile_ymax = (double)(row0 + (uint32_t)(ROWS - 1));
-        double zmin = 0.0, gz = kGuardZmmFloor;            // wave-uniform (SGPR pairs) once set below
+        double zmin = 0.0, gz = kGuardZmmFloor, tnear = 0.0;   // wave-uniform (SGPR pairs) once set below
         // the dense payload sets write every pixel, so their tiles are never culled -- but they take the pass all the same: the
         // band comes from the tile's own largest sample (with the format's 65 535 mm it is ~13 x wider, and on distant views
         // whole rows of lanes "near the camera-2 plane" went to the reference chain: dense_xyz 0.98 -> 1.38 ms on `low`)
@@ -1109,11 +1094,9 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                 const double cx = (double)((k & 1) ? cB : stripe * 64u);
                 const double cy = (double)((k & 2) ? rB : row0);
                 const double cd = (double)((k & 4) ? hi : lo + 1);
-                const double hxn = __builtin_fma(__builtin_fma(M[0][1], cy, __builtin_fma(M[0][0], cx, M[0][2])), cd, M[0][3]);
-                const double hyn = __builtin_fma(__builtin_fma(M[1][1], cy, __builtin_fma(M[1][0], cx, M[1][2])), cd, M[1][3]);
+                const double hx = __builtin_fma(__builtin_fma(M[0][1], cy, __builtin_fma(M[0][0], cx, M[0][2])), cd, M[0][3]);
+                const double hy = __builtin_fma(__builtin_fma(M[1][1], cy, __builtin_fma(M[1][0], cx, M[1][2])), cd, M[1][3]);
                 const double hz = __builtin_fma(__builtin_fma(M[2][1], cy, __builtin_fma(M[2][0], cx, M[2][2])), cd, M[2][3]);
-                const double hx = __builtin_fma(hw2, hz, hxn * a.khw);           // rows 0 / 1 are centred and scaled: undo
-                const double hy = __builtin_fma(hh2, hz, hyn * a.khh);
                 // margins in homogeneous units (pixel * millimetre; millimetres for the depth); a tile about to be culled
                 // checks that they are at least four times what two evaluation orders can differ by (mspa_common.h)
                 const bool all_behind = ballot64(hz <= -kCullMarginZ) == ~0ull;
@@ -1130,6 +1113,7 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                     all_front = ballot64(hz > gd.zsafe) == ~0ull;
                     zmin = uniform(gd.zmin);
                     gz = uniform(gd.gz);
+                    tnear = uniform(2.0 * a.wh_max * gd.zmin);
                 }
             }
             if (culled) {
@@ -1185,14 +1169,14 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                 // Lane predicates live as 64-bit ballots (SGPR pairs) from here on: carried as `bool` across the
                 // branch below the compiler parks them in 0/1 VGPRs and re-compares them (8 VALU issues per row);
                 // `opaque_mask` keeps it from folding inverse_ballot(ballot(x)) back into such a bool.
-                double xn[RG], yn[RG], qz[RG];
+                double u[RG], v[RG], qz[RG];
                 float fx[RG], fy[RG], fz[RG];
                 unsigned long long vmk[RG], ivm[RG];
                 unsigned long long any = 0;
 #pragma unroll
                 for (int j = 0; j < RG; ++j) {
                     const double dmm = (double)d16[j];
-                    const double ix = __builtin_fma(t0, dmm, M[0][3]);          // centred, in units of the half extent
+                    const double ix = __builtin_fma(t0, dmm, M[0][3]);
                     const double iy = __builtin_fma(t1, dmm, M[1][3]);
                     const double iz = __builtin_fma(t2, dmm, M[2][3]);          // camera-2 depth, millimetres
                     if (WANT_XYZ) {
@@ -1206,18 +1190,26 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                     t0 += M[0][1];
                     t1 += M[1][1];
                     t2 += M[2][1];
-                    xn[j] = ix;
-                    yn[j] = iy;
+                    double rz = __builtin_amdgcn_rcp(iz);
+                    rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
+                    u[j] = ix * rz;
+                    v[j] = iy * rz;
                     qz[j] = iz;
                     // every ballot is the SGPR result of ONE compare; the conjunctions are scalar ANDs of those words
                     // (a ballot of an AND of predicates is lowered to v_cndmask 0/1 + v_cmp again)
                     vmk[j] = ballot64(d16[j] != 0u);                             // OPS:297
-                    // |x - (W/2) z| < (W/2 + g) z  <=>  -g < u < W + g for z > 0; false for z <= 0 and for NaN
-                    ivm[j] = vmk[j] & ballot64(__builtin_fabs(ix) < iz) & ballot64(__builtin_fabs(iy) < iz);
+                    ivm[j] = vmk[j] & ballot64(u[j] > -kGuardPx) & ballot64(u[j] < Wd + kGuardPx) & ballot64(v[j] > -kGuardPx) &
+                             ballot64(v[j] < Hd + kGuardPx);
                     // CAREFUL tiles (the camera-2 plane may cut the tile's frustum): in front of the plane by more than zmin,
                     // or within zmin of it -- there u and v mean nothing, the lane is a candidate whatever they say and stage 2
                     // hands it to the reference chain.  (NaN depth lands in the second set.)
-                    if (CAREFUL) ivm[j] = vmk[j] & ((ivm[j] & ballot64(iz > zmin)) | ballot64(!(__builtin_fabs(iz) > zmin)));
+                    // Of the lanes near the plane only those within 2 max(W, H) zmin of the optical axis (homogeneous x, y) can be
+                    // accepted by ANY evaluation order (0 <= x < W z with z <= zmin + B_2): a point within millimetres of the
+                    // camera-2 CENTRE, not merely of its plane -- without this cut every row that crosses the plane sent a
+                    // lane to the reference chain (dense_xyz on distant views: +14 %).
+                    if (CAREFUL)
+                        ivm[j] = vmk[j] & ((ivm[j] & ballot64(iz > zmin)) |
+                                           (ballot64(!(__builtin_fabs(iz) > zmin)) & ballot64(__builtin_fabs(ix) < tnear) & ballot64(__builtin_fabs(iy) < tnear)));
                     any |= ivm[j];
                 }
                 const uint32_t rowg = row0 + (uint32_t)r0;
@@ -1237,14 +1229,9 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                     unsigned long long rkc[RG];
 #pragma unroll
                     for (int j = 0; j < RG; ++j) {
-                        // the division, only now: reciprocal (hardware estimate + one Newton step: the guard band needs
-                        // ~1e-9 relative), coordinates relative to the image centre
-                        double rz = __builtin_amdgcn_rcp(qz[j]);
-                        rz = __builtin_fma(__builtin_fma(-qz[j], rz, 1.0), rz, rz);
-                        const double uj = xn[j] * (rz * a.khw), vj = yn[j] * (rz * a.khh);
-                        const double ru = __builtin_rint(uj), rv = __builtin_rint(vj);
-                        const int xi = med3_0((int)ru + a.hwi, hi_x);
-                        const int yi = med3_0((int)rv + a.hhi, hi_y);
+                        const double ru = __builtin_rint(u[j]), rv = __builtin_rint(v[j]);
+                        const int xi = med3_0((int)ru, hi_x);
+                        const int yi = med3_0((int)rv, hi_y);
                         // every lane gathers: the clamped index is always inside the image
 #if !defined(MSPA_EXPERIMENT_GATHER)
                         dv16[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, (int)(__umul24((uint32_t)yi, dw2) + ((uint32_t)xi << 1)), 0, 0);
@@ -1257,8 +1244,8 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair
                         // With t = u - rint(u) in [-0.5, 0.5] a decision can flip only if |t| is within the guard of
                         // 0.5 (rounding tie) or of 0 (u at an integer: the image bounds are integers), i.e. unless
                         // guard < |t| < 0.5 - guard  <=>  ||t| - 0.25| < 0.25 - guard.  NaN fails the ordered compare.
-                        const double wu = __builtin_fabs(uj - ru) - 0.25;
-                        const double wv = __builtin_fabs(vj - rv) - 0.25;
+                        const double wu = __builtin_fabs(u[j] - ru) - 0.25;
+                        const double wv = __builtin_fabs(v[j] - rv) - 0.25;
                         rkc[j] = ballot64(!(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx));
                         if (CAREFUL) rkc[j] |= ballot64(!(qz[j] > zmin));        // lanes behind the plane are not in ivm
                         // Scheduling barrier between rows: left to itself the scheduler interleaves the four rows' rounding / guard
@@ -1623,11 +1610,12 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
         const double *__restrict__ bnd1 = m1 + MSPA_MAT_BOUNDS * 16;
         const double *__restrict__ bnd2 = m2 + MSPA_MAT_BOUNDS * 16;
         constexpr double wh_max = (double)(W_ > H_ ? W_ : H_);
-        double zmin = 0.0, gz = kGuardZmmFloor;
+        double zmin = 0.0, gz = kGuardZmmFloor, tnear = 0.0;
         if (last || !MSPA_SCALED_TILE_CULL) {             // no pre-pass for the last stripe: the bound over the full sample range
             const Guard gd = guard_from_bounds(bnd1, bnd2, (double)(W_ - 1), (double)(row0 + (uint32_t)(kRows - 1)), 65535.0, wh_max);
             zmin = uniform(gd.zmin);
             gz = uniform(gd.gz);
+            tnear = uniform(2.0 * wh_max * gd.zmin);
         }
 #if MSPA_SCALED_TILE_CULL
         if (!last) {
@@ -1682,6 +1670,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
                     all_front = ballot64(hz > gd.zsafe) == ~0ull;
                     zmin = uniform(gd.zmin);
                     gz = uniform(gd.gz);
+                    tnear = uniform(2.0 * wh_max * gd.zmin);
                 }
             }
             culled = __builtin_amdgcn_readfirstlane((int)culled) != 0;                  // wave-uniform, and known to be
@@ -1785,7 +1774,9 @@ __global__ __launch_bounds__(kThreads) void pair_fast_scaled_kernel(const uint16
                     vmk[e] = ballot64(d16[e] != 0u);
                     ivm[e] = vmk[e] & ballot64(u[e] > -kGuardPx) & ballot64(u[e] < DWd + kGuardPx) & ballot64(v[e] > -kGuardPx) &
                              ballot64(v[e] < DHd + kGuardPx);
-                    if (CAREFUL) ivm[e] = vmk[e] & ((ivm[e] & ballot64(iz > zmin)) | ballot64(!(__builtin_fabs(iz) > zmin)));
+                    if (CAREFUL)      // near the plane: only within 2 max(W, H) zmin of the optical axis (see the tight kernel)
+                        ivm[e] = vmk[e] & ((ivm[e] & ballot64(iz > zmin)) |
+                                           (ballot64(!(__builtin_fabs(iz) > zmin)) & ballot64(__builtin_fabs(ix) < tnear) & ballot64(__builtin_fabs(iy) < tnear)));
                     any |= ivm[e];
                 }
                 unsigned long long vm[NCH] = {};
@@ -1976,7 +1967,7 @@ static bool tight_shape(int32_t dh, int32_t dw, int32_t H, int32_t W, int rows =
 // shapes the tight kernel takes in its SCALED form (rectangular tiles on any colour / depth grid combination): bitset rows in
 // whole 16-bit pieces, whole 4-row groups, depth rows in whole 8-byte pieces, 32-bit byte offsets
 static bool rect_shape(int32_t dh, int32_t dw, int32_t H, int32_t W) {
-    return !tight_shape(dh, dw, H, W) && (W % 16 == 0) && (H % 4 == 0) && (dw % 4 == 0) && (dh % 2 == 0) &&
+    return !tight_shape(dh, dw, H, W) && (W % 16 == 0) && (H % 4 == 0) && (dw % 4 == 0) &&
            ((uint64_t)H * (uint64_t)W * 4 < (1ull << 31)) && ((uint64_t)dh * (uint64_t)dw * 2 < (1ull << 31));
 }
 
@@ -2013,9 +2004,6 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
     const int n_xcd = xcd_count();
     a.xcd_shift = n_xcd == 8 ? 3u : 0u;
     a.wm1 = (double)(W - 1); a.hm1 = (double)(H - 1); a.wh_max = (double)(W > H ? W : H);
-    a.hwi = dw / 2; a.hhi = dh / 2;                       // u, v live on the depth grid (== the colour grid for the tight shapes)
-    a.khw = (double)a.hwi + kGuardPx; a.khh = (double)a.hhi + kGuardPx;
-    a.ikhw = 1.0 / a.khw; a.ikhh = 1.0 / a.khh;
 
     if (out_counts) {      // 2 us per launch (tools/ab_k3.py: 0.5044 vs 0.5062 ms without / with)
         int rc = check_hip(hipMemsetAsync(out_counts, 0, sizeof(int32_t) * 2 * n_pairs, s), "hipMemsetAsync(counts)");

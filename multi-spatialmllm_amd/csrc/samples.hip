@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void project_samples_kernel(const double *__re
     const int img = samples[2 * s + 1];
     const double x = xyz[v * point_stride], y = xyz[v * point_stride + comp_stride],
                  z = xyz[v * point_stride + 2 * comp_stride];
-    const double *Einv = cam_mats + (int64_t)img * 32, *K = Einv + 16;
+    const double *Einv = cam_mats + (int64_t)img * (MSPA_CAM_MATS * 16), *K = Einv + 16;
     const double qx = affine_row(Einv + 0, x, y, z);      // IH:57-69, per-lane matrices (samples differ in image)
     const double qy = affine_row(Einv + 4, x, y, z);
     const double qz = affine_row(Einv + 8, x, y, z);

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_kernel(const doub
     const int64_t dpix = (int64_t)a.dh * a.dw;
 
     for (int img = img0; img < img1; ++img) {
-        const double *__restrict__ Einv = cam_mats + (int64_t)img * 32;
+        const double *__restrict__ Einv = cam_mats + (int64_t)img * (MSPA_CAM_MATS * 16);
         const double *__restrict__ K = Einv + 16;
         const uint16_t *__restrict__ dimg = depth + (int64_t)img * dpix;
         // IH:57-69
@@ -120,8 +120,8 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_kernel(const doub
 // is kept exactly as in K3's fast path: a lane whose decisions (half-to-even rounding of the pixel index, the image bounds,
 // the strict depth comparison) sit within a guard band of a decision boundary is re-evaluated with the reference chain.
 // The band is a BOUND (round 4; mspa_common.h): two float64 evaluation orders of K inv(A E) p differ by at most
-// B_k = c 2^-53 (Nabs[k][:3] . |p| + Nabs[k][3]), Nabs = |K| |inv(A E)|, in the k-th homogeneous coordinate; one thread per
-// image forms Nabs and leaves four numbers in LDS from which every lane takes, with s = |x| + |y| + |z| of its vertex,
+// B_k = c 2^-53 (Nabs[k][:3] . |p| + Nabs[k][3]), Nabs = |K| |inv(A E)|, in the k-th homogeneous coordinate; the image record
+// carries the magnitudes (slot MSPA_CAM_BOUNDS), from which every lane takes, with s = |x| + |y| + |z| of its vertex,
 //   zmin = za s + zb   (camera depth, mm, at or below which the projection is not trusted: the error of u grows like 1 / depth)
 //   gz   = ga s + gb   (depth-test guard, mm).
 // Needs a pinhole K (third row 0 0 1 0: the third homogeneous coordinate IS the camera depth); any other image takes
@@ -130,30 +130,15 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_kernel(const doub
 // ---------------------------------------------------------------------------------------------------------
 constexpr double kVGuardPx = 1e-6;              // K1's own pixel guard (K3's is tunable: mspa_common.h MSPA_GUARD_PX)
 
-// Per-image guard coefficients (za, zb, ga, gb), by ONE thread per image: 36 multiply-adds of magnitudes, once per block, while
-// the other threads fetch their vertices.  The composed matrix is millimetre-scaled, hence the factor 1000.
-__device__ __forceinline__ void image_guard_coefficients(const double *__restrict__ Einv, const double *__restrict__ K, double wh_max,
-                                                         double *out4) {
-    double nr[3], nt[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        double row[4];
-#pragma unroll
-        for (int cidx = 0; cidx < 4; ++cidx) {
-            double acc = __builtin_fabs(K[4 * r + 0]) * __builtin_fabs(Einv[0 + cidx]);
-            acc = __builtin_fma(__builtin_fabs(K[4 * r + 1]), __builtin_fabs(Einv[4 + cidx]), acc);
-            acc = __builtin_fma(__builtin_fabs(K[4 * r + 2]), __builtin_fabs(Einv[8 + cidx]), acc);
-            if (cidx == 3) acc += __builtin_fabs(K[4 * r + 3]);
-            row[cidx] = acc;
-        }
-        nr[r] = (row[0] + row[1]) + row[2];
-        nt[r] = row[3];
-    }
-    const double c = MSPA_GUARD_C * 0x1p-53 * 1000.0;
-    out4[0] = (2.0 / kVGuardPx) * c * __builtin_fma(wh_max + 1.0, nr[2], nr[0] + nr[1]);
-    out4[1] = (2.0 / kVGuardPx) * c * __builtin_fma(wh_max + 1.0, nt[2], nt[0] + nt[1]);
-    out4[2] = 2.0 * c * nr[2];
-    out4[3] = __builtin_fma(2.0 * c, nt[2], kGuardZmmFloor);
+// Per-image guard coefficients (za, zb, ga, gb) from slot MSPA_CAM_BOUNDS of the image record (host-side:
+// mspa_camera_bounds_host; round 4's first form computed the 36 multiply-adds of magnitudes in the kernel, one thread per
+// image in front of the block's first barrier: K1 +14 %).
+__device__ __forceinline__ void image_guard_coefficients(const double *__restrict__ rec, double wh_max, double *out4) {
+    const double *__restrict__ b = rec + MSPA_CAM_BOUNDS * 16;
+    out4[0] = (2.0 / kVGuardPx) * __builtin_fma(wh_max + 1.0, b[1], b[0]);
+    out4[1] = (2.0 / kVGuardPx) * __builtin_fma(wh_max + 1.0, b[3], b[2]);
+    out4[2] = 2.0 * b[1];
+    out4[3] = __builtin_fma(2.0, b[3], kGuardZmmFloor);
 }
 #ifndef MSPA_VBATCH
 #define MSPA_VBATCH 8
@@ -179,7 +164,7 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_fast_kernel(const
     if (threadIdx.x < kImgPerBlock * 12) {
         const int im = threadIdx.x / 12, e = threadIdx.x % 12, r = e / 4, cidx = e % 4;
         if (img0 + im < img1) {
-            const double *__restrict__ Einv = cam_mats + (int64_t)(img0 + im) * 32;
+            const double *__restrict__ Einv = cam_mats + (int64_t)(img0 + im) * (MSPA_CAM_MATS * 16);
             const double *__restrict__ K = Einv + 16;
             double acc = K[4 * r + 0] * Einv[0 + cidx];
             acc = __builtin_fma(K[4 * r + 1], Einv[4 + cidx], acc);
@@ -189,8 +174,8 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_fast_kernel(const
             if (e == 0) lds_pinhole[im] = (K[8] == 0.0 && K[9] == 0.0 && K[10] == 1.0 && K[11] == 0.0) ? 1 : 0;
         }
     } else if (threadIdx.x >= 128 && threadIdx.x < 128 + kImgPerBlock && img0 + (int)(threadIdx.x - 128) < img1) {
-        const double *__restrict__ Einv = cam_mats + (int64_t)(img0 + (int)(threadIdx.x - 128)) * 32;
-        image_guard_coefficients(Einv, Einv + 16, (double)max(a.W, a.H), lds_g[threadIdx.x - 128]);
+        image_guard_coefficients(cam_mats + (int64_t)(img0 + (int)(threadIdx.x - 128)) * (MSPA_CAM_MATS * 16), (double)max(a.W, a.H),
+                                 lds_g[threadIdx.x - 128]);
     }
     const int64_t i = (int64_t)vblock * kVThreads + threadIdx.x;
     const bool live = i < a.n_points;
@@ -267,7 +252,7 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_fast_kernel(const
             const unsigned long long rk = cand_m[q] & (risky_m[q] | __builtin_amdgcn_ballot_w64(!(__builtin_fabs(sd) > gz)));
             const bool pin = lds_pinhole[im] != 0;               // block-uniform
             if (rk != 0 || !pin) {                               // rare: the reference chain (IH:57-69, 337-386) for those lanes
-                const double *__restrict__ Einv = cam_mats + (int64_t)img * 32;
+                const double *__restrict__ Einv = cam_mats + (int64_t)img * (MSPA_CAM_MATS * 16);
                 const double *__restrict__ K = Einv + 16;
                 const uint16_t *__restrict__ dimg = depth + (int64_t)img * dpix;
                 const bool mine = pin ? (((rk >> lane) & 1ull) != 0) : live;
@@ -356,7 +341,7 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
     if (tid < kImgPerBlock * 12) {
         const int im = tid / 12, e = tid % 12, r = e / 4, cidx = e % 4;
         if (im < nimg) {
-            const double *__restrict__ Einv = cam_mats + (int64_t)(img0 + im) * 32;
+            const double *__restrict__ Einv = cam_mats + (int64_t)(img0 + im) * (MSPA_CAM_MATS * 16);
             const double *__restrict__ K = Einv + 16;
             double acc = K[4 * r + 0] * Einv[0 + cidx];
             acc = __builtin_fma(K[4 * r + 1], Einv[4 + cidx], acc);
@@ -366,17 +351,14 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
             if (e == 0) lds_pinhole[im] = (K[8] == 0.0 && K[9] == 0.0 && K[10] == 1.0 && K[11] == 0.0) ? 1 : 0;
         }
     }
-    // Guard coefficients: lane q of the block's LAST wave forms image q's four numbers, the wave takes the maximum over its
+    // Guard coefficients: lane q of the block's LAST wave reads image q's four numbers, the wave takes the maximum over its
     // images (they are non-negative: 0 is neutral) and leaves ONE set per block -- a lane's zmin then costs one FMA per
     // block instead of one per image, at the price of the widest image's band for all eight.
     static_assert(kImgPerBlock <= 8, "three xor-shuffle steps cover eight lanes");
     if (tid >= kVThreads - 64) {
         const int q = tid - (kVThreads - 64);
         double g4[4] = {0.0, 0.0, 0.0, 0.0};
-        if (q < nimg) {
-            const double *__restrict__ Einv = cam_mats + (int64_t)(img0 + q) * 32;
-            image_guard_coefficients(Einv, Einv + 16, (double)max(a.W, a.H), g4);
-        }
+        if (q < nimg) image_guard_coefficients(cam_mats + (int64_t)(img0 + q) * (MSPA_CAM_MATS * 16), (double)max(a.W, a.H), g4);
 #pragma unroll
         for (int off = 4; off > 0; off >>= 1) {
 #pragma unroll
@@ -523,7 +505,7 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
 #endif
                 if (rk) {
                     const int img = img0 + (int)qq[k];
-                    const double *__restrict__ Einv = cam_mats + (int64_t)img * 32;
+                    const double *__restrict__ Einv = cam_mats + (int64_t)img * (MSPA_CAM_MATS * 16);
                     const double *__restrict__ K = Einv + 16;
                     const double qx = affine_row(Einv + 0, pxs[k], pys[k], pzs[k]);
                     const double qy = affine_row(Einv + 4, pxs[k], pys[k], pzs[k]);

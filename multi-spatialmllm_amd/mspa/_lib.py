@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("MSPA_LIB", os.path.join(_PKG_ROOT, "libmspa.so"))
 MSPA_OK, MSPA_EINVAL, MSPA_EHIP, MSPA_EUNSUPPORTED = 0, -1, -2, -3
 MAT_KINV, MAT_E, MAT_A, MAT_EINV_ALIGNED, MAT_K, MAT_UNPROJ, MAT_REPROJ, MAT_BOUNDS, FRAME_MATS = 0, 1, 2, 3, 4, 5, 6, 7, 8
 GUARD_C = 256.0
+CAM_EINV, CAM_K, CAM_BOUNDS, CAM_MATS = 0, 1, 2, 3
 PAIR_FAST = 1
 PAIR_STREAM = 2
 PAIR_RECT_TILES = 0x100
@@ -31,6 +32,7 @@ _SIGNATURES = {
     "mspa_version": (c_int, []),
     "mspa_last_error_string": (c_char_p, []),
     "mspa_frame_bounds_host": (c_int, [c_void_p, c_int32]),
+    "mspa_camera_bounds_host": (c_int, [c_void_p, c_int32]),
     "mspa_device_info": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int64), POINTER(c_int),
                                  c_char_p, c_int]),
     "mspa_pair_reproject": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64,

@@ -116,15 +116,25 @@ def fast_path_ok(K: np.ndarray) -> bool:
 
 
 def camera_matrices(K: np.ndarray, E_aligned_list: Sequence[np.ndarray]) -> np.ndarray:
-    """[n, 2, 16] float64 records for mspa_vertex_visibility: inv(E_aligned), K (one batched inverse, see frame_matrices)."""
+    """[n, 3, 16] float64 records for mspa_vertex_visibility: inv(E_aligned), K (one batched inverse, see frame_matrices) and
+    the guard-bound coefficients of the composed kernels (slot MSPA_CAM_BOUNDS of include/mspa.h: magnitudes of
+    |K| |inv(E_aligned)|; the same numbers mspa_camera_bounds_host computes)."""
     K = check_affine("K", K)
     n = len(E_aligned_list)
-    out = np.empty((n, 2, 16), dtype=np.float64)
+    out = np.zeros((n, _lib.CAM_MATS, 16), dtype=np.float64)
     if n == 0:
         return out
     E = _check_affine_stack("E_aligned", np.stack([np.asarray(e, dtype=np.float64) for e in E_aligned_list]))
-    out[:, 0] = _check_affine_stack("inv(E_aligned)", np.linalg.inv(E)).reshape(n, 16)   # IH:57
-    out[:, 1] = K.reshape(16)
+    Einv = _check_affine_stack("inv(E_aligned)", np.linalg.inv(E))                         # IH:57
+    out[:, _lib.CAM_EINV] = Einv.reshape(n, 16)
+    out[:, _lib.CAM_K] = K.reshape(16)
+    Na = np.abs(K) @ np.abs(Einv)
+    c = _lib.GUARD_C * 2.0 ** -53 * 1000.0
+    nr = (Na[:, :3, 0] + Na[:, :3, 1]) + Na[:, :3, 2]
+    out[:, _lib.CAM_BOUNDS, 0] = c * (nr[:, 0] + nr[:, 1])
+    out[:, _lib.CAM_BOUNDS, 1] = c * nr[:, 2]
+    out[:, _lib.CAM_BOUNDS, 2] = c * (Na[:, 0, 3] + Na[:, 1, 3])
+    out[:, _lib.CAM_BOUNDS, 3] = c * Na[:, 2, 3]
     return out
 
 
@@ -307,7 +317,7 @@ def vertex_visibility(xyz: torch.Tensor, cam_mats: torch.Tensor, depth: torch.Te
                       want: Iterable[str] = ("bits", "count"), homogeneous: bool = False,
                       depth_scale: float = 0.001) -> Dict[str, torch.Tensor]:
     """Enqueue K1.  xyz [N,3] or [N,C>=3] float64 rows (or a [3,N] SoA tensor with soa=True layout
-    given as xyz.t()); cam_mats [I,2,16]; depth [I,DH,DW].  Returns the requested outputs.
+    given as xyz.t()); cam_mats [I,3,16]; depth [I,DH,DW].  Returns the requested outputs.
     ``homogeneous``: the rows are general homogeneous points (x, y, z, w) (``project_points`` takes any [N, 4], IH:46-72);
     ``depth_scale``: the handler's ``depth_value_scale`` (IH:76, IH:368)."""
     _require_gpu()
@@ -317,7 +327,7 @@ def vertex_visibility(xyz: torch.Tensor, cam_mats: torch.Tensor, depth: torch.Te
     ps, cs = xyz.stride(0), xyz.stride(1)
     _require(xyz.shape[1] >= (4 if homogeneous else 3) and ps > 0 and cs > 0, "xyz: [N, >= 3] rows ([N, >= 4] when homogeneous)")
     I, DH, DW = depth.shape
-    _require(cam_mats.dtype == torch.float64 and tuple(cam_mats.shape) == (I, 2, 16), "cam_mats.dtype == torch.float64 and tuple(cam_mats.shape) == (I, 2, 16)")
+    _require(cam_mats.dtype == torch.float64 and tuple(cam_mats.shape) == (I, _lib.CAM_MATS, 16), "cam_mats: float64 [n_images, 3, 16] (engine.camera_matrices)")
     H, W = image_hw
     dev = xyz.device
     out: Dict[str, torch.Tensor] = {}
@@ -566,7 +576,7 @@ def project_samples(xyz: torch.Tensor, cam_mats: torch.Tensor, depth: torch.Tens
     I, DH, DW = depth.shape
     _require(xyz.is_cuda and xyz.stride(0) > 0 and xyz.stride(1) > 0, "xyz: device tensor with positive strides")
     _require(depth.dtype in (torch.int16, torch.uint16), "depth.dtype in (torch.int16, torch.uint16)")
-    _require(cam_mats.dtype == torch.float64 and tuple(cam_mats.shape) == (I, 2, 16), "cam_mats: float64 [n_images, 2, 16]")
+    _require(cam_mats.dtype == torch.float64 and tuple(cam_mats.shape) == (I, _lib.CAM_MATS, 16), "cam_mats: float64 [n_images, 3, 16] (engine.camera_matrices)")
     n = samples.shape[0]
     dev = xyz.device
     uv = torch.empty((n, 2), dtype=torch.float64, device=dev)

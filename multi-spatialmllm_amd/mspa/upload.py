@@ -50,7 +50,7 @@ class UploadSlot:
             self.d_depth = torch.empty(shape, dtype=torch.int16, device=self.device)
             self.h_fmats = torch.empty((self.cap_frames, engine._lib.FRAME_MATS, 16), dtype=torch.float64).pin_memory()
             self.d_fmats = torch.empty_like(self.h_fmats, device=self.device)
-            self.h_cmats = torch.empty((self.cap_frames, 2, 16), dtype=torch.float64).pin_memory()
+            self.h_cmats = torch.empty((self.cap_frames, engine._lib.CAM_MATS, 16), dtype=torch.float64).pin_memory()
             self.d_cmats = torch.empty_like(self.h_cmats, device=self.device)
             self.h_pose = torch.empty((self.cap_frames * 18,), dtype=torch.float64).pin_memory()   # A @ E, yaw, pitch (K4)
             self.d_pose = torch.empty_like(self.h_pose, device=self.device)

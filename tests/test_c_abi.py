@@ -22,7 +22,19 @@ int main(void) {
     if (mspa_corr_tiles(480, 640) != 100 || mspa_corr_tiles(968, 1296) != 21 * 21 || mspa_corr_tiles(1, 640) != -1) return 7;
     if (mspa_pair_correspondences_workspace_bytes(10, 480, 640, 480, 640, MSPA_PAIR_FAST) != 0) return 8;   /* fused */
     if (mspa_pair_correspondences_workspace_bytes(10, 480, 640, 480, 640, 0) != 10LL * 480 * 640 * 4) return 9;
-    if (mspa_pair_correspondences_workspace_bytes(2, 480, 640, 968, 1296, MSPA_PAIR_FAST) != 2LL * 968 * 1296 * 4) return 10;
+    if (mspa_pair_correspondences_workspace_bytes(2, 480, 640, 968, 1296, MSPA_PAIR_FAST) != 0) return 10;   /* fused at ScanNet's shape too (round 4) */
+    if (mspa_pair_correspondences_workspace_bytes(2, 480, 640, 968, 1296, 0) != 2LL * 968 * 1296 * 4) return 14;
+    if (mspa_pair_correspondences_workspace_bytes(2, 60, 81, 121, 162, MSPA_PAIR_FAST) != 2LL * 121 * 162 * 4) return 15;   /* W % 16 != 0: dense route */
+    {   /* the host-side helpers that fill the guard-bound slots of the frame / image records */
+        double frec[MSPA_FRAME_MATS * 16] = {0}, crec[MSPA_CAM_MATS * 16] = {0};
+        int s, k;
+        for (s = 0; s < MSPA_MAT_BOUNDS; ++s) for (k = 0; k < 4; ++k) frec[s * 16 + 5 * k] = 1.0;   /* identities */
+        for (s = 0; s < MSPA_CAM_BOUNDS; ++s) for (k = 0; k < 4; ++k) crec[s * 16 + 5 * k] = 1.0;
+        if (mspa_frame_bounds_host(frec, 1) != MSPA_OK || mspa_camera_bounds_host(crec, 1) != MSPA_OK) return 16;
+        if (!(frec[MSPA_MAT_BOUNDS * 16 + 0] == 1.0 && frec[MSPA_MAT_BOUNDS * 16 + 3] == 0.0 && frec[MSPA_MAT_BOUNDS * 16 + 4] > 0.0)) return 17;
+        if (!(crec[MSPA_CAM_BOUNDS * 16 + 0] > 0.0 && crec[MSPA_CAM_BOUNDS * 16 + 4] == 0.0)) return 18;
+        if (mspa_frame_bounds_host(NULL, 1) != MSPA_EINVAL || mspa_camera_bounds_host(NULL, 1) != MSPA_EINVAL) return 19;
+    }
     if (mspa_pair_correspondences(NULL, NULL, 1, NULL, 1, 480, 640, 480, 640, NULL, NULL, NULL, NULL, NULL, 0, MSPA_PAIR_FAST,
                                   NULL) != MSPA_EINVAL) return 11;
     if (!strstr(mspa_last_error_string(), "required")) return 12;

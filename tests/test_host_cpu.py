@@ -141,7 +141,13 @@ def test_matrix_preparation_matches_numpy():
     for f in range(3):
         pass
     c = engine.camera_matrices(sc.K, [sc.A @ e for e in E])
+    assert c.shape == (3, _lib.CAM_MATS, 16)
     assert np.array_equal(c[1, 0].reshape(4, 4), np.linalg.inv(sc.A @ E[1]))
+    c2 = c.copy()
+    c2[:, _lib.CAM_BOUNDS] = -1.0                    # slot MSPA_CAM_BOUNDS: NumPy form == the library's host helper
+    _lib.check(_lib.load().mspa_camera_bounds_host(c2.ctypes.data, c2.shape[0]))
+    assert np.allclose(c2[:, _lib.CAM_BOUNDS], c[:, _lib.CAM_BOUNDS], rtol=1e-14, atol=0) and (c[:, _lib.CAM_BOUNDS, :4] > 0).all()
+    assert np.array_equal(c2[:, :_lib.CAM_BOUNDS], c[:, :_lib.CAM_BOUNDS])
     with pytest.raises(ValueError):
         engine.frame_matrices(sc.K, sc.A, [np.full((4, 4), np.nan)])
 
