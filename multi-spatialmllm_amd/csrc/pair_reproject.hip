@@ -758,6 +758,12 @@ constexpr int tight_bw_of(uint32_t set) {
            : (set & (O_XYZ32 | O_VIS_U8)) ? 8
            : (set & O_PIX) ? 4 : 2;
 }
+// waves per SIMD the register allocator must leave room for (second argument of __launch_bounds__): the sets without an
+// index table run best at six (80 VGPRs); round 4's guard-band bookkeeping had pushed `minimal` to 82 = five waves, +5 %
+// (the SCALED correspondence set sat at 97 VGPRs = four waves: held at five)
+constexpr int tight_minwaves_of(uint32_t set, bool scaled) {
+    return (set & (O_XYZ32 | O_RGBA | O_VIS_U8)) ? 1 : (set & O_PIX) ? (scaled ? 5 : 1) : 6;
+}
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int med3_0(int x, int hi) {   // clamp(x, 0, hi), hi wave-uniform
@@ -826,7 +832,7 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m, uint32_t base)
 //   * the bitset: W % 16 == 0 makes a tile row's 64 bits four ALIGNED 16-bit pieces of the row-major bitset whatever the
 //     row -- four 2-byte stores per tile (lane = row) instead of one 8-byte store, no atomics, no wobble.
 template <uint32_t SET, bool STREAM, int ROWS, int RG, bool SCALED = false>
-__global__ __launch_bounds__(tight_bw_of(SET) * kWave) MSPA_TIGHT_ATTR void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
+__global__ __launch_bounds__(tight_bw_of(SET) * kWave, tight_minwaves_of(SET, SCALED)) MSPA_TIGHT_ATTR void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
                                                                    const uint8_t *__restrict__ rgb,
                                                                    const double *__restrict__ mats,
                                                                    const int32_t *__restrict__ pairs, PairArgs a) {

@@ -14,6 +14,8 @@ for f in api pair_reproject vertex_visibility pair_overlap pose_tracks samples o
 done
 git show $REV:multi-spatialmllm_amd/csrc/mspa_common.h > $B/multi-spatialmllm_amd/csrc/mspa_common.h
 git show $REV:include/mspa.h | sed 's/#define MSPA_FRAME_MATS 7/#define MSPA_FRAME_MATS 8/' > $B/include/mspa.h
+# ... and against round 4's image-record stride of K1 / K6b (3 slots of 16 instead of 2)
+sed -i 's/(int64_t)\(img\|(img0 + im)\|(img0 + q)\|(img0 + (int)(threadIdx.x - 128))\|(img0 + tid - 128)\) \* 32\b/(int64_t)\1 * 48/g' $B/multi-spatialmllm_amd/csrc/vertex_visibility.hip $B/multi-spatialmllm_amd/csrc/samples.hip
 cd $B/multi-spatialmllm_amd/csrc
 for f in api pair_reproject vertex_visibility pair_overlap pose_tracks samples object_extents bitset_index; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-result -c $f.hip -o $f.o &
