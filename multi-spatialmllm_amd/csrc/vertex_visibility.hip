@@ -351,23 +351,27 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
             if (e == 0) lds_pinhole[im] = (K[8] == 0.0 && K[9] == 0.0 && K[10] == 1.0 && K[11] == 0.0) ? 1 : 0;
         }
     }
-    // Guard coefficients: lane q of the block's LAST wave reads image q's four numbers, the wave takes the maximum over its
-    // images (they are non-negative: 0 is neutral) and leaves ONE set per block -- a lane's zmin then costs one FMA per
-    // block instead of one per image, at the price of the widest image's band for all eight.
-    static_assert(kImgPerBlock <= 8, "three xor-shuffle steps cover eight lanes");
+    // Guard coefficients: lane q of the block's LAST wave reads image q's four numbers and folds them into ONE set per block
+    // with an LDS atomic maximum on their bit patterns (they are non-negative doubles: the unsigned order of the bits is
+    // their order) -- a lane's zmin then costs one FMA per block instead of one per image, at the price of the widest
+    // image's band for all eight.  (A shuffle reduction here -- 24 ds_bpermute in front of the block's first barrier --
+    // cost K1 8-10 %: tools/ab_k1.py.)  The wave's LDS operations execute in order: the zeros land before the maxima.
     if (tid >= kVThreads - 64) {
         const int q = tid - (kVThreads - 64);
-        double g4[4] = {0.0, 0.0, 0.0, 0.0};
-        if (q < nimg) image_guard_coefficients(cam_mats + (int64_t)(img0 + q) * (MSPA_CAM_MATS * 16), (double)max(a.W, a.H), g4);
+        if (q < 4) lds_g[q] = 0.0;
+        if (q < nimg) {
+            double g4[4];
+            image_guard_coefficients(cam_mats + (int64_t)(img0 + q) * (MSPA_CAM_MATS * 16), (double)max(a.W, a.H), g4);
+            // ds_max_u64 spelled out: through atomicMax() LLVM's atomic optimizer turns four same-address LDS atomics into four
+            // serial readlane scans over the active lanes (~2 000 cycles in front of the barrier); the LDS unit resolves eight
+            // lanes on one address in a few cycles itself
+            typedef __attribute__((address_space(3))) double lds_double_t;
+            const uint32_t base = (uint32_t)(uintptr_t)(lds_double_t *)&lds_g[0];
 #pragma unroll
-        for (int off = 4; off > 0; off >>= 1) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) g4[k] = __builtin_fmax(g4[k], __shfl_xor(g4[k], off));
+            for (int k = 0; k < 4; ++k)
+                asm volatile("ds_max_u64 %0, %1 offset:%2" ::"v"(base), "v"(__double_as_longlong(g4[k])), "n"(8 * k) : "memory");
         }
-        if (q == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) lds_g[k] = g4[k];
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the compiler's scoreboard does not see the asm's LDS operations
     }
     if (tid < kImgPerBlock * (kVThreads / 32)) (&lds_bits[0][0])[tid] = 0u;
     if (tid == 0) lds_n = 0u;
