@@ -20,7 +20,6 @@ bash tools/profile.sh ${T}_compact_high --variant compact --workload high > /dev
 bash tools/profile.sh ${T}_dense_xyz_vc --variant dense_xyz > /dev/null 2>&1
 bash tools/profile.sh ${T}_minimal_vc --variant minimal > /dev/null 2>&1
 bash tools/pmc.sh ${T}_k3corr pair_fast_tight python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-scene-legs --also none --no-sweep > /dev/null 2>&1
-bash tools/pmc.sh ${T}_k3compact pair_fast_tight python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-scene-legs --also none --no-sweep --variant compact > /dev/null 2>&1
 bash tools/profile_scene.sh > /dev/null 2>&1
 bash tools/profile_scene_pmc.sh > /dev/null 2>&1
 python tools/ab_k3.py --sets corr,compact,minimal,dense_xyz,dense --steps 30 --rounds 3 > $O/ab_k3.txt 2>&1
