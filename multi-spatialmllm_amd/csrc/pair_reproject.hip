@@ -53,6 +53,10 @@ struct PairArgs {
     int32_t *tile_counts;     // [n_pairs][n_tiles] entries per tile segment
     uint32_t xcd_shift;       // log2 of the XCDs workgroups are dealt over (3 on an MI355X in SPX mode, 0 otherwise)
     double wm1, hm1, wh_max;  // W - 1, H - 1, max(W, H) as float64 (guard band: mspa_common.h guard_from_bounds)
+    // tight kernel: u, v are taken relative to the centre of the grid they live on (the depth grid), so that "inside the image
+    // up to the guard" is ONE compare per axis: |u - W/2| < W/2 + g
+    double hw, hh, khw, khh;  // dw / 2, dh / 2 (integers), and the same + kGuardPx
+    int hwi, hhi;
 };
 
 // Output sets.  A kernel instantiated with GENERIC = true tests every output pointer at run time
@@ -726,6 +730,12 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 #ifndef MSPA_SCALED_FULL_WAIT
 #define MSPA_SCALED_FULL_WAIT 1        // ScanNet-shape kernel: one vmcnt(0) for a group's gathers instead of a counted wait per row (-1..4 %)
 #endif
+#ifndef MSPA_COMPACT_LDS_PAD
+#define MSPA_COMPACT_LDS_PAD 0
+#endif
+#ifndef MSPA_CENTRED_TEST
+#define MSPA_CENTRED_TEST 1            // rows 0 / 1 of the composed matrix centred on the image: 2 instead of 4 bounds compares per row
+#endif
 #ifndef MSPA_TIGHT_WAVES_PER_EU
 #define MSPA_TIGHT_WAVES_PER_EU 0      // > 0: ask the register allocator for that many waves per SIMD
 #endif
@@ -881,7 +891,9 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave, tight_minwaves_of(SET, SC
     // predecessor).  The wave's LDS operations execute in order; the next group reads ITS rows before its stage overwrites them.
     constexpr bool PX_IN_TILE = !SCALED && (SET & O_PIX) && !(SET & (O_XYZ32 | O_RGBA));
     constexpr int kPadPx = PX_IN_TILE ? 256 : 0;                        // uint16 units: 512 bytes
-    __shared__ __attribute__((aligned(16))) uint16_t lds_w[kTightBW][SCALED ? 16 : kPadPx + ROWS * 64];   // SCALED: counter slots only
+    // (MSPA_COMPACT_LDS_PAD: A/B knob -- bytes of LDS added per wave of the compacted set to cap its waves per SIMD)
+    constexpr int kOccPad = (COMPACT && !SCALED) ? MSPA_COMPACT_LDS_PAD / 2 : 0;
+    __shared__ __attribute__((aligned(16))) uint16_t lds_w[kTightBW][SCALED ? 16 : kPadPx + ROWS * 64 + kOccPad];   // SCALED: counter slots only
     uint16_t *const lds_d1w = &lds_w[wave][kPadPx];                     // this wave's 48 x 64 depth-1 samples
     if (tile_ok && !SCALED) {
         typedef __attribute__((address_space(1))) const void gvoid_t;
@@ -909,21 +921,41 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave, tight_minwaves_of(SET, SC
     const double *__restrict__ U = m1 + MSPA_MAT_UNPROJ * 16;
     const double *__restrict__ N = m2 + MSPA_MAT_REPROJ * 16;
     double M[3][4], Us[3][4];
+    // millimetre-scaled homogeneous coordinates: M maps (mx*d, my*d, d) with d the RAW millimetre sample to 1000 x the
+    // image-space triple, so u and v are unchanged and the third coordinate is the camera-2 depth in millimetres --
+    // directly comparable with the raw depth-2 sample (no 0.001 multiply per pixel)
+    // (Forming the twelve entries lane-parallel -- one entry per lane, 24 v_readlane -- saves ~60 of the ~100 issue slots this
+    // costs per tile, and measured SLOWER: compact +10 %, corr +2 %, dense_xyz +4 %, tools/ab_k3.py round 4: its per-lane
+    // matrix loads go through the vector memory path and sit in front of everything else a tile does, where the wave-uniform
+    // form reads the scalar cache all tiles of a pair share.)
+    {
+        double raw[3][4];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        double row[4];
-        compose_row(N, U, r, row);
+        for (int r = 0; r < 3; ++r) {
+            double row[4];
+            compose_row(N, U, r, row);
 #pragma unroll
-        // millimetre-scaled homogeneous coordinates: M maps (mx*d, my*d, d) with d the RAW millimetre sample to 1000 x the
-        // image-space triple, so u and v are unchanged and the third coordinate is the camera-2 depth in millimetres --
-        // directly comparable with the raw depth-2 sample (no 0.001 multiply per pixel)
-        for (int k = 0; k < 4; ++k) {
-            if (SCALED) M[r][k] = uniform((k < 3 ? row[k] : row[k] * 1000.0) * (r == 0 ? a.sx : r == 1 ? a.sy : 1.0));
-            else M[r][k] = uniform(k < 3 ? row[k] : row[k] * 1000.0);
+            for (int k = 0; k < 4; ++k) {
+                raw[r][k] = k < 3 ? row[k] : row[k] * 1000.0;
+                if (SCALED) raw[r][k] *= (r == 0 ? a.sx : r == 1 ? a.sy : 1.0);
+            }
+            if (WANT_XYZ) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) Us[r][k] = k < 3 ? U[4 * r + k] * 0.001 : U[4 * r + k];
+            }
         }
-        if (WANT_XYZ) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) Us[r][k] = k < 3 ? U[4 * r + k] * 0.001 : U[4 * r + k];
+        for (int k = 0; k < 4; ++k) {
+#if MSPA_CENTRED_TEST
+            // rows 0 / 1 minus (W/2, H/2) times row 2: u and v come out relative to the image centre (W/2, H/2 are integers:
+            // rounding ties and integer bounds keep their fractional parts; the extra rounding per entry is inside MSPA_GUARD_C)
+            M[0][k] = uniform(__builtin_fma(-a.hw, raw[2][k], raw[0][k]));
+            M[1][k] = uniform(__builtin_fma(-a.hh, raw[2][k], raw[1][k]));
+#else
+            M[0][k] = uniform(raw[0][k]);
+            M[1][k] = uniform(raw[1][k]);
+#endif
+            M[2][k] = uniform(raw[2][k]);
         }
     }
 
@@ -1100,9 +1132,13 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave, tight_minwaves_of(SET, SC
                 const double cx = (double)((k & 1) ? cB : stripe * 64u);
                 const double cy = (double)((k & 2) ? rB : row0);
                 const double cd = (double)((k & 4) ? hi : lo + 1);
-                const double hx = __builtin_fma(__builtin_fma(M[0][1], cy, __builtin_fma(M[0][0], cx, M[0][2])), cd, M[0][3]);
-                const double hy = __builtin_fma(__builtin_fma(M[1][1], cy, __builtin_fma(M[1][0], cx, M[1][2])), cd, M[1][3]);
+                double hx = __builtin_fma(__builtin_fma(M[0][1], cy, __builtin_fma(M[0][0], cx, M[0][2])), cd, M[0][3]);
+                double hy = __builtin_fma(__builtin_fma(M[1][1], cy, __builtin_fma(M[1][0], cx, M[1][2])), cd, M[1][3]);
                 const double hz = __builtin_fma(__builtin_fma(M[2][1], cy, __builtin_fma(M[2][0], cx, M[2][2])), cd, M[2][3]);
+                if (MSPA_CENTRED_TEST) {          // rows 0 / 1 are centred: back to image coordinates
+                    hx = __builtin_fma(a.hw, hz, hx);
+                    hy = __builtin_fma(a.hh, hz, hy);
+                }
                 // margins in homogeneous units (pixel * millimetre; millimetres for the depth); a tile about to be culled
                 // checks that they are at least four times what two evaluation orders can differ by (mspa_common.h)
                 const bool all_behind = ballot64(hz <= -kCullMarginZ) == ~0ull;
@@ -1204,8 +1240,11 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave, tight_minwaves_of(SET, SC
                     // every ballot is the SGPR result of ONE compare; the conjunctions are scalar ANDs of those words
                     // (a ballot of an AND of predicates is lowered to v_cndmask 0/1 + v_cmp again)
                     vmk[j] = ballot64(d16[j] != 0u);                             // OPS:297
-                    ivm[j] = vmk[j] & ballot64(u[j] > -kGuardPx) & ballot64(u[j] < Wd + kGuardPx) & ballot64(v[j] > -kGuardPx) &
-                             ballot64(v[j] < Hd + kGuardPx);
+                    if (MSPA_CENTRED_TEST)        // u, v relative to the image centre
+                        ivm[j] = vmk[j] & ballot64(__builtin_fabs(u[j]) < a.khw) & ballot64(__builtin_fabs(v[j]) < a.khh);
+                    else
+                        ivm[j] = vmk[j] & ballot64(u[j] > -kGuardPx) & ballot64(u[j] < Wd + kGuardPx) & ballot64(v[j] > -kGuardPx) &
+                                 ballot64(v[j] < Hd + kGuardPx);
                     // CAREFUL tiles (the camera-2 plane may cut the tile's frustum): in front of the plane by more than zmin,
                     // or within zmin of it -- there u and v mean nothing, the lane is a candidate whatever they say and stage 2
                     // hands it to the reference chain.  (NaN depth lands in the second set.)
@@ -1236,8 +1275,9 @@ __global__ __launch_bounds__(tight_bw_of(SET) * kWave, tight_minwaves_of(SET, SC
 #pragma unroll
                     for (int j = 0; j < RG; ++j) {
                         const double ru = __builtin_rint(u[j]), rv = __builtin_rint(v[j]);
-                        const int xi = med3_0((int)ru, hi_x);
-                        const int yi = med3_0((int)rv, hi_y);
+                        constexpr bool kCentred = MSPA_CENTRED_TEST;
+                        const int xi = med3_0((int)ru + (kCentred ? a.hwi : 0), hi_x);
+                        const int yi = med3_0((int)rv + (kCentred ? a.hhi : 0), hi_y);
                         // every lane gathers: the clamped index is always inside the image
 #if !defined(MSPA_EXPERIMENT_GATHER)
                         dv16[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, (int)(__umul24((uint32_t)yi, dw2) + ((uint32_t)xi << 1)), 0, 0);
@@ -1973,7 +2013,7 @@ static bool tight_shape(int32_t dh, int32_t dw, int32_t H, int32_t W, int rows =
 // shapes the tight kernel takes in its SCALED form (rectangular tiles on any colour / depth grid combination): bitset rows in
 // whole 16-bit pieces, whole 4-row groups, depth rows in whole 8-byte pieces, 32-bit byte offsets
 static bool rect_shape(int32_t dh, int32_t dw, int32_t H, int32_t W) {
-    return !tight_shape(dh, dw, H, W) && (W % 16 == 0) && (H % 4 == 0) && (dw % 4 == 0) &&
+    return !tight_shape(dh, dw, H, W) && (W % 16 == 0) && (H % 4 == 0) && (dw % 4 == 0) && (dh % 2 == 0) &&
            ((uint64_t)H * (uint64_t)W * 4 < (1ull << 31)) && ((uint64_t)dh * (uint64_t)dw * 2 < (1ull << 31));
 }
 
@@ -2010,6 +2050,9 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
     const int n_xcd = xcd_count();
     a.xcd_shift = n_xcd == 8 ? 3u : 0u;
     a.wm1 = (double)(W - 1); a.hm1 = (double)(H - 1); a.wh_max = (double)(W > H ? W : H);
+    a.hwi = dw / 2; a.hhi = dh / 2;                       // u, v live on the depth grid (== the colour grid for the whole-tile shapes)
+    a.hw = (double)a.hwi; a.hh = (double)a.hhi;
+    a.khw = a.hw + kGuardPx; a.khh = a.hh + kGuardPx;
 
     if (out_counts) {      // 2 us per launch (tools/ab_k3.py: 0.5044 vs 0.5062 ms without / with)
         int rc = check_hip(hipMemsetAsync(out_counts, 0, sizeof(int32_t) * 2 * n_pairs, s), "hipMemsetAsync(counts)");
