@@ -502,7 +502,7 @@ def time_scene_pipeline(device, n_scenes=24, n_points=131072, n_frames=320):
 
 def time_scannet_shape(device, n_pairs=200, base_frames=16, steps=5):
     """K3 at ScanNet's OWN shape: a 1296 x 968 colour grid over 640 x 480 depth frames (extract_posed_images.py:93-97; the
-    reference's project_mask_to_3d spans the colour grid, OPS:276-290) -- `pair_fast_scaled_kernel`, correspondence output
+    reference's project_mask_to_3d spans the colour grid, OPS:276-290) -- the tight kernel's rectangular-tile form, correspondence output
     set, pairs drawn by the reference's overlap-binned sampler from a 16-frame sweep of the SURVEY 8d room.
     Algorithmic bytes per pair: the two depth frames once (2 x 2 B x 307 200) + per colour pixel 1/8 B of bitset and 4 B of
     pixel index (4.125 B x 1 254 528) = 6 403 728 B."""
@@ -549,9 +549,9 @@ def time_scannet_shape(device, n_pairs=200, base_frames=16, steps=5):
         torch.cuda.synchronize()
         return a0.elapsed_time(a1) / steps
 
-    # the same set through the rectangular-tile kernel (what the compacted set runs on at this shape), and the fused
-    # compacted set itself: bitset + 4 B per VISIBLE pixel + a count per tile, no dense table
-    ms_rect = timed(lambda: engine.pair_reproject(depth, mats, pairs, (CH, CW), out, flags=flags | _lib.PAIR_RECT_TILES))
+    # the same set through round 2-3's wobbling-stripe kernel (MSPA_PAIR_WORD_STRIPES; the rectangular-tile kernel is the
+    # default since round 4), and the fused compacted set: bitset + 4 B per VISIBLE pixel + a count per tile, no dense table
+    ms_rect = timed(lambda: engine.pair_reproject(depth, mats, pairs, (CH, CW), out, flags=flags | _lib.PAIR_WORD_STRIPES))
     kern_rect = _lib.load().mspa_pair_reproject_last_kernel()
     comp = engine.alloc_pair_correspondences(n_pairs, (CH, CW), device)
     ms_comp = timed(lambda: engine.pair_correspondences(depth, mats, pairs, (CH, CW), comp, flags=flags))
@@ -568,9 +568,9 @@ def time_scannet_shape(device, n_pairs=200, base_frames=16, steps=5):
                "achieved_GBs": round(bcomp / (ms_comp * 1e-3) / 1e9, 1), "frac": round(bcomp / (ms_comp * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                "visible_fraction": round(float(c[:, 1].sum() / max(1, c[:, 0].sum())), 4)}
     return {"shape": "colour 1296x968 over depth 640x480", "pairs": n_pairs, "kernel_ms": round(ms, 4),
-            "rect_tiles_ms_per_1000_pairs": round(ms_rect / n_pairs * 1000, 4) if kern_rect == _lib.KERNEL_PAIR_FAST_RECT else None,
+            "word_stripes_ms_per_1000_pairs": round(ms_rect / n_pairs * 1000, 4) if kern_rect == _lib.KERNEL_PAIR_FAST_SCALED else None,
             "compact": compact,
-            "kernel": "mspa::pair_fast_scaled_kernel" if kern == _lib.KERNEL_PAIR_FAST_SCALED else f"kernel id {kern}",
+            "kernel": "mspa::pair_fast_tight_kernel<corr, SCALED> (rectangular tiles)" if kern == _lib.KERNEL_PAIR_FAST_RECT else f"kernel id {kern}",
             "ms_per_1000_pairs": round(ms / n_pairs * 1000, 4), "pairs_per_s_1gpu": round(n_pairs / (ms * 1e-3), 1),
             "colour_pixels_per_s": round(n_pairs * CH * CW / (ms * 1e-3), 1),
             "bytes_per_pair": int(bpp), "bytes_formula": "2 x 2 B x 307 200 (both depth frames, once) + 4.125 B x 1 254 528 (bitset + pixel index per colour pixel)",

@@ -95,9 +95,9 @@ typedef void *mspa_stream_t;        /* hipStream_t */
                                        displace frame-2 lines that ARE revisited (gathers).  Results are identical with or
                                        without it; measured +3 % with distinct frames, -10 % when 48 frames serve 1000 pairs */
 
-#define MSPA_PAIR_RECT_TILES 0x100u  /* diagnostic / A-B: take the rectangular-tile kernel (MSPA_KERNEL_PAIR_FAST_RECT) also where a
-                                       shape has a kernel of its own (ScanNet's 1296x968 over 640x480, correspondence / minimal
-                                       sets).  Results are identical. */
+#define MSPA_PAIR_WORD_STRIPES 0x200u /* diagnostic / A-B: at ScanNet's shape (1296x968 over 640x480), correspondence / minimal sets, take
+                                       round 2-3's word-aligned wobbling-stripe kernel (MSPA_KERNEL_PAIR_FAST_SCALED) instead of
+                                       the rectangular-tile kernel that is the default since round 4.  Results are identical. */
 
 int mspa_version(void);
 const char *mspa_last_error_string(void);
@@ -157,10 +157,10 @@ int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, const double 
 #define MSPA_KERNEL_PAIR_FAST_LINEAR 3    /* the same with the linear pixel mapping (bitset, W % 64 != 0) */
 #define MSPA_KERNEL_PAIR_FAST_TIGHT 4     /* whole-tile images (W % 64 == 0, H % 48 == 0, colour == depth grid), output set
                                              corr / dense / dense without colour / minimal / compact */
-#define MSPA_KERNEL_PAIR_FAST_SCALED 5    /* colour grid over a smaller depth grid (ScanNet: 1296x968 over 640x480), word-aligned stripes */
+#define MSPA_KERNEL_PAIR_FAST_SCALED 5    /* ScanNet's 1296x968 over 640x480 on word-aligned wobbling stripes (MSPA_PAIR_WORD_STRIPES only) */
 #define MSPA_KERNEL_PAIR_FAST_RECT 6      /* the tight kernel on rectangular tiles of ANY colour / depth grid pair with W % 16 == 0,
-                                             H % 4 == 0, dw % 4 == 0 (ScanNet's shape: the compacted set; other shapes: corr /
-                                             minimal / compact) */
+                                             H % 4 == 0, dw % 4 == 0, dh % 2 == 0 (ScanNet's shape included): correspondence /
+                                             minimal / compacted sets */
 int mspa_pair_reproject_last_kernel(void);
 
 /*

@@ -762,8 +762,12 @@ constexpr int tight_rows_of(uint32_t set) { return (set & (O_XYZ32 | O_RGBA | O_
 // minimal 0.325 / 0.309 / 0.319 / 0.351, compact 0.388 / 0.377 / 0.388 / 0.424; corr 0.525 / 0.505 / 0.503 / 0.558; the dense
 // point set without colour a large one, dense_xyz 1.303 / 1.200 / 1.149 / 1.132 (with colour words 4 stay better than 8:
 // 1.572 vs 1.587).  MSPA_TIGHT_BLOCK_WAVES > 0 forces one size for all (A/B builds).
-constexpr int tight_bw_of(uint32_t set) {
+// The SCALED form (no LDS depth tile: a workgroup's size costs no occupancy) runs best at four for every set
+// (tools/ab_scannet.py at ScanNet's shape, ms per 1 000 pairs at 1 / 2 / 4 / 8 waves: minimal 2.76 / 1.94 / 1.55-1.63 / 1.63,
+// compact 3.03 / 2.18 / 1.93 / 2.01, corr 2.55 / - / 1.72-1.80 / 1.79).
+constexpr int tight_bw_of(uint32_t set, bool scaled = false) {
     return MSPA_TIGHT_BLOCK_WAVES > 0 ? MSPA_TIGHT_BLOCK_WAVES
+           : scaled ? 4
            : (set & O_RGBA) ? 4
            : (set & (O_XYZ32 | O_VIS_U8)) ? 8
            : (set & O_PIX) ? 4 : 2;
@@ -842,12 +846,12 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m, uint32_t base)
 //   * the bitset: W % 16 == 0 makes a tile row's 64 bits four ALIGNED 16-bit pieces of the row-major bitset whatever the
 //     row -- four 2-byte stores per tile (lane = row) instead of one 8-byte store, no atomics, no wobble.
 template <uint32_t SET, bool STREAM, int ROWS, int RG, bool SCALED = false>
-__global__ __launch_bounds__(tight_bw_of(SET) * kWave, tight_minwaves_of(SET, SCALED)) MSPA_TIGHT_ATTR void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
+__global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of(SET, SCALED)) MSPA_TIGHT_ATTR void pair_fast_tight_kernel(const uint16_t *__restrict__ depth,
                                                                    const uint8_t *__restrict__ rgb,
                                                                    const double *__restrict__ mats,
                                                                    const int32_t *__restrict__ pairs, PairArgs a) {
     using O = Outs<SET, false>;
-    constexpr int kTightBW = tight_bw_of(SET);
+    constexpr int kTightBW = tight_bw_of(SET, SCALED);
     constexpr bool WANT_XYZ = (SET & O_XYZ32) != 0;
     constexpr bool COMPACT = (SET & O_CPIX) != 0;
     static_assert(RG == 4 || !(SET & (O_PIX | O_XYZ32 | O_RGBA | O_VIS_U8)), "the transpose stages move 4-row blocks");
@@ -2032,7 +2036,7 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
     const uint64_t P = (uint64_t)H * (uint64_t)W;
     if (P * (uint64_t)W >= (1ull << 32)) return fail(MSPA_EINVAL, "mspa_pair_reproject: H*W*W must be < 2^32");
     if (out_rgba && !rgb) return fail(MSPA_EINVAL, "mspa_pair_reproject: out_rgba needs rgb");
-    if (flags & ~(MSPA_PAIR_FAST | MSPA_PAIR_STREAM | MSPA_PAIR_RECT_TILES)) return fail(MSPA_EINVAL, "mspa_pair_reproject: unknown flag");
+    if (flags & ~(MSPA_PAIR_FAST | MSPA_PAIR_STREAM | MSPA_PAIR_WORD_STRIPES)) return fail(MSPA_EINVAL, "mspa_pair_reproject: unknown flag");
     if (n_pairs == 0) return MSPA_OK;
     hipStream_t s = (hipStream_t)stream;
 
@@ -2076,12 +2080,14 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
                          (((uintptr_t)out_vis_u8 & 3u) == 0);
     const bool tight24 = fast && aligned && tight_shape(dh, dw, H, W, tight_rows_of(set)) &&
                          (set == kSetCorr || set == kSetDense || set == kSetDenseXyz || set == kSetMinimal || set == kSetCompact);
-    // ScanNet's own shape (1296 x 968 colour over 640 x 480 depth) has a wobbling-stripe kernel of its own for the
-    // correspondence / minimal sets; the tight kernel's SCALED form (rectangular tiles) takes the compacted set there, all
-    // three sets on every other such shape, and all three under MSPA_PAIR_RECT_TILES
+    // The tight kernel's SCALED form (rectangular tiles) takes the correspondence / minimal / compacted sets on every
+    // rect_shape, ScanNet's own (1296 x 968 colour over 640 x 480 depth) included: at four waves per workgroup it beats round
+    // 2-3's wobbling-stripe kernel there (corr 1.72-1.80 vs 1.90-2.05, minimal 1.55-1.63 vs 1.64-1.69 ms per 1 000 pairs,
+    // tools/ab_scannet.py), which stays reachable under MSPA_PAIR_WORD_STRIPES
     const bool scannet = W == 1296 && H == 968 && dw == 640 && dh == 480;
-    const bool rect = fast && !tight24 && aligned && rect_shape(dh, dw, H, W) &&
-                      (set == kSetCompact || ((set == kSetCorr || set == kSetMinimal) && (!scannet || (flags & MSPA_PAIR_RECT_TILES))));
+    const bool word_stripes = scannet && (flags & MSPA_PAIR_WORD_STRIPES) && (set == kSetCorr || set == kSetMinimal);
+    const bool rect = fast && !tight24 && aligned && rect_shape(dh, dw, H, W) && !word_stripes &&
+                      (set == kSetCompact || set == kSetCorr || set == kSetMinimal);
     if (out_cpix && !((tight24 || rect) && out_tile_counts))
         return fail(MSPA_EINVAL, "pair_reproject_impl: the fused compacted set needs the tight kernel and a tile-count table");
     const bool scaled = fast && !tight24 && !rect && aligned && scannet && (set == kSetCorr || set == kSetMinimal);
@@ -2096,7 +2102,7 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
         a.n_tiles = (linear && !rect) ? (int)((P + (int64_t)kTileRows * 64 - 1) / ((int64_t)kTileRows * 64))
                                       : a.n_stripes * ((H + tile_rows - 1) / tile_rows);
         a.stripe_magic = (uint32_t)((1ull << 32) / (uint64_t)a.n_stripes) + 1u;
-        const int bw = (tight24 || rect) ? tight_bw_of(set) : (kThreads / kWave);
+        const int bw = rect ? tight_bw_of(set, true) : tight24 ? tight_bw_of(set) : (kThreads / kWave);
         a.strips = (a.n_tiles + bw - 1) / bw;
     } else {
         a.n_stripes = a.n_tiles = 0;
@@ -2125,9 +2131,9 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
 #define MSPA_LAUNCH_RECT(SET_) \
     do { \
         if (flags & MSPA_PAIR_STREAM) \
-            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, true, tight_rows_of(SET_), tight_rg_of(SET_), true>), grid, dim3(tight_bw_of(SET_) * kWave), 0, s, depth, rgb, frame_mats, pairs, a); \
+            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, true, tight_rows_of(SET_), tight_rg_of(SET_), true>), grid, dim3(tight_bw_of(SET_, true) * kWave), 0, s, depth, rgb, frame_mats, pairs, a); \
         else \
-            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, false, tight_rows_of(SET_), tight_rg_of(SET_), true>), grid, dim3(tight_bw_of(SET_) * kWave), 0, s, depth, rgb, frame_mats, pairs, a); \
+            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, false, tight_rows_of(SET_), tight_rg_of(SET_), true>), grid, dim3(tight_bw_of(SET_, true) * kWave), 0, s, depth, rgb, frame_mats, pairs, a); \
     } while (0)
         if (set == kSetCorr) MSPA_LAUNCH_RECT(kSetCorr);
         else if (set == kSetCompact) MSPA_LAUNCH_RECT(kSetCompact);

@@ -14,7 +14,7 @@ GUARD_C = 256.0
 CAM_EINV, CAM_K, CAM_BOUNDS, CAM_MATS = 0, 1, 2, 3
 PAIR_FAST = 1
 PAIR_STREAM = 2
-PAIR_RECT_TILES = 0x100
+PAIR_WORD_STRIPES = 0x200
 CORR_TILE_W, CORR_TILE_H, CORR_TILE_CAP = 64, 48, 64 * 48
 KERNEL_NONE, KERNEL_PAIR_EXACT, KERNEL_PAIR_FAST, KERNEL_PAIR_FAST_LINEAR, KERNEL_PAIR_FAST_TIGHT, KERNEL_PAIR_FAST_SCALED, KERNEL_PAIR_FAST_RECT = range(7)
 

@@ -43,7 +43,7 @@ def one_seed(seed, hw, dhw, n_frames, n_oracle):
     refs = {k: O.frame_pair(depth_np[k // n_frames], depth_np[k % n_frames], K, E[k // n_frames], E[k % n_frames], A, hw) for k in pick}
     tight = tuple(hw) == tuple(dhw)
     sets = list(SETS) if tight else ["corr", "minimal"]
-    want = _lib.KERNEL_PAIR_FAST_TIGHT if tight else _lib.KERNEL_PAIR_FAST_SCALED
+    want = _lib.KERNEL_PAIR_FAST_TIGHT if tight else _lib.KERNEL_PAIR_FAST_RECT
     for name in sets:
         outs = SETS[name]
         exact = engine.alloc_pair_outputs(n, hw, outs, DEV)

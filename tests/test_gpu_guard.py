@@ -108,7 +108,8 @@ def test_camera2_on_frame1_points_640x480():
 
 @pytest.mark.gpu
 def test_camera2_on_frame1_points_scannet_shape():
-    """ScanNet's own shape (1296x968 colour over 640x480 depth): the wobbling-stripe kernel incl. its last stripe."""
+    """ScanNet's own shape (1296x968 colour over 640x480 depth): the rectangular-tile kernel (the default there) and the
+    wobbling-stripe kernel incl. its last stripe (MSPA_PAIR_WORD_STRIPES)."""
     hw, dhw = (968, 1296), (480, 640)
     rng = np.random.default_rng(33)
     K, A, E, depth_np, pairs = ADV.near_plane_case(rng, hw, (1e-5, 1e-7, 1e-9), per_delta=2, dhw=dhw)
@@ -117,10 +118,11 @@ def test_camera2_on_frame1_points_scannet_shape():
     pt = torch.tensor(pairs, dtype=torch.int32, device=DEV)
     refs = [O.frame_pair(depth_np[a], depth_np[b], K, E[a], E[b], A, hw) for a, b in pairs]
     for name in ("corr", "minimal"):
-        res, kern = launch(depth, mats, None, pt, hw, SETS[name], _lib.PAIR_FAST)
-        assert kern == _lib.KERNEL_PAIR_FAST_SCALED
-        for n, ref in enumerate(refs):
-            check_integers(res, n, ref, hw)
+        for extra, want in ((0, _lib.KERNEL_PAIR_FAST_RECT), (_lib.PAIR_WORD_STRIPES, _lib.KERNEL_PAIR_FAST_SCALED)):
+            res, kern = launch(depth, mats, None, pt, hw, SETS[name], _lib.PAIR_FAST | extra)
+            assert kern == want
+            for n, ref in enumerate(refs):
+                check_integers(res, n, ref, hw)
 
 
 @pytest.mark.gpu

@@ -115,7 +115,7 @@ def test_rect_kernel_equals_exact_on_adversarial_poses(name):
 @pytest.mark.gpu
 def test_rect_kernel_at_scannet_shape():
     """ScanNet's own shape: the fused compacted set needs no workspace and equals np.nonzero(oracle vis) order; the
-    rectangular-tile kernel's correspondence / minimal sets (MSPA_PAIR_RECT_TILES) equal the oracle's AND the wobbling-stripe
+    rectangular-tile kernel's correspondence / minimal sets equal the oracle's AND the wobbling-stripe
     kernel's; 30 adversarial pairs against the exact kernel."""
     hw, dhw = (968, 1296), (480, 640)
     lib = _lib.load()
@@ -138,8 +138,8 @@ def test_rect_kernel_at_scannet_shape():
         assert np.array_equal(i.cpu().numpy(), nz) and np.array_equal(xi.cpu().numpy(), ref["xi"][nz])
         assert np.array_equal(yi.cpu().numpy(), ref["yi"][nz])
     for sname in ("corr", "minimal"):
-        wob, kw = launch(depth, mats, None, pairs, hw, SETS[sname], _lib.PAIR_FAST)
-        rect, kr = launch(depth, mats, None, pairs, hw, SETS[sname], _lib.PAIR_FAST | _lib.PAIR_RECT_TILES)
+        wob, kw = launch(depth, mats, None, pairs, hw, SETS[sname], _lib.PAIR_FAST | _lib.PAIR_WORD_STRIPES)
+        rect, kr = launch(depth, mats, None, pairs, hw, SETS[sname], _lib.PAIR_FAST)
         assert kw == _lib.KERNEL_PAIR_FAST_SCALED and kr == _lib.KERNEL_PAIR_FAST_RECT
         for k in SETS[sname]:
             assert np.array_equal(wob[k], rect[k]), k

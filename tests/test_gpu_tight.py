@@ -307,19 +307,21 @@ def test_scaled_kernel_equals_exact_on_adversarial_poses(name, stream):
     pairs = torch.from_numpy(pair_np).to(DEV)
     flags = _lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0)
     outs = SETS[name]
-    fast = engine.alloc_pair_outputs(len(pair_np), SCANNET_HW, outs, DEV)
     exact = engine.alloc_pair_outputs(len(pair_np), SCANNET_HW, outs, DEV)
-    for t in fast.values():
-        t.fill_(23)
-    engine.pair_reproject(depth, mats, pairs, SCANNET_HW, fast, flags=flags)
-    assert _lib.load().mspa_pair_reproject_last_kernel() == _lib.KERNEL_PAIR_FAST_SCALED
     engine.pair_reproject(depth, mats, pairs, SCANNET_HW, exact, flags=0)
     assert _lib.load().mspa_pair_reproject_last_kernel() == _lib.KERNEL_PAIR_EXACT
-    torch.cuda.synchronize()
-    for k in outs:
-        if not torch.equal(fast[k], exact[k]):
-            bad = (fast[k] != exact[k]).reshape(len(pair_np), -1).any(dim=1).nonzero().flatten().tolist()
-            raise AssertionError(f"{name}/{'stream' if stream else 'plain'}: {k} differs from the exact kernel in pairs {bad[:8]}")
+    # round 4: the rectangular-tile kernel is the default at this shape; the wobbling-stripe kernel under MSPA_PAIR_WORD_STRIPES
+    for extra, want in ((_lib.PAIR_WORD_STRIPES, _lib.KERNEL_PAIR_FAST_SCALED), (0, _lib.KERNEL_PAIR_FAST_RECT)):
+        fast = engine.alloc_pair_outputs(len(pair_np), SCANNET_HW, outs, DEV)
+        for t in fast.values():
+            t.fill_(23)
+        engine.pair_reproject(depth, mats, pairs, SCANNET_HW, fast, flags=flags | extra)
+        assert _lib.load().mspa_pair_reproject_last_kernel() == want
+        torch.cuda.synchronize()
+        for k in outs:
+            if not torch.equal(fast[k], exact[k]):
+                bad = (fast[k] != exact[k]).reshape(len(pair_np), -1).any(dim=1).nonzero().flatten().tolist()
+                raise AssertionError(f"{name}/{'stream' if stream else 'plain'}/kernel {want}: {k} differs from the exact kernel in pairs {bad[:8]}")
     assert int(exact["counts"][:, 1].sum()) > 100000
 
 
@@ -333,9 +335,10 @@ def test_scaled_kernel_reproduces_reference_digest():
     pairs = torch.tensor([[0, 1], [1, 0]], dtype=torch.int32, device=DEV)
     P = g.color_hw[0] * g.color_hw[1]
     ex, _ = launch(depth, mats, None, pairs, g.color_hw, ("valid_u8", "vis_bits", "pix_i16", "counts"), 0)
-    for stream in (False, True):
-        res, kern = launch(depth, mats, None, pairs, g.color_hw, SETS["corr"], _lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0))
-        assert kern == _lib.KERNEL_PAIR_FAST_SCALED
+    for stream, extra, want in ((False, _lib.PAIR_WORD_STRIPES, _lib.KERNEL_PAIR_FAST_SCALED), (True, _lib.PAIR_WORD_STRIPES, _lib.KERNEL_PAIR_FAST_SCALED),
+                                (False, 0, _lib.KERNEL_PAIR_FAST_RECT), (True, 0, _lib.KERNEL_PAIR_FAST_RECT)):
+        res, kern = launch(depth, mats, None, pairs, g.color_hw, SETS["corr"], _lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0) | extra)
+        assert kern == want
         valid = ex["valid_u8"][0].astype(bool)
         vis = unpack_bits(res["vis_bits"][0], P)
         assert sha(vis[valid]) == str(g["pair_sha_vis"]) and int(vis.sum()) == int(g["pair_n_vis"]) == int(res["counts"][0, 1])
@@ -344,7 +347,8 @@ def test_scaled_kernel_reproduces_reference_digest():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hw,dhw,kernel", [((480, 640), (480, 640), "tight"), (SCANNET_HW, SCANNET_DHW, "scaled")], ids=["640x480", "scannet"])
+@pytest.mark.parametrize("hw,dhw,kernel", [((480, 640), (480, 640), "tight"), (SCANNET_HW, SCANNET_DHW, "scaled"), (SCANNET_HW, SCANNET_DHW, "rect")],
+                         ids=["640x480", "scannet-word-stripes", "scannet"])
 def test_tile_culling_with_large_holes_and_distant_views(hw, dhw, kernel):
     """Tile-level culling: tiles whose depth box holds no valid sample at all (a quarter of frame 0 is a hole), tiles
     that cannot land in the other view (cameras back to back, side by side looking apart) and tiles that straddle the edge
@@ -384,8 +388,10 @@ def test_tile_culling_with_large_holes_and_distant_views(hw, dhw, kernel):
         exact = engine.alloc_pair_outputs(len(pair_np), hw, outs, DEV)
         for t in fast.values():
             t.fill_(23)
-        engine.pair_reproject(depth, mats, pairs, hw, fast, flags=_lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0))
-        assert _lib.load().mspa_pair_reproject_last_kernel() == (_lib.KERNEL_PAIR_FAST_TIGHT if kernel == "tight" else _lib.KERNEL_PAIR_FAST_SCALED)
+        engine.pair_reproject(depth, mats, pairs, hw, fast, flags=_lib.PAIR_FAST | (_lib.PAIR_STREAM if stream else 0) |
+                              (_lib.PAIR_WORD_STRIPES if kernel == "scaled" else 0))
+        assert _lib.load().mspa_pair_reproject_last_kernel() == {"tight": _lib.KERNEL_PAIR_FAST_TIGHT, "scaled": _lib.KERNEL_PAIR_FAST_SCALED,
+                                                                "rect": _lib.KERNEL_PAIR_FAST_RECT}[kernel]
         engine.pair_reproject(depth, mats, pairs, hw, exact, flags=0)
         torch.cuda.synchronize()
         for k in outs:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ScanNet's own shape (1296x968 colour over 640x480 depth), one process, interleaved rounds: the wobbling-stripe kernel
-(correspondence / minimal sets), the rectangular-tile kernel on the same sets (MSPA_PAIR_RECT_TILES) and the fused compacted
+(correspondence / minimal sets, MSPA_PAIR_WORD_STRIPES), the rectangular-tile kernel on the same sets (the default) and the fused compacted
 set (rectangular tiles), ms per 1 000 pairs.
     python tools/ab_scannet.py [--pairs 200] [--steps 20] [--rounds 3]"""
 import argparse
@@ -41,10 +41,10 @@ def main():
     outs = {"corr": engine.alloc_pair_outputs(a.pairs, (CH, CW), ("vis_bits", "pix_i16", "counts"), dev),
             "minimal": engine.alloc_pair_outputs(a.pairs, (CH, CW), ("vis_bits", "counts"), dev)}
     comp = engine.alloc_pair_correspondences(a.pairs, (CH, CW), dev)
-    legs = {"corr:wobble": lambda: engine.pair_reproject(depth, mats, pairs, (CH, CW), outs["corr"], flags=F),
-            "corr:rect": lambda: engine.pair_reproject(depth, mats, pairs, (CH, CW), outs["corr"], flags=F | _lib.PAIR_RECT_TILES),
-            "minimal:wobble": lambda: engine.pair_reproject(depth, mats, pairs, (CH, CW), outs["minimal"], flags=F),
-            "minimal:rect": lambda: engine.pair_reproject(depth, mats, pairs, (CH, CW), outs["minimal"], flags=F | _lib.PAIR_RECT_TILES),
+    legs = {"corr:wobble": lambda: engine.pair_reproject(depth, mats, pairs, (CH, CW), outs["corr"], flags=F | _lib.PAIR_WORD_STRIPES),
+            "corr:rect": lambda: engine.pair_reproject(depth, mats, pairs, (CH, CW), outs["corr"], flags=F),
+            "minimal:wobble": lambda: engine.pair_reproject(depth, mats, pairs, (CH, CW), outs["minimal"], flags=F | _lib.PAIR_WORD_STRIPES),
+            "minimal:rect": lambda: engine.pair_reproject(depth, mats, pairs, (CH, CW), outs["minimal"], flags=F),
             "compact:rect": lambda: engine.pair_correspondences(depth, mats, pairs, (CH, CW), comp, flags=F)}
     res = {k: [] for k in legs}
     for _ in range(a.rounds):

@@ -72,7 +72,7 @@ def main():
                         t.fill_(23)
                     engine.pair_reproject(depth, mats, pairs, hw, fast, rgb=rgb if "rgba" in outs else None, flags=_lib.PAIR_FAST | stream)
                     kern = _lib.load().mspa_pair_reproject_last_kernel()
-                    assert kern == (_lib.KERNEL_PAIR_FAST_TIGHT if tight else _lib.KERNEL_PAIR_FAST_SCALED), kern
+                    assert kern == (_lib.KERNEL_PAIR_FAST_TIGHT if tight else _lib.KERNEL_PAIR_FAST_RECT), kern
                     for k in outs:
                         if k == "xyz_f32":
                             fe, ff = exact[k], fast[k]
