@@ -223,7 +223,9 @@ __global__ __launch_bounds__(kVThreads) void vertex_visibility_fast_kernel(const
             asm("v_med3_i32 %0, %1, 0, %2" : "=v"(yi) : "v"((int)rv), "s"(hi_y));
             // candidate = what the reference would accept, widened by the guard (a lane inside the widening is risky); within
             // zmin of the camera plane u and v mean nothing: candidate whatever they say, and risky below
-            const bool nearz = !(__builtin_fabs(iz) > zmin);
+            // ... and only if it is also within 2 max(W, H) zmin of the optical axis: nothing else near the plane can be accepted
+            const double tn = 2.0 * __builtin_fmax(Wd, Hd) * zmin;
+            const bool nearz = !(__builtin_fabs(iz) > zmin) & (__builtin_fabs(ix) < tn) & (__builtin_fabs(iy) < tn);
             const bool cand = live & (((u > -kVGuardPx) & (u < Wd + kVGuardPx) & (v > -kVGuardPx) & (v < Hd + kVGuardPx) &
                                        (iz > zmin)) | nearz);
             // guard < |t| < 0.5 - guard for both coordinates  <=>  max(||tu| - .25|, ||tv| - .25|) < .25 - guard
@@ -335,7 +337,9 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
     __shared__ __attribute__((aligned(16))) double lds_g[4];         // guard coefficients: the LARGEST over the block's images
     __shared__ int lds_pinhole[kImgPerBlock];
     __shared__ __attribute__((aligned(16))) double lds_xyz[kVThreads][3];
-    __shared__ uint16_t lds_list[kVThreads * kImgPerBlock];
+    __shared__ uint16_t lds_list[kVThreads * kImgPerBlock];          // tid | image << 8 | (near the camera plane and axis) << 15
+    __shared__ double lds_gz[kVThreads];                              // per vertex: depth-test guard (mm)
+    static_assert(kImgPerBlock <= 64, "list entry: 6 bits of image index under the flag bit");
     __shared__ uint32_t lds_bits[kImgPerBlock][kVThreads / 32];
     __shared__ uint32_t lds_n;
     if (tid < kImgPerBlock * 12) {
@@ -406,10 +410,15 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
         gc[k] = __longlong_as_double(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)b));
     }
+    // this lane's vertex, any image of the block: camera-depth threshold, its "near the optical axis" companion (homogeneous
+    // x, y within 2 max(W, H) zmin: nothing else near the camera plane can be accepted by any evaluation order: 0 <= x < W z with
+    // z <= zmin + B_2), and the depth-test guard, which phase B reads back per list entry
     const double zmin_l = __builtin_fma(gc[0], psum, gc[1]);
+    const double tn_l = 2.0 * (double)max(a.W, a.H) * zmin_l;
+    lds_gz[tid] = __builtin_fma(gc[2], psum, gc[3]);
 
     // ---- phase A: candidates of this wave's 64 vertices for the block's images ----
-    unsigned long long cm[kImgPerBlock];
+    unsigned long long cm[kImgPerBlock], nm[kImgPerBlock];
     int total = 0;
 #pragma unroll
     for (int q = 0; q < kImgPerBlock; ++q) {
@@ -420,13 +429,19 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
             const double iy = __builtin_fma(m[4], x, __builtin_fma(m[5], y, __builtin_fma(m[6], z, m[7])));
             const double iz = __builtin_fma(m[8], x, __builtin_fma(m[9], y, __builtin_fma(m[10], z, m[11])));   // mm
             const double gb = kVBandPx * iz;
-            const double zmin = zmin_l;                                                         // this vertex, any image of the block
-            const unsigned long long near0 = __builtin_amdgcn_ballot_w64(!(iz > zmin));         // NaN lands here too
+            const double zmin = zmin_l;
+            unsigned long long near0 = __builtin_amdgcn_ballot_w64(!(iz > zmin));               // NaN lands here too
+            // near the plane AND near the axis (rare: a wave-uniform branch).  Listing every vertex near the plane of SOME image --
+            // 0.5 % of the list entries: one phase-B wave trip in four ran the reference chain -- had cost K1 9 %.
+            if (near0 != 0ull)
+                near0 &= __builtin_amdgcn_ballot_w64(__builtin_fabs(ix) < tn_l) & __builtin_amdgcn_ballot_w64(__builtin_fabs(iy) < tn_l);
+            nm[q] = near0;
             const unsigned long long inside =
                 __builtin_amdgcn_ballot_w64(ix > -gb) & __builtin_amdgcn_ballot_w64(ix < (Wd + kVBandPx) * iz) &
                 __builtin_amdgcn_ballot_w64(iy > -gb) & __builtin_amdgcn_ballot_w64(iy < (Hd + kVBandPx) * iz);
             c = lds_pinhole[q] ? (live_m & __builtin_amdgcn_ballot_w64(!(iz <= -zmin)) & (near0 | inside)) : live_m;
         }
+        else nm[q] = 0;
         cm[q] = c;
         total += __popcll(c);
     }
@@ -438,7 +453,7 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
         for (int q = 0; q < kImgPerBlock; ++q) {
             if (cm[q] == 0) continue;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm[q], 0u));
-            if ((cm[q] >> lane) & 1ull) lds_list[run + rank] = (uint16_t)(tid | (q << 8));
+            if ((cm[q] >> lane) & 1ull) lds_list[run + rank] = (uint16_t)(tid | (q << 8) | (((nm[q] >> lane) & 1ull) ? 0x8000u : 0u));
             run += (uint32_t)__popcll(cm[q]);
         }
     }
@@ -461,7 +476,8 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
             const uint32_t e = e0 + (uint32_t)(k * kVThreads + tid);
             active[k] = e < n;
             const uint32_t ent = active[k] ? (uint32_t)lds_list[e] : 0u;
-            const uint32_t v = ent & 255u, q = ent >> 8;
+            const uint32_t v = ent & 255u, q = (ent >> 8) & 63u;
+            const bool nearp = (ent >> 15) != 0u;
             vv[k] = v;
             qq[k] = q;
             const double px = lds_xyz[v][0], py = lds_xyz[v][1], pz = lds_xyz[v][2];
@@ -482,11 +498,10 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
             asm("v_med3_i32 %0, %1, 0, %2" : "=v"(xi) : "v"((int)ru), "s"(hi_x));
             asm("v_med3_i32 %0, %1, 0, %2" : "=v"(yi) : "v"((int)rv), "s"(hi_y));
             const double wu = __builtin_fabs(us - ru) - 0.25, wv = __builtin_fabs(vs - rv) - 0.25;
-            const double es = (__builtin_fabs(px) + __builtin_fabs(py)) + __builtin_fabs(pz);
-            const double zmin = __builtin_fma(gc[0], es, gc[1]);
-            gzs[k] = __builtin_fma(gc[2], es, gc[3]);
-            bool rk = !(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kVTiePx) | !(iz > zmin) |
-                      (lds_pinhole[q] == 0);
+            gzs[k] = lds_gz[v];
+            // entries phase A flagged (within zmin of the camera plane and near the optical axis: the projection itself is not
+            // trusted there) take the reference chain; every other entry has a camera depth above its zmin
+            bool rk = !(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kVTiePx) | nearp | (lds_pinhole[q] == 0);
             if (!IDENT) {   // the bounds are integers of the COLOUR grid, the rounding ties belong to the depth grid
                 const double bu = __builtin_fmin(__builtin_fabs(u), __builtin_fabs(u - Wd));
                 const double bv = __builtin_fmin(__builtin_fabs(w), __builtin_fabs(w - Hd));
