@@ -1124,9 +1124,18 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
                 lo = min(min((int)mn.x, (int)mn.y), min((int)mn.z, (int)mn.w));
                 hi = max(max((int)mxv.x, (int)mxv.y), max((int)mxv.z, (int)mxv.w));
             }
-            for (int off = 32; off > 0; off >>= 1) {
-                lo = min(lo, __shfl_xor(lo, off));
-                hi = max(hi, __shfl_xor(hi, off));
+            {   // one packed reduction for both: (largest sample, 0xFFFF - smallest sample - 1) as two u16 halves, v_pk_max_u16
+                us2 key = {(unsigned short)hi, (unsigned short)(0xFFFF - lo)};
+                for (int off = 32; off > 0; off >>= 1) {
+                    uint32_t kb;
+                    __builtin_memcpy(&kb, &key, 4);
+                    kb = (uint32_t)__shfl_xor((int)kb, off);
+                    us2 other;
+                    __builtin_memcpy(&other, &kb, 4);
+                    key = __builtin_elementwise_max(key, other);
+                }
+                hi = (int)key.x;
+                lo = 0xFFFF - (int)key.y;
             }
             if (hi == 0) {
                 culled = CAN_CULL;                                        // no valid depth sample at all
@@ -1164,12 +1173,15 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
             }
             if (culled) {
                 if (!SCALED) {
-                    us2 nz = {0, 0};
+                    // valid samples of the tile: two ballots per LDS dword (low half != 0, high half != 0), counted on the
+                    // scalar side -- no cross-lane reduction (the packed-add form + six shuffle steps cost 151 VALU issues of a
+                    // culled tile's ~490)
+                    const uint32_t *wd32 = reinterpret_cast<const uint32_t *>(lds_d1w);
 #pragma unroll
-                    for (int k = 0; k < ROWS / 2; ++k) nz += __builtin_elementwise_min(wds[c.lane + 64 * k], one);
-                    int cnt = (int)nz.x + (int)nz.y;
-                    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-                    n_valid = cnt;
+                    for (int k = 0; k < ROWS / 2; ++k) {
+                        const uint32_t w = wd32[c.lane + 64 * k];
+                        n_valid += __popcll(ballot64((w & 0xFFFFu) != 0u)) + __popcll(ballot64(w > 0xFFFFu));
+                    }
                 } else {                                   // the tile's own samples (the box only bounded their range)
 #pragma unroll 1
                     for (int r0 = 0; r0 < n_rows; r0 += RG) {
