@@ -453,7 +453,9 @@ void vertex_visibility_compact_kernel(const double *__restrict__ xyz,
         for (int q = 0; q < kImgPerBlock; ++q) {
             if (cm[q] == 0) continue;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm[q], 0u));
-            if ((cm[q] >> lane) & 1ull) lds_list[run + rank] = (uint16_t)(tid | (q << 8) | (((nm[q] >> lane) & 1ull) ? 0x8000u : 0u));
+            // lane predicates straight from the scalar masks (inverse ballot: exec mask / v_cndmask operand, no shifts)
+            if (__builtin_amdgcn_inverse_ballot_w64(cm[q]))
+                lds_list[run + rank] = (uint16_t)((tid | (q << 8)) | (__builtin_amdgcn_inverse_ballot_w64(nm[q]) ? 0x8000 : 0));
             run += (uint32_t)__popcll(cm[q]);
         }
     }
