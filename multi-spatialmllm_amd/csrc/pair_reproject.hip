@@ -719,7 +719,7 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 #define MSPA_TIGHT_DMA16 1
 #endif
 #ifndef MSPA_STAGE2_ROW_BARRIER
-#define MSPA_STAGE2_ROW_BARRIER 3      // 0 never, 1 after every row, 2 after the second row only, 3 after the second row for the compacted set only
+#define MSPA_STAGE2_ROW_BARRIER 0      // 0 never, 1 after every row, 2 after the second row only, 3 after the second row for the compacted set only
 #endif
 #ifndef MSPA_SCALED_ROW_BARRIER
 #define MSPA_SCALED_ROW_BARRIER 1      // ScanNet-shape kernel: 100 -> 73 VGPRs (4 -> 6 waves per SIMD), 2.30 -> 2.11 ms per 1 000 pairs
@@ -729,6 +729,12 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 #endif
 #ifndef MSPA_SCALED_FULL_WAIT
 #define MSPA_SCALED_FULL_WAIT 1        // ScanNet-shape kernel: one vmcnt(0) for a group's gathers instead of a counted wait per row (-1..4 %)
+#endif
+#ifndef MSPA_MAGIC_ROUND
+#define MSPA_MAGIC_ROUND 1             // A/B knob: 0 = rint + conversion + centring add + clamp (round 3's index arithmetic)
+#endif
+#if defined(MSPA_EXPERIMENT_GATHER) && MSPA_MAGIC_ROUND
+#error "the gather timing experiments are written against MSPA_MAGIC_ROUND=0"
 #endif
 #ifndef MSPA_COMPACT_LDS_PAD
 #define MSPA_COMPACT_LDS_PAD 0
@@ -775,10 +781,14 @@ constexpr int tight_bw_of(uint32_t set, bool scaled = false) {
 // waves per SIMD the register allocator must leave room for (second argument of __launch_bounds__): the sets without an
 // index table run best at six (80 VGPRs); round 4's guard-band bookkeeping had pushed `minimal` to 82 = five waves, +5 %
 // (the SCALED correspondence set sat at 97 VGPRs = four waves: held at five)
+#ifndef MSPA_CORR_MINWAVES
+#define MSPA_CORR_MINWAVES 1           // A/B knob: waves per SIMD the correspondence-table instantiation is held to (register budget)
+#endif
 constexpr int tight_minwaves_of(uint32_t set, bool scaled) {
-    return (set & (O_XYZ32 | O_RGBA | O_VIS_U8)) ? 1 : (set & O_PIX) ? (scaled ? 5 : 1) : 6;
+    return (set & (O_XYZ32 | O_RGBA | O_VIS_U8)) ? 1 : (set & O_PIX) ? (scaled ? 5 : MSPA_CORR_MINWAVES) : 6;
 }
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int med3_0(int x, int hi) {   // clamp(x, 0, hi), hi wave-uniform
     int r;
@@ -1016,14 +1026,17 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
         __amdgpu_buffer_rsrc_t rs_xyz = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(a.xyz_f32 ? a.xyz_f32 + 3 * c.obase : nullptr), 0, (SET & O_XYZ32) ? (int)(a.P * 12) : 0, kRsrcFlags);
         // compacted set: the tile's own segment of MSPA_CORR_TILE_CAP entries (4 bytes each)
+        // -- a STRUCTURED resource (stride 4): an entry is addressed by its index (`idxen`), the address unit does the x 4
         __amdgpu_buffer_rsrc_t rs_cpix = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(COMPACT ? a.cpix + ((pair * (int64_t)a.n_tiles + (int64_t)tile) * MSPA_CORR_TILE_CAP) * 2 : nullptr), 0,
-            COMPACT ? MSPA_CORR_TILE_CAP * 4 : 0, kRsrcFlags);
+            (void *)(COMPACT ? a.cpix + ((pair * (int64_t)a.n_tiles + (int64_t)tile) * MSPA_CORR_TILE_CAP) * 2 : nullptr), 4,
+            COMPACT ? MSPA_CORR_TILE_CAP : 0, kRsrcFlags);
+        auto store_entry = [&](uint32_t value, uint32_t index, uint32_t soffset_bytes) {   // no builtin takes an index operand
+            asm volatile("buffer_store_dword %0, %1, %2, %3 idxen" ::"v"(value), "v"(index), "s"(rs_cpix), "s"(soffset_bytes) : "memory");
+        };
         uint32_t cfill = 0;                          // compacted set, wave-uniform: entries of the tile so far
         // one row's visible lanes store their pixel index at their rank: entries so far (scalar offset) + set bits below the lane
         auto compact_row = [&](unsigned long long vmask, int pixv) {
-            if (__builtin_amdgcn_inverse_ballot_w64(vmask))
-                __builtin_amdgcn_raw_buffer_store_b32((uint32_t)pixv, rs_cpix, (int)(mbcnt64(vmask, 0u) * 4u), (int)(cfill * 4u), 0);
+            if (__builtin_amdgcn_inverse_ballot_w64(vmask)) store_entry((uint32_t)pixv, mbcnt64(vmask, 0u), cfill * 4u);
             cfill += (uint32_t)__popcll(vmask);
         };
         const int vis_voff = (int)(((uint32_t)c.lane >> 4) * Wb + stripe * 64u + ((uint32_t)c.lane & 15u) * 4u);
@@ -1036,6 +1049,13 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
         }
         const int hi_x = a.dw - 1, hi_y = a.dh - 1;
         const uint32_t dw2 = (uint32_t)a.dw * 2u;
+        // stage 2's rounding constants (see there): 1.5 * 2^52 + half the grid + the bias that saturates at the last column / row
+        const uint32_t bias_x = 32767u - (uint32_t)hi_x, bias_y = 32767u - (uint32_t)hi_y;
+        const uint32_t pk_bias = bias_x | (bias_y << 16);
+        const uint32_t dot_k = 2u | (dw2 << 16);                                   // (2, 2 DW): DW <= 32 767
+        const uint32_t dot_c = 0u - (2u * bias_x + dw2 * bias_y);
+        (void)pk_bias; (void)dot_k; (void)dot_c;
+        const double magic_u = 6755399441055744.0 + (a.hw + (double)bias_x), magic_v = 6755399441055744.0 + (a.hh + (double)bias_y);   // 1.5 * 2^52 + half the grid
 
         const double mxd = (double)col;
         const double myd0 = (double)row0;
@@ -1290,19 +1310,45 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
                     unsigned long long rkc[RG];
 #pragma unroll
                     for (int j = 0; j < RG; ++j) {
-                        const double ru = __builtin_rint(u[j]), rv = __builtin_rint(v[j]);
                         constexpr bool kCentred = MSPA_CENTRED_TEST;
+#if MSPA_MAGIC_ROUND
+                        // Rounding by addition: u + (1.5 * 2^52 + n) is rounded to an integer by the adder (ties fall in the guard
+                        // band, whichever way they go), the sum's low dword IS rint(u) + n, and subtracting the constant again is
+                        // exact.  n = W / 2 (u is relative to the image centre) + a bias that puts column W - 1 at 32 767: the
+                        // reference's clip (IH:362-365: u in [W - 0.5, W) is in bounds and reads column W - 1) then is the
+                        // saturation of ONE v_cvt_pk_i16_i32 for both axes, and the byte offset of the sample ONE
+                        // v_dot2_u32_u16 of the packed pair with (2, 2 DW).  Seven issues per row where rint, conversion,
+                        // centring add and clamp per axis, shift and multiply-add were ten (+ the pack of the index pair).  A lane
+                        // that is not in view gathers at an offset the buffer resource drops: no memory access for it.
+                        static_assert(kCentred, "the rounding constant carries the centring shift");
+                        const double tu = u[j] + magic_u, tv = v[j] + magic_v;
+                        const double ru = tu - magic_u, rv = tv - magic_v;
+                        const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(__double2loint(tu), __double2loint(tv)));
+                        int goff = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, pk), __builtin_bit_cast(us2_t, dot_k), dot_c, false);
+#if MSPA_MAGIC_ROUND == 1
+                        asm("" : "+v"(goff));        // one v_cndmask below, not an exec-masked block around the lines above
+#endif
+#if MSPA_MAGIC_ROUND != 3   // 3: A/B only -- lanes out of view gather wherever their saturated pair points (inside the frame or dropped)
+                        goff = __builtin_amdgcn_inverse_ballot_w64(ivm[j]) ? goff : kDropOffset;
+#endif
+                        const int pixv = (int)(pk - pk_bias);      // in-view lanes: both halves at or above their bias, no borrow
+#else
+                        const double ru = __builtin_rint(u[j]), rv = __builtin_rint(v[j]);
                         const int xi = med3_0((int)ru + (kCentred ? a.hwi : 0), hi_x);
                         const int yi = med3_0((int)rv + (kCentred ? a.hhi : 0), hi_y);
                         // every lane gathers: the clamped index is always inside the image
+                        const int goff = (int)(__umul24((uint32_t)yi, dw2) + ((uint32_t)xi << 1));
+                        const int pixv = (int)((uint32_t)xi | ((uint32_t)yi << 16));
+#endif
 #if !defined(MSPA_EXPERIMENT_GATHER)
-                        dv16[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, (int)(__umul24((uint32_t)yi, dw2) + ((uint32_t)xi << 1)), 0, 0);
+                        dv16[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, goff, 0, 0);
+                        asm("" : "+v"(dv16[j]));     // buffer_load_ushort zero-extends: no v_and in front of the conversion
 #elif MSPA_EXPERIMENT_GATHER == 1   // timing only (wrong results): every lane reads the first lane's row -- a coalesced gather
                         dv16[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, (int)(__umul24((uint32_t)__builtin_amdgcn_readfirstlane(yi), dw2) + ((uint32_t)xi << 1)), 0, 0);
 #else                               // timing only (wrong results): no gather at all
                         dv16[j] = (uint32_t)xi + 1000u;
 #endif
-                        pix[j] = (int)((uint32_t)xi | ((uint32_t)yi << 16));
+                        pix[j] = pixv;
                         // With t = u - rint(u) in [-0.5, 0.5] a decision can flip only if |t| is within the guard of
                         // 0.5 (rounding tie) or of 0 (u at an integer: the image bounds are integers), i.e. unless
                         // guard < |t| < 0.5 - guard  <=>  ||t| - 0.25| < 0.25 - guard.  NaN fails the ordered compare.
@@ -1460,8 +1506,8 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
                     if (fresh != old) {
                         redo = true;
                     } else if (mine && vis) {
-                        __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(uint16_t)cxi | ((uint32_t)(uint16_t)cyi << 16), rs_cpix,
-                                                              (int)(mbcnt64(old, (uint32_t)__builtin_amdgcn_readlane((int)cpref, g)) * 4u), 0, 0);
+                        store_entry((uint32_t)(uint16_t)cxi | ((uint32_t)(uint16_t)cyi << 16),
+                                    mbcnt64(old, (uint32_t)__builtin_amdgcn_readlane((int)cpref, g)), 0u);
                     }
                 }
             }
@@ -1484,8 +1530,7 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
                         exact_unproject(m1, mxd, (double)row, (double)sample1(row, col) * 0.001, p.ax, p.ay, p.az);
                         exact_project(m2, p.ax, p.ay, p.az, p.u, p.v, p.qz);
                         depth_test(false, p.u, p.v, p.qz, c.depth2, a.dh, a.dw, a.H, a.W, a.sx, a.sy, p.xi, p.yi);
-                        __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(uint16_t)p.xi | ((uint32_t)(uint16_t)p.yi << 16), rs_cpix,
-                                                              (int)(mbcnt64(w, base) * 4u), 0, 0);
+                        store_entry((uint32_t)(uint16_t)p.xi | ((uint32_t)(uint16_t)p.yi << 16), mbcnt64(w, base), 0u);
                     }
                     base += (uint32_t)__popcll(w);
                 }
