@@ -784,8 +784,19 @@ constexpr int tight_bw_of(uint32_t set, bool scaled = false) {
 #ifndef MSPA_CORR_MINWAVES
 #define MSPA_CORR_MINWAVES 1           // A/B knob: waves per SIMD the correspondence-table instantiation is held to (register budget)
 #endif
+#ifndef MSPA_NOPIX_MINWAVES
+#define MSPA_NOPIX_MINWAVES 6
+#endif
+#ifndef MSPA_SCALED_NOPIX_MINWAVES
+#define MSPA_SCALED_NOPIX_MINWAVES 6
+#endif
+#ifndef MSPA_SCALED_CORR_MINWAVES
+#define MSPA_SCALED_CORR_MINWAVES 5
+#endif
 constexpr int tight_minwaves_of(uint32_t set, bool scaled) {
-    return (set & (O_XYZ32 | O_RGBA | O_VIS_U8)) ? 1 : (set & O_PIX) ? (scaled ? 5 : MSPA_CORR_MINWAVES) : 6;
+    return (set & (O_XYZ32 | O_RGBA | O_VIS_U8)) ? 1
+           : (set & O_PIX) ? (scaled ? MSPA_SCALED_CORR_MINWAVES : MSPA_CORR_MINWAVES)
+           : (scaled ? MSPA_SCALED_NOPIX_MINWAVES : MSPA_NOPIX_MINWAVES);
 }
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
@@ -942,7 +953,7 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
     // costs per tile, and measured SLOWER: compact +10 %, corr +2 %, dense_xyz +4 %, tools/ab_k3.py round 4: its per-lane
     // matrix loads go through the vector memory path and sit in front of everything else a tile does, where the wave-uniform
     // form reads the scalar cache all tiles of a pair share.)
-    {
+    auto compose = [&]() {
         double raw[3][4];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -971,7 +982,10 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
 #endif
             M[2][k] = uniform(raw[2][k]);
         }
-    }
+    };
+    // The whole-tile form composes here, behind its LDS-DMA requests.  The SCALED form has no such requests in flight yet: it
+    // composes further down, behind the loads of its depth box and of its first row group.
+    if (!SCALED) compose();
 
     // transpose stage: the group's pixel indices, then (dense set) its rgba words, then its 4 x 64 x 3 point coordinates
     __shared__ __attribute__((aligned(16))) uint32_t lds_pxs[kTightBW][(PX_IN_TILE || !(SET & (O_PIX | O_XYZ32 | O_RGBA))) ? 4 : RG * 64 * (WANT_XYZ ? 3 : 1)];
@@ -1015,6 +1029,40 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
             if (!SCALED) return c.depth1[row * Wb + colx];
             return c.depth1[round_clip((double)row * a.sy, a.dh - 1) * a.dw + round_clip((double)colx * a.sx, a.dw - 1)];
         };
+        // SCALED: the depth BOX the tile's corners map to (both maps are monotone) is scanned for its smallest / largest sample
+        // below, in 8-byte pieces, 16 lanes across a depth row, 4 rows per pass (dw % 4 == 0: pieces never straddle a row; the
+        // host checks).  ScanNet's 64 x 48 colour tile maps to a 33 x 25 box: one piece column, seven passes.  Up to eight
+        // passes are requested HERE, with the first row group's samples, and the matrix composition runs behind them (a
+        // tile's first vector-memory round trip used to sit bare between the composition and the culling test).
+        constexpr int kBoxPre = 8;
+        u32x2 boxw[kBoxPre] = {};
+        uint32_t d16_first[RG] = {};
+        bool box_pre = false;
+        uint32_t box_dyA = 0, box_xb0 = 0, box_nxb = 1, box_nrow = 1;
+        const uint32_t cB = SCALED ? min(stripe * 64u + 63u, Wb - 1u) : stripe * 64u + 63u;     // the tile's last live column / row
+        const uint32_t rB = row0 + (uint32_t)n_rows - 1u;
+        if (SCALED) {
+            const uint32_t dw2s = (uint32_t)a.dw * 2u;
+            const uint32_t dxA = 2u * (uint32_t)round_clip((double)(stripe * 64u) * a.sx, a.dw - 1);
+            const uint32_t dxB = 2u * (uint32_t)round_clip((double)cB * a.sx, a.dw - 1);
+            box_dyA = __builtin_amdgcn_readfirstlane((uint32_t)round_clip((double)row0 * a.sy, a.dh - 1) * dw2s);
+            const uint32_t dyB = (uint32_t)round_clip((double)rB * a.sy, a.dh - 1) * dw2s;
+            box_xb0 = __builtin_amdgcn_readfirstlane(dxA & ~7u);
+            box_nxb = __builtin_amdgcn_readfirstlane((dxB + 2u - box_xb0 + 7u) >> 3);
+            box_nrow = __builtin_amdgcn_readfirstlane((dyB - box_dyA) / dw2s + 1u);
+            box_pre = box_nxb <= 16u && box_nrow <= 4u * kBoxPre;        // wave-uniform
+            if (box_pre) {
+                const uint32_t piece = min((uint32_t)c.lane & 15u, box_nxb - 1u);
+#pragma unroll
+                for (int k = 0; k < kBoxPre; ++k) {                      // passes past the box repeat its last row
+                    const uint32_t r = min(4u * (uint32_t)k + ((uint32_t)c.lane >> 4), box_nrow - 1u);
+                    boxw[k] = __builtin_amdgcn_raw_buffer_load_b64(rs_d1, (int)(box_dyA + r * dw2s + box_xb0 + piece * 8u), 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RG; ++j) d16_first[j] = load_d1_row(j);
+            compose();
+        }
         // dense payload: byte mask (lane L: 4 pixels of row L >> 4), colour in / rgba out, points (16-byte pieces of the
         // group's 4 x 768 bytes: piece 64 k + L lies in row (16 (64 k + L)) / 768)
         __amdgpu_buffer_rsrc_t rs_vis = __builtin_amdgcn_make_buffer_rsrc(
@@ -1104,8 +1152,6 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
             const us2 *wds = reinterpret_cast<const us2 *>(lds_d1w);
             const us2 one = {1, 1};
             int lo, hi;
-            const uint32_t cB = SCALED ? min(stripe * 64u + 63u, Wb - 1u) : stripe * 64u + 63u;     // the tile's last live column / row
-            const uint32_t rB = row0 + (uint32_t)n_rows - 1u;
             if (!SCALED) {
                 us2 mn = {0xFFFF, 0xFFFF}, mxv = {0, 0};
 #pragma unroll
@@ -1117,28 +1163,29 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
                 lo = min((int)mn.x, (int)mn.y);
                 hi = max((int)mxv.x, (int)mxv.y);
             } else {
-                // the depth BOX the tile's corners map to (both maps are monotone): 8-byte pieces, 16 lanes across a depth row,
-                // 4 rows per pass; needs dw % 4 == 0 (pieces never straddle a row; the host checks)
                 typedef unsigned short us4 __attribute__((ext_vector_type(4)));
-                const uint32_t dxA = 2u * (uint32_t)round_clip((double)(stripe * 64u) * a.sx, a.dw - 1);
-                const uint32_t dxB = 2u * (uint32_t)round_clip((double)cB * a.sx, a.dw - 1);
-                const uint32_t dyA = (uint32_t)round_clip((double)row0 * a.sy, a.dh - 1) * dw2;
-                const uint32_t dyB = (uint32_t)round_clip((double)rB * a.sy, a.dh - 1) * dw2;
-                const uint32_t xb0 = dxA & ~7u;
-                const uint32_t nxb = __builtin_amdgcn_readfirstlane((dxB + 2u - xb0 + 7u) >> 3);
-                const uint32_t nrow = __builtin_amdgcn_readfirstlane((dyB - dyA) / dw2 + 1u);
-                const uint32_t q = (uint32_t)c.lane >> 4;
                 us4 mn = {0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF}, mxv = {0, 0, 0, 0};
                 const us4 one4 = {1, 1, 1, 1};
-                for (uint32_t k = 0; k < (nrow + 3u) >> 2; ++k) {
-                    const uint32_t r = min(4u * k + q, nrow - 1u);
-                    for (uint32_t j = 0; j < (nxb + 15u) >> 4; ++j) {
-                        const uint32_t piece = min(16u * j + ((uint32_t)c.lane & 15u), nxb - 1u);
-                        const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs_d1, (int)(dyA + r * dw2 + xb0 + piece * 8u), 0, 0);
+                if (box_pre) {                                           // wave-uniform: the pieces requested above
+#pragma unroll
+                    for (int k = 0; k < kBoxPre; ++k) {
                         us4 x;
-                        __builtin_memcpy(&x, &w, 8);
+                        __builtin_memcpy(&x, &boxw[k], 8);
                         mn = __builtin_elementwise_min(mn, (us4)(x - one4));
                         mxv = __builtin_elementwise_max(mxv, x);
+                    }
+                } else {
+                    const uint32_t q = (uint32_t)c.lane >> 4;
+                    for (uint32_t k = 0; k < (box_nrow + 3u) >> 2; ++k) {
+                        const uint32_t r = min(4u * k + q, box_nrow - 1u);
+                        for (uint32_t j = 0; j < (box_nxb + 15u) >> 4; ++j) {
+                            const uint32_t piece = min(16u * j + ((uint32_t)c.lane & 15u), box_nxb - 1u);
+                            const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs_d1, (int)(box_dyA + r * dw2 + box_xb0 + piece * 8u), 0, 0);
+                            us4 x;
+                            __builtin_memcpy(&x, &w, 8);
+                            mn = __builtin_elementwise_min(mn, (us4)(x - one4));
+                            mxv = __builtin_elementwise_max(mxv, x);
+                        }
                     }
                 }
                 lo = min(min((int)mn.x, (int)mn.y), min((int)mn.z, (int)mn.w));
@@ -1227,7 +1274,7 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
             uint32_t d16n[RG] = {};                  // SCALED: the next row group's samples, requested one group ahead
             if (SCALED) {
 #pragma unroll
-                for (int j = 0; j < RG; ++j) d16n[j] = load_d1_row(j);
+                for (int j = 0; j < RG; ++j) d16n[j] = d16_first[j];
             }
 #pragma unroll 1
             for (int r0 = 0; r0 < n_rows; r0 += RG) {

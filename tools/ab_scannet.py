@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=200)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--legs", default="", help="comma list of substrings: only the legs whose name contains one of them (PMC runs)")
     a = ap.parse_args()
     import torch
     from mspa import _lib, engine, synth, workload
@@ -76,6 +77,8 @@ def main():
     h0 = handles[list(handles)[-1]]
     legs["corr:wobble"] = (h0, "corr", F | _lib.PAIR_WORD_STRIPES)
     legs["minimal:wobble"] = (h0, "minimal", F | _lib.PAIR_WORD_STRIPES)
+    if a.legs:
+        legs = {k: v for k, v in legs.items() if any(t in k for t in a.legs.split(","))}
     res = {k: [] for k in legs}
     for _ in range(a.rounds):
         for k, (h, which, fl) in legs.items():
