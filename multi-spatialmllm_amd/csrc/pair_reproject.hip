@@ -730,17 +730,8 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 #ifndef MSPA_SCALED_FULL_WAIT
 #define MSPA_SCALED_FULL_WAIT 1        // ScanNet-shape kernel: one vmcnt(0) for a group's gathers instead of a counted wait per row (-1..4 %)
 #endif
-#ifndef MSPA_MAGIC_ROUND
-#define MSPA_MAGIC_ROUND 1             // A/B knob: 0 = rint + conversion + centring add + clamp (round 3's index arithmetic)
-#endif
-#if defined(MSPA_EXPERIMENT_GATHER) && MSPA_MAGIC_ROUND
-#error "the gather timing experiments are written against MSPA_MAGIC_ROUND=0"
-#endif
 #ifndef MSPA_COMPACT_LDS_PAD
 #define MSPA_COMPACT_LDS_PAD 0
-#endif
-#ifndef MSPA_CENTRED_TEST
-#define MSPA_CENTRED_TEST 1            // rows 0 / 1 of the composed matrix centred on the image: 2 instead of 4 bounds compares per row
 #endif
 #ifndef MSPA_TIGHT_WAVES_PER_EU
 #define MSPA_TIGHT_WAVES_PER_EU 0      // > 0: ask the register allocator for that many waves per SIMD
@@ -875,6 +866,8 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
     constexpr int kTightBW = tight_bw_of(SET, SCALED);
     constexpr bool WANT_XYZ = (SET & O_XYZ32) != 0;
     constexpr bool COMPACT = (SET & O_CPIX) != 0;
+    constexpr bool FRACT_GUARD = !COMPACT && !(SCALED && (SET & O_PIX));     // stage 2's tie / bound test by v_fract (see there)
+    constexpr double kUV = FRACT_GUARD ? 2.0 : 1.0;                           // ... on doubled image coordinates
     static_assert(RG == 4 || !(SET & (O_PIX | O_XYZ32 | O_RGBA | O_VIS_U8)), "the transpose stages move 4-row blocks");
     static_assert(ROWS % RG == 0, "whole row groups");
     static_assert(!COMPACT || !(SET & (O_PIX | O_XYZ32 | O_RGBA | O_VIS_U8)), "the compacted set shares the transpose stage's LDS");
@@ -971,15 +964,12 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-#if MSPA_CENTRED_TEST
             // rows 0 / 1 minus (W/2, H/2) times row 2: u and v come out relative to the image centre (W/2, H/2 are integers:
             // rounding ties and integer bounds keep their fractional parts; the extra rounding per entry is inside MSPA_GUARD_C)
-            M[0][k] = uniform(__builtin_fma(-a.hw, raw[2][k], raw[0][k]));
-            M[1][k] = uniform(__builtin_fma(-a.hh, raw[2][k], raw[1][k]));
-#else
-            M[0][k] = uniform(raw[0][k]);
-            M[1][k] = uniform(raw[1][k]);
-#endif
+            // -- and, for the sets whose stage 2 tests ties and bounds with v_fract, TWICE that (an exact scaling): their row loop
+            // works on 2u, 2v, whose distance from an integer says "rounding tie OR integer bound" in one instruction
+            M[0][k] = uniform(kUV * __builtin_fma(-a.hw, raw[2][k], raw[0][k]));
+            M[1][k] = uniform(kUV * __builtin_fma(-a.hh, raw[2][k], raw[1][k]));
             M[2][k] = uniform(raw[2][k]);
         }
     };
@@ -1102,7 +1092,7 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
         const uint32_t pk_bias = bias_x | (bias_y << 16);
         const uint32_t dot_k = 2u | (dw2 << 16);                                   // (2, 2 DW): DW <= 32 767
         const uint32_t dot_c = 0u - (2u * bias_x + dw2 * bias_y);
-        (void)pk_bias; (void)dot_k; (void)dot_c;
+        const double k2hw = kUV * a.khw, k2hh = kUV * a.khh;                       // bounds of kUV (u - W / 2), kUV (v - H / 2)
         const double magic_u = 6755399441055744.0 + (a.hw + (double)bias_x), magic_v = 6755399441055744.0 + (a.hh + (double)bias_y);   // 1.5 * 2^52 + half the grid
 
         const double mxd = (double)col;
@@ -1142,7 +1132,7 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
         const double *__restrict__ bnd1 = m1 + MSPA_MAT_BOUNDS * 16;
         const double *__restrict__ bnd2 = m2 + MSPA_MAT_BOUNDS * 16;
         const double tile_xmax = (double)(stripe * 64u + 63u), tile_ymax = (double)(row0 + (uint32_t)(ROWS - 1));
-        double zmin = 0.0, gz = kGuardZmmFloor, tnear = 0.0;   // wave-uniform (SGPR pairs) once set below
+        double zmin = 0.0, gz = kGuardZmmFloor, tnear2 = 0.0;  // wave-uniform (SGPR pairs) once set below
         // the dense payload sets write every pixel, so their tiles are never culled -- but they take the pass all the same: the
         // band comes from the tile's own largest sample (with the format's 65 535 mm it is ~13 x wider, and on distant views
         // whole rows of lanes "near the camera-2 plane" went to the reference chain: dense_xyz 0.98 -> 1.38 ms on `low`)
@@ -1215,10 +1205,8 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
                 double hx = __builtin_fma(__builtin_fma(M[0][1], cy, __builtin_fma(M[0][0], cx, M[0][2])), cd, M[0][3]);
                 double hy = __builtin_fma(__builtin_fma(M[1][1], cy, __builtin_fma(M[1][0], cx, M[1][2])), cd, M[1][3]);
                 const double hz = __builtin_fma(__builtin_fma(M[2][1], cy, __builtin_fma(M[2][0], cx, M[2][2])), cd, M[2][3]);
-                if (MSPA_CENTRED_TEST) {          // rows 0 / 1 are centred: back to image coordinates
-                    hx = __builtin_fma(a.hw, hz, hx);
-                    hy = __builtin_fma(a.hh, hz, hy);
-                }
+                hx = __builtin_fma(a.hw, hz, (1.0 / kUV) * hx);      // rows 0 / 1 are centred (and doubled): back to image coordinates
+                hy = __builtin_fma(a.hh, hz, (1.0 / kUV) * hy);
                 // margins in homogeneous units (pixel * millimetre; millimetres for the depth); a tile about to be culled
                 // checks that they are at least four times what two evaluation orders can differ by (mspa_common.h)
                 const bool all_behind = ballot64(hz <= -kCullMarginZ) == ~0ull;
@@ -1235,7 +1223,7 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
                     all_front = ballot64(hz > gd.zsafe) == ~0ull;
                     zmin = uniform(gd.zmin);
                     gz = uniform(gd.gz);
-                    tnear = uniform(2.0 * a.wh_max * gd.zmin);
+                    tnear2 = uniform(kUV * 2.0 * a.wh_max * gd.zmin);      // against the (doubled) homogeneous x, y
                 }
             }
             if (culled) {
@@ -1317,17 +1305,14 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
                     t2 += M[2][1];
                     double rz = __builtin_amdgcn_rcp(iz);
                     rz = __builtin_fma(__builtin_fma(-iz, rz, 1.0), rz, rz);
-                    u[j] = ix * rz;
+                    u[j] = ix * rz;                       // kUV (u - W / 2), kUV (v - H / 2)
                     v[j] = iy * rz;
                     qz[j] = iz;
                     // every ballot is the SGPR result of ONE compare; the conjunctions are scalar ANDs of those words
                     // (a ballot of an AND of predicates is lowered to v_cndmask 0/1 + v_cmp again)
                     vmk[j] = ballot64(d16[j] != 0u);                             // OPS:297
-                    if (MSPA_CENTRED_TEST)        // u, v relative to the image centre
-                        ivm[j] = vmk[j] & ballot64(__builtin_fabs(u[j]) < a.khw) & ballot64(__builtin_fabs(v[j]) < a.khh);
-                    else
-                        ivm[j] = vmk[j] & ballot64(u[j] > -kGuardPx) & ballot64(u[j] < Wd + kGuardPx) & ballot64(v[j] > -kGuardPx) &
-                                 ballot64(v[j] < Hd + kGuardPx);
+                    // u, v relative to the image centre: one compare per axis
+                    ivm[j] = vmk[j] & ballot64(__builtin_fabs(u[j]) < k2hw) & ballot64(__builtin_fabs(v[j]) < k2hh);
                     // CAREFUL tiles (the camera-2 plane may cut the tile's frustum): in front of the plane by more than zmin,
                     // or within zmin of it -- there u and v mean nothing, the lane is a candidate whatever they say and stage 2
                     // hands it to the reference chain.  (NaN depth lands in the second set.)
@@ -1337,7 +1322,7 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
                     // lane to the reference chain (dense_xyz on distant views: +14 %).
                     if (CAREFUL)
                         ivm[j] = vmk[j] & ((ivm[j] & ballot64(iz > zmin)) |
-                                           (ballot64(!(__builtin_fabs(iz) > zmin)) & ballot64(__builtin_fabs(ix) < tnear) & ballot64(__builtin_fabs(iy) < tnear)));
+                                           (ballot64(!(__builtin_fabs(iz) > zmin)) & ballot64(__builtin_fabs(ix) < tnear2) & ballot64(__builtin_fabs(iy) < tnear2)));
                     any |= ivm[j];
                 }
                 const uint32_t rowg = row0 + (uint32_t)r0;
@@ -1357,51 +1342,41 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
                     unsigned long long rkc[RG];
 #pragma unroll
                     for (int j = 0; j < RG; ++j) {
-                        constexpr bool kCentred = MSPA_CENTRED_TEST;
-#if MSPA_MAGIC_ROUND
-                        // Rounding by addition: u + (1.5 * 2^52 + n) is rounded to an integer by the adder (ties fall in the guard
-                        // band, whichever way they go), the sum's low dword IS rint(u) + n, and subtracting the constant again is
-                        // exact.  n = W / 2 (u is relative to the image centre) + a bias that puts column W - 1 at 32 767: the
+                        // Rounding by addition: u + (1.5 * 2^52 + n) -- with doubled coordinates 0.5 (2u) + ..., one FMA, one rounding
+                        // either way -- is rounded to an integer by
+                        // the adder (ties fall in the guard band, whichever way they go) and the sum's low dword IS rint(u) + n.
+                        // n = W / 2 (u is relative to the image centre) + a bias that puts column W - 1 at 32 767: the
                         // reference's clip (IH:362-365: u in [W - 0.5, W) is in bounds and reads column W - 1) then is the
                         // saturation of ONE v_cvt_pk_i16_i32 for both axes, and the byte offset of the sample ONE
-                        // v_dot2_u32_u16 of the packed pair with (2, 2 DW).  Seven issues per row where rint, conversion,
+                        // v_dot2_u32_u16 of the packed pair with (2, 2 DW).  Five issues per row where rint, conversion,
                         // centring add and clamp per axis, shift and multiply-add were ten (+ the pack of the index pair).  A lane
                         // that is not in view gathers at an offset the buffer resource drops: no memory access for it.
-                        static_assert(kCentred, "the rounding constant carries the centring shift");
-                        const double tu = u[j] + magic_u, tv = v[j] + magic_v;
-                        const double ru = tu - magic_u, rv = tv - magic_v;
+                        const double tu = FRACT_GUARD ? __builtin_fma(u[j], 0.5, magic_u) : u[j] + magic_u;
+                        const double tv = FRACT_GUARD ? __builtin_fma(v[j], 0.5, magic_v) : v[j] + magic_v;
                         const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(__double2loint(tu), __double2loint(tv)));
                         int goff = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, pk), __builtin_bit_cast(us2_t, dot_k), dot_c, false);
-#if MSPA_MAGIC_ROUND == 1
                         asm("" : "+v"(goff));        // one v_cndmask below, not an exec-masked block around the lines above
-#endif
-#if MSPA_MAGIC_ROUND != 3   // 3: A/B only -- lanes out of view gather wherever their saturated pair points (inside the frame or dropped)
                         goff = __builtin_amdgcn_inverse_ballot_w64(ivm[j]) ? goff : kDropOffset;
-#endif
-                        const int pixv = (int)(pk - pk_bias);      // in-view lanes: both halves at or above their bias, no borrow
-#else
-                        const double ru = __builtin_rint(u[j]), rv = __builtin_rint(v[j]);
-                        const int xi = med3_0((int)ru + (kCentred ? a.hwi : 0), hi_x);
-                        const int yi = med3_0((int)rv + (kCentred ? a.hhi : 0), hi_y);
-                        // every lane gathers: the clamped index is always inside the image
-                        const int goff = (int)(__umul24((uint32_t)yi, dw2) + ((uint32_t)xi << 1));
-                        const int pixv = (int)((uint32_t)xi | ((uint32_t)yi << 16));
-#endif
-#if !defined(MSPA_EXPERIMENT_GATHER)
                         dv16[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, goff, 0, 0);
                         asm("" : "+v"(dv16[j]));     // buffer_load_ushort zero-extends: no v_and in front of the conversion
-#elif MSPA_EXPERIMENT_GATHER == 1   // timing only (wrong results): every lane reads the first lane's row -- a coalesced gather
-                        dv16[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_d2, (int)(__umul24((uint32_t)__builtin_amdgcn_readfirstlane(yi), dw2) + ((uint32_t)xi << 1)), 0, 0);
-#else                               // timing only (wrong results): no gather at all
-                        dv16[j] = (uint32_t)xi + 1000u;
-#endif
-                        pix[j] = pixv;
-                        // With t = u - rint(u) in [-0.5, 0.5] a decision can flip only if |t| is within the guard of
-                        // 0.5 (rounding tie) or of 0 (u at an integer: the image bounds are integers), i.e. unless
-                        // guard < |t| < 0.5 - guard  <=>  ||t| - 0.25| < 0.25 - guard.  NaN fails the ordered compare.
-                        const double wu = __builtin_fabs(u[j] - ru) - 0.25;
-                        const double wv = __builtin_fabs(v[j] - rv) - 0.25;
-                        rkc[j] = ballot64(!(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx));
+                        pix[j] = (int)(pk - pk_bias);              // in-view lanes: both halves at or above their bias, no borrow
+                        // A decision can flip only if u is within the guard of a rounding tie (k + 0.5) or of an integer (the image
+                        // bounds are integers), i.e. if 2u is within twice the guard of an integer: h = fract(2u) in [0, 1) must
+                        // stay clear of both ends, |h - 0.5| < 0.5 - 2 guard.  (fract is exact; a tiny negative 2u gives the
+                        // largest double below 1.)  Two issues per axis where rint's result, its difference from u and the
+                        // fold |t| - 0.25 were three.  NaN fails the ordered compare.
+                        // (The compacted set and the SCALED correspondence set keep the three-issue form -- the rounded value back
+                        // from the sum, its exact difference from u, the fold | |t| - 0.25 | < 0.25 - guard: with v_fract the
+                        // register allocator spills / drops a wave for them, +1..6 %, tools/ab_k3.py, ab_scannet.py.)
+                        if (FRACT_GUARD) {
+                            const double wu = __builtin_amdgcn_fract(u[j]) - 0.5;
+                            const double wv = __builtin_amdgcn_fract(v[j]) - 0.5;
+                            rkc[j] = ballot64(!(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.5 - 2.0 * kGuardPx));
+                        } else {
+                            const double wu = __builtin_fabs(u[j] - (tu - magic_u)) - 0.25;
+                            const double wv = __builtin_fabs(v[j] - (tv - magic_v)) - 0.25;
+                            rkc[j] = ballot64(!(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx));
+                        }
                         if (CAREFUL) rkc[j] |= ballot64(!(qz[j] > zmin));        // lanes behind the plane are not in ivm
                         // Scheduling barrier between rows: left to itself the scheduler interleaves the four rows' rounding / guard
                         // code and keeps all their temporaries live (86-88 VGPRs: 5 waves per SIMD); one row at a time needs 66-69
