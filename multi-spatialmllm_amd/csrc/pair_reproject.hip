@@ -1422,7 +1422,10 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
                 for (int j = 0; j < RG; ++j) {
                     n_valid += __popcll(vmk[j]);
                     n_vis += __popcll(vm[j]);
-                    writelane64(vm[j], r0 + j, bits_lo, bits_hi);      // also what the cold loop reads back
+                    // (also what the cold loop reads back.  v_mov_b32 from the SGPRs under a one-lane EXEC mask -- a 2-cycle
+                    // instruction where v_writelane_b32 takes 4, tools/micro/valu_rates.hip -- measured no different: the four
+                    // EXEC writes per group cost what the moves save)
+                    writelane64(vm[j], r0 + j, bits_lo, bits_hi);
                 }
                 // ---- dense payload of the group (byte mask, coloured points): every store is a whole-wave, 4- or 16-byte
                 // per lane store.  The previous form -- a byte store per pixel for the mask, three byte loads and a dword
