@@ -79,6 +79,13 @@ def main():
     legs["minimal:wobble"] = (h0, "minimal", F | _lib.PAIR_WORD_STRIPES)
     if a.legs:
         legs = {k: v for k, v in legs.items() if any(t in k for t in a.legs.split(","))}
+    for k in list(legs):                     # an older library may not take a set at this shape (rc != 0): drop the leg
+        try:
+            launch(*legs[k])
+        except RuntimeError as e:
+            print(f"# {k}: not available in this library ({e})")
+            del legs[k]
+    torch.cuda.synchronize()
     res = {k: [] for k in legs}
     for _ in range(a.rounds):
         for k, (h, which, fl) in legs.items():
