@@ -700,13 +700,15 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 // fast path, whole-tile images (the BASELINE shape 640x480: W % 64 == 0, H % kTightRows == 0)
 // --------------------------------------------------------------------------------------------
 // Same arithmetic and guard as pair_fast_kernel, trimmed for VALU issue, which is what bounds the
-// fast path (profiles/r01c: VALU pipe 75 % busy, every VALU instruction ~4 cycles on gfx950 whether
-// it is 64- or 32-bit, so the lever is the instruction COUNT per pixel):
+// fast path (profiles/r01c: VALU pipe 75 % busy; profiles/r04_valu_rates.md: every float64, compare, conversion, VOP3 or packed
+// instruction issues at 4 cycles per wave and SIMD, v_rcp_f64 at 16, only v_add_u32 / v_sub_u32 / v_and_b32 / v_mov_b32 and the
+// plain float32 add / mul / fma at 2 -- so the lever is the instruction COUNT per pixel):
 //   * depth reads, gathers and pixel-index stores go through buffer resources (SGPR base + SGPR row
 //     offset + one loop-invariant VGPR column offset): no 64-bit address arithmetic in the vector pipe;
-//   * the gather is issued for every lane (the clamped index is always a valid address), no select;
-//   * clamps are single v_med3_i32; decisions stay in SGPR masks (s_and/s_or are free next to the
-//     vector pipe); risky rows are recorded per wave (ballot -> LDS) instead of per-lane bit masks;
+//   * the pixel index comes out of a rounding ADDITION, its clamp out of one saturating pack for both axes, the byte offset
+//     of the gather out of one v_dot2_u32_u16; lanes that are not in view gather at an offset the resource drops;
+//   * decisions stay in SGPR masks (s_and/s_or are free next to the
+//     vector pipe); risky rows are recorded per wave (ballot -> VGPR lane) instead of per-lane bit masks;
 //   * 48 rows per wave tile amortise the per-tile matrix composition;
 //   * a group of 4 rows none of whose 256 pixels can land in frame 2 skips gather, guard and depth test.
 #ifndef MSPA_TIGHT_ROWS
@@ -775,6 +777,12 @@ constexpr int tight_bw_of(uint32_t set, bool scaled = false) {
 #ifndef MSPA_CORR_MINWAVES
 #define MSPA_CORR_MINWAVES 1           // A/B knob: waves per SIMD the correspondence-table instantiation is held to (register budget)
 #endif
+#ifndef MSPA_COMPACT_FRACT
+#define MSPA_COMPACT_FRACT 0
+#endif
+#ifndef MSPA_COMPACT_MINWAVES
+#define MSPA_COMPACT_MINWAVES MSPA_NOPIX_MINWAVES
+#endif
 #ifndef MSPA_NOPIX_MINWAVES
 #define MSPA_NOPIX_MINWAVES 6
 #endif
@@ -787,7 +795,7 @@ constexpr int tight_bw_of(uint32_t set, bool scaled = false) {
 constexpr int tight_minwaves_of(uint32_t set, bool scaled) {
     return (set & (O_XYZ32 | O_RGBA | O_VIS_U8)) ? 1
            : (set & O_PIX) ? (scaled ? MSPA_SCALED_CORR_MINWAVES : MSPA_CORR_MINWAVES)
-           : (scaled ? MSPA_SCALED_NOPIX_MINWAVES : MSPA_NOPIX_MINWAVES);
+           : (scaled ? MSPA_SCALED_NOPIX_MINWAVES : (set & O_CPIX) ? MSPA_COMPACT_MINWAVES : MSPA_NOPIX_MINWAVES);
 }
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
@@ -866,7 +874,7 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
     constexpr int kTightBW = tight_bw_of(SET, SCALED);
     constexpr bool WANT_XYZ = (SET & O_XYZ32) != 0;
     constexpr bool COMPACT = (SET & O_CPIX) != 0;
-    constexpr bool FRACT_GUARD = !COMPACT && !(SCALED && (SET & O_PIX));     // stage 2's tie / bound test by v_fract (see there)
+    constexpr bool FRACT_GUARD = (!COMPACT || (MSPA_COMPACT_FRACT && !SCALED)) && !(SCALED && (SET & O_PIX));   // stage 2's tie / bound test by v_fract (see there)
     constexpr double kUV = FRACT_GUARD ? 2.0 : 1.0;                           // ... on doubled image coordinates
     static_assert(RG == 4 || !(SET & (O_PIX | O_XYZ32 | O_RGBA | O_VIS_U8)), "the transpose stages move 4-row blocks");
     static_assert(ROWS % RG == 0, "whole row groups");
@@ -1378,12 +1386,11 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
                             rkc[j] = ballot64(!(__builtin_fmax(__builtin_fabs(wu), __builtin_fabs(wv)) < 0.25 - kGuardPx));
                         }
                         if (CAREFUL) rkc[j] |= ballot64(!(qz[j] > zmin));        // lanes behind the plane are not in ivm
-                        // Scheduling barrier between rows: left to itself the scheduler interleaves the four rows' rounding / guard
-                        // code and keeps all their temporaries live (86-88 VGPRs: 5 waves per SIMD); one row at a time needs 66-69
-                        // (6 waves).  Which is worth more depends on the set (tools/ab_k3.py, one box): the sixth wave for the
-                        // compacted set (0.493 -> 0.463 ms), the interleaving for the correspondence table (0.506 vs 0.552).
-                        // One barrier, after the second row, gives the compacted set the same 73 VGPRs and the better time
-                        // (0.381 vs 0.388 with four; 0.387 +- 0.026 with none).
+                        // Scheduling barrier between rows (A/B knob, off): left to itself the scheduler interleaves the four rows'
+                        // rounding / guard code and keeps all their temporaries live.  Until round 4's second half the compacted set
+                        // took one barrier, after the second row (73 VGPRs; 0.381 vs 0.387 ms with none); with the shorter stage 2
+                        // the interleaved form is the better one for every set (compact 0.353 vs 0.391 ms with that barrier,
+                        // tools/ab_k3.py, one box; a barrier after every row: corr 0.66, minimal 0.40 ms).
                         if (MSPA_STAGE2_ROW_BARRIER == 1 || (MSPA_STAGE2_ROW_BARRIER == 2 && j == 1) ||
                             (MSPA_STAGE2_ROW_BARRIER == 3 && COMPACT && j == 1))
                             __builtin_amdgcn_sched_barrier(0);
