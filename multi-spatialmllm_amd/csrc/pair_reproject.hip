@@ -732,6 +732,9 @@ __global__ __launch_bounds__(kThreads) void pair_fast_kernel(const uint16_t *__r
 #ifndef MSPA_SCALED_FULL_WAIT
 #define MSPA_SCALED_FULL_WAIT 1        // ScanNet-shape kernel: one vmcnt(0) for a group's gathers instead of a counted wait per row (-1..4 %)
 #endif
+#ifndef MSPA_PRIO
+#define MSPA_PRIO 1                    // s_setprio: a tile's prologue above the row loops (correspondence and minimal sets; 0 = off)
+#endif
 #ifndef MSPA_COMPACT_LDS_PAD
 #define MSPA_COMPACT_LDS_PAD 0
 #endif
@@ -883,6 +886,11 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
     int64_t pair;
     uint32_t tgroup;
     if (!decode_block(a, pair, tgroup)) return;
+    // A new wave gets its requests and its per-tile work out ahead of the row loops of the others (s_setprio; back to 0 in front
+    // of the row loop): corr -1.5 %, minimal -0.5 % (ScanNet's shape: -2.7 %), compact +2 % -- so not for the compacted set
+    // (tools/ab_k3.py, ab_scannet.py, one box; raising stage 2 above the rest as well changed nothing).
+    constexpr bool PROLOGUE_PRIO = MSPA_PRIO && !(SET & (O_CPIX | O_XYZ32 | O_RGBA | O_VIS_U8));
+    if (PROLOGUE_PRIO) __builtin_amdgcn_s_setprio(2);
     const int f1 = pairs[2 * pair + 0];
     const int f2 = pairs[2 * pair + 1];
     const double *m1 = mats + (int64_t)f1 * (MSPA_FRAME_MATS * 16);
@@ -1483,6 +1491,7 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
                 }
             }
         };
+        if (PROLOGUE_PRIO) __builtin_amdgcn_s_setprio(0);
         if (!culled) {
             if (all_front) run_rows(std::false_type{});
             else run_rows(std::true_type{});
