@@ -68,3 +68,26 @@ def test_translated_scene(ref, shift):
     depth = [ADV.render_mm(A @ e, K, hw, boxes, rng) for e in E]
     A2, E2 = ADV.translated(A, E, [shift, -shift, shift])
     _check(ref, K, A2, E2, depth, [(i, j) for i in range(6) for j in range(6) if i != j][::3], hw)
+
+
+@pytest.mark.parametrize("delta", [1e-3, 1e-6, 1e-9])
+def test_cameras_centred_behind_vertices(ref, delta):
+    """K1's regime (tests/test_gpu_guard.py): aligned camera poses centred `delta` behind scene vertices."""
+    from mspa import synth
+    rng = np.random.default_rng(5 + int(-np.log10(delta)))
+    hw = (96, 128)
+    sc = synth.make_scene(1003, n_points=4000, n_frames=3, color_hw=hw, depth_hw=hw, invalid_pose_frac=0.0, with_color=False)
+    pts = sc.points[:, :3]
+    cams = ADV.near_vertex_cameras(rng, pts, sc.K, hw, [delta], 4)
+    depth = sc.depth[sc.valid_image_ids[0]]
+    H, W = hw
+    for E_al in cams:
+        uv_r, d_r = ref.IH.project_points(np.hstack([pts, np.ones((pts.shape[0], 1))]), sc.K, E_al)
+        m_o, uv_o, d_o = O.vertex_visibility(pts, sc.K, E_al, depth, hw)
+        assert np.array_equal(_bits(uv_o), _bits(uv_r)) and np.array_equal(_bits(d_o), _bits(d_r))
+        with np.errstate(invalid="ignore"):
+            inb = (uv_r[:, 0] >= 0) & (uv_r[:, 0] < W) & (uv_r[:, 1] >= 0) & (uv_r[:, 1] < H)
+            xi = np.clip(np.round(uv_r[:, 0]).astype(int), 0, W - 1)
+            yi = np.clip(np.round(uv_r[:, 1]).astype(int), 0, H - 1)
+            vis = inb & (d_r > 0) & (d_r < depth[yi, xi] * 0.001)
+        assert np.array_equal(m_o, vis)
