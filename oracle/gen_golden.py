@@ -228,6 +228,56 @@ def golden_k3_640x480(ns):
     print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def golden_k3_near_plane(ns):
+    """The reference in the regime round 4's guard band is about: camera 2 centred 1e-4 / 1e-7 / 1e-9 m
+    behind a back-projected frame-1 point, the point engineered onto rounding ties and image bounds +- 2e-6 px
+    (tests/adversarial.py near_plane_case), and adversarial poses with the world shifted by 1e4 m (E' = T E, A' = A inv(T)).
+    96x128, colour = depth.  Per pair, through the reference's own functions (OPS:235-329 -> IH:46-72, then IH:337-371's
+    expressions): the visibility mask as a bitset, counters, SHA-256 of the float64 projections."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import adversarial as ADV
+    hw = (96, 128)
+    H, W = hw
+    rng = np.random.default_rng(4242)
+    cases = []
+    K, A, E, depth, pairs = ADV.near_plane_case(rng, hw, [1e-4, 1e-7, 1e-9], 3)
+    cases.append(("near", K, A, E, depth, pairs))
+    K2, A2, E2 = ADV.adversarial_pairs(rng, 4, hw)
+    boxes = synth._make_boxes(rng)
+    depth2 = [ADV.render_mm(A2 @ e, K2, hw, boxes, rng) for e in E2]
+    A3, E3 = ADV.translated(A2, E2, [1e4, -1e4, 1e4])
+    cases.append(("far", K2, A3, E3, depth2, [(0, 1), (1, 0), (2, 3), (3, 1)]))
+    g = {"hw": np.array(hw), "cases": np.array([c[0] for c in cases])}
+    for name, K, A, E, depth, pairs in cases:
+        g[f"{name}_K"], g[f"{name}_A"], g[f"{name}_E"] = K, A, np.stack(E)
+        g[f"{name}_depth"], g[f"{name}_pairs"] = np.stack(depth), np.array(pairs)
+        for n, (ia, ib) in enumerate(pairs):
+            mask = np.ones(hw, dtype=bool)
+            a7 = ns.OPS.project_mask_to_3d(depth[ia], K, E[ia], mask, A, None)
+            uv, d = ns.IH.project_points(np.hstack([a7[:, :3], np.ones((a7.shape[0], 1))]), K, A @ E[ib])
+            with np.errstate(invalid="ignore"):
+                inb = (uv[:, 0] >= 0) & (uv[:, 0] < W) & (uv[:, 1] >= 0) & (uv[:, 1] < H)             # IH:337-344
+                xi = np.clip(np.round(uv[:, 0]).astype(int), 0, W - 1)                                     # IH:362-366
+                yi = np.clip(np.round(uv[:, 1]).astype(int), 0, H - 1)
+                vis = inb & (d > 0) & (d < depth[ib][yi, xi] * 0.001)                                      # IH:368-371
+                inview = inb & (d > 0)
+            valid = depth[ia].reshape(-1) > 0
+            rows = np.nonzero(valid)[0]
+            full = np.zeros(H * W, dtype=bool)
+            full[rows] = vis
+            pix = np.full((H * W, 2), -1, dtype=np.int16)
+            pix[rows[inview], 0], pix[rows[inview], 1] = xi[inview], yi[inview]
+            g[f"{name}{n}_rows"], g[f"{name}{n}_n_vis"] = np.array(a7.shape[0]), np.array(int(vis.sum()))
+            g[f"{name}{n}_vis_bits"] = np.packbits(full, bitorder="little")
+            g[f"{name}{n}_sha_uv"], g[f"{name}{n}_sha_depth"] = np.array(sha(uv)), np.array(sha(d))
+            g[f"{name}{n}_sha_pix"] = np.array(sha(pix))
+            g[f"{name}{n}_min_abs_depth2"] = np.array(float(np.nanmin(np.abs(d))))
+    g["meta"] = np.array(_meta())
+    path = os.path.join(GOLDEN_DIR, "k3_near_plane.npz")
+    np.savez_compressed(path, **g)
+    print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def golden_cme256(ns):
     """G6 of SURVEY.md 8c: CME.build_training_sample answer_values for 256 pairs of a 24-frame walk -- both swap branches,
     yaw differences pushed beyond +-180 (wrap), a static pair, mirrored pairs."""
@@ -489,6 +539,8 @@ def main():
         return golden_cme256(ns)
     if len(sys.argv) > 1 and sys.argv[1] == "k3_640x480":
         return golden_k3_640x480(ns)
+    if len(sys.argv) > 1 and sys.argv[1] == "k3_near_plane":
+        return golden_k3_near_plane(ns)
     golden_scene(ns, "scene_ident", 2001, (48, 64), (48, 64), n_points=700, n_frames=6, with_color=True)
     golden_scene(ns, "scene_scaled", 2002, (73, 98), (48, 64), n_points=700, n_frames=6, with_color=False)
     golden_ties(ns)
@@ -498,6 +550,7 @@ def main():
     golden_scannet_shape(ns)
     golden_cme256(ns)
     golden_k3_640x480(ns)
+    golden_k3_near_plane(ns)
 
 
 if __name__ == "__main__":
