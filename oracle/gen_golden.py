@@ -278,6 +278,40 @@ def golden_k3_near_plane(ns):
     print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def golden_k1_near_vertex(ns):
+    """K1's half of the same regime: aligned camera poses centred 1e-3 / 1e-6 / 1e-9 m behind scene vertices (the vertex on a
+    rounding tie / an image bound +- 2e-6 px, tests/adversarial.py near_vertex_cameras), and the same cameras and vertices 1e5 m
+    from the origin.  Per camera, the reference's project_points (IH:46-72) and IH:337-371's expressions: visibility mask as a
+    bitset, SHA-256 of the float64 projections.  96x128, colour = depth."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import adversarial as ADV
+    hw = (96, 128)
+    H, W = hw
+    rng = np.random.default_rng(4343)
+    sc = synth.make_scene(778, n_points=4096 + 37, n_frames=2, color_hw=hw, depth_hw=hw, invalid_pose_frac=0.0, with_color=False)
+    pts = np.ascontiguousarray(sc.points[:, :3])
+    boxes = synth._make_boxes(rng)
+    E_al = ADV.near_vertex_cameras(rng, pts, sc.K, hw, (1e-3, 1e-6, 1e-9), per_delta=3)
+    depth = [ADV.render_mm(e, sc.K, hw, boxes, rng) for e in E_al]
+    shift = np.array([1e5, -1e5, 1e5])
+    g = {"hw": np.array(hw), "K": sc.K, "points": pts, "E": np.stack(E_al), "depth": np.stack(depth), "shift": shift}
+    for tag, P3, Es in (("near", pts, E_al), ("far", pts + shift, [np.block([[e[:3, :3], (e[:3, 3] + shift)[:, None]], [e[3:, :]]]) for e in E_al])):
+        for k, e in enumerate(Es):
+            uv, d = ns.IH.project_points(np.hstack([P3, np.ones((P3.shape[0], 1))]), sc.K, e)
+            with np.errstate(invalid="ignore"):
+                inb = (uv[:, 0] >= 0) & (uv[:, 0] < W) & (uv[:, 1] >= 0) & (uv[:, 1] < H)
+                xi = np.clip(np.round(uv[:, 0]).astype(int), 0, W - 1)
+                yi = np.clip(np.round(uv[:, 1]).astype(int), 0, H - 1)
+                vis = inb & (d > 0) & (d < depth[k][yi, xi] * 0.001)
+            g[f"{tag}{k}_vis_bits"] = np.packbits(vis, bitorder="little")
+            g[f"{tag}{k}_n_vis"] = np.array(int(vis.sum()))
+            g[f"{tag}{k}_sha_uv"], g[f"{tag}{k}_sha_depth"] = np.array(sha(uv)), np.array(sha(d))
+    g["meta"] = np.array(_meta())
+    path = os.path.join(GOLDEN_DIR, "k1_near_vertex.npz")
+    np.savez_compressed(path, **g)
+    print(f"{path}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def golden_cme256(ns):
     """G6 of SURVEY.md 8c: CME.build_training_sample answer_values for 256 pairs of a 24-frame walk -- both swap branches,
     yaw differences pushed beyond +-180 (wrap), a static pair, mirrored pairs."""
@@ -541,6 +575,8 @@ def main():
         return golden_k3_640x480(ns)
     if len(sys.argv) > 1 and sys.argv[1] == "k3_near_plane":
         return golden_k3_near_plane(ns)
+    if len(sys.argv) > 1 and sys.argv[1] == "k1_near_vertex":
+        return golden_k1_near_vertex(ns)
     golden_scene(ns, "scene_ident", 2001, (48, 64), (48, 64), n_points=700, n_frames=6, with_color=True)
     golden_scene(ns, "scene_scaled", 2002, (73, 98), (48, 64), n_points=700, n_frames=6, with_color=False)
     golden_ties(ns)
@@ -551,6 +587,7 @@ def main():
     golden_cme256(ns)
     golden_k3_640x480(ns)
     golden_k3_near_plane(ns)
+    golden_k1_near_vertex(ns)
 
 
 if __name__ == "__main__":

@@ -64,3 +64,46 @@ def test_kernels_reproduce_the_frozen_reference():
                     assert np.array_equal(np.packbits(res["vis_u8"][n].astype(bool), bitorder="little"), g[f"{name}{n}_vis_bits"])
                 if "pix_i16" in res:
                     assert sha(np.ascontiguousarray(res["pix_i16"][n]).astype(np.int16)) == str(g[f"{name}{n}_sha_pix"])
+
+
+K1_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "k1_near_vertex.npz")
+
+
+def _k1_cases():
+    g = np.load(K1_GOLDEN)
+    hw = tuple(int(v) for v in g["hw"])
+    E = list(g["E"])
+    far = []
+    for e in E:
+        f = e.copy()
+        f[:3, 3] += g["shift"]
+        far.append(f)
+    return g, hw, (("near", g["points"], E), ("far", g["points"] + g["shift"], far))
+
+
+def test_oracle_reproduces_the_frozen_reference_k1():
+    g, hw, cases = _k1_cases()
+    total = 0
+    for tag, pts, Es in cases:
+        for k, e in enumerate(Es):
+            m, uv, d = O.vertex_visibility(pts, g["K"], e, g["depth"][k], hw)
+            assert sha(uv) == str(g[f"{tag}{k}_sha_uv"]) and sha(d) == str(g[f"{tag}{k}_sha_depth"])
+            assert np.array_equal(np.packbits(m, bitorder="little"), g[f"{tag}{k}_vis_bits"]) and int(m.sum()) == int(g[f"{tag}{k}_n_vis"])
+            total += int(m.sum())
+    assert total > 50
+
+
+@pytest.mark.gpu
+def test_vertex_visibility_reproduces_the_frozen_reference():
+    import torch
+    from mspa import engine
+    g, hw, cases = _k1_cases()
+    depth = engine.depth_to_device(np.ascontiguousarray(g["depth"]), "cuda")
+    for tag, pts, Es in cases:
+        cam = torch.from_numpy(engine.camera_matrices(g["K"], Es)).to("cuda")
+        out = engine.vertex_visibility(torch.from_numpy(np.ascontiguousarray(pts)).to("cuda"), cam, depth, hw, ("mask", "count"))
+        torch.cuda.synchronize()
+        mask = out["mask"].cpu().numpy().astype(bool)
+        for k in range(len(Es)):
+            assert np.array_equal(np.packbits(mask[k], bitorder="little"), g[f"{tag}{k}_vis_bits"]), (tag, k)
+            assert int(out["count"][k]) == int(g[f"{tag}{k}_n_vis"])
