@@ -58,6 +58,15 @@ def test_near_plane_pairs(ref, delta):
     _check(ref, K, A, E, depth, pairs, hw)
 
 
+@pytest.mark.parametrize("delta", [1e-4, 1e-7, 1e-9])
+def test_near_plane_pairs_scaled_grids(ref, delta):
+    """A colour grid over a smaller depth grid (ScanNet's situation, OPS:276-290 / IH:357-366): 146x196 over 72x96."""
+    rng = np.random.default_rng(77 + int(-np.log10(delta)))
+    hw, dhw = (146, 196), (72, 96)
+    K, A, E, depth, pairs = ADV.near_plane_case(rng, hw, [delta], 4, dhw=dhw)
+    _check(ref, K, A, E, depth, pairs, hw)
+
+
 @pytest.mark.parametrize("shift", [1e4, 1e6])
 def test_translated_scene(ref, shift):
     rng = np.random.default_rng(11)
