@@ -11,6 +11,7 @@ import os
 import numpy as np
 import pytest
 
+from oracle import c_oracle as C
 from oracle import np_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "k3_near_plane.npz")
@@ -37,6 +38,9 @@ def test_oracle_reproduces_the_frozen_reference():
             assert sha(r["uv2"][v]) == str(g[f"{name}{n}_sha_uv"]) and sha(r["depth2"][v]) == str(g[f"{name}{n}_sha_depth"])
             assert np.array_equal(np.packbits(r["vis"], bitorder="little"), g[f"{name}{n}_vis_bits"])
             seen_tiny |= float(g[f"{name}{n}_min_abs_depth2"]) < 1e-6
+            c = C.frame_pair(depth[ia], depth[ib], K, E[ia], E[ib], A, hw)        # the C restatement (plain loops, no BLAS) as well
+            assert np.array_equal(np.packbits(c["vis"], bitorder="little"), g[f"{name}{n}_vis_bits"]) and c["n_vis"] == r["n_vis"]
+            assert np.array_equal(c["xi"][v], r["xi"][v]) and np.array_equal(c["yi"][v], r["yi"][v])
     assert seen_tiny                      # the fixture does hold camera-2 depths below a micrometre
 
 
