@@ -37,8 +37,8 @@
 extern "C" {
 #endif
 
-#define MSPA_VERSION 140            /* 0.4.0: frame records carry guard-bound coefficients (slot MSPA_MAT_BOUNDS, MSPA_FRAME_MATS
-                                       7 -> 8): the fast kernels' guard band is a bound, not a constant */
+#define MSPA_VERSION 150            /* 0.5.0: host-side depth-PNG ingest (mspa_read_depth_png_host); 0.4.0: frame records carry
+                                       guard-bound coefficients (slot MSPA_MAT_BOUNDS, MSPA_FRAME_MATS 7 -> 8) */
 
 #define MSPA_OK 0
 #define MSPA_EINVAL (-1)            /* bad argument (null pointer, size out of range, ...) */
@@ -342,6 +342,22 @@ int mspa_gather_blocks_host(const void *const *src_blocks_host, int64_t n_blocks
  */
 int mspa_inflate_blocks_host(const void *const *src_blocks_host, const int64_t *src_bytes_host, int64_t n_blocks,
                              int64_t block_bytes, void *dst_host, int32_t n_threads);
+
+/*
+ * Host-side ingest of a scene's depth frames from disk: the per-frame `cv2.imread(depth_png, -1)` of
+ * SceneInfoHandler.get_depth_image (info_handler.py:149-155), which CFR.process_scene / MVI.process_scene call once per
+ * image (CFR:152-157, MVI:93-100) and which the reference hides behind a process pool over scenes (CFR:222-229,
+ * MVI:151-156).  The n_files files named by paths_host (NUL-terminated) are read and decoded into
+ * dst_host[k * h * w ...] (host byte order) by up to n_threads native threads; no interpreter lock is involved.
+ * Decoded natively: PNG, 16-bit greyscale, non-interlaced, of exactly h x w pixels (what extract_posed_images.py:118-123
+ * writes).  status_host[k]: 0 decoded; 1 file unreadable; 2 a PNG of another pixel format or size (decode that frame with
+ * a general reader); 3 corrupt.  Returns MSPA_OK when the call ran (the per-file status tells), MSPA_EINVAL on a bad argument.
+ *   mspa_png_header_host   (h, w, bit depth, colour type, interlace flag) of one file's IHDR; each output optional
+ */
+int mspa_read_depth_png_host(const char *const *paths_host, int64_t n_files, int32_t h, int32_t w, uint16_t *dst_host,
+                             int32_t n_threads, int32_t *status_host);
+int mspa_png_header_host(const char *path_host, int32_t *h, int32_t *w, int32_t *bit_depth, int32_t *color_type,
+                         int32_t *interlace);
 
 /*
  * K4 -- per-pair camera relations: the distance / yaw / pitch columns of CFR.process_scene's pair

@@ -1,0 +1,92 @@
+"""Host-side ingest of on-disk scenes: a scene's depth frames read and decoded by native threads.
+
+The reference reads one frame per call (``cv2.imread(path, -1)``, info_handler.py:149-155) inside the per-image loops of
+CFR.process_scene / MVI.process_scene and hides that behind a process pool over scenes (CFR:222-229, MVI:151-156).  Here one
+process feeds one GPU: ``read_depth_frames`` hands the file names of a scene's frames to ``mspa_read_depth_png_host``
+(csrc/host_ingest.hip), which fills one contiguous [F, h, w] uint16 block without touching the interpreter.  Frames in a
+format the native reader does not take (status 2: not 16-bit greyscale non-interlaced PNG) go through the caller's general
+reader one by one -- that is image decoding, not geometry: there is no fallback for the kernels anywhere.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, Dict, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+
+def png_header(path: str):
+    """(h, w, bit_depth, colour_type, interlace) of a PNG file's IHDR."""
+    v = [ctypes.c_int32(0) for _ in range(5)]
+    _lib.check(_lib.load().mspa_png_header_host(path.encode(), *[ctypes.byref(x) for x in v]))
+    return tuple(x.value for x in v)
+
+
+def read_depth_frames(paths: Sequence[str], n_threads: int = 8, general_reader: Optional[Callable[[str], np.ndarray]] = None,
+                      memory: Optional[Dict[str, np.ndarray]] = None, out: Optional[np.ndarray] = None) -> np.ndarray:
+    """[F, h, w] uint16: the depth frames at ``paths``, in order.  ``memory`` (path -> array) serves frames that are not on
+    disk (synthetic scenes, tests); ``general_reader(path)`` decodes what the native reader declines.  ``out`` may be a
+    preallocated (e.g. pinned) destination of the right shape."""
+    paths = list(paths)
+    F = len(paths)
+    memory = memory or {}
+    if F == 0:
+        return np.zeros((0, 0, 0), dtype=np.uint16) if out is None else out[:0]
+    on_disk = [k for k, p in enumerate(paths) if p not in memory]
+    if on_disk:
+        try:
+            h, w, bits, ctype, lace = png_header(paths[on_disk[0]])
+            native = bits == 16 and ctype == 0 and lace == 0
+        except _lib.MspaError:
+            if general_reader is None:
+                raise
+            first = np.asarray(general_reader(paths[on_disk[0]]))
+            (h, w), native = first.shape[:2], False
+    else:
+        h, w = memory[paths[0]].shape[:2]
+        native = False
+    if out is None:
+        out = np.empty((F, h, w), dtype=np.uint16)
+    elif out.shape != (F, h, w) or out.dtype != np.uint16 or not out.flags.c_contiguous:
+        raise ValueError("read_depth_frames: `out` must be a C-contiguous uint16 array of shape (F, h, w)")
+
+    def general(k):
+        if general_reader is None:
+            raise ValueError(f"{paths[k]}: not a 16-bit greyscale PNG and no general reader was given")
+        a = np.asarray(general_reader(paths[k]))
+        if a.shape[:2] != (h, w):
+            raise ValueError(f"{paths[k]}: frame of {a.shape[:2]}, the scene's first frame is {(h, w)}")
+        out[k] = a if a.ndim == 2 else a[..., 0]
+
+    for k, p in enumerate(paths):
+        if p in memory:
+            a = np.asarray(memory[p])
+            if a.shape[:2] != (h, w):
+                raise ValueError(f"{p}: frame of {a.shape[:2]}, the scene's first frame is {(h, w)}")
+            out[k] = a
+    if on_disk and not native:
+        for k in on_disk:
+            general(k)
+    elif on_disk:
+        if len(on_disk) == F:
+            dst, idx = out, None
+        else:                                              # a mix of registered and on-disk frames: decode, then scatter
+            dst, idx = np.empty((len(on_disk), h, w), dtype=np.uint16), on_disk
+        enc = [paths[k].encode() for k in on_disk]
+        arr = (ctypes.c_char_p * len(enc))(*enc)
+        status = np.zeros(len(enc), dtype=np.int32)
+        _lib.check(_lib.load().mspa_read_depth_png_host(arr, len(enc), h, w, dst.ctypes.data, int(max(1, n_threads)),
+                                                        status.ctypes.data))
+        if idx is not None:
+            out[idx] = dst
+        for j in np.nonzero(status)[0]:
+            k, st = on_disk[int(j)], int(status[j])
+            if st == 1:
+                raise FileNotFoundError(paths[k])
+            if st == 2:
+                general(k)
+            else:
+                raise ValueError(f"{paths[k]}: corrupt PNG stream")
+    return out

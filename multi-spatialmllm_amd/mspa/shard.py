@@ -149,3 +149,47 @@ def collate_records(local: torch.Tensor, ctx: DistContext, dst: int = None) -> t
     if all(c == n_max for c in counts):
         return gathered
     return torch.cat([gathered[r * n_max:r * n_max + c] for r, c in enumerate(counts)], dim=0)
+
+
+def gather_bytes(payload, ctx: DistContext, dst: int = 0):
+    """Collate one byte string per rank on rank ``dst``: finished UTF-8 text (JSONL records, warning lines) or an arrow IPC
+    stream built by its owner -- text stays where it was produced and crosses the fabric once, as bytes.  Two collectives,
+    like ``collate_records``: the lengths (all_gather of one int64), then a gather of uint8 tensors padded to the longest.
+    Returns a list of ``world`` uint8 NumPy arrays on rank ``dst`` (zero-copy views of the received buffers), None elsewhere."""
+    import numpy as np
+    arr = np.frombuffer(payload, dtype=np.uint8) if not isinstance(payload, np.ndarray) else payload.reshape(-1).view(np.uint8)
+    dev = ctx.collective_device
+    n_local = torch.tensor([arr.size], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n_local) for _ in range(ctx.world)]
+    dist.all_gather(counts, n_local, group=ctx.group)
+    counts = [int(c.item()) for c in counts]
+    n_max = max(counts)
+    if n_max == 0:
+        return [np.zeros(0, np.uint8) for _ in range(ctx.world)] if ctx.rank == dst else None
+    padded = torch.zeros(n_max, dtype=torch.uint8, device=dev)
+    if arr.size:
+        padded[:arr.size] = torch.from_numpy(np.array(arr, copy=True) if not arr.flags.writeable else arr).to(dev)
+    parts = [torch.empty_like(padded) for _ in range(ctx.world)] if ctx.rank == dst else None
+    dist.gather(padded, parts, dst=dst, group=ctx.group)
+    if ctx.rank != dst:
+        return None
+    return [parts[r][:c].cpu().numpy() for r, c in enumerate(counts)]
+
+
+def context_from_env(device=None) -> "DistContext | None":
+    """The communicator of a job launched with one process per GPU (RANK / WORLD_SIZE / LOCAL_RANK in the environment, as
+    torch.distributed.run sets them), or None for a plain single-process run: what the drop-in entry points
+    (``run_split``, ``generate_qa_training_data``, ``mspa.pipeline``) call when no context is handed to them.
+    ``MSPA_DIST_BACKEND`` overrides the backend (``gloo``: ranks that share one GPU, CPU tests)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 and not dist.is_initialized():
+        return None
+    if device is None:
+        if torch.cuda.is_available():
+            local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local)
+            device = torch.device("cuda", local)
+        else:
+            device = torch.device("cpu")
+    ctx = init_distributed(torch.device(device), backend=os.environ.get("MSPA_DIST_BACKEND"))
+    return ctx if ctx.world > 1 else None

@@ -1,0 +1,236 @@
+"""Sharded, prefetched sweeps over on-disk scenes: what runs behind the drop-in entry points.
+
+The reference fans scenes out over a ``multiprocessing.Pool`` (CFR:222-229 ``num_workers=25``, MVI:151-156,
+OM_C:584-585) because every scene is seconds of NumPy on one core.  Here a scene is ~0.2 ms of kernels, so the fan-out is
+reshaped around what is left:
+
+  * **one process per GPU** (``shard.context_from_env``): the scenes of a split are cut into consecutive *windows* of
+    ``world x per_rank`` scenes, each window dealt to the ranks longest-processing-time-first (``shard.lpt_assign``, cost
+    ~ F^2 N / 64 + F N).  No collective on the data path; after each window ONE exchange towards rank 0 -- the numeric rows
+    through ``shard.collate_records`` (RCCL gather of float64 records), finished text / arrow buffers through
+    ``shard.gather_bytes`` -- and rank 0 consumes the window's scenes in the split's own order, so what it writes is byte for
+    byte what a single process writes (windows bound what rank 0 has to hold: a few scenes per rank, not the split);
+  * **``num_workers`` = host decode threads** feeding the GPU: scene n+1's depth PNGs are read and inflated by native
+    threads (``mspa.ingest``) and its vertices loaded while scene n's H2D copy runs on the copy stream and scene n-1's
+    kernels on the compute stream (``SceneLoader`` -> ``upload.ScenePrefetcher``).
+
+torch is plumbing here (streams, collectives); nothing is computed in this module.
+"""
+from __future__ import annotations
+
+import collections
+import dataclasses
+import struct
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+from typing import Callable, Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import shard
+
+
+@dataclasses.dataclass
+class HostScene:
+    """One scene in host memory, in the form ``upload.UploadSlot.stage_and_upload`` consumes."""
+    scene_id: str
+    K: np.ndarray
+    A: np.ndarray
+    E: Dict[str, np.ndarray]
+    depth: Dict[str, np.ndarray]           # valid frames only; views of one [F, h, w] block
+    color_hw: Tuple[int, int]
+    points: Optional[np.ndarray] = None    # [N, >=3] float64
+    depth_scale: float = 0.001
+    load_s: float = 0.0                    # wall time the loader spent on this scene (decode + np.load)
+
+
+class Timings:
+    """Wall-clock seconds per stage of a sweep, summed over scenes.  The stages overlap (that is the point), so the sum
+    exceeds the sweep's own wall time; ``as_dict`` reports both."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self.s: Dict[str, float] = collections.defaultdict(float)
+        self.n: Dict[str, int] = collections.defaultdict(int)
+
+    def add(self, stage: str, seconds: float, count: int = 1):
+        with self._lock:
+            self.s[stage] += seconds
+            self.n[stage] += count
+
+    class _Span:
+        def __init__(self, owner, stage):
+            self.owner, self.stage = owner, stage
+
+        def __enter__(self):
+            self.t = time.perf_counter()
+
+        def __exit__(self, *exc):
+            self.owner.add(self.stage, time.perf_counter() - self.t)
+
+    def span(self, stage: str):
+        return Timings._Span(self, stage)
+
+    def as_dict(self) -> Dict[str, float]:
+        with self._lock:
+            return {k: round(v, 6) for k, v in sorted(self.s.items())}
+
+
+class SceneLoader:
+    """``for host_scene in SceneLoader(load, keys)``: ``load(key)`` runs on worker threads, up to ``lookahead`` scenes ahead of
+    the consumer, results in key order.  ``load`` spends its time in native code that holds no interpreter lock (PNG
+    inflate, np.load, LAPACK), so two scenes in flight keep ``2 x num_workers`` host cores busy."""
+
+    def __init__(self, load: Callable, keys: Iterable, lookahead: int = 2, timings: Optional[Timings] = None):
+        self.load, self.keys, self.lookahead, self.timings = load, keys, max(1, int(lookahead)), timings
+
+    def _timed(self, key):
+        t = time.perf_counter()
+        out = self.load(key)
+        dt = time.perf_counter() - t
+        if self.timings is not None:
+            self.timings.add("decode", dt)
+        if hasattr(out, "load_s"):
+            out.load_s = dt
+        return out
+
+    def __iter__(self):
+        it = iter(self.keys)
+        pending: collections.deque = collections.deque()
+        ex = ThreadPoolExecutor(max_workers=self.lookahead, thread_name_prefix="mspa-load")
+        try:
+            for key in it:
+                pending.append(ex.submit(self._timed, key))
+                if len(pending) >= self.lookahead:
+                    break
+            while pending:
+                fut = pending.popleft()
+                nxt = next(it, _END)
+                if nxt is not _END:
+                    pending.append(ex.submit(self._timed, nxt))
+                yield fut.result()
+        finally:
+            for fut in pending:
+                fut.cancel()
+            ex.shutdown(wait=True)
+
+
+_END = object()
+
+
+def windows(costs: Sequence[float], world: int, per_rank: int = 8) -> List[List[List[int]]]:
+    """Consecutive windows of ``world * per_rank`` items, each dealt longest-first: ``result[w][rank]`` = ascending indices."""
+    n, size = len(costs), max(1, world * max(1, int(per_rank)))
+    out = []
+    for lo in range(0, n, size):
+        hi = min(n, lo + size)
+        bins = shard.lpt_assign(list(costs[lo:hi]), world)
+        out.append([[lo + i for i in b] for b in bins])
+    return out
+
+
+# ---- framing of a window's blobs: [n_items] then per item (index, n_blobs, len_0 .. len_k) + the bytes --------------------
+def _pack_blobs(items: List[Tuple[int, Sequence]]) -> bytes:
+    head = [struct.pack("<q", len(items))]
+    body = []
+    for index, blobs in items:
+        blobs = [memoryview(b).cast("B") if not isinstance(b, (bytes, bytearray)) else b for b in blobs]
+        head.append(struct.pack(f"<qq{len(blobs)}q", index, len(blobs), *[len(b) for b in blobs]))
+        body.extend(blobs)
+    return b"".join(head + body)
+
+
+def _unpack_blobs(buf: np.ndarray) -> Dict[int, List[np.ndarray]]:
+    if buf.size == 0:
+        return {}
+    mv = memoryview(buf)                                      # headers through struct; the payloads stay views of `buf`
+    (n,) = struct.unpack_from("<q", mv, 0)
+    pos, table = 8, []
+    for _ in range(n):
+        index, k = struct.unpack_from("<qq", mv, pos)
+        lens = struct.unpack_from(f"<{k}q", mv, pos + 16)
+        table.append((index, lens))
+        pos += 16 + 8 * k
+    out: Dict[int, List[np.ndarray]] = {}
+    for index, lens in table:
+        parts = []
+        for ln in lens:
+            parts.append(buf[pos:pos + ln])
+            pos += ln
+        out[index] = parts
+    return out
+
+
+def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work_items: Callable[[List[int]], Iterator],
+                  produce: Callable, consume: Callable, record_width: Optional[int] = None, per_rank: int = 8,
+                  timings: Optional[Timings] = None) -> None:
+    """Run ``produce(index, item) -> (records | None, [blob, ...])`` for this rank's items and ``consume(index, records,
+    blobs)`` on rank 0 for EVERY item, in index order.
+
+    ``work_items(indices)`` yields this rank's items (prefetched however it likes) in the order of ``indices``.
+    ``records`` is a [n, record_width] float64 tensor (any device) or None; blobs are bytes-like.  With a communicator the
+    records of a window go to rank 0 through ``shard.collate_records(dst=0)`` and the blobs through ``shard.gather_bytes``;
+    without one (``ctx`` None) nothing is exchanged and the same ``consume`` calls happen in the same order.
+    """
+    import torch
+    rank, world = (ctx.rank, ctx.world) if ctx is not None else (0, 1)
+    wins = windows(costs, world, per_rank)
+    order = [i for w in wins for i in w[rank]]
+    items = iter(work_items(order))
+    timings = timings or Timings()
+    for w in wins:
+        local_rows, local_blobs = [], []
+        for index in w[rank]:
+            item = next(items)
+            with timings.span("produce"):
+                records, blobs = produce(index, item)
+            if record_width is not None:
+                if records is None:
+                    records = torch.zeros((0, record_width), dtype=torch.float64)
+                tagged = torch.empty((records.shape[0], record_width + 1), dtype=torch.float64, device=records.device)
+                tagged[:, 0] = index
+                tagged[:, 1:] = records
+                local_rows.append(tagged)
+            local_blobs.append((index, list(blobs)))
+        # ---- the window's one exchange ---------------------------------------------------------------------------
+        with timings.span("exchange"):
+            rows_by_index: Dict[int, np.ndarray] = {}
+            if record_width is not None:
+                dev = ctx.collective_device if ctx is not None else "cpu"
+                local = torch.cat([r.to(dev) for r in local_rows], 0) if local_rows else \
+                    torch.zeros((0, record_width + 1), dtype=torch.float64, device=dev)
+                table = shard.collate_records(local, ctx, dst=0) if ctx is not None else local
+                if rank == 0:
+                    table = table.cpu().numpy()
+                    tags = table[:, 0].astype(np.int64)
+                    # each item's rows are contiguous (cat per item, ranks concatenated): cut at the tag changes
+                    cuts = np.flatnonzero(np.diff(tags)) + 1 if len(tags) else np.zeros(0, np.int64)
+                    for lo, hi in zip(np.concatenate([[0], cuts]).astype(np.int64), np.concatenate([cuts, [len(tags)]]).astype(np.int64)):
+                        if hi > lo:
+                            rows_by_index[int(tags[lo])] = table[lo:hi, 1:]
+            packed = _pack_blobs(local_blobs)
+            if ctx is not None:
+                parts = shard.gather_bytes(packed, ctx, dst=0)
+            else:
+                parts = [np.frombuffer(packed, dtype=np.uint8)]
+        if rank != 0:
+            continue
+        blobs_by_index: Dict[int, List[np.ndarray]] = {}
+        for p in parts:
+            blobs_by_index.update(_unpack_blobs(p))
+        with timings.span("consume"):
+            for index in sorted(i for b in w for i in b):
+                rows = rows_by_index.get(index)
+                if record_width is not None and rows is None:
+                    rows = np.zeros((0, record_width))
+                consume(index, rows, blobs_by_index[index])
+    for _ in items:                                            # drain: lets the prefetcher's generator finish cleanly
+        pass
+
+
+def prefetched_scenes(host_scenes: Iterable[HostScene], device="cuda", timings: Optional[Timings] = None):
+    """HostScenes -> resident ``SceneOnDevice`` objects through pinned staging on a copy stream (upload.ScenePrefetcher);
+    a yielded scene stays valid until the next one is asked for."""
+    from .upload import ScenePrefetcher
+    yield from ScenePrefetcher(host_scenes, device=device, timings=timings)

@@ -13,7 +13,7 @@ reference (golden generation), so no second generator can drift.
 from __future__ import annotations
 
 import dataclasses
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -288,3 +288,36 @@ def make_tracks(seed: int, T: int = 300, P: int = 256, n_groups: int = 8,
             k += run
             state = rng.random() < 0.8
     return SynthTracks(f"synth_tracks_{seed:04d}", cam, vis, w2c, fx_fy_cx_cy, image_hw)
+
+
+def write_scannet_layout(scenes: Sequence["SynthScene"], root: str, info_name: str = "scenes_info.pkl",
+                         compress_level: int = 1) -> Dict[str, str]:
+    """Write synthetic scenes to disk the way the reference's pipeline finds ScanNet:
+    ``<root>/posed_images/<scene>/<image>.png`` (16-bit depth, extract_posed_images.py:118-123) and ``<image>.jpg``,
+    ``<root>/scannet_instance_data/<scene>/aligned_points.npy`` (N x 6 float64, batch_load_scannet_data.py:201) and the
+    scene-info pickle (info_handler.py:7-30).  A scene without colour frames gets a flat grey JPEG of the right size for its
+    first image (only its header is ever read: IH:133-139 takes the image size from it).  Returns the paths to hand to
+    ``SceneInfoHandler(info_path, posed_images_root=..., instance_data_root=...)``."""
+    import os
+    import pickle
+    from PIL import Image
+    posed, inst = os.path.join(root, "posed_images"), os.path.join(root, "scannet_instance_data")
+    infos = {}
+    for sc in scenes:
+        os.makedirs(os.path.join(posed, sc.scene_id), exist_ok=True)
+        os.makedirs(os.path.join(inst, sc.scene_id), exist_ok=True)
+        np.save(os.path.join(inst, sc.scene_id, "aligned_points.npy"), sc.points)
+        H, W = sc.color_hw
+        for n, (image_id, d) in enumerate(sc.depth.items()):
+            Image.fromarray(np.ascontiguousarray(d, dtype=np.uint16)).save(
+                os.path.join(posed, sc.scene_id, f"{image_id}.png"), compress_level=compress_level)
+            col = sc.color.get(image_id) if sc.color else None
+            if col is not None:
+                Image.fromarray(col).save(os.path.join(posed, sc.scene_id, f"{image_id}.jpg"), quality=90)
+            elif n == 0:
+                Image.new("RGB", (W, H), (128, 128, 128)).save(os.path.join(posed, sc.scene_id, f"{image_id}.jpg"), quality=50)
+        infos[sc.scene_id] = sc.info_dict()
+    info_path = os.path.join(inst, info_name)
+    with open(info_path, "wb") as f:
+        pickle.dump(infos, f)
+    return {"info_path": info_path, "posed_images_root": posed, "instance_data_root": inst}

@@ -120,10 +120,12 @@ class UploadSlot:
             if N:
                 self.d_xyz[:N].copy_(self.h_xyz[:N], non_blocking=True)
             self.ready.record(copy_stream)
-        return SceneOnDevice.from_resident(K, A, ids, E_al, self.d_depth[:F], self.d_fmats[:F], self.d_cmats[:F],
-                                           self.d_xyz[:N] if N else None, tuple(sc.color_hw), self.device,
-                                           pose_tables=(self.d_pose[:16 * F].view(F, 16), self.d_pose[16 * F:17 * F],
-                                                        self.d_pose[17 * F:18 * F]))
+        scene = SceneOnDevice.from_resident(K, A, ids, E_al, self.d_depth[:F], self.d_fmats[:F], self.d_cmats[:F],
+                                            self.d_xyz[:N] if N else None, tuple(sc.color_hw), self.device,
+                                            pose_tables=(self.d_pose[:16 * F].view(F, 16), self.d_pose[16 * F:17 * F],
+                                                         self.d_pose[17 * F:18 * F]))
+        scene.depth_scale = float(getattr(sc, "depth_scale", 0.001))      # the handler's depth_value_scale (IH:76)
+        return scene
 
 
 _STAGE_POOL = None
@@ -160,11 +162,18 @@ class ScenePrefetcher:
     resident (the consumer's stream waits on the upload event, the host does not), while the next scene is being staged and
     copied.  A yielded scene is valid until the next iteration step (its slot is recycled two scenes later)."""
 
-    def __init__(self, scenes: Iterable, device="cuda", slots: int = UPLOAD_SLOTS, threaded: bool = True):
+    def __init__(self, scenes: Iterable, device="cuda", slots: int = UPLOAD_SLOTS, threaded: bool = True, timings=None):
         self.scenes = scenes
         self.device = torch.device(device)
         self.n_slots = max(2, int(slots))
         self.threaded = threaded
+        self.timings = timings                        # mspa.sweep.Timings: "stage" = pinned staging + H2D enqueue, per scene
+
+    def _stage(self, slot, sc, copy_stream):
+        if self.timings is None:
+            return slot.stage_and_upload(sc, copy_stream)
+        with self.timings.span("stage"):
+            return slot.stage_and_upload(sc, copy_stream)
 
     def __iter__(self) -> Iterator[SceneOnDevice]:
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
@@ -195,7 +204,7 @@ class ScenePrefetcher:
                             slot = free_slots.get(timeout=0.05)
                         except queue.Empty:
                             pass
-                    if slot is None or not put((slot.stage_and_upload(sc, copy_stream), slot, None)):
+                    if slot is None or not put((self._stage(slot, sc, copy_stream), slot, None)):
                         return
             except BaseException as e:                 # surfaces in the consumer
                 put((None, None, e))
@@ -216,7 +225,7 @@ class ScenePrefetcher:
                     staged = None
                     if nxt is not None:
                         slot = free_slots.get()
-                        staged = (slot.stage_and_upload(nxt, copy_stream), slot)
+                        staged = (self._stage(slot, nxt, copy_stream), slot)
                     if pending is not None:
                         yield from self._consume(pending, free_slots)
                     if staged is None:

@@ -110,31 +110,65 @@ class PairTable:
         })
 
 
+def _scene_table(scene_id, scene):
+    """(PairTable, warning lines) of a resident scene: the numbers of ``process_scene`` as columns."""
+    lines = [f"{scene_id}: {image_id} has no in bound points\n" for image_id in scene.empty_frames()]
+    arrays = scene.frames_relations_arrays()
+    lines += _bad_value_lines(scene_id, scene.ids, arrays)
+    return PairTable(scene_id, list(scene.ids), arrays), lines
+
+
+def _bad_value_lines(scene_id, ids, arrays):
+    vals = np.stack([arrays[k] for k in ("overlap", "distance", "yaw", "pitch")], axis=1)
+    return [f"{scene_id}: {(ids[arrays['i'][n]], ids[arrays['j'][n]])} has something wrong "
+            f"{[np.float64(v) for v in vals[n]]}. \n" for n in np.where(~np.isfinite(vals).all(axis=1))[0]]
+
+
 def process_scene_columns(scene_id, scene_infos, warning_file) -> PairTable:
     """``process_scene`` without a Python object per pair: the same numbers as columns, the same warning lines."""
     print(f"Start processing {scene_id}.")
-    scene = scene_infos.scene_on_device(scene_id)
-    for image_id in scene.empty_frames():
+    table, lines = _scene_table(scene_id, scene_infos.scene_on_device(scene_id))
+    if lines:
         with open(warning_file, "a") as f:
-            f.write(f"{scene_id}: {image_id} has no in bound points\n")
-    arrays = scene.frames_relations_arrays()
-    vals = np.stack([arrays[k] for k in ("overlap", "distance", "yaw", "pitch")], axis=1)
-    for n in np.where(~np.isfinite(vals).all(axis=1))[0]:
-        key = (scene.ids[arrays["i"][n]], scene.ids[arrays["j"][n]])
-        with open(warning_file, "a") as f:
-            f.write(f"{scene_id}: {key} has something wrong {[np.float64(v) for v in vals[n]]}. \n")
+            f.writelines(lines)
     print(f"Finished scene {scene_id}.")
-    return PairTable(scene_id, list(scene.ids), arrays)
+    return table
 
 
-def run_split(scene_info_path, output_parquet, warning_file, num_workers=15, save_interval=20, keep=True):
+def _empty_frames(scene):
+    return scene.empty_frames()
+
+
+def _device_rows(scene):
+    """[n_pairs, 6] float64 rows (i, j, overlap, distance, yaw, pitch) of a resident scene, left on the device: what crosses
+    the fabric (``shard.collate_records``) when the split is sharded over several GPUs."""
+    F = len(scene.ids)
+    if F < 2:
+        return torch.zeros((0, 6), dtype=torch.float64, device=scene.device)
+    pairs = engine.all_pairs(F, scene.device)
+    out = torch.empty((pairs.shape[0], 6), dtype=torch.float64, device=scene.device)
+    out[:, 0:2] = pairs.to(torch.float64)
+    out[:, 2] = engine.scene_overlap(scene._visibility()["bits"])
+    out[:, 3:6] = engine.pair_pose(*scene.pose_tables(), pairs)[:, 0:3]
+    return out
+
+
+def run_split(scene_info_path, output_parquet, warning_file, num_workers=15, save_interval=20, keep=True, ctx=None,
+              timings=None):
     """Pair tables of every scene of a split -> ``output_parquet`` (+ ``*_nonzero.parquet``) (reference: :200-253).
-    ``num_workers`` is accepted and ignored: scenes run back to back on the GPU (a ScanNet-sized scene takes ~0.25 ms of
-    kernel time).  The tables stay columnar from the kernels to the parquet row groups -- ScanNet's 106.8 M pairs as a
-    dict with one entry per pair would not fit in memory -- and both files are streamed, one row group per scene, instead
-    of being rewritten every ``save_interval`` scenes.  Returns {scene_id: PairTable}; with ``keep=False`` each table is
-    dropped once its row groups are written (48 B per pair: ~5 GB for ScanNet's 106.8 M pairs) and {} is returned."""
+
+    The reference maps scenes over ``Pool(num_workers)`` (:222-229).  Here ``num_workers`` is the number of host threads that
+    read and inflate the NEXT scene's depth PNGs while the current scene's kernels run (mspa/sweep.py), and the scenes are
+    sharded over the GPUs of the job -- one process per GPU, ``RANK`` / ``WORLD_SIZE`` from the environment
+    (torch.distributed.run) or an explicit ``ctx`` (mspa.shard.DistContext): longest-first within windows of scenes, the
+    numeric rows of each window collated on rank 0 over RCCL (``shard.collate_records``), rank 0 writing the row groups in
+    the split's scene order.  The files are byte for byte those of a one-process run.
+
+    The tables stay columnar from the kernels to the parquet row groups -- ScanNet's 106.8 M pairs as a dict with one entry
+    per pair would not fit in memory -- and both files are streamed, one row group per scene.  Returns {scene_id: PairTable}
+    on rank 0 ({} elsewhere); with ``keep=False`` each table is dropped once written and {} is returned."""
     import pyarrow.parquet as pq
+    from mspa import shard, sweep
     from spatial_engine.utils.scannet_utils.handler.info_handler import SceneInfoHandler
     scene_infos = SceneInfoHandler(scene_info_path)
     all_scene_ids = scene_infos.get_all_scene_ids()
@@ -142,33 +176,63 @@ def run_split(scene_info_path, output_parquet, warning_file, num_workers=15, sav
     if DEBUG and len(all_scene_ids) > 1:
         all_scene_ids = all_scene_ids[:1]
         print("[run_split] DEBUG mode: processing only the first scene.")
+    if ctx is None:
+        ctx = shard.context_from_env()
+    rank = ctx.rank if ctx is not None else 0
     nonzero_parquet = output_parquet.replace(".parquet", "_nonzero.parquet")
     out_dir = os.path.dirname(output_parquet)
-    if out_dir:
+    if out_dir and rank == 0:
         os.makedirs(out_dir, exist_ok=True)
-    tables, writers, total, nonzero = {}, [None, None], 0, 0
-    try:
-        for count, scene_id in enumerate(all_scene_ids):
-            t = process_scene_columns(scene_id, scene_infos, warning_file)
-            if keep:
-                tables[scene_id] = t
+    timings = timings if timings is not None else sweep.Timings()
+    costs = [scene_infos.scene_cost(s) for s in all_scene_ids]
+    device = ctx.device if ctx is not None else "cuda"
+    tables, writers, totals = {}, [None, None], [0, 0]
+
+    def work_items(indices):
+        return scene_infos.prefetched_scenes([all_scene_ids[i] for i in indices], max(1, int(num_workers)), device, timings)
+
+    def produce(index, scene):
+        scene_id = all_scene_ids[index]
+        print(f"Start processing {scene_id}.")
+        lines = [f"{scene_id}: {image_id} has no in bound points\n" for image_id in _empty_frames(scene)]
+        rows = _device_rows(scene)
+        print(f"Finished scene {scene_id}.")
+        return rows, ["".join(lines).encode()]
+
+    def consume(index, rows, blobs):
+        scene_id = all_scene_ids[index]
+        ids = scene_infos.get_all_extrinsic_valid_image_ids(scene_id)
+        arrays = {"i": rows[:, 0].astype(np.int32), "j": rows[:, 1].astype(np.int32),
+                  "overlap": np.ascontiguousarray(rows[:, 2]), "distance": np.ascontiguousarray(rows[:, 3]),
+                  "yaw": np.ascontiguousarray(rows[:, 4]), "pitch": np.ascontiguousarray(rows[:, 5])}
+        text = bytes(blobs[0]).decode() + "".join(_bad_value_lines(scene_id, ids, arrays))
+        if text:
+            with open(warning_file, "a") as f:
+                f.write(text)
+        t = PairTable(scene_id, list(ids), arrays)
+        if keep:
+            tables[scene_id] = t
+        with timings.span("write"):
             for w, (path, nz) in enumerate(((output_parquet, False), (nonzero_parquet, True))):
                 arrow = t.to_arrow(nz)
                 if writers[w] is None:
                     writers[w] = pq.ParquetWriter(path, arrow.schema)
                 writers[w].write_table(arrow)
-                if nz:
-                    nonzero += arrow.num_rows
-                else:
-                    total += arrow.num_rows
-            if (count + 1) % save_interval == 0:
-                print(f"[run_split] {count + 1} scenes written to {output_parquet}")
+                totals[w] += arrow.num_rows
+        if (index + 1) % save_interval == 0:
+            print(f"[run_split] {index + 1} scenes written to {output_parquet}")
+
+    try:
+        sweep.sharded_sweep(costs, ctx, work_items, produce, consume, record_width=6, timings=timings)
     finally:
         for w in writers:
             if w is not None:
                 w.close()
-    print(f"[run_split] Total number of records: {total}")
-    print(f"[run_split] Total number of nonzero records: {nonzero}")
+    if ctx is not None:
+        ctx.barrier()
+    if rank == 0:
+        print(f"[run_split] Total number of records: {totals[0]}")
+        print(f"[run_split] Total number of nonzero records: {totals[1]}")
     return tables
 
 

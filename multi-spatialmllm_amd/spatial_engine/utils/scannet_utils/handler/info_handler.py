@@ -272,15 +272,45 @@ class SceneInfoHandler:
         return np.where(mask_image == target_id + 1, 1, 0)
 
     # ---- resident scene (what the per-scene scripts use) -----------------------------------------
-    def scene_on_device(self, scene_id, with_points=True):
-        from mspa.scene import SceneOnDevice
+    def host_scene(self, scene_id, num_workers=8, with_points=True):
+        """The scene in host memory (``mspa.sweep.HostScene``): poses, the depth frames of the frames with a finite pose --
+        read and inflated by ``num_workers`` native threads (``mspa.ingest``; one ``cv2.imread`` per frame upstream,
+        IH:149-155) into one [F, h, w] block -- and the axis-aligned vertices."""
+        from mspa import ingest
+        from mspa.sweep import HostScene
         ids = self.get_all_image_ids(scene_id)
         E = {i: self.infos[scene_id]["images_info"][i]["extrinsic_matrix"] for i in ids}
         valid = [i for i in ids if np.all(np.isfinite(E[i]))]
-        depth = {i: self.get_depth_image(scene_id, i) for i in valid}
+        block = ingest.read_depth_frames([self.get_depth_image_path(scene_id, i) for i in valid], num_workers,
+                                         general_reader=_images.read_depth, memory=_images.MEMORY)
         pts = self.get_scene_points_align(scene_id)[:, :3] if with_points else None
-        return SceneOnDevice(self.get_intrinsic_matrix(scene_id), self.get_world_to_axis_align_matrix(scene_id),
-                             E, depth, self.get_image_shape(scene_id), pts, depth_scale=self.depth_value_scale)
+        return HostScene(scene_id, self.get_intrinsic_matrix(scene_id), self.get_world_to_axis_align_matrix(scene_id), E,
+                         {i: block[k] for k, i in enumerate(valid)}, tuple(self.get_image_shape(scene_id)), pts,
+                         float(self.depth_value_scale))
+
+    def scene_on_device(self, scene_id, with_points=True, num_workers=8):
+        from mspa.scene import SceneOnDevice
+        hs = self.host_scene(scene_id, num_workers, with_points)
+        return SceneOnDevice(hs.K, hs.A, hs.E, hs.depth, hs.color_hw, hs.points, depth_scale=self.depth_value_scale)
+
+    def scene_cost(self, scene_id):
+        """Estimated cost of a scene for the longest-first assignment (F^2 N / 64 + F N) without loading it:
+        F from the poses, N from the header of the vertex file."""
+        from mspa import shard
+        F = len(self.get_all_extrinsic_valid_image_ids(scene_id))
+        try:
+            N = int(np.load(os.path.join(self.instance_data_root, scene_id, "aligned_points.npy"), mmap_mode="r").shape[0])
+        except Exception:
+            N = 1
+        return shard.scene_cost(F, N)
+
+    def prefetched_scenes(self, scene_ids, num_workers=8, device="cuda", timings=None, with_points=True, lookahead=2):
+        """``scene_ids`` -> resident scenes, one after the other: scene n+1 is decoded by ``num_workers`` host threads and
+        copied on the copy stream while the caller runs scene n's kernels (mspa/sweep.py, mspa/upload.py)."""
+        from mspa import sweep
+        loader = sweep.SceneLoader(lambda sid: self.host_scene(sid, num_workers, with_points), list(scene_ids), lookahead,
+                                   timings)
+        return sweep.prefetched_scenes(loader, device, timings)
 
 
 class VisibilityInfoHandler:

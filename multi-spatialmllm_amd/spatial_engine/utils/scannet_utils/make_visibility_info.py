@@ -60,49 +60,103 @@ def process_scene_columns(scene_id, scene_infos, warning_file):
     return csr
 
 
-def run_split(scene_info_path, output_file, warning_file, num_workers=8, keep=True):
-    """Visibility index of every scene of a split -> ``output_file`` (.parquet in the readers' format, or
-    .pkl as the nested dict).  ``num_workers`` is accepted and ignored (GPU loop); ``keep=False`` drops each scene's
-    index after it has been written (parquet output), for splits that do not fit in memory."""
+def _visibility_csr(scene):
+    return scene.visibility_csr()
+
+
+_CSR_FIELDS = ("i2p_offsets", "i2p_indices", "p2i_offsets", "p2i_indices")
+
+
+def run_split(scene_info_path, output_file, warning_file, num_workers=8, keep=True, ctx=None, timings=None):
+    """Visibility index of every scene of a split -> ``output_file`` (.parquet in the readers' format, or .pkl as the nested
+    dict) (reference: :127-177, which maps scenes over ``Pool(num_workers)``, :151-156).
+
+    ``num_workers`` = host threads that read and inflate the next scene's depth PNGs under the current scene's kernels; the
+    scenes are sharded over the job's GPUs (one process per GPU: ``RANK`` / ``WORLD_SIZE`` from the environment, or ``ctx``).
+    Every rank turns its scenes' bitsets into CSR tables on its GPU and formats the JSON text itself; the finished arrow
+    buffers of a window of scenes go to rank 0 as bytes (``shard.gather_bytes``), which writes one row group per scene in the
+    split's order -- the file is byte for byte that of a one-process run.  ``keep=False`` drops each scene's index after it
+    has been written (parquet output), for splits that do not fit in memory; the dict comes back on rank 0 only."""
+    import numpy as np
+    from mspa import shard, sweep, visindex
     from spatial_engine.utils.scannet_utils.handler.info_handler import SceneInfoHandler
     scene_infos = SceneInfoHandler(scene_info_path)
     all_scene_ids = scene_infos.get_all_scene_ids()
+    if ctx is None:
+        ctx = shard.context_from_env()
+    rank = ctx.rank if ctx is not None else 0
     out_dir = os.path.dirname(output_file)
-    if out_dir:
+    if out_dir and rank == 0:
         os.makedirs(out_dir, exist_ok=True)
     if DEBUG and len(all_scene_ids) > 1:
         all_scene_ids = all_scene_ids[:1]
         print("[run_split] DEBUG mode. Only processing first scene.")
     print(f"[run_split] Found {len(all_scene_ids)} scenes in {scene_info_path}")
-    scene_visibility_dict = {}
-    if output_file.endswith(".pkl"):
-        for scene_id in all_scene_ids:
-            _, scene_visibility_dict[scene_id] = process_scene(scene_id, scene_infos, warning_file)
-        with open(output_file, "wb") as f:
-            pickle.dump(scene_visibility_dict, f)
-        n = sum(len(v["image_to_points"]) + len(v["point_to_images"]) for v in scene_visibility_dict.values())
-    else:
-        # parquet: one row group per scene, streamed -- the train split is 13 GB of JSON strings and need not sit in memory
+    as_pkl = output_file.endswith(".pkl")
+    want_csr = as_pkl or keep                      # rank 0 rebuilds the nested dict from the CSR tables
+    timings = timings if timings is not None else sweep.Timings()
+    costs = [scene_infos.scene_cost(s) for s in all_scene_ids]
+    device = ctx.device if ctx is not None else "cuda"
+    scene_visibility_dict, state = {}, {"writer": None, "n": 0}
+
+    def work_items(indices):
+        return scene_infos.prefetched_scenes([all_scene_ids[i] for i in indices], max(1, int(num_workers)), device, timings)
+
+    def produce(index, scene):
+        import pyarrow as pa
+        scene_id = all_scene_ids[index]
+        print(f"[process_scene] Start: {scene_id}")
+        csr = _visibility_csr(scene)
+        lines = [f"[Warning] {scene_id}: {image_id} has no in-bound points.\n" for image_id in csr.empty_images()]
+        blobs = ["".join(lines).encode()]
+        if not as_pkl:
+            # columns all the way: bitsets -> CSR on the device -> JSON text by libmspa's host formatters, straight into
+            # arrow's buffers; what leaves this rank is the finished table as one IPC stream
+            sink = pa.BufferOutputStream()
+            table = csr.to_arrow(scene_id)
+            with pa.ipc.new_stream(sink, table.schema) as w:
+                w.write_table(table)
+            blobs.append(sink.getvalue())
+        if want_csr:
+            blobs += [np.ascontiguousarray(getattr(csr, f)) for f in _CSR_FIELDS]
+        print(f"[process_scene] Done: {scene_id}")
+        return None, blobs
+
+    def consume(index, _rows, blobs):
         import pyarrow as pa
         import pyarrow.parquet as pq
-        writer, n = None, 0
-        try:
-            for scene_id in all_scene_ids:
-                # columns all the way: bitsets -> CSR on the device -> JSON text by arrow compute kernels; the nested dict is
-                # only built when the caller wants it back
-                csr = process_scene_columns(scene_id, scene_infos, warning_file)
-                if keep:
-                    scene_visibility_dict[scene_id] = csr.to_dict()
-                table = csr.to_arrow(scene_id)
-                if writer is None:
-                    writer = pq.ParquetWriter(output_file, table.schema)
-                writer.write_table(table)
-                n += table.num_rows
-        finally:
-            if writer is not None:
-                writer.close()
-    print(f"[run_split] Done. Wrote {n} entries to {output_file}")
-    return scene_visibility_dict
+        scene_id = all_scene_ids[index]
+        if blobs[0].size:
+            with open(warning_file, "a") as f:
+                f.write(bytes(blobs[0]).decode())
+        if want_csr:
+            o1, i1, o2, i2 = blobs[-4:]
+            ids = scene_infos.get_all_extrinsic_valid_image_ids(scene_id)
+            csr = visindex.VisibilityCSR(list(ids), len(o2.view(np.int64)) - 1, o1.view(np.int64), i1.view(np.int32),
+                                         o2.view(np.int64), i2.view(np.int32))
+            scene_visibility_dict[scene_id] = csr.to_dict()
+        if not as_pkl:
+            with timings.span("write"):
+                table = pa.ipc.open_stream(pa.py_buffer(blobs[1])).read_all()
+                if state["writer"] is None:
+                    state["writer"] = pq.ParquetWriter(output_file, table.schema)
+                state["writer"].write_table(table)
+                state["n"] += table.num_rows
+
+    try:
+        sweep.sharded_sweep(costs, ctx, work_items, produce, consume, timings=timings)
+    finally:
+        if state["writer"] is not None:
+            state["writer"].close()
+    if as_pkl and rank == 0:
+        with open(output_file, "wb") as f:
+            pickle.dump(scene_visibility_dict, f)
+        state["n"] = sum(len(v["image_to_points"]) + len(v["point_to_images"]) for v in scene_visibility_dict.values())
+    if ctx is not None:
+        ctx.barrier()
+    if rank == 0:
+        print(f"[run_split] Done. Wrote {state['n']} entries to {output_file}")
+    return scene_visibility_dict if (keep or as_pkl) else {}
 
 
 def main():

@@ -1,0 +1,302 @@
+"""The sharded, prefetched sweep behind the drop-in entry points (mspa/sweep.py, mspa/ingest.py), on CPU.
+
+What runs for real here: the native depth-PNG reader, the scene loader threads, the window / longest-first assignment, the
+per-window exchange (``shard.collate_records`` + ``shard.gather_bytes`` over gloo, world 2) and rank 0's ordered writers of
+``calculate_frames_relations.run_split`` / ``make_visibility_info.run_split``, over scenes written to disk in the
+reference's layout.  What is stood in for: the kernels -- there is no GPU in this container and no CPU fallback in the product,
+so the per-scene numbers come from the oracle (test infrastructure) through the two hooks the scripts expose.  The same test
+with the kernels in place is tests/test_gpu_sweep.py.
+"""
+import hashlib
+import os
+import pickle
+import struct
+import sys
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "multi-spatialmllm_amd")
+for p in (PKG, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from mspa import ingest, shard, sweep, synth  # noqa: E402
+
+
+# ---- native PNG reader ---------------------------------------------------------------------------------------------
+def _png_gray16(a: np.ndarray, filters, level=6, idat_chunks=1) -> bytes:
+    """A 16-bit greyscale PNG of ``a`` with row y filtered by filters[y % len]: all five filter types on demand."""
+    h, w = a.shape
+    be = a.astype(">u2").view(np.uint8).reshape(h, 2 * w).astype(np.int32)
+    prior = np.zeros(2 * w, np.int32)
+    rows = []
+    for y in range(h):
+        x = be[y]
+        left = np.concatenate([[0, 0], x[:-2]])
+        ul = np.concatenate([[0, 0], prior[:-2]])
+        ft = filters[y % len(filters)]
+        if ft == 0:
+            f = x
+        elif ft == 1:
+            f = x - left
+        elif ft == 2:
+            f = x - prior
+        elif ft == 3:
+            f = x - ((left + prior) >> 1)
+        else:
+            p = left + prior - ul
+            pa, pb, pc = np.abs(p - left), np.abs(p - prior), np.abs(p - ul)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prior, ul))
+            f = x - pred
+        rows.append(bytes([ft]) + (f & 255).astype(np.uint8).tobytes())
+        prior = x
+    z = zlib.compress(b"".join(rows), level)
+
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data))
+    cut = [len(z) * k // idat_chunks for k in range(idat_chunks + 1)]
+    body = b"".join(chunk(b"IDAT", z[cut[k]:cut[k + 1]]) for k in range(idat_chunks))
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 0, 0, 0, 0)) + chunk(b"tEXt", b"k\0v") + body
+            + chunk(b"IEND", b""))
+
+
+def test_native_png_reader_all_filters_and_errors(tmp_path):
+    rng = np.random.default_rng(0)
+    frames, paths = [], []
+    for k, (filters, level, chunks) in enumerate([([0], 0, 1), ([1], 6, 1), ([2], 9, 3), ([3], 1, 2), ([4], 6, 5),
+                                                  ([0, 1, 2, 3, 4], 6, 4), ([4, 3, 2, 1], 6, 1)]):
+        a = rng.integers(0, 65536, (37, 53), dtype=np.uint16) if k % 2 else \
+            (np.add.outer(np.arange(37), np.arange(53)) * 419 % 65536).astype(np.uint16)
+        p = str(tmp_path / f"f{k}.png")
+        with open(p, "wb") as f:
+            f.write(_png_gray16(a, filters, level, chunks))
+        frames.append(a)
+        paths.append(p)
+    assert ingest.png_header(paths[0]) == (37, 53, 16, 0, 0)
+    for threads in (1, 3, 16):
+        out = ingest.read_depth_frames(paths, threads)
+        assert out.dtype == np.uint16 and out.shape == (7, 37, 53)
+        assert all(np.array_equal(out[k], frames[k]) for k in range(7))
+    # the files PIL writes (what synth.write_scannet_layout and ScanNet's exporter produce) and a registered frame
+    from PIL import Image
+    pil = str(tmp_path / "pil.png")
+    Image.fromarray(frames[1]).save(pil, compress_level=3)
+    mixed = ingest.read_depth_frames(["mem://a", pil, paths[4]], 2, memory={"mem://a": frames[3]})
+    assert np.array_equal(mixed[0], frames[3]) and np.array_equal(mixed[1], frames[1]) and np.array_equal(mixed[2], frames[4])
+    # other pixel formats go to the caller's general reader; without one the frame is named
+    p8 = str(tmp_path / "eight.png")
+    Image.fromarray((frames[1] >> 8).astype(np.uint8)).save(p8)
+    with pytest.raises(ValueError, match="eight.png"):
+        ingest.read_depth_frames([paths[1], p8], 2)
+    got = ingest.read_depth_frames([paths[1], p8], 2, general_reader=lambda p: np.array(Image.open(p)))
+    assert np.array_equal(got[1], frames[1] >> 8)
+    with pytest.raises(FileNotFoundError):
+        ingest.read_depth_frames([paths[0], str(tmp_path / "missing.png")], 2)
+    cut = str(tmp_path / "cut.png")
+    with open(cut, "wb") as f:
+        f.write(open(paths[5], "rb").read()[:300])
+    with pytest.raises(ValueError, match="corrupt"):
+        ingest.read_depth_frames([paths[0], cut], 2)
+    other = str(tmp_path / "other_size.png")
+    with open(other, "wb") as f:
+        f.write(_png_gray16(frames[0][:20], [1]))
+    with pytest.raises(ValueError, match="other_size"):      # status 2 -> general reader missing
+        ingest.read_depth_frames([paths[0], other], 2)
+    assert ingest.read_depth_frames([], 4).shape[0] == 0
+
+
+# ---- scenes on disk, reference layout ----------------------------------------------------------------------------------
+N_SCENES = 7
+
+
+def _make_scenes():
+    scenes = []
+    for k in range(N_SCENES):
+        sc = synth.make_scene(9100 + k, n_points=260 + 40 * k, n_frames=3 + (k * 3) % 5, color_hw=(24, 32), depth_hw=(24, 32),
+                              invalid_pose_frac=0.3 if k == 2 else 0.0, with_color=False, scene_id=f"scene{9100 + k:04d}_00")
+        if k == 4:                                            # two frames that see nothing (all depth invalid): a NaN overlap
+            for image_id in sc.valid_image_ids[:2]:
+                sc.depth[image_id] = np.zeros_like(sc.depth[image_id])
+        scenes.append(sc)
+    return scenes
+
+
+def _write_layout(root):
+    os.makedirs(os.path.join(root, "data", "scannet"), exist_ok=True)
+    return synth.write_scannet_layout(_make_scenes(), os.path.join(root, "data", "scannet"))
+
+
+def _install_oracle_standins():
+    """The kernels' place is taken by the oracle; everything around them is the product code."""
+    from oracle import np_oracle as O
+    from mspa import visindex
+    import spatial_engine.camera_movement.calculate_frames_relations as CFR
+    import spatial_engine.utils.scannet_utils.make_visibility_info as MVI
+    sweep.prefetched_scenes = lambda host_scenes, device="cuda", timings=None: iter(host_scenes)
+
+    def masks(hs):
+        return O.scene_visibility_masks(hs.points[:, :3], hs.K, hs.A, hs.E, hs.depth, hs.color_hw)
+
+    def empty_frames(hs):
+        return [i for i, m in masks(hs).items() if not m.any()]
+
+    def device_rows(hs):
+        ids = O.valid_image_ids(hs.E)
+        table = O.frames_relations_scene(hs.points[:, :3], hs.K, hs.A, hs.E, hs.depth, hs.color_hw)
+        pos = {i: n for n, i in enumerate(ids)}
+        rows = [[pos[a], pos[b], v["overlap"], v["distance"], v["yaw"], v["pitch"]] for (a, b), v in table.items()]
+        return torch.tensor(rows, dtype=torch.float64).reshape(-1, 6)
+
+    def visibility_csr(hs):
+        idx = O.visibility_index_scene(hs.points[:, :3], hs.K, hs.A, hs.E, hs.depth, hs.color_hw)
+        ids = O.valid_image_ids(hs.E)
+        pos = {i: n for n, i in enumerate(ids)}
+        i2p = [idx["image_to_points"][i] for i in ids]
+        p2i = [[pos[i] for i in idx["point_to_images"][v]] for v in range(hs.points.shape[0])]
+
+        def csr(lists):
+            off = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64)
+            flat = np.array([v for x in lists for v in x], dtype=np.int32)
+            return off, flat
+        return visindex.VisibilityCSR(list(ids), hs.points.shape[0], *csr(i2p), *csr(p2i))
+
+    CFR._empty_frames, CFR._device_rows, MVI._visibility_csr = empty_frames, device_rows, visibility_csr
+    return CFR, MVI
+
+
+def _run_both(out_dir, ctx=None, num_workers=3):
+    CFR, MVI = _install_oracle_standins()
+    info = "data/scannet/scannet_instance_data/scenes_info.pkl"
+    os.makedirs(out_dir, exist_ok=True)
+    t = sweep.Timings()
+    tables = CFR.run_split(info, os.path.join(out_dir, "pairs.parquet"), os.path.join(out_dir, "cfr_warn.txt"),
+                           num_workers=num_workers, save_interval=2, ctx=ctx, timings=t)
+    vis = MVI.run_split(info, os.path.join(out_dir, "vis.parquet"), os.path.join(out_dir, "mvi_warn.txt"),
+                        num_workers=num_workers, ctx=ctx)
+    MVI.run_split(info, os.path.join(out_dir, "vis.pkl"), os.path.join(out_dir, "mvi_warn_pkl.txt"), num_workers=1, ctx=ctx)
+    return tables, vis, t
+
+
+FILES = ("pairs.parquet", "pairs_nonzero.parquet", "vis.parquet", "vis.pkl", "cfr_warn.txt", "mvi_warn.txt")
+
+
+def _digests(out_dir):
+    return {n: hashlib.sha256(open(os.path.join(out_dir, n), "rb").read()).hexdigest() for n in FILES}
+
+
+def _rank_main(rank, world, port, root, out_dir, q):
+    os.chdir(root)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), MSPA_DIST_BACKEND="gloo")
+    for p in (PKG, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    ctx = shard.context_from_env(torch.device("cpu"))
+    assert ctx is not None and ctx.world == world and ctx.backend == "gloo"
+    # the byte exchange on its own: ragged lengths, an empty contribution, NumPy input
+    parts = shard.gather_bytes(b"x" * (5 * rank), ctx)
+    assert (parts is None) == (rank != 0)
+    if rank == 0:
+        assert [bytes(p) for p in parts] == [b"x" * (5 * r) for r in range(world)]
+    parts = shard.gather_bytes(np.arange(3 + rank, dtype=np.int32), ctx, dst=world - 1)
+    if rank == world - 1:
+        assert [p.view(np.int32).tolist() for p in parts] == [list(range(3 + r)) for r in range(world)]
+    nothing = shard.gather_bytes(b"", ctx)                   # nobody has anything: no second collective
+    assert (nothing is None) if rank else (len(nothing) == world and all(p.size == 0 for p in nothing))
+    tables, vis, _ = _run_both(out_dir, ctx=None)            # ctx=None: the entry points pick RANK / WORLD_SIZE up themselves
+    q.put((rank, sorted(tables), sorted(vis)))
+    ctx.barrier()
+    ctx.close()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def test_run_split_sharded_over_two_ranks_is_byte_identical(tmp_path, monkeypatch):
+    from oracle import np_oracle as O
+    import pandas as pd
+    root = str(tmp_path)
+    _write_layout(root)
+    monkeypatch.chdir(root)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    keep = (sweep.prefetched_scenes,)
+    try:
+        tables, vis, timings = _run_both(os.path.join(root, "one"))
+    finally:
+        sweep.prefetched_scenes = keep[0]
+    scenes = _make_scenes()
+    assert list(tables) == [s.scene_id for s in scenes] == list(vis)
+    assert timings.n["decode"] == N_SCENES and timings.s["write"] > 0
+    # one process == the oracle's tables, in the split's order
+    df = pd.read_parquet(os.path.join(root, "one", "pairs.parquet"))
+    want_rows = []
+    for sc in scenes:
+        for (a, b), v in O.frames_relations_scene(sc.points[:, :3], sc.K, sc.A, sc.E, sc.depth, sc.color_hw).items():
+            want_rows.append((sc.scene_id, a, b, v["overlap"], v["distance"], v["yaw"], v["pitch"]))
+    assert list(zip(df.scene_id, df.image_id1, df.image_id2)) == [r[:3] for r in want_rows]
+    got = df[["overlap", "distance", "yaw", "pitch"]].to_numpy()
+    assert np.array_equal(got.view(np.int64), np.array([r[3:] for r in want_rows], dtype=np.float64).view(np.int64))
+    nz = pd.read_parquet(os.path.join(root, "one", "pairs_nonzero.parquet"))
+    assert len(nz) == sum(1 for r in want_rows if r[3] != 0.0)
+    with open(os.path.join(root, "one", "vis.pkl"), "rb") as f:
+        vis_pkl = pickle.load(f)
+    for sc in scenes:
+        want = O.visibility_index_scene(sc.points[:, :3], sc.K, sc.A, sc.E, sc.depth, sc.color_hw)
+        assert vis[sc.scene_id] == want == vis_pkl[sc.scene_id]
+    warn = open(os.path.join(root, "one", "cfr_warn.txt")).read()
+    empty = scenes[4].valid_image_ids[0]
+    assert f"{scenes[4].scene_id}: {empty} has no in bound points\n" in warn and "has something wrong" in warn   # NaN overlaps
+    assert f"[Warning] {scenes[4].scene_id}: {empty} has no in-bound points.\n" in open(os.path.join(root, "one", "mvi_warn.txt")).read()
+    # two ranks over gloo: the same files, byte for byte
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_rank_main, args=(r, 2, port, root, os.path.join(root, "two"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert results[0][1] == sorted(s.scene_id for s in scenes) == results[0][2] and results[1][1] == [] == results[1][2]
+    assert _digests(os.path.join(root, "two")) == _digests(os.path.join(root, "one"))
+
+
+def test_windows_and_blob_framing():
+    costs = [5, 1, 1, 9, 2, 2, 2, 7, 3]
+    w = sweep.windows(costs, 2, per_rank=2)                 # windows of 4 items
+    assert [sorted(i for b in win for i in b) for win in w] == [[0, 1, 2, 3], [4, 5, 6, 7], [8]]
+    assert w[0] == [[3], [0, 1, 2]] and all(b == sorted(b) for win in w for b in win)
+    assert sweep.windows([], 4) == []
+    items = [(7, [b"abc", b"", np.arange(4, dtype=np.int64)]), (2, []), (9, [b"z" * 5000])]
+    back = sweep._unpack_blobs(np.frombuffer(sweep._pack_blobs(items), dtype=np.uint8))
+    assert sorted(back) == [2, 7, 9] and back[2] == []
+    assert bytes(back[7][0]) == b"abc" and back[7][1].size == 0 and back[7][2].view(np.int64).tolist() == [0, 1, 2, 3]
+    assert bytes(back[9][0]) == b"z" * 5000
+    # the loader keeps order and bounds what is in flight
+    import threading
+    live, peak, lock = [0], [0], threading.Lock()
+
+    def load(k):
+        with lock:
+            live[0] += 1
+            peak[0] = max(peak[0], live[0])
+        import time
+        time.sleep(0.01)
+        with lock:
+            live[0] -= 1
+        return k * k
+    assert list(sweep.SceneLoader(load, range(9), lookahead=3)) == [k * k for k in range(9)]
+    assert peak[0] <= 3
+    with pytest.raises(ZeroDivisionError):
+        list(sweep.SceneLoader(lambda k: 1 // (k - 2), range(5), lookahead=2))
