@@ -23,6 +23,53 @@ def rigid_body_segmentation(points, threshold=0.1, smoothing_factor=0.01):
     return [np.where(labels == i)[0].tolist() for i in range(1, max(labels) + 1)]
 
 
+class _LoadedSample(dict):
+    """A TAPVid-3D sample file read into memory by a loader thread (same access pattern as the lazy ``np.load`` object)."""
+
+    @property
+    def files(self):
+        return list(self.keys())
+
+
+def load_tapvid_sample(input_file):
+    with np.load(input_file, allow_pickle=True) as gt:
+        return _LoadedSample({k: gt[k] for k in gt.files})
+
+
+def sharded_scenes(files, run_one, num_workers=20, ctx=None):
+    """Records of every sample file, in file order, on rank 0 -- the reference's ``pool.map`` over scenes (OM_C:584-585).
+
+    One process per GPU (``RANK`` / ``WORLD_SIZE`` from the environment, or ``ctx``): files dealt longest-first by size,
+    ``num_workers`` (capped at 4) loader threads read the next files while the current one is on the GPU, and every rank's
+    finished records travel to rank 0 as JSON-lines bytes (``shard.gather_bytes``): text is built where the numbers are.
+    ``run_one(path, loaded)`` returns one file's records; other ranks get []."""
+    import json
+    from mspa import shard, sweep
+    if ctx is None:
+        ctx = shard.context_from_env()
+    costs = [float(os.path.getsize(f)) if os.path.exists(f) else 1.0 for f in files]
+    data, direct = [], {}
+
+    def work_items(indices):
+        return sweep.SceneLoader(lambda i: load_tapvid_sample(files[i]), indices, lookahead=max(1, min(int(num_workers), 4)))
+
+    def produce(index, loaded):
+        records = run_one(files[index], loaded)
+        if ctx is None:                                      # nothing to exchange: the records themselves are handed on
+            direct[index] = records
+            return None, []
+        return None, ["".join(json.dumps(r) + "\n" for r in records).encode()]
+
+    def consume(index, _rows, blobs):
+        if ctx is None:
+            data.extend(direct.pop(index))
+        else:
+            data.extend(json.loads(line) for line in bytes(blobs[0]).splitlines())
+
+    sweep.sharded_sweep(costs, ctx, work_items, produce, consume, per_rank=4)
+    return data, ctx
+
+
 def filter_large_groups(groups, min_size=5):
     return [g for g in groups if len(g) > min_size]
 
@@ -56,12 +103,12 @@ class TwoFrameVideoQAEngine:
 
     # -- scene level (reference: :405-575) ---------------------------------------------------------
     def generate_qa_training_single_scene(self, input_file, npoints_per_group=5, npairs_per_bin=1e8, img_output_dir="",
-                                          augment=True, augment_ratio=1.0):
+                                          augment=True, augment_ratio=1.0, _loaded=None):
         """All records of one TAPVid-3D sample file: frames to ``img_output_dir/<scene>/``, rigid groups (K7 + SciPy),
         frame-pair mining (K5c), records (K5a + K5b).  The JPEG payloads are written as stored -- upstream decodes
         and re-encodes them -- and the image size is read from the first payload's header."""
         scene_id = os.path.splitext(os.path.basename(input_file))[0]
-        gt = np.load(input_file, allow_pickle=True)
+        gt = _loaded if _loaded is not None else np.load(input_file, allow_pickle=True)
         scene_img_dir = os.path.join(img_output_dir, scene_id)
         os.makedirs(scene_img_dir, exist_ok=True)
         payloads = gt["images_jpeg_bytes"]
@@ -93,18 +140,27 @@ class TwoFrameVideoQAEngine:
                                             image_width=image_width, extrinsics_w2c=extrinsics_w2c)
 
     def _all_scenes(self, scene_id_list, source_data_root, img_output_dir, npoints_per_group, npairs_per_bin, augment,
-                    augment_ratio):
-        """Upstream maps the scenes over a fork pool, so every scene starts from a copy of the parent's ``random``
-        state and the parent's own stream is untouched by them; reproduced here scene by scene on the one GPU."""
+                    augment_ratio, num_workers=20, ctx=None):
+        """Upstream maps the scenes over a fork pool (:584-585), so every scene starts from a copy of the parent's ``random``
+        state and the parent's own stream is untouched by them; reproduced here scene by scene, the scenes sharded over the
+        job's GPUs (``sharded_scenes``).  Returns the records in scene order on rank 0, [] on the other ranks."""
         parent = random.getstate()
-        data = []
-        for scene_id in scene_id_list:
+
+        def run_one(path, loaded):
             random.setstate(parent)
-            data.extend(self.generate_qa_training_single_scene(os.path.join(source_data_root, f"{scene_id}.npz"),
-                                                               npoints_per_group, npairs_per_bin, img_output_dir, augment,
-                                                               augment_ratio))
+            return self.generate_qa_training_single_scene(path, npoints_per_group, npairs_per_bin, img_output_dir, augment,
+                                                          augment_ratio, _loaded=loaded)
+        data, self._ctx = sharded_scenes([os.path.join(source_data_root, f"{scene_id}.npz") for scene_id in scene_id_list],
+                                         run_one, num_workers, ctx)
         random.setstate(parent)
         return data
+
+    def _is_writer(self):
+        """Rank 0 writes the files (every rank of a multi-GPU job runs the same script)."""
+        ctx = getattr(self, "_ctx", None)
+        if ctx is not None:
+            ctx.barrier()
+        return ctx is None or ctx.rank == 0
 
     @staticmethod
     def _report(kind, output_file, data):
@@ -117,7 +173,9 @@ class TwoFrameVideoQAEngine:
     def generate_qa_training_data(self, scene_id_list, source_data_root, output_dir, output_file, img_output_dir,
                                   npoints_per_group, npairs_per_bin, augment, augment_ratio=1.0, max_samples=-1, num_workers=20):
         data = self._all_scenes(scene_id_list, source_data_root, img_output_dir, npoints_per_group, npairs_per_bin, augment,
-                                augment_ratio)
+                                augment_ratio, num_workers)
+        if not self._is_writer():
+            return
         if max_samples > 0 and len(data) > max_samples:
             data = random.sample(data, max_samples)
         random.shuffle(data)
@@ -131,7 +189,9 @@ class TwoFrameVideoQAEngine:
     def generate_qa_eval_data(self, scene_id_list, source_data_root, output_dir, output_file, img_output_dir,
                               npoints_per_group, npairs_per_bin, augment, augment_ratio=0.3, max_samples=300, num_workers=20):
         data = self._all_scenes(scene_id_list, source_data_root, img_output_dir, npoints_per_group, npairs_per_bin, augment,
-                                augment_ratio)
+                                augment_ratio, num_workers)
+        if not self._is_writer():
+            return
         if max_samples > 0 and len(data) > max_samples:
             data = random.sample(data, max_samples)
         heads.write_jsonl(output_file, [self.format_eval_sample(s) for s in data])

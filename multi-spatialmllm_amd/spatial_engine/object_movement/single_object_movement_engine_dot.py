@@ -12,7 +12,8 @@ from mspa import engine, heads
 from mspa import templates as T
 from mspa.annotate import Mark
 from spatial_engine.object_movement.single_object_movement_engine_coord import (TwoFrameVideoQAEngine, filter_large_groups,
-                                                                                jpeg_size, rigid_body_segmentation)
+                                                                                jpeg_size, rigid_body_segmentation,
+                                                                                sharded_scenes)
 from spatial_engine.object_movement.single_object_movement_engine_coord import main as _main
 
 random.seed(1)
@@ -61,9 +62,9 @@ class TwoFrameVideoQAEngineDot(TwoFrameVideoQAEngine):
                                              cam_threshold=self.camera_not_moving_threshold)
 
     def generate_qa_training_single_scene(self, input_file, base_img_dir, npoints_per_group=5, npairs_per_bin=1e8,
-                                          img_output_dir="", augment=True, augment_ratio=1.0):
+                                          img_output_dir="", augment=True, augment_ratio=1.0, _loaded=None):
         scene_id = os.path.splitext(os.path.basename(input_file))[0]
-        gt = np.load(input_file, allow_pickle=True)
+        gt = _loaded if _loaded is not None else np.load(input_file, allow_pickle=True)
         scene_img_dir = os.path.join(base_img_dir, scene_id)
         os.makedirs(scene_img_dir, exist_ok=True)
         payloads = gt["images_jpeg_bytes"]
@@ -93,21 +94,24 @@ class TwoFrameVideoQAEngineDot(TwoFrameVideoQAEngine):
                                             extrinsics_w2c, base_img_dir, img_output_dir)
 
     def _all_scenes_dot(self, scene_id_list, source_data_root, base_img_dir, img_output_dir, npoints_per_group, npairs_per_bin,
-                        augment, augment_ratio):
+                        augment, augment_ratio, num_workers=20, ctx=None):
         parent = random.getstate()                  # fork-pool semantics, see TwoFrameVideoQAEngine._all_scenes
-        data = []
-        for scene_id in scene_id_list:
+
+        def run_one(path, loaded):
             random.setstate(parent)
-            data.extend(self.generate_qa_training_single_scene(os.path.join(source_data_root, f"{scene_id}.npz"), base_img_dir,
-                                                               npoints_per_group, npairs_per_bin, img_output_dir, augment,
-                                                               augment_ratio))
+            return self.generate_qa_training_single_scene(path, base_img_dir, npoints_per_group, npairs_per_bin, img_output_dir,
+                                                          augment, augment_ratio, _loaded=loaded)
+        data, self._ctx = sharded_scenes([os.path.join(source_data_root, f"{scene_id}.npz") for scene_id in scene_id_list],
+                                         run_one, num_workers, ctx)
         random.setstate(parent)
         return data
 
     def generate_qa_training_data(self, scene_id_list, source_data_root, base_img_dir, output_dir, output_file, img_output_dir,
                                   npoints_per_group, npairs_per_bin, augment, augment_ratio=1.0, max_samples=-1, num_workers=20):
         data = self._all_scenes_dot(scene_id_list, source_data_root, base_img_dir, img_output_dir, npoints_per_group,
-                                    npairs_per_bin, augment, augment_ratio)
+                                    npairs_per_bin, augment, augment_ratio, num_workers)
+        if not self._is_writer():
+            return
         if max_samples > 0 and len(data) > max_samples:
             data = random.sample(data, max_samples)
         random.shuffle(data)
@@ -118,7 +122,9 @@ class TwoFrameVideoQAEngineDot(TwoFrameVideoQAEngine):
                               npoints_per_group, npairs_per_bin, augment, augment_ratio=0.3, max_samples=300, num_workers=20):
         """Writes ``*_orig.jsonl`` (everything) and the subsampled file (reference: :640-683)."""
         data = self._all_scenes_dot(scene_id_list, source_data_root, base_img_dir, img_output_dir, npoints_per_group,
-                                    npairs_per_bin, augment, augment_ratio)
+                                    npairs_per_bin, augment, augment_ratio, num_workers)
+        if not self._is_writer():
+            return
         eval_data = [self.format_eval_sample(s) for s in data]
         heads.write_jsonl(output_file.replace(".jsonl", "_orig.jsonl"), eval_data)
         subsampled = random.sample(eval_data, max_samples) if max_samples > 0 and len(eval_data) > max_samples else eval_data

@@ -296,14 +296,8 @@ def test_pipeline_end_to_end_and_sharding_invariance(tmp_path):
             assert {"id", "image", "conversations", "height_list", "width_list", "question_type", "gt_value"} <= set(r)
             assert r["conversations"][0]["from"] == "human" and r["conversations"][1]["from"] == "gpt"
             assert len(r["image"]) == len(r["height_list"]) == len(r["width_list"])
-    # the numeric tapes on their own (one process): every unit is recorded, replayed from its tape on a ReplayScene that holds
-    # no device data, and must give the very records the direct run gave (asserted inside); the files are byte-identical
-    taped = str(tmp_path / "taped")
-    counts_t = pipeline.run(_pipeline_scenes(), taped, None, DEV, seed=3, n_camera=24, n_correspondence=24,
-                            depth_images_per_scene=3, tracks=_pipeline_tracks(), selftest_tape=True)
-    assert counts_t == counts
-    for name in counts:
-        assert open(f"{single}/{name}.jsonl", "rb").read() == open(f"{taped}/{name}.jsonl", "rb").read(), name
+    assert {"load_s", "pair_table_s", "heads_s", "exchange_s", "write_s", "records_bytes"} <= set(pipeline.LAST_TIMINGS)
+    assert "rank0_replay_s" not in pipeline.LAST_TIMINGS           # rank 0 rebuilds nothing: records arrive as finished text
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

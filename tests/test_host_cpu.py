@@ -202,20 +202,24 @@ def _worker(rank, world, port, q):
     work.wait()
     assert g.shape == (5 * world, 2) and all(int(g[5 * r, 0]) == r + 1 for r in range(world))
     t = ctx.max_over_ranks(float(rank + 1))
-    # numeric tapes of different length per rank, as mspa/pipeline.py collates them: [header, rows...] per unit, width 8
-    from mspa import tape as TP
-    rec = TP.Recorder(None)
-    rec.note(torch.arange(3 + 5 * rank, dtype=torch.float64) * 0.1 + rank)
-    local = TP.frame(10 + rank, rec.rows())
-    if rank == 1:                                  # a second unit on one rank, with an empty tape
-        local += TP.frame(99, TP.Recorder(None).rows())
-    table = S.collate_records(torch.from_numpy(np.concatenate(local, 0)), ctx).numpy()
-    tapes = TP.unframe(table)
-    assert sorted(tapes) == [10, 11, 99] and len(tapes[99]) == 0
-    got = {key: TP.Player(None, tapes[key], "cpu").next().numpy().tolist() for key in (10, 11)}
-    # the same exchange towards rank 0 only (what the pipeline does since round 4: rank 0 is the only reader)
-    to0 = S.collate_records(torch.from_numpy(np.concatenate(local, 0)), ctx, dst=0).numpy()
-    assert np.array_equal(to0, table) if rank == 0 else to0.shape == (0, TP.WIDTH)
+    # ragged float64 rows towards rank 0 only, as the scene sweeps collate a window (mspa/sweep.py): a rank may have none
+    rows = torch.arange(7 * (3 + 5 * rank), dtype=torch.float64).reshape(-1, 7) * 0.1 + rank if rank else torch.zeros((0, 7), dtype=torch.float64)
+    to0 = S.collate_records(rows, ctx, dst=0).numpy()
+    everywhere = S.collate_records(rows, ctx).numpy()
+    assert np.array_equal(to0, everywhere) if rank == 0 else to0.shape == (0, 7)
+    assert everywhere.shape == (8, 7) and everywhere[0, 0] == 1.0
+    # the pipeline's exchange of FINISHED records (mspa/pipeline.py): per-rank JSON lines + sort keys as bytes, to rank 0
+    from mspa import pipeline as PL
+    mine = {"head_a": [{"id": f"a{rank}_{k}", "v": [rank, k, 0.1 * k]} for k in range(2 + rank)]}
+    if rank == 1:
+        mine["head_b"] = [{"id": 7, "text": "caf\u00e9 \n two"}]            # a file only one rank contributes to; non-ASCII, newline
+    parts = S.gather_bytes(PL._pack_outputs(mine), ctx, dst=0)
+    got = None
+    if rank == 0:
+        merged = {}
+        for p in parts:
+            PL._unpack_outputs(p, merged)
+        got = {name: sorted((k, ln.decode()) for k, ln in v) for name, v in merged.items()}
     ctx.barrier()
     q.put((rank, full.numpy().tolist(), t, got))
     ctx.close()
@@ -246,7 +250,12 @@ def test_shard_and_collate_gloo_world2():
     for rank, full, t, tapes in results:
         assert full == expect, f"rank {rank}: collated records differ from the single-process table"
         assert t == 2.0
-        assert tapes == {10 + r: (np.arange(3 + 5 * r) * 0.1 + r).tolist() for r in range(2)}, "every rank's tape, whole, on every rank"
+        if rank == 0:
+            import json
+            want_a = sorted((f"a{r}_{k}", json.dumps({"id": f"a{r}_{k}", "v": [r, k, 0.1 * k]})) for r in range(2) for k in range(2 + r))
+            assert tapes == {"head_a": want_a, "head_b": [("7", json.dumps({"id": 7, "text": "caf\u00e9 \n two"}))]}
+        else:
+            assert tapes is None
 
 
 def test_correspondences_rowmajor_view_on_host_tensors():

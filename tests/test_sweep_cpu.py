@@ -134,6 +134,11 @@ def _install_oracle_standins():
     """The kernels' place is taken by the oracle; everything around them is the product code."""
     from oracle import np_oracle as O
     from mspa import visindex
+    for name in [m for m in sys.modules if m == "spatial_engine" or m.startswith("spatial_engine.")]:
+        if not (getattr(sys.modules[name], "__file__", None) or "").startswith(PKG):     # the reference's package, imported by
+            del sys.modules[name]                                                         # an earlier test module
+    if sys.path[0] != PKG:
+        sys.path.insert(0, PKG)
     import spatial_engine.camera_movement.calculate_frames_relations as CFR
     import spatial_engine.utils.scannet_utils.make_visibility_info as MVI
     sweep.prefetched_scenes = lambda host_scenes, device="cuda", timings=None: iter(host_scenes)
@@ -228,6 +233,9 @@ def test_run_split_sharded_over_two_ranks_is_byte_identical(tmp_path, monkeypatc
     monkeypatch.chdir(root)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
+    for stub in ("mmengine", "cv2"):                         # oracle/ref_harness.py's stand-ins, if an earlier test imported the reference
+        if getattr(sys.modules.get(stub), "__file__", None) is None:
+            monkeypatch.delitem(sys.modules, stub, raising=False)
     keep = (sweep.prefetched_scenes,)
     try:
         tables, vis, timings = _run_both(os.path.join(root, "one"))
