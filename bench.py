@@ -77,6 +77,7 @@ def _legs(spec):
 
 
 WORKLOADS = ("vc", "low", "high")
+SCENE_WORKLOAD = "scenes"        # BASELINE.json configs[2] in the bench's shape: whole scenes (K1 + K2 + K4), sharded longest-first
 
 
 def parse_args():
@@ -89,9 +90,12 @@ def parse_args():
     ap.add_argument("--base-frames", type=int, default=64, help="frames of the synthetic scene rendered on the host per "
                     "GPU (SURVEY.md 8d: F = 64 cameras per scene)")
     ap.add_argument("--scene-points", type=int, default=131072, help="scene vertices the overlap table is measured on")
-    ap.add_argument("--workload", choices=WORKLOADS, default="vc",
+    ap.add_argument("--workload", choices=WORKLOADS + (SCENE_WORKLOAD,), default="vc",
                     help="which pairs of the scene (mspa/workload.py): vc = the reference's overlap-binned sample 6..35 %% "
-                         "(headline), low = overlap < 6 %%, high = near-identical views")
+                         "(headline), low = overlap < 6 %%, high = near-identical views; 'scenes' = the scene-shaped job of "
+                         "configs[2] (K1 + K2 + K4 over 8 ScanNet-sized scenes per GPU, pair-table rows collated over RCCL)")
+    ap.add_argument("--scenes-per-gpu", type=int, default=8, help="--workload scenes: resident scenes per GPU")
+    ap.add_argument("--no-dropin-sweep", action="store_true", help="skip the from-disk run_split leg")
     ap.add_argument("--variant", choices=sorted(VARIANTS), default="corr")
     ap.add_argument("--mode", choices=("fast", "exact"), default="fast",
                     help="fast: MSPA_PAIR_FAST (bit-exact integers via guarded composed matrices); exact: the "
@@ -574,6 +578,222 @@ def time_scannet_shape(device, n_pairs=200, base_frames=16, steps=20, warm=8):
             "timing": f"{warm} untimed + {steps} timed launches per leg, one HIP event pair (one untimed pass of the first leg before)"}
 
 
+def time_track_geometry(device, T=300, P=256, n_scenes=256, reps=5):
+    """K5a (mspa_track_to_world: camera->world + normalised projection + validity, OM_C:446-454, 293-315) on TAPVid-3D-shaped
+    blocks -- BASELINE.json configs[3].  One block (T = 300 frames x P = 256 tracks) is 3.7 MB: a single launch
+    is latency-bound, so the leg also times `n_scenes` blocks concatenated along the frame axis (every frame carries its own
+    camera matrix, so scenes batch into one launch).  Bytes: SURVEY.md 8d's K5 figure T*P*(12 in + 12 out) + T*128 + T*P is
+    written for float32 points; the path computes in the reference's float64, so the bytes actually moved are
+    T*P*(24 in + 24 world + 16 uvn + 1 ok) + T*128 -- both fractions are printed."""
+    import torch
+    from mspa import engine, synth
+    tr = synth.make_tracks(300, T=T, P=P, n_groups=8)
+    c2w = np.linalg.inv(tr.extrinsics_w2c).reshape(T, 16)
+    out = {}
+    for name, n in (("one_block", 1), ("batched", n_scenes)):
+        tracks = torch.from_numpy(np.ascontiguousarray(tr.tracks_XYZ)).to(device).repeat(n, 1, 1)
+        cam = torch.from_numpy(c2w).to(device).repeat(n, 1)
+        want = ("world", "uvn", "ok")
+        for _ in range(2):
+            engine.track_to_world(tracks, cam, tr.fx_fy_cx_cy, tr.image_hw, want)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            engine.track_to_world(tracks, cam, tr.fx_fy_cx_cy, tr.image_hw, want)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        Tn = T * n
+        b_8d = Tn * P * 24 + Tn * 128 + Tn * P
+        b_f64 = Tn * P * (24 + 24 + 16 + 1) + Tn * 128
+        out[name] = {"scenes": n, "frames": Tn, "tracks": P, "ms_per_launch": round(ms, 4),
+                     "scenes_per_s": round(n / (ms * 1e-3), 1), "track_points_per_s": round(Tn * P / (ms * 1e-3), 1),
+                     "bytes_8d_formula": int(b_8d), "frac_8d_formula": round(b_8d / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "bytes_f64_moved": int(b_f64), "achieved_GBs": round(b_f64 / (ms * 1e-3) / 1e9, 1),
+                     "frac": round(b_f64 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del tracks, cam
+    out["includes"] = "launch + allocation of the three outputs by the caching allocator (one HIP event pair around the launches)"
+    return out
+
+
+def _disk_scenes(n_scenes, n_frames, n_points):
+    """Synthetic scenes for the from-disk leg: 8 rendered 640x480 frames each, referenced n_frames times under distinct
+    image ids (every file is written and decoded separately)."""
+    from mspa import synth
+    out = []
+    for k in range(n_scenes):
+        base = synth.make_scene(5000 + k, n_points=n_points, n_frames=8, color_hw=(H, W), depth_hw=(H, W), invalid_pose_frac=0.0,
+                                with_color=False, scene_id=f"scene{5000 + k:04d}_00")
+        ids = base.image_ids
+        E = {f"{5 * f:05d}": base.E[ids[f % 8]] for f in range(n_frames)}
+        depth = {f"{5 * f:05d}": base.depth[ids[f % 8]] for f in range(n_frames)}
+        out.append(synth.SynthScene(base.scene_id, base.K, base.A, E, base.points, depth, {}, base.color_hw, base.depth_hw,
+                                    base.boxes))
+    return out
+
+
+def time_dropin_sweep(n_scenes=8, n_frames=64, n_points=131072, num_workers=None):
+    """The drop-in entry point on on-disk inputs, one GPU: ``calculate_frames_relations.run_split`` (CFR:200-253) over scenes
+    written in the reference's layout (scene-info pickle, posed_images/<scene>/<id>.png 16-bit depth, aligned_points.npy):
+    native PNG ingest on `num_workers` host threads -> pinned staging -> H2D on the copy stream -> K1 + K2 + K4 -> parquet row
+    groups.  Reports scenes/s and the seconds each stage was busy (they overlap, so they sum to more than the wall time)."""
+    import shutil
+    import tempfile
+    from mspa import synth, sweep
+    import spatial_engine.camera_movement.calculate_frames_relations as CFR
+    from spatial_engine.utils.scannet_utils.handler import info_handler as IH
+    num_workers = num_workers or min(25, os.cpu_count() or 1)       # the reference's worker count (CFR:280)
+    root = tempfile.mkdtemp(prefix="mspa_dropin_")
+    try:
+        t0 = time.perf_counter()
+        paths = synth.write_scannet_layout(_disk_scenes(n_scenes, n_frames, n_points), root, compress_level=6)
+        t_write_inputs = time.perf_counter() - t0
+        png_bytes = sum(os.path.getsize(os.path.join(b, n)) for b, _, fs in os.walk(paths["posed_images_root"]) for n in fs
+                        if n.endswith(".png"))
+        orig_init = IH.SceneInfoHandler.__init__
+
+        def init(self, info_path, *a, **k):                          # run_split builds its handler with the default roots
+            orig_init(self, info_path, posed_images_root=paths["posed_images_root"], instance_data_root=paths["instance_data_root"])
+        IH.SceneInfoHandler.__init__ = init
+        try:
+            import contextlib
+            import io
+            runs = []
+            for rep in range(3):                                     # first pass warms the page cache, slots and kernels
+                tm = sweep.Timings()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    t0 = time.perf_counter()
+                    CFR.run_split(paths["info_path"], os.path.join(root, f"out{rep}", "pairs.parquet"),
+                                  os.path.join(root, f"warn{rep}.txt"), num_workers=num_workers, keep=False, timings=tm)
+                    dt = time.perf_counter() - t0
+                runs.append((dt, tm.as_dict()))
+        finally:
+            IH.SceneInfoHandler.__init__ = orig_init
+        dt, stages = sorted(runs[1:], key=lambda r: r[0])[0]
+        n_pairs = n_scenes * n_frames * (n_frames - 1) // 2
+        return {"entry_point": "spatial_engine.camera_movement.calculate_frames_relations.run_split", "scenes": n_scenes,
+                "frames_per_scene": n_frames, "vertices": n_points, "num_workers": num_workers,
+                "seconds": round(dt, 4), "scenes_per_s": round(n_scenes / dt, 2), "frames_per_s": round(n_scenes * n_frames / dt, 1),
+                "pair_rows_per_s": round(n_pairs / dt, 1), "png_MB_per_s": round(png_bytes / dt / 1e6, 1),
+                "stage_busy_s": {"decode (PNG read + inflate + np.load, loader threads)": stages.get("decode"),
+                                 "stage (pinned staging + H2D enqueue, copy stream)": stages.get("stage"),
+                                 "produce (K1 + K2 + K4 + the scene's small D2H)": stages.get("produce"),
+                                 "consume (arrow tables + parquet row groups)": stages.get("consume"),
+                                 "write (parquet only)": stages.get("write")},
+                "first_pass_seconds": round(runs[0][0], 4), "inputs_written_in_s": round(t_write_inputs, 2),
+                "png_bytes": int(png_bytes), "statistic": "faster of two warm passes (page cache warm: disk is not what is measured)"}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def run_scene_workload(args, rank, world, device, dist_ctx, share):
+    """--workload scenes: BASELINE.json configs[2] in the bench's shape.  `scenes_per_gpu` x world ScanNet-sized scenes
+    (131 072 vertices; 160..400 frames, so costs differ) are dealt longest-first (shard.lpt_assign, cost F^2 N / 64 + F N); each
+    rank keeps its scenes resident and a step = K1 + K2 + K4 over all of them, the [n_pairs, 7] float64 pair-table rows
+    written into one job tensor which is collated with ONE all_gather (shard.collate_records: RCCL over xGMI) inside the timed
+    region -- SURVEY.md 8e's exchange, 56 B per frame pair.  `value` = pair-table rows of all ranks / slowest rank's time."""
+    import torch
+    import torch.distributed as dist
+    from mspa import engine, shard, synth
+    from mspa.scene import SceneOnDevice
+    n_total = args.scenes_per_gpu * world
+    frames = [160 + 40 * ((3 * k) % 7) for k in range(n_total)]                   # 160 .. 400, the every-5th-frame range
+    costs = [shard.scene_cost(f, args.scene_points) for f in frames]
+    bins = shard.lpt_assign(costs, world)
+    base = synth.make_scene(4000 + rank, n_points=args.scene_points, n_frames=8, color_hw=(H, W), depth_hw=(H, W),
+                            invalid_pose_frac=0.0, with_color=False)
+    ids = base.image_ids
+    scenes = []
+    for k in bins[rank]:
+        F = frames[k]
+        E = {f"{f:05d}": base.E[ids[f % 8]] for f in range(F)}
+        depth = {f"{f:05d}": base.depth[ids[f % 8]] for f in range(F)}
+        scenes.append((k, SceneOnDevice(base.K, base.A, E, depth, (H, W), base.points, device)))
+    n_rows = sum(frames[k] * (frames[k] - 1) // 2 for k in bins[rank])
+    job = torch.empty((n_rows, 7), dtype=torch.float64, device=device)
+    pair_idx = {k: engine.all_pairs(frames[k], device) for k in bins[rank]}
+
+    def step():
+        lo = 0
+        for k, sc in scenes:
+            sc._vis = None                                                        # K1 runs again every step
+            vis = sc._visibility()
+            pairs = pair_idx[k]
+            n = pairs.shape[0]
+            rows = job[lo:lo + n]
+            rows[:, 0] = k
+            rows[:, 1:3] = pairs.to(torch.float64)
+            rows[:, 3] = engine.scene_overlap(vis["bits"])
+            rows[:, 4:7] = engine.pair_pose(*sc.pose_tables(), pairs)[:, 0:3]
+            lo += n
+        return shard.collate_records(job, dist_ctx) if dist_ctx is not None else job
+
+    for _ in range(max(1, args.warmup)):
+        table = step()
+    if dist_ctx is not None:
+        dist_ctx.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        table = step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist_ctx is not None:
+        dist_ctx.barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1) / args.steps
+    rank_walls, rows_all = [wall], [n_rows]
+    if dist_ctx is not None:
+        t = torch.tensor([wall, float(n_rows)], dtype=torch.float64, device=dist_ctx.collective_device)
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t, group=dist_ctx.group)
+        rank_walls, rows_all = [float(p[0]) for p in parts], [int(p[1]) for p in parts]
+        wall = max(rank_walls)
+    total_rows = sum(rows_all)
+    if rank != 0:
+        return None
+    assert table.shape[0] == total_rows, "the collated pair table does not hold every rank's rows"
+    got = np.sort(np.unique(table[:, 0].cpu().numpy().astype(np.int64)))
+    assert got.tolist() == list(range(n_total)), "a scene's rows are missing from the collated table"
+    # algorithmic bytes of this rank's step: K1 compulsory (vertices once per scene, every depth frame, every bitset row) +
+    # K2 (every bitset row once per scene + 8 B per pair out) + the row table written once
+    mine = bins[0]
+    b_k1 = sum(24 * args.scene_points + frames[k] * (2 * H * W + args.scene_points // 8) for k in mine)
+    b_k2 = sum(frames[k] * args.scene_points // 8 for k in mine) + 56 * rows_all[0]
+    rates = [r * args.steps / w for r, w in zip(rows_all, rank_walls)]
+    line = {"metric": "frame-pairs/sec MultiSPA geometry pipe (640x480 RGB-D)", "value": round(total_rows * args.steps / wall, 1),
+            "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "camera_movement pair table (BASELINE.json configs[2] shape): K1 vertex visibility + K2 all-pairs "
+                                   "overlap + K4 relative pose over whole scenes, every frame pair i < j of a scene is one row",
+                       "scenes_per_gpu": args.scenes_per_gpu, "scenes": n_total, "vertices_per_scene": args.scene_points,
+                       "frames_per_scene": sorted(set(frames)), "assignment": "shard.lpt_assign (longest first, cost F^2 N / 64 + F N)",
+                       "rows_per_rank": {"min": min(rows_all), "max": max(rows_all)},
+                       "collation": ("none (1 GPU)" if dist_ctx is None else
+                                     "ONE all_gather of every rank's [rows, 7] float64 pair-table rows per step, inside the timed "
+                                     "region (" + ("gloo: ranks share GPUs" if share else "RCCL") + ")"),
+                       "collation_backend": dist_ctx.backend if dist_ctx is not None else None,
+                       "bytes_collated_per_step": 56 * total_rows if dist_ctx is not None else 0,
+                       "parallelism": f"dp{world}"},
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                         "achieved": round((b_k1 + b_k2) / (dev_ms * 1e-3) / 1e9, 1),
+                         "frac": round((b_k1 + b_k2) / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "mspa::vertex_visibility_compact_kernel + overlap tiles + pair_pose (whole step on rank 0)",
+                         "kernel_ms": round(dev_ms, 4), "bytes_per_launch": int(b_k1 + b_k2),
+                         "note": "compulsory bytes of rank 0's step / its HIP-event time; K1 is latency-bound (DESIGN 7.4), so this "
+                                 "fraction is low by construction -- the headline roofline is the K3 line of the default workload"},
+            "cpu_baseline": None,
+            "per_rank_pairs_per_s": {"min": round(min(rates), 1), "max": round(max(rates), 1)},
+            "device": None}
+    if dist_ctx is not None:
+        line["rccl_world"] = dist.get_world_size()
+        line["gpus_shared"] = bool(share)
+    return line
+
+
 _CPU_SCENE = None
 
 
@@ -676,6 +896,23 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     _lib.load()
+    if args.workload == SCENE_WORKLOAD:
+        dist_ctx = (shard.init_distributed(device, backend="gloo" if share else None)
+                    if (world > 1 or os.environ.get("MSPA_BENCH_FORCE_DIST")) else None)
+        line = run_scene_workload(args, rank, world, device, dist_ctx, share)
+        if rank == 0:
+            line["device"] = _lib.device_info(dev_index)
+        if dist_ctx is not None:
+            dist_ctx.barrier()
+            dist_ctx.close()
+        if rank == 0:
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            print(json.dumps(line), flush=True)
+        return
     sc = make_base_scene(args, rank)
     depth, mats, rgb, nb, reps = build_inputs(args, rank, device, sc)
     overlap = scene_overlap_table(sc, device)
@@ -735,6 +972,24 @@ def main():
             d["traffic_frac"] = None
         return d
 
+    dev_info = _lib.device_info(dev_index)
+
+    def valu_roofline(v, m, wl, k_ms):
+        """The instruction-issue roofline of a leg that is VALU-bound rather than HBM-bound: VALU instructions per launch
+        (SQ_INSTS_VALU of the committed PMC pass, as `traffic`) x 64 lanes / this run's kernel time, against the chip's
+        lane-instruction issue peak n_cu x 4 SIMDs x 16 lanes x clock.  Every instruction is counted at the 4-cycle full rate
+        although float64 multiply / fma / divide-step issue at half of it or less (profiles/r04_valu_rates.md), so `frac` is a
+        LOWER bound of how busy the pipe is."""
+        t = committed_traffic(f"{v}:{m}:{wl}") if args.pairs == 1000 else None
+        if not t or not t.get("valu_insts_per_launch"):
+            return None
+        peak = dev_info["n_cu"] * 4 * 16 * dev_info["clock_khz"] * 1e3
+        ach = t["valu_insts_per_launch"] * 64.0 / (k_ms * 1e-3)
+        return {"bound": "fp64_valu_issue", "unit": "lane-instr/s", "peak_lane_instr_per_s": peak, "achieved": round(ach, 1),
+                "frac": round(ach / peak, 4), "valu_insts_per_launch": t["valu_insts_per_launch"],
+                "valu_insts_per_wave": round(t["valu_insts_per_launch"] / max(1, t.get("waves_per_launch", 0) or 1), 1),
+                "source": t.get("valu_source", t.get("source")) + " -- committed PMC pass, NOT measured in this run"}
+
     def leg(v, m, prs, steps, wl):
         w2, k2, o2 = time_variant(v, m, depth, mats, rgb, prs, steps, 1, None, stream)
         b2 = variant_bytes(v, args.pairs, o2)
@@ -754,7 +1009,11 @@ def main():
             d["note"] = ("pair_exact_kernel: the reference's own operation order (five 3x4 products + IEEE division per pixel), "
                          "FP64-issue bound, not HBM bound -- the bit-exact path every float64-output call takes; the fast kernels "
                          "reproduce its integers")
-        return with_traffic(d, v, m, wl, k2)
+        d = with_traffic(d, v, m, wl, k2)
+        rv = valu_roofline(v, m, wl, k2)
+        if rv:
+            d["roofline_valu"] = rv
+        return d
 
     extra, sweep = {}, {}
     head_vis = vis_fraction(out) if rank == 0 else None
@@ -797,6 +1056,12 @@ def main():
             extra["scannet_shape:compact"] = extra["scannet_shape:fast"].pop("compact")
             extra["scene"] = time_scene_kernels(device)
             extra["pipeline"] = time_scene_pipeline(device)
+            extra["K5_track_geometry"] = time_track_geometry(device)
+            if not args.no_dropin_sweep:
+                try:
+                    extra["dropin_sweep"] = time_dropin_sweep()
+                except Exception as e:                       # e.g. no Pillow / no pyarrow on the box: the leg is informational
+                    extra["dropin_sweep"] = {"skipped": f"{type(e).__name__}: {e}"}
             t1 = committed_traffic("K1_vertex_visibility")
             if t1:
                 k1 = extra["scene"]["K1_vertex_visibility"]["shuffled_worst_case"]   # the PMC passes ran on the shuffled cloud
@@ -817,7 +1082,7 @@ def main():
         tkey = f"{args.variant}:{args.mode}:{args.workload}"
         t = committed_traffic(tkey) if args.pairs == 1000 else None
         traffic = t["hbm_bytes_per_launch"] if t else None
-        info = _lib.device_info(dev_index)
+        info = dev_info
         ceilings = measured_hbm_ceilings(device) if (world == 1 and not args.no_scene_legs) else None
         tight = args.mode != "exact"
         line = {
@@ -857,7 +1122,11 @@ def main():
                          "kernel_ms": round(kern_ms, 4), "bytes_per_pair": int(bytes_per_launch / args.pairs),
                          "bytes_per_launch": int(bytes_per_launch),
                          "measured_ceilings_GBs": ceilings},
+            "roofline_valu": valu_roofline(args.variant, args.mode, args.workload, kern_ms),
             "cpu_baseline": cpu,
+            "cpu_baseline_pool": None if not cpu or not cpu.get("pool") else dict(
+                cpu["pool"], unit="frame-pairs/s", kind="port",
+                what="the same NumPy restatement over multiprocessing.Pool(min(25, cores)) -- the reference's own fan-out (CFR:280)"),
             "sweep": sweep,
             "variants": extra,
             "device": info,

@@ -301,22 +301,26 @@ def write_scannet_layout(scenes: Sequence["SynthScene"], root: str, info_name: s
     import os
     import pickle
     from PIL import Image
+    from concurrent.futures import ThreadPoolExecutor
     posed, inst = os.path.join(root, "posed_images"), os.path.join(root, "scannet_instance_data")
-    infos = {}
+    infos, jobs = {}, []
     for sc in scenes:
         os.makedirs(os.path.join(posed, sc.scene_id), exist_ok=True)
         os.makedirs(os.path.join(inst, sc.scene_id), exist_ok=True)
         np.save(os.path.join(inst, sc.scene_id, "aligned_points.npy"), sc.points)
         H, W = sc.color_hw
         for n, (image_id, d) in enumerate(sc.depth.items()):
-            Image.fromarray(np.ascontiguousarray(d, dtype=np.uint16)).save(
-                os.path.join(posed, sc.scene_id, f"{image_id}.png"), compress_level=compress_level)
+            jobs.append((Image.fromarray(np.ascontiguousarray(d, dtype=np.uint16)),
+                         os.path.join(posed, sc.scene_id, f"{image_id}.png"), {"compress_level": compress_level}))
             col = sc.color.get(image_id) if sc.color else None
             if col is not None:
-                Image.fromarray(col).save(os.path.join(posed, sc.scene_id, f"{image_id}.jpg"), quality=90)
+                jobs.append((Image.fromarray(col), os.path.join(posed, sc.scene_id, f"{image_id}.jpg"), {"quality": 90}))
             elif n == 0:
-                Image.new("RGB", (W, H), (128, 128, 128)).save(os.path.join(posed, sc.scene_id, f"{image_id}.jpg"), quality=50)
+                jobs.append((Image.new("RGB", (W, H), (128, 128, 128)), os.path.join(posed, sc.scene_id, f"{image_id}.jpg"),
+                             {"quality": 50}))
         infos[sc.scene_id] = sc.info_dict()
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:      # the encoders release the interpreter lock
+        list(ex.map(lambda j: j[0].save(j[1], **j[2]), jobs))
     info_path = os.path.join(inst, info_name)
     with open(info_path, "wb") as f:
         pickle.dump(infos, f)

@@ -37,6 +37,7 @@ def check_line(j, n):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert "traffic_source" in r
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
+    assert "cpu_baseline_pool" in j and "roofline_valu" in j
     assert j["config"]["pairs"]["rule"].startswith("equal quotas over the overlap bins 6..35")
     assert 0 < j["config"]["visible_fraction"] < 1
 
@@ -97,3 +98,42 @@ def test_collate_records_on_device_tensors_over_rccl():
         env.pop(k, None)
     out = subprocess.run([sys.executable, "-c", RCCL_WORLD1], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0 and "rccl world-1 ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+SCENES_SMALL = ["--workload", "scenes", "--steps", "2", "--warmup", "1", "--scenes-per-gpu", "3", "--scene-points", "8192"]
+
+
+def check_scene_line(j, n):
+    assert j["n_gpus"] == n and j["unit"] == "frame-pairs/s" and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["config"]["scenes"] == 3 * n and j["config"]["parallelism"] == f"dp{n}"
+    assert j["config"]["rows_per_rank"]["min"] > 10000 and j["roofline"]["kernel_ms"] > 0
+    assert j["per_rank_pairs_per_s"]["min"] > 0
+
+
+def test_bench_scene_workload_one_rank_rccl_and_two_ranks():
+    """`--workload scenes` (BASELINE.json configs[2] shape): whole scenes dealt longest-first, K1 + K2 + K4 per rank, the
+    pair-table rows collated inside the timed region -- as one rank over RCCL (a world of one: the device-tensor branch) and as
+    two ranks sharing the GPU over gloo."""
+    j = run([sys.executable, "bench.py", "--gpus", "1"] + SCENES_SMALL)
+    check_scene_line(j, 1)
+    assert j["config"]["collation"].startswith("none")
+    j = run([sys.executable, "bench.py", "--gpus", "1"] + SCENES_SMALL, MSPA_BENCH_FORCE_DIST="1")
+    check_scene_line(j, 1)
+    assert j["config"]["collation_backend"] == "nccl" and j["rccl_world"] == 1 and j["config"]["bytes_collated_per_step"] > 0
+    j = run([sys.executable, "bench.py", "--gpus", "2"] + SCENES_SMALL)
+    check_scene_line(j, 2)
+    assert j["rccl_world"] == 2 and j["config"]["bytes_collated_per_step"] == 56 * sum(
+        f * (f - 1) // 2 for f in [160 + 40 * ((3 * k) % 7) for k in range(6)])
+
+
+def test_bench_informational_legs_run_small():
+    """The from-disk drop-in leg and the K5 leg of the default line, at sizes that take seconds."""
+    sys.path[:0] = [ROOT]
+    import bench
+    import torch
+    d = bench.time_dropin_sweep(n_scenes=3, n_frames=6, n_points=4096, num_workers=4)
+    assert d["scenes"] == 3 and d["scenes_per_s"] > 0 and d["pair_rows_per_s"] > 0
+    busy = d["stage_busy_s"]
+    assert all(v is not None and v >= 0 for v in busy.values()) and len(busy) == 5
+    k5 = bench.time_track_geometry(torch.device("cuda", 0), T=60, P=32, n_scenes=4, reps=2)
+    assert k5["batched"]["frames"] == 240 and k5["one_block"]["frac"] > 0
