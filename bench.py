@@ -447,6 +447,8 @@ def time_scene_kernels(device, n_points=131072, n_frames=320, reps=5):
                                      "compulsory_frac": round(b1 / (t1s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                      "includes": "vertex_visibility_compact_kernel + bits_count_kernel",
                                      "vertex_order": "spatially coherent (Morton curve over the synthetic cloud: mesh-like)",
+                                     "method_changed_in_round": 4,    # rounds 1-3 printed the shuffled cloud under these keys
+                                                                      # (now `shuffled_worst_case`): not like for like across it
                                      "same_counts_as_shuffled": same_counts,
                                      "shuffled_worst_case": {"kernel_ms": round(t1, 4), "images_per_s": round(F / (t1 * 1e-3), 1),
                                                              "compulsory_frac": round(b1 / (t1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -549,8 +551,8 @@ def time_scannet_shape(device, n_pairs=200, base_frames=16, steps=20, warm=8):
 
     # the same set through round 2-3's wobbling-stripe kernel (MSPA_PAIR_WORD_STRIPES; the rectangular-tile kernel is the
     # default since round 4), and the fused compacted set: bitset + 4 B per VISIBLE pixel + a count per tile, no dense table
-    ms_rect = timed(lambda: engine.pair_reproject(depth, mats, pairs, (CH, CW), out, flags=flags | _lib.PAIR_WORD_STRIPES))
-    kern_rect = _lib.load().mspa_pair_reproject_last_kernel()
+    ms_ws = timed(lambda: engine.pair_reproject(depth, mats, pairs, (CH, CW), out, flags=flags | _lib.PAIR_WORD_STRIPES))
+    kern_ws = _lib.load().mspa_pair_reproject_last_kernel()
     comp = engine.alloc_pair_correspondences(n_pairs, (CH, CW), device)
     ms_comp = timed(lambda: engine.pair_correspondences(depth, mats, pairs, (CH, CW), comp, flags=flags))
     kern_comp = _lib.load().mspa_pair_reproject_last_kernel()
@@ -566,7 +568,7 @@ def time_scannet_shape(device, n_pairs=200, base_frames=16, steps=20, warm=8):
                "achieved_GBs": round(bcomp / (ms_comp * 1e-3) / 1e9, 1), "frac": round(bcomp / (ms_comp * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                "visible_fraction": round(float(c[:, 1].sum() / max(1, c[:, 0].sum())), 4)}
     return {"shape": "colour 1296x968 over depth 640x480", "pairs": n_pairs, "kernel_ms": round(ms, 4),
-            "word_stripes_ms_per_1000_pairs": round(ms_rect / n_pairs * 1000, 4) if kern_rect == _lib.KERNEL_PAIR_FAST_SCALED else None,
+            "word_stripes_ms_per_1000_pairs": round(ms_ws / n_pairs * 1000, 4) if kern_ws == _lib.KERNEL_PAIR_FAST_SCALED else None,
             "compact": compact,
             "kernel": "mspa::pair_fast_tight_kernel<corr, SCALED> (rectangular tiles)" if kern == _lib.KERNEL_PAIR_FAST_RECT else f"kernel id {kern}",
             "ms_per_1000_pairs": round(ms / n_pairs * 1000, 4), "pairs_per_s_1gpu": round(n_pairs / (ms * 1e-3), 1),

@@ -158,9 +158,10 @@ int mspa_pair_reproject(const uint16_t *depth, const uint8_t *rgb, const double 
 #define MSPA_KERNEL_PAIR_FAST_TIGHT 4     /* whole-tile images (W % 64 == 0, H % 48 == 0, colour == depth grid), output set
                                              corr / dense / dense without colour / minimal / compact */
 #define MSPA_KERNEL_PAIR_FAST_SCALED 5    /* ScanNet's 1296x968 over 640x480 on word-aligned wobbling stripes (MSPA_PAIR_WORD_STRIPES only) */
-#define MSPA_KERNEL_PAIR_FAST_RECT 6      /* the tight kernel on rectangular tiles of ANY colour / depth grid pair with W % 16 == 0,
-                                             H % 4 == 0, dw % 4 == 0, dh % 2 == 0 (ScanNet's shape included): correspondence /
-                                             minimal / compacted sets */
+#define MSPA_KERNEL_PAIR_FAST_RECT 6      /* the tight kernel on rectangular tiles of a colour / depth grid pair with dw <= W, dh <= H,
+                                             W % 16 == 0, H % 4 == 0, dw % 4 == 0, dh % 2 == 0, H * W * 4 < 2^31 and
+                                             dh * dw * 2 < 2^31 that is not a whole-tile shape (ScanNet's shape included):
+                                             correspondence / minimal / compacted sets */
 int mspa_pair_reproject_last_kernel(void);
 
 /*
@@ -179,8 +180,10 @@ int mspa_pair_reproject_last_kernel(void);
  *   out_tile_counts  [n_pairs, n_tiles] int32       visible pixels per tile (= entries of its segment)
  *   out_counts       [n_pairs, 2] int32 or NULL     (#valid, #visible); zeroed by the call
  * With MSPA_PAIR_FAST on a whole-tile shape (W % 64 == 0, H % 48 == 0, colour grid == depth grid: BASELINE's 640x480) and on
- * every shape with W % 16 == 0, H % 4 == 0, dw % 4 == 0 (ScanNet's own 1296x968 colour over 640x480 depth; ragged tiles hold
- * fewer pixels, same indexing) one fused kernel produces all of it; every other shape / mode runs mspa_pair_reproject into a dense table in
+ * every shape with dw <= W, dh <= H, W % 16 == 0, H % 4 == 0, dw % 4 == 0, dh % 2 == 0, H * W * 4 < 2^31 and dh * dw * 2 < 2^31
+ * (the predicate of MSPA_KERNEL_PAIR_FAST_RECT: ScanNet's own 1296x968 colour over 640x480 depth; ragged tiles hold fewer
+ * pixels, same indexing) one fused kernel produces all of it -- mspa_pair_correspondences_workspace_bytes() is the authority
+ * on which shapes those are (it returns 0 for them); every other shape / mode runs mspa_pair_reproject into a dense table in
  * `workspace` (caller-owned, 16-byte aligned, at least mspa_pair_correspondences_workspace_bytes(...) bytes; NULL / 0 when
  * that returns 0) and compacts it with mspa_compact_correspondences.  Identical results either way (bit-exact integers).
  * out_cpix_i16 must be 16-byte aligned.  MSPA_PAIR_STREAM as in mspa_pair_reproject.  The fused kernel additionally needs

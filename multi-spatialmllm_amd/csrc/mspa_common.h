@@ -89,21 +89,24 @@ __device__ __forceinline__ Guard guard_from_bounds(const double *__restrict__ b1
     const double B1 = __builtin_fma(b2[5], w, b2[9]);
     const double B2 = __builtin_fma(b2[6], w, b2[10]);
     Guard g;
-    g.zmin = __builtin_fma(wh_max + 1.0, B2, B0 + B1) * (2.0 / kGuardPx);
-    g.zsafe = __builtin_fma(2.0, B2, g.zmin);
-    g.gz = __builtin_fma(2.0, B2, kGuardZmmFloor);
+    // A record whose bound slot was never filled (zeros: a caller that skipped mspa_frame_bounds_host) or holds NaN must not
+    // yield a thin band: then nothing is trusted -- every lane takes the exact chain, results stay right, only speed is lost.
+    const bool sane = (B0 + B1 + B2) > 0.0;                   // false for zeros and for NaN (wave-uniform: a scalar select)
+    g.zmin = sane ? __builtin_fma(wh_max + 1.0, B2, B0 + B1) * (2.0 / kGuardPx) : __builtin_inf();
+    g.zsafe = sane ? __builtin_fma(2.0, B2, g.zmin) : __builtin_inf();
+    g.gz = sane ? __builtin_fma(2.0, B2, kGuardZmmFloor) : __builtin_inf();
     return g;
 }
 
 // The culling margins against the pair's bound over the whole image (columns <= xmax, rows <= ymax) and the full sample range.
-// NaN coefficients compare false: nothing is culled.
+// NaN coefficients compare false and an unfilled (all-zero) slot is refused: nothing is culled then.
 __device__ __forceinline__ bool cull_margins_hold(const double *__restrict__ b1, const double *__restrict__ b2, double xmax,
                                                   double ymax, double wh_max) {
     const double w = __builtin_fma(__builtin_fma(b1[0], xmax, __builtin_fma(b1[1], ymax, b1[2])), 65535.0, b1[3]);
     const double B0 = __builtin_fma(b2[4], w, b2[8]);
     const double B1 = __builtin_fma(b2[5], w, b2[9]);
     const double B2 = __builtin_fma(b2[6], w, b2[10]);
-    return (__builtin_fma(wh_max, B2, B0 + B1) < 0.25 * kCullMarginXY) & (B2 < 0.25 * kCullMarginZ);
+    return ((B0 + B1 + B2) > 0.0) & (__builtin_fma(wh_max, B2, B0 + B1) < 0.25 * kCullMarginXY) & (B2 < 0.25 * kCullMarginZ);
 }
 
 // np.round(v).astype(int) then np.clip(.., 0, hi) (IH:362-366, OPS:285-290): half-to-even, the

@@ -2112,10 +2112,10 @@ static bool tight_shape(int32_t dh, int32_t dw, int32_t H, int32_t W, int rows =
     return dh == H && dw == W && (W % 64 == 0) && (H % rows == 0) && ((uint64_t)H * (uint64_t)W * 4 < (1ull << 31));
 }
 
-// shapes the tight kernel takes in its SCALED form (rectangular tiles on any colour / depth grid combination): bitset rows in
-// whole 16-bit pieces, whole 4-row groups, depth rows in whole 8-byte pieces, 32-bit byte offsets
+// shapes the tight kernel takes in its SCALED form (rectangular tiles on a colour grid at least as fine as the depth grid):
+// bitset rows in whole 16-bit pieces, whole 4-row groups, depth rows in whole 8-byte pieces, 32-bit byte offsets
 static bool rect_shape(int32_t dh, int32_t dw, int32_t H, int32_t W) {
-    return !tight_shape(dh, dw, H, W) && (W % 16 == 0) && (H % 4 == 0) && (dw % 4 == 0) && (dh % 2 == 0) &&
+    return !tight_shape(dh, dw, H, W) && dw <= W && dh <= H && (W % 16 == 0) && (H % 4 == 0) && (dw % 4 == 0) && (dh % 2 == 0) &&
            ((uint64_t)H * (uint64_t)W * 4 < (1ull << 31)) && ((uint64_t)dh * (uint64_t)dw * 2 < (1ull << 31));
 }
 
@@ -2165,7 +2165,9 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
     // ... and so does a bitset output whose words straddle the 64-column stripes (W % 64 != 0, e.g. ScanNet's
     // 1296-wide colour grid): the stripe-mapped fast kernel would need two atomicOr per wave-row there and
     // measures slower than the exact kernel's word-aligned linear mapping (7.7 vs 6.7 ms per 1 000 pairs).
-    const bool fast = (flags & MSPA_PAIR_FAST) && !out_xyz_f64 && !out_uv_f64 && !out_depth_f64;
+    // ... and so does a depth grid LARGER than the colour grid (sx or sy > 1; no dataset has one): the guard band is built from
+    // colour-grid quantities and its half-guard margin is only argued for sx, sy <= 1.
+    const bool fast = (flags & MSPA_PAIR_FAST) && !out_xyz_f64 && !out_uv_f64 && !out_depth_f64 && dw <= W && dh <= H;
     const bool linear = fast && out_vis_bits && (W % 64 != 0);   // bitset on a width that is not a multiple of 64
     uint32_t set = 0;
     set |= out_vis_bits ? O_VIS_BITS : 0; set |= out_vis_u8 ? O_VIS_U8 : 0; set |= out_valid_u8 ? O_VALID_U8 : 0;

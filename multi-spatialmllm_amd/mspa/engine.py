@@ -282,6 +282,10 @@ def pair_correspondences(depth: torch.Tensor, mats: torch.Tensor, pairs: torch.T
              "out['vis_bits']: int64 [n_pairs, ceil(P / 64)]")
     need = int(lib.mspa_pair_correspondences_workspace_bytes(n, DH, DW, H, W, flags))
     _require(need >= 0, "image size within [2, 32767]")
+    if need == 0 and depth.data_ptr() & 3:
+        # a depth VIEW at an odd 2-byte offset: the fused kernel's 4-byte LDS-DMA cannot take it and the C entry point goes
+        # through the dense table, which needs a workspace although the size query (it cannot see the pointer) said 0
+        need = n * H * W * 4
     if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
         workspace = torch.empty((need + 3) // 4, dtype=torch.int32, device=depth.device)
     _lib.check(lib.mspa_pair_correspondences(

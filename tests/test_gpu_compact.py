@@ -195,6 +195,11 @@ def test_compact_argument_checks():
     n0 = fused["tile_counts"][0].cpu().numpy()
     for t in range(n0.size):
         assert torch.equal(out["cpix"][0, t, :n0[t]], fused["cpix"][0, t, :n0[t]])
+    # the Python wrapper allocates that workspace itself, as its docstring promises ("allocated here when not given")
+    via_wrapper = engine.pair_correspondences(odd, mats, pairs, hw, flags=_lib.PAIR_FAST)
+    torch.cuda.synchronize()
+    for k in ("vis_bits", "tile_counts", "counts"):
+        assert torch.equal(via_wrapper[k], fused[k]), k
     # zero pairs: nothing to do
     empty = engine.alloc_pair_correspondences(0, hw, DEV)
     engine.pair_correspondences(depth, mats, pairs[:0], hw, empty)

@@ -191,3 +191,55 @@ def test_rect_kernel_near_camera2_plane():
     out_np = {k: v.cpu().numpy() for k, v in out.items()}
     for n, ref in enumerate(refs):
         check_compact_pair(out_np, n, ref, hw)
+
+
+@pytest.mark.gpu
+def test_depth_grid_larger_than_colour_takes_the_reference_order_kernel():
+    """A depth grid finer than the colour grid (sx, sy > 1; no dataset has one): the fast kernels' guard band is only argued for
+    sx, sy <= 1, so MSPA_PAIR_FAST is ignored there -- the exact kernel runs, the compacted set goes through the dense table --
+    and the integers match the oracle."""
+    hw, dhw = (48, 64), (96, 128)
+    sc, ids, depth, mats = scene(hw, dhw, 3031)
+    pair_idx = [(0, 1), (1, 0), (2, 2), (4, 0)]
+    pairs = torch.tensor(pair_idx, dtype=torch.int32, device=DEV)
+    refs = [O.frame_pair(sc.depth[ids[a]], sc.depth[ids[b]], sc.K, sc.E[ids[a]], sc.E[ids[b]], sc.A, hw) for a, b in pair_idx]
+    assert sum(r["n_vis"] for r in refs) > 200
+    lib = _lib.load()
+    assert lib.mspa_pair_correspondences_workspace_bytes(len(pair_idx), dhw[0], dhw[1], hw[0], hw[1], _lib.PAIR_FAST) > 0
+    for sname in ("corr", "minimal"):
+        res, kern = launch(depth, mats, None, pairs, hw, SETS[sname], _lib.PAIR_FAST)
+        assert kern == _lib.KERNEL_PAIR_EXACT
+        for n, ref in enumerate(refs):
+            check_integers(res, n, ref, hw)
+    out = poisoned_outputs(len(pair_idx), hw)
+    engine.pair_correspondences(depth, mats, pairs, hw, out, flags=_lib.PAIR_FAST)
+    torch.cuda.synchronize()
+    out_np = {k: v.cpu().numpy() for k, v in out.items()}
+    for n, ref in enumerate(refs):
+        check_compact_pair(out_np, n, ref, hw)
+
+
+@pytest.mark.gpu
+def test_unfilled_or_nan_bound_slots_lose_speed_not_correctness():
+    """A C caller that moves to the 8-slot frame records but never calls mspa_frame_bounds_host leaves slot MSPA_MAT_BOUNDS
+    zeroed; a NaN may sit there as well.  The guard then trusts nothing (every lane takes the exact chain) and nothing is
+    culled: integers still equal the oracle, on the whole-tile kernel and on the rectangular one."""
+    for hw, dhw, want in (((96, 128), (96, 128), _lib.KERNEL_PAIR_FAST_TIGHT), ((100, 144), (48, 72), _lib.KERNEL_PAIR_FAST_RECT)):
+        sc, ids, depth, mats = scene(hw, dhw, 3032)
+        pair_idx = [(0, 1), (1, 0), (0, 4), (3, 3)]
+        pairs = torch.tensor(pair_idx, dtype=torch.int32, device=DEV)
+        refs = [O.frame_pair(sc.depth[ids[a]], sc.depth[ids[b]], sc.K, sc.E[ids[a]], sc.E[ids[b]], sc.A, hw) for a, b in pair_idx]
+        for fill in (0.0, float("nan")):
+            bad = mats.clone()
+            bad[:, _lib.MAT_BOUNDS, :] = fill
+            for sname in ("corr", "minimal"):
+                res, kern = launch(depth, bad, None, pairs, hw, SETS[sname], _lib.PAIR_FAST)
+                assert kern == want
+                for n, ref in enumerate(refs):
+                    check_integers(res, n, ref, hw)
+            out = poisoned_outputs(len(pair_idx), hw)
+            engine.pair_correspondences(depth, bad, pairs, hw, out, flags=_lib.PAIR_FAST)
+            torch.cuda.synchronize()
+            out_np = {k: v.cpu().numpy() for k, v in out.items()}
+            for n, ref in enumerate(refs):
+                check_compact_pair(out_np, n, ref, hw)
