@@ -758,7 +758,27 @@ constexpr int kTightRowsDense = MSPA_TIGHT_ROWS_DENSE;
 #endif
 // rows whose depth-2 gathers are in flight together: the sets without a transpose stage (minimal, compact) may take more
 constexpr int tight_rg_of(uint32_t set) { return (set & (O_PIX | O_XYZ32 | O_RGBA | O_VIS_U8)) ? kRowGroup : MSPA_TIGHT_RG_LIGHT; }
-constexpr int tight_rows_of(uint32_t set) { return (set & (O_XYZ32 | O_RGBA | O_VIS_U8)) ? kTightRowsDense : kTightRows; }
+#ifndef MSPA_WG_COMPOSE
+#define MSPA_WG_COMPOSE 0              // 1: the pair's composed matrix once per WORKGROUP (wave 0 -> LDS -> the others), not per wave
+#endif
+#ifndef MSPA_SCALED_CULL_BATCH
+#define MSPA_SCALED_CULL_BATCH 4       // SCALED form, culled tile: rows whose samples are requested together for the valid-sample count
+#endif
+// Tile height of the SCALED form (no LDS tile: height costs no occupancy; one lane per tile row holds its visibility word, so
+// 64 at most).  A tile's fixed work -- box scan, composition, culling test, ~400 VALU issues and their round trips -- is paid
+// per tile whatever it goes on to do, and at ScanNet's shape about half the tiles are culled: the minimal set runs 10 % faster
+// on 64-row tiles (1.298 vs 1.445 ms per 1 000 pairs), the correspondence set 7 % slower (1.821 vs 1.708: coarser culling
+// writes more of its index table), tools/ab_scannet.py round 5.  The compacted set's tile is part of the API (48).
+#ifndef MSPA_SCALED_ROWS
+#define MSPA_SCALED_ROWS 48
+#endif
+#ifndef MSPA_SCALED_ROWS_NOPIX
+#define MSPA_SCALED_ROWS_NOPIX 64
+#endif
+constexpr int tight_rows_of(uint32_t set, bool scaled = false) {
+    return (set & (O_XYZ32 | O_RGBA | O_VIS_U8)) ? kTightRowsDense
+           : (scaled && !(set & O_CPIX)) ? ((set & O_PIX) ? MSPA_SCALED_ROWS : MSPA_SCALED_ROWS_NOPIX) : kTightRows;
+}
 // waves (= tiles) per workgroup, per output set (tools/ab_k3.py, one box, ms per 1 000 pairs at 1 / 2 / 4 / 8 waves): the sets
 // without an index table like small workgroups -- a workgroup's LDS is released only when its slowest tile is done --
 // minimal 0.325 / 0.309 / 0.319 / 0.351, compact 0.388 / 0.377 / 0.388 / 0.424; corr 0.525 / 0.505 / 0.503 / 0.558; the dense
@@ -989,9 +1009,37 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
             M[2][k] = uniform(raw[2][k]);
         }
     };
+    // MSPA_WG_COMPOSE: the tiles of a workgroup belong to one pair, so its waves would all form the same twelve numbers (~100
+    // VALU issues of a tile's ~400 of fixed work).  Wave 0 forms them, parks them in LDS, the others pick them up behind a
+    // workgroup barrier (12 broadcast reads + 24 v_readfirstlane).  `all_here`: every wave of the workgroup reaches this point
+    // (block-uniform) -- otherwise each wave composes for itself as before.
+    constexpr bool WG_COMPOSE = MSPA_WG_COMPOSE && kTightBW > 1 && !WANT_XYZ;
+    __shared__ __attribute__((aligned(16))) double lds_mat[WG_COMPOSE ? 12 : 1];
+    auto obtain_matrix = [&](bool all_here) {
+        if (!WG_COMPOSE || !all_here) {
+            compose();
+            return;
+        }
+        if (wave == 0) {
+            compose();
+            if (c.lane == 0) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) lds_mat[4 * r + k] = M[r][k];
+            }
+        }
+        __syncthreads();
+        if (wave != 0) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) M[r][k] = uniform(lds_mat[4 * r + k]);
+        }
+    };
     // The whole-tile form composes here, behind its LDS-DMA requests.  The SCALED form has no such requests in flight yet: it
     // composes further down, behind the loads of its depth box and of its first row group.
-    if (!SCALED) compose();
+    if (!SCALED) obtain_matrix(true);
 
     // transpose stage: the group's pixel indices, then (dense set) its rgba words, then its 4 x 64 x 3 point coordinates
     __shared__ __attribute__((aligned(16))) uint32_t lds_pxs[kTightBW][(PX_IN_TILE || !(SET & (O_PIX | O_XYZ32 | O_RGBA))) ? 4 : RG * 64 * (WANT_XYZ ? 3 : 1)];
@@ -1040,7 +1088,7 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
         // host checks).  ScanNet's 64 x 48 colour tile maps to a 33 x 25 box: one piece column, seven passes.  Up to eight
         // passes are requested HERE, with the first row group's samples, and the matrix composition runs behind them (a
         // tile's first vector-memory round trip used to sit bare between the composition and the culling test).
-        constexpr int kBoxPre = 8;
+        constexpr int kBoxPre = ROWS > 48 ? (ROWS + 7) / 8 + 1 : 8;     // 4 depth rows per pass; a colour tile of ROWS rows maps to <= ROWS / 2 + 1 of them at ScanNet's scale
         u32x2 boxw[kBoxPre] = {};
         uint32_t d16_first[RG] = {};
         bool box_pre = false;
@@ -1067,7 +1115,7 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
             }
 #pragma unroll
             for (int j = 0; j < RG; ++j) d16_first[j] = load_d1_row(j);
-            compose();
+            obtain_matrix((tgroup * (uint32_t)kTightBW + (uint32_t)(kTightBW - 1)) < (uint32_t)a.n_tiles);
         }
         // dense payload: byte mask (lane L: 4 pixels of row L >> 4), colour in / rgba out, points (16-byte pieces of the
         // group's 4 x 768 bytes: piece 64 k + L lies in row (16 (64 k + L)) / 768)
@@ -1254,13 +1302,17 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
                         n_valid += __popcll(ballot64((w & 0xFFFFu) != 0u)) + __popcll(ballot64(w > 0xFFFFu));
                     }
                 } else {                                   // the tile's own samples (the box only bounded their range)
+                    // MSPA_SCALED_CULL_BATCH rows per round trip: a culled tile does nothing else, so its registers are free
+                    // for the requests (4 per trip made a 48-row tile twelve serial round trips)
+                    constexpr int CB = MSPA_SCALED_CULL_BATCH;
 #pragma unroll 1
-                    for (int r0 = 0; r0 < n_rows; r0 += RG) {
-                        uint32_t d[RG];
+                    for (int r0 = 0; r0 < n_rows; r0 += CB) {
+                        uint32_t d[CB];
 #pragma unroll
-                        for (int j = 0; j < RG; ++j) d[j] = load_d1_row(r0 + j);
-#pragma unroll
-                        for (int j = 0; j < RG; ++j) n_valid += __popcll(ballot64(d[j] != 0u));
+                        for (int j = 0; j < CB; ++j) d[j] = load_d1_row(min(r0 + j, ROWS - 1));     // rows past the band: counted below
+#pragma unroll                                                                                    // only if they exist
+                        for (int j = 0; j < CB; ++j)
+                            if (r0 + j < n_rows) n_valid += __popcll(ballot64(d[j] != 0u));
                     }
                 }
                 if (O::template has<O_PIX>(a.pix_i16)) {
@@ -2197,7 +2249,7 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
         a.stripe_magic = 0;
         a.strips = (a.n_tiles + (kThreads / kWave) - 1) / (kThreads / kWave);
     } else if (fast) {
-        const int tile_rows = (tight24 || rect) ? tight_rows_of(set) : kTileRows;
+        const int tile_rows = (tight24 || rect) ? tight_rows_of(set, rect) : kTileRows;
         a.n_stripes = (W + 63) / 64;
         a.n_tiles = (linear && !rect) ? (int)((P + (int64_t)kTileRows * 64 - 1) / ((int64_t)kTileRows * 64))
                                       : a.n_stripes * ((H + tile_rows - 1) / tile_rows);
@@ -2231,9 +2283,9 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
 #define MSPA_LAUNCH_RECT(SET_) \
     do { \
         if (flags & MSPA_PAIR_STREAM) \
-            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, true, tight_rows_of(SET_), tight_rg_of(SET_), true>), grid, dim3(tight_bw_of(SET_, true) * kWave), 0, s, depth, rgb, frame_mats, pairs, a); \
+            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, true, tight_rows_of(SET_, true), tight_rg_of(SET_), true>), grid, dim3(tight_bw_of(SET_, true) * kWave), 0, s, depth, rgb, frame_mats, pairs, a); \
         else \
-            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, false, tight_rows_of(SET_), tight_rg_of(SET_), true>), grid, dim3(tight_bw_of(SET_, true) * kWave), 0, s, depth, rgb, frame_mats, pairs, a); \
+            hipLaunchKernelGGL((pair_fast_tight_kernel<SET_, false, tight_rows_of(SET_, true), tight_rg_of(SET_), true>), grid, dim3(tight_bw_of(SET_, true) * kWave), 0, s, depth, rgb, frame_mats, pairs, a); \
     } while (0)
         if (set == kSetCorr) MSPA_LAUNCH_RECT(kSetCorr);
         else if (set == kSetCompact) MSPA_LAUNCH_RECT(kSetCompact);

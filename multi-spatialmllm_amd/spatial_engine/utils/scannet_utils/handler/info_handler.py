@@ -304,10 +304,13 @@ class SceneInfoHandler:
             N = 1
         return shard.scene_cost(F, N)
 
-    def prefetched_scenes(self, scene_ids, num_workers=8, device="cuda", timings=None, with_points=True, lookahead=2):
+    def prefetched_scenes(self, scene_ids, num_workers=8, device="cuda", timings=None, with_points=True, lookahead=None):
         """``scene_ids`` -> resident scenes, one after the other: scene n+1 is decoded by ``num_workers`` host threads and
-        copied on the copy stream while the caller runs scene n's kernels (mspa/sweep.py, mspa/upload.py)."""
+        copied on the copy stream while the caller runs scene n's kernels (mspa/sweep.py, mspa/upload.py).  ``lookahead`` scenes
+        are in flight on the host at once (default: 2, more -- up to 4 -- when the host has cores to spare for them)."""
         from mspa import sweep
+        if lookahead is None:
+            lookahead = min(4, max(2, (os.cpu_count() or 1) // (2 * max(1, int(num_workers)))))
         loader = sweep.SceneLoader(lambda sid: self.host_scene(sid, num_workers, with_points), list(scene_ids), lookahead,
                                    timings)
         return sweep.prefetched_scenes(loader, device, timings)

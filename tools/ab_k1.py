@@ -51,6 +51,8 @@ def main():
     bits = torch.empty((F, (n + 63) // 64), dtype=torch.int64, device=dev)
     count = torch.empty((F,), dtype=torch.int32, device=dev)
     libs = sorted(glob.glob(os.path.join(ROOT, "tools/ab/libmspa_*.so"))) + [_lib.LIB_PATH]
+    if os.environ.get("MSPA_AB_ONLY"):                    # PMC passes (tools/pmc_k1_traffic.sh): one library per process
+        libs = [p for p in libs if os.path.basename(p) == os.environ["MSPA_AB_ONLY"]]
     stream = torch.cuda.current_stream().cuda_stream
     handles = {}
     for path in libs:
