@@ -38,6 +38,7 @@ struct PairArgs {
     double sx, sy;         // dw / W, dh / H  (IH:359-360, OPS:272-273)
     int strips;            // exact kernel: 4096-pixel strips per pair;  fast kernel: groups of 4 wave tiles
     int n_stripes, n_tiles;   // fast kernel: 64-column stripes per row band, wave tiles per pair
+    int n_wave_tiles;         // tight kernel: tile GROUPS per pair (a wave walks TPW vertically adjacent tiles); == n_tiles when TPW == 1
     uint32_t stripe_magic;    // floor(2^32 / n_stripes) + 1
     uint64_t *vis_bits;
     uint8_t *vis_u8;
@@ -758,6 +759,11 @@ constexpr int kTightRowsDense = MSPA_TIGHT_ROWS_DENSE;
 #endif
 // rows whose depth-2 gathers are in flight together: the sets without a transpose stage (minimal, compact) may take more
 constexpr int tight_rg_of(uint32_t set) { return (set & (O_PIX | O_XYZ32 | O_RGBA | O_VIS_U8)) ? kRowGroup : MSPA_TIGHT_RG_LIGHT; }
+// Two A/B knobs of round 5, both measured at noise level and left off (tools/ab_scannet.py / ab_k3.py, one box, ms per 1 000
+// pairs, shipped -> knob): MSPA_WG_COMPOSE = 1 -- ScanNet's shape corr 1.717 -> 1.701, minimal 1.343 -> 1.336, compact 1.798 ->
+// 1.814; 640x480 corr 0.4494 -> 0.4514, compact 0.3489 -> 0.3497, minimal 0.2855 -> 0.2834: the workgroup barrier costs what
+// the ~65 saved issues per tile save.  MSPA_SCALED_CULL_BATCH = 16 -- corr 1.717 -> 1.716, minimal 1.343 -> 1.361, compact
+// 1.798 -> 1.793: a culled tile's twelve serial round trips are hidden by the other waves already.
 #ifndef MSPA_WG_COMPOSE
 #define MSPA_WG_COMPOSE 0              // 1: the pair's composed matrix once per WORKGROUP (wave 0 -> LDS -> the others), not per wave
 #endif
@@ -775,6 +781,24 @@ constexpr int tight_rg_of(uint32_t set) { return (set & (O_PIX | O_XYZ32 | O_RGB
 #ifndef MSPA_SCALED_ROWS_NOPIX
 #define MSPA_SCALED_ROWS_NOPIX 64
 #endif
+// Tiles per wave of the SCALED form (MSPA_SCALED_TPW_*, A/B knob, 1 = off): a wave walks this many vertically adjacent tiles --
+// launch, the pair's matrices, the column's depth-grid offsets and the other per-stripe constants are paid once for them, the
+// culling stays per tile.  Measured at ScanNet's shape (tools/ab_scannet.py, round 5, ms per 1 000 pairs at 1 / 2 / 3 / 4 tiles):
+// corr 1.745 / 2.102 / 2.125 / 2.256, minimal 1.349 / 2.021 / 2.055 / 1.996 -- bit-identical and 20-50 % SLOWER: what is live
+// across the tile loop costs the row loop its registers (minimal: 42 VGPRs spilled to scratch in it).  Not for the compacted
+// set at all: with its spills the SGPR quad of the inline-asm `idxen` store came back wrong (memory fault; static_assert below).
+#ifndef MSPA_SCALED_TPW_CORR
+#define MSPA_SCALED_TPW_CORR 1
+#endif
+#ifndef MSPA_SCALED_TPW_COMPACT
+#define MSPA_SCALED_TPW_COMPACT 1
+#endif
+#ifndef MSPA_SCALED_TPW_NOPIX
+#define MSPA_SCALED_TPW_NOPIX 1
+#endif
+constexpr int tight_tpw_of(uint32_t set, bool scaled) {
+    return !scaled ? 1 : (set & O_CPIX) ? MSPA_SCALED_TPW_COMPACT : (set & O_PIX) ? MSPA_SCALED_TPW_CORR : MSPA_SCALED_TPW_NOPIX;
+}
 constexpr int tight_rows_of(uint32_t set, bool scaled = false) {
     return (set & (O_XYZ32 | O_RGBA | O_VIS_U8)) ? kTightRowsDense
            : (scaled && !(set & O_CPIX)) ? ((set & O_PIX) ? MSPA_SCALED_ROWS : MSPA_SCALED_ROWS_NOPIX) : kTightRows;
@@ -927,12 +951,15 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
 
     // wave tile -> (row band, column stripe); both wave-uniform
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = tgroup * kTightBW + wave;
-    const uint32_t band = a.n_stripes == 1 ? tile : __umulhi(tile, a.stripe_magic);
-    const uint32_t stripe = tile - band * (uint32_t)a.n_stripes;
-    const bool tile_ok = tile < (uint32_t)a.n_tiles;
+    constexpr int TPW = tight_tpw_of(SET, SCALED);
+    static_assert(TPW == 1 || !(SET & O_CPIX), "tiles per wave > 1 is not available for the compacted set (see tight_tpw_of)");
+    const uint32_t wtile = tgroup * kTightBW + wave;                 // this wave's tile group: TPW vertically adjacent tiles
+    const uint32_t sband = a.n_stripes == 1 ? wtile : __umulhi(wtile, a.stripe_magic);
+    const uint32_t stripe = wtile - sband * (uint32_t)a.n_stripes;
+    const bool tile_ok = wtile < (uint32_t)a.n_wave_tiles;
     const uint32_t col = stripe * 64u + (uint32_t)c.lane;
-    const uint32_t row0 = band * (uint32_t)ROWS;
+    uint32_t row0 = sband * (uint32_t)(TPW * ROWS);                  // of the group's first tile; advanced per tile below
+    uint32_t tile = sband * (uint32_t)TPW * (uint32_t)a.n_stripes + stripe;   // tile index of the API (band-major)
 
     // The tile's depth-1 samples (48 rows x 128 B) go HBM -> LDS by LDS-DMA, two rows per wave
     // instruction (lanes 0-31 fetch row 2k, lanes 32-63 row 2k+1, 4 bytes = 2 pixels each): all 24
@@ -1048,7 +1075,14 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
     static_assert(!COMPACT || (ROWS * 64 == MSPA_CORR_TILE_CAP && ROWS == MSPA_CORR_TILE_H), "tile segment of the compacted set");
 #endif
     int n_valid = 0, n_vis = 0;
-    if (tile_ok) {
+#pragma unroll 1
+    for (int sub = 0; tile_ok && sub < TPW; ++sub) {
+        if (sub) {                                       // the next tile down (wave-uniform)
+            row0 += (uint32_t)ROWS;
+            tile += (uint32_t)a.n_stripes;
+            if (row0 >= (uint32_t)a.H) break;
+        }
+        const int n_vis_before = n_vis;
         const uint32_t Wb = (uint32_t)a.W;
         // buffer resources: SGPR base + byte count; raw addressing = base + voffset (VGPR) + soffset (SGPR)
         const int kRsrcFlags = 0x00020000;
@@ -1115,7 +1149,7 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
             }
 #pragma unroll
             for (int j = 0; j < RG; ++j) d16_first[j] = load_d1_row(j);
-            obtain_matrix((tgroup * (uint32_t)kTightBW + (uint32_t)(kTightBW - 1)) < (uint32_t)a.n_tiles);
+            if (sub == 0) obtain_matrix((tgroup * (uint32_t)kTightBW + (uint32_t)(kTightBW - 1)) < (uint32_t)a.n_wave_tiles);
         }
         // dense payload: byte mask (lane L: 4 pixels of row L >> 4), colour in / rgba out, points (16-byte pieces of the
         // group's 4 x 768 bytes: piece 64 k + L lies in row (16 (64 k + L)) / 768)
@@ -1628,7 +1662,7 @@ __global__ __launch_bounds__(tight_bw_of(SET, SCALED) * kWave, tight_minwaves_of
                     base += (uint32_t)__popcll(w);
                 }
             }
-            if (c.lane == 0) a.tile_counts[pair * (int64_t)a.n_tiles + (int64_t)tile] = n_vis;
+            if (c.lane == 0) a.tile_counts[pair * (int64_t)a.n_tiles + (int64_t)tile] = n_vis - n_vis_before;
         }
         // the tile's visibility words: lane r stores the word of row row0 + r (8 bytes; rows are W/8 bytes apart)
         if (SCALED && (Wb & 63u)) {
@@ -2245,7 +2279,7 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
     const bool scaled = fast && !tight24 && !rect && aligned && scannet && (set == kSetCorr || set == kSetMinimal);
     if (scaled) {
         a.n_stripes = 1296 / 64;
-        a.n_tiles = a.n_stripes * ((968 + 47) / 48);
+        a.n_tiles = a.n_wave_tiles = a.n_stripes * ((968 + 47) / 48);
         a.stripe_magic = 0;
         a.strips = (a.n_tiles + (kThreads / kWave) - 1) / (kThreads / kWave);
     } else if (fast) {
@@ -2255,9 +2289,11 @@ static int pair_reproject_impl(const uint16_t *depth, const uint8_t *rgb, const 
                                       : a.n_stripes * ((H + tile_rows - 1) / tile_rows);
         a.stripe_magic = (uint32_t)((1ull << 32) / (uint64_t)a.n_stripes) + 1u;
         const int bw = rect ? tight_bw_of(set, true) : tight24 ? tight_bw_of(set) : (kThreads / kWave);
-        a.strips = (a.n_tiles + bw - 1) / bw;
+        const int tpw = rect ? tight_tpw_of(set, true) : 1;                       // tiles a wave walks (vertically adjacent)
+        a.n_wave_tiles = (tight24 || rect) ? a.n_stripes * (((H + tile_rows - 1) / tile_rows + tpw - 1) / tpw) : a.n_tiles;
+        a.strips = (a.n_wave_tiles + bw - 1) / bw;
     } else {
-        a.n_stripes = a.n_tiles = 0;
+        a.n_stripes = a.n_tiles = a.n_wave_tiles = 0;
         a.stripe_magic = 0;
     }
     const int64_t groups = (n_pairs + n_xcd - 1) / n_xcd;
