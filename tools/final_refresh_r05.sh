@@ -18,8 +18,8 @@ bash tools/profile.sh ${T}_corr_vc > /dev/null 2>&1
 bash tools/profile.sh ${T}_compact_vc --variant compact > /dev/null 2>&1
 bash tools/profile.sh ${T}_minimal_vc --variant minimal > /dev/null 2>&1
 bash tools/pmc.sh ${T}_k3corr pair_fast_tight python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-scene-legs --also none --no-sweep > /dev/null 2>&1
-bash tools/pmc.sh ${T}_rect_minimal pair_fast_tight python $ROOT/tools/ab_scannet.py --legs minimal:rect@in-tree --rounds 1 --steps 6 > /dev/null 2>&1
-bash tools/pmc.sh ${T}_rect_corr pair_fast_tight python $ROOT/tools/ab_scannet.py --legs corr:rect@in-tree --rounds 1 --steps 6 > /dev/null 2>&1
+bash tools/pmc.sh ${T}_rect_minimal pair_fast_tight python $ROOT/tools/ab_scannet.py --legs minimal:rect --rounds 1 --steps 6 > /dev/null 2>&1
+bash tools/pmc.sh ${T}_rect_corr pair_fast_tight python $ROOT/tools/ab_scannet.py --legs corr:rect --rounds 1 --steps 6 > /dev/null 2>&1
 bash tools/profile_scene.sh > /dev/null 2>&1
 bash tools/profile_scene_pmc.sh > /dev/null 2>&1
 # the scene-shaped workload under --kernel-trace --stats (which kernels a step consists of, and their share)
