@@ -36,10 +36,16 @@ def to_eval_sample(train_sample: dict) -> dict:
     return train_sample
 
 
-def write_jsonl(path: str, records: Iterable[dict]):
-    with open(path, "w") as f:
+class JsonLine(bytes):
+    """One record already serialised by the rank that built it (``json.dumps(record).encode()``): what a sharded dataset
+    builder hands to ``write_jsonl`` on rank 0 -- the text crossed the fabric once and is not parsed again."""
+    __slots__ = ()
+
+
+def write_jsonl(path: str, records: Iterable):
+    with open(path, "wb") as f:
         for r in records:
-            f.write(json.dumps(r) + "\n")
+            f.write((r if isinstance(r, JsonLine) else json.dumps(r).encode()) + b"\n")
 
 
 def sample_indices(n: int, k: int, rng=_random) -> List[int]:
@@ -74,15 +80,29 @@ def camera_movement_answer_values(d, yaw_angle: float, pitch_angle: float) -> di
     }
 
 
+def camera_movement_draw(row: dict, question_type: str, templates: T.TemplateSet = T.CAMERA_MOVEMENT, rng=_random):
+    """The four draws of one camera-movement record, in the reference's order (CME:163, 196, 203-204): swap coin, task
+    description, question, answer template -- as (swap, ti, qi, ai).  They depend on nothing the kernels compute, so a
+    sharded builder lets every rank run this (microseconds per row) for ALL rows and format only its own."""
+    swap = rng.random() < 0.5                                                                  # CME:163-166
+    ti = rng.choice(range(len(templates.task_description)))
+    if float(row["overlap"]) < 0.1:
+        raise NotImplementedError("overlap < 0.1 is not supported yet.")                       # CME:199-201
+    qi = rng.choice(range(len(templates.questions[question_type])))
+    ai = rng.choice(range(len(templates.answers[question_type])))
+    return swap, ti, qi, ai
+
+
 def camera_movement_record(row: dict, idx: int, question_type: str, rel_t_12, rel_t_21, image_hw: Tuple[int, int],
-                           templates: T.TemplateSet = T.CAMERA_MOVEMENT, rng=_random) -> dict:
+                           templates: T.TemplateSet = T.CAMERA_MOVEMENT, rng=_random, draw=None) -> dict:
     """One record of the camera-movement head.  ``row`` has scene_id, image_id1, image_id2, overlap, yaw,
     pitch, distance (a row of the pair table); ``rel_t_12`` / ``rel_t_21`` are the translation columns of
-    inv(E1)@E2 and inv(E2)@E1 (K4 computes both directions)."""
+    inv(E1)@E2 and inv(E2)@E1 (K4 computes both directions).  ``draw``: the record's draws when they were made ahead
+    (``camera_movement_draw``); otherwise they are made here, interleaved with the checks exactly as upstream."""
     scene_id, image1, image2 = row["scene_id"], row["image_id1"], row["image_id2"]
     overlap, yaw_angle, pitch_angle = float(row["overlap"]), float(row["yaw"]), float(row["pitch"])
     d = np.asarray(rel_t_12, dtype=np.float64)
-    if rng.random() < 0.5:                                   # CME:163-166
+    if (rng.random() < 0.5) if draw is None else draw[0]:    # CME:163-166
         yaw_angle, pitch_angle = -yaw_angle, -pitch_angle
         image1, image2 = image2, image1
         d = np.asarray(rel_t_21, dtype=np.float64)
@@ -91,11 +111,11 @@ def camera_movement_record(row: dict, idx: int, question_type: str, rel_t_12, re
     distance = np.linalg.norm(d)
     assert abs(distance - row["distance"]) < 0.1, \
         f"distance is not close to the distance from df for {scene_id} {image1} {image2}."     # CME:193
-    task_description = rng.choice(templates.task_description)
+    task_description = rng.choice(templates.task_description) if draw is None else templates.task_description[draw[1]]
     if overlap < 0.1:
         raise NotImplementedError("overlap < 0.1 is not supported yet.")                       # CME:199-201
-    question = rng.choice(templates.questions[question_type])
-    answer_template = rng.choice(templates.answers[question_type])
+    question = rng.choice(templates.questions[question_type]) if draw is None else templates.questions[question_type][draw[2]]
+    answer_template = rng.choice(templates.answers[question_type]) if draw is None else templates.answers[question_type][draw[3]]
     answer_values = camera_movement_answer_values(d, yaw_angle, pitch_angle)
     H, W = image_hw
     return {
@@ -131,37 +151,69 @@ def camera_movement_records(scene, rows: Sequence[dict], question_type: str, ima
 
 
 def camera_movement_dataset(rows: Sequence, frame_pose, image_hw_of, question_type: str,
-                            templates: T.TemplateSet = T.CAMERA_MOVEMENT, rng=_random, device="cuda") -> List[dict]:
+                            templates: T.TemplateSet = T.CAMERA_MOVEMENT, rng=_random, device="cuda", ctx=None,
+                            transform=None) -> List:
     """The record loop of CME.build_train_dataset (CME:295-299) for rows that may span many scenes: the relative
-    poses of ALL rows come from one K4 launch over a table of the distinct frames, then the records are filled in
+    poses of the rows come from one K4 launch over a table of the distinct frames, then the records are filled in
     row order -- the numerics never influence a draw, so the ``random`` stream is the per-row loop's.
 
     ``frame_pose(scene_id, image_id)`` -> axis-aligned camera-to-world 4x4; ``image_hw_of(scene_id, image_id)`` -> (H, W).
+
+    With a communicator (``ctx``: one process per GPU) the TEXT is built in parallel: every rank makes the draws of all rows
+    (``camera_movement_draw``: the generator ends where a single process leaves it, on every rank), formats a contiguous
+    slice of the rows -- its own K4 launch, its own image-size lookups, ``transform`` (e.g. the eval form) applied -- and
+    the finished JSON lines go to rank 0 through ONE ``shard.gather_bytes``.  Rank 0 gets the records as ``JsonLine``s in
+    row order, the other ranks an empty list.  Without one the records are returned as dicts, as before.
     """
     import torch
     from . import engine
-    if len(rows) == 0:
+    n = len(rows)
+    if n == 0:
         return []
+    rank, world = (ctx.rank, ctx.world) if ctx is not None else (0, 1)
+    draws = None
+    if ctx is not None:                                        # all rows, every rank: ~4 generator calls per row
+        draws = [camera_movement_draw(r, question_type, templates, rng) for r in rows]
+    lo, hi = (0, n) if ctx is None else _partition(n, world, rank)
     table: Dict[Tuple[str, str], int] = {}
     poses = []
-    idx = np.empty((len(rows), 2), dtype=np.int32)
-    for k, r in enumerate(rows):
+    idx = np.empty((hi - lo, 2), dtype=np.int32)
+    for k in range(lo, hi):
+        r = rows[k]
         for c, key in enumerate(((r["scene_id"], r["image_id1"]), (r["scene_id"], r["image_id2"]))):
             if key not in table:
                 E = np.asarray(frame_pose(*key), dtype=np.float64)
                 assert not np.isnan(E).any(), f"E is nan for {key[0]} {key[1]}"        # CME:160-161
                 table[key] = len(poses)
                 poses.append(E)
-            idx[k, c] = table[key]
-    E_all = np.stack(poses)
-    E_t = torch.from_numpy(E_all.reshape(-1, 16)).to(device)
-    Einv_t = torch.from_numpy(np.linalg.inv(E_all).reshape(-1, 16)).to(device)       # same LAPACK call as per frame
-    zeros = torch.zeros(len(poses), dtype=torch.float64, device=device)
-    both = torch.from_numpy(np.concatenate([idx, idx[:, ::-1]], axis=0).copy()).to(device)
-    out = engine.pair_pose(E_t, Einv_t, zeros, zeros, both).cpu().numpy()
-    n = len(rows)
-    return [camera_movement_record(r, k, question_type, out[k, 3:6], out[n + k, 3:6],
-                                   image_hw_of(r["scene_id"], r["image_id1"]), templates, rng) for k, r in enumerate(rows)]
+            idx[k - lo, c] = table[key]
+    mine: List[dict] = []
+    if hi > lo:
+        E_all = np.stack(poses)
+        E_t = torch.from_numpy(E_all.reshape(-1, 16)).to(device)
+        Einv_t = torch.from_numpy(np.linalg.inv(E_all).reshape(-1, 16)).to(device)   # same LAPACK call as per frame
+        zeros = torch.zeros(len(poses), dtype=torch.float64, device=device)
+        both = torch.from_numpy(np.concatenate([idx, idx[:, ::-1]], axis=0).copy()).to(device)
+        out = engine.pair_pose(E_t, Einv_t, zeros, zeros, both).cpu().numpy()
+        m = hi - lo
+        mine = [camera_movement_record(rows[k], k, question_type, out[k - lo, 3:6], out[m + k - lo, 3:6],
+                                       image_hw_of(rows[k]["scene_id"], rows[k]["image_id1"]), templates, rng,
+                                       draw=None if draws is None else draws[k]) for k in range(lo, hi)]
+    if transform is not None:
+        mine = [transform(rec) for rec in mine]
+    if ctx is None:
+        return mine
+    from . import shard
+    parts = shard.gather_bytes("".join(json.dumps(rec) + "\n" for rec in mine).encode(), ctx, dst=0)
+    if rank != 0:
+        return []
+    return [JsonLine(line) for p in parts for line in bytes(p).split(b"\n")[:-1]]
+
+
+def _partition(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
 
 
 # --------------------------------------------------------------------------------------------

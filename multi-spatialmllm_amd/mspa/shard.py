@@ -192,4 +192,8 @@ def context_from_env(device=None) -> "DistContext | None":
         else:
             device = torch.device("cpu")
     ctx = init_distributed(torch.device(device), backend=os.environ.get("MSPA_DIST_BACKEND"))
+    if ctx.owns_process_group:                          # created here: torn down when the script ends, whichever entry point came first
+        import atexit
+        atexit.register(lambda: dist.is_initialized() and dist.destroy_process_group())
+        ctx.owns_process_group = False
     return ctx if ctx.world > 1 else None

@@ -291,12 +291,13 @@ def make_tracks(seed: int, T: int = 300, P: int = 256, n_groups: int = 8,
 
 
 def write_scannet_layout(scenes: Sequence["SynthScene"], root: str, info_name: str = "scenes_info.pkl",
-                         compress_level: int = 1) -> Dict[str, str]:
+                         compress_level: int = 1, jpeg_for_every_image: bool = False) -> Dict[str, str]:
     """Write synthetic scenes to disk the way the reference's pipeline finds ScanNet:
     ``<root>/posed_images/<scene>/<image>.png`` (16-bit depth, extract_posed_images.py:118-123) and ``<image>.jpg``,
     ``<root>/scannet_instance_data/<scene>/aligned_points.npy`` (N x 6 float64, batch_load_scannet_data.py:201) and the
     scene-info pickle (info_handler.py:7-30).  A scene without colour frames gets a flat grey JPEG of the right size for its
-    first image (only its header is ever read: IH:133-139 takes the image size from it).  Returns the paths to hand to
+    first image (only its header is ever read: IH:133-139 takes the image size from it; ``jpeg_for_every_image``: for all
+    of them -- the dataset builders look the size up per row, CME:238-239).  Returns the paths to hand to
     ``SceneInfoHandler(info_path, posed_images_root=..., instance_data_root=...)``."""
     import os
     import pickle
@@ -315,7 +316,7 @@ def write_scannet_layout(scenes: Sequence["SynthScene"], root: str, info_name: s
             col = sc.color.get(image_id) if sc.color else None
             if col is not None:
                 jobs.append((Image.fromarray(col), os.path.join(posed, sc.scene_id, f"{image_id}.jpg"), {"quality": 90}))
-            elif n == 0:
+            elif n == 0 or jpeg_for_every_image:
                 jobs.append((Image.new("RGB", (W, H), (128, 128, 128)), os.path.join(posed, sc.scene_id, f"{image_id}.jpg"),
                              {"quality": 50}))
         infos[sc.scene_id] = sc.info_dict()

@@ -38,8 +38,14 @@ def build_training_sample(scene_infos, row, idx: int, question_type: str):
 convert_train_sample_to_eval_sample = heads.to_eval_sample
 
 
-def _build_samples(parquet_path, scene_infos, qtype, desired_count, overlap_min, overlap_max, interval, tag):
+def _build_samples(parquet_path, scene_infos, qtype, desired_count, overlap_min, overlap_max, interval, tag, transform=None):
+    """(records in row order, communicator or None).  In a job with one process per GPU (RANK / WORLD_SIZE from the
+    launcher) every rank samples the same rows (seeded) and makes every row's draws, formats its own slice of the records
+    and rank 0 receives the finished lines (``heads.camera_movement_dataset``); upstream builds them in one loop
+    (CME:295-299)."""
     import pandas as pd
+    from mspa import shard
+    ctx = shard.context_from_env()
     df = pd.read_parquet(parquet_path)
     print(f"[{tag}: {qtype}] Loaded DF with {len(df)} rows from {parquet_path}")
     print(f"[{tag}: {qtype}] sampling {desired_count} samples in overlap=[{overlap_min}..{overlap_max}]")
@@ -47,28 +53,38 @@ def _build_samples(parquet_path, scene_infos, qtype, desired_count, overlap_min,
                                   overlap_max=overlap_max, interval=interval)
     print(f"[{tag}: {qtype}] got {len(df_sampled)} sampled rows")
     rows = [df_sampled.iloc[k] for k in range(len(df_sampled))]
-    # one K4 launch for the relative poses of every sampled row, then the records in row order
-    return heads.camera_movement_dataset(rows, scene_infos.get_extrinsic_matrix_align, scene_infos.get_image_shape, qtype,
-                                         TEMPLATE_SET, random)
+    # one K4 launch for the relative poses of the rows a rank formats, then the records in row order
+    samples = heads.camera_movement_dataset(rows, scene_infos.get_extrinsic_matrix_align, scene_infos.get_image_shape, qtype,
+                                            TEMPLATE_SET, random, device=ctx.device if ctx is not None else "cuda", ctx=ctx,
+                                            transform=transform)
+    return samples, len(rows), ctx
+
+
+def _shuffle_and_write(samples, n_rows, ctx, out_file, tag, qtype):
+    """``random.shuffle(out_samples)`` + the JSONL (CME:301-308).  The shuffle is applied to an index list of the same
+    length -- the same permutation, and every rank of a sharded job advances its generator exactly as rank 0 does."""
+    order = list(range(n_rows))
+    random.shuffle(order)
+    if ctx is not None and ctx.rank != 0:
+        ctx.barrier()
+        return
+    print(f"[{tag}: {qtype}] writing {len(samples)} items to {out_file}")
+    heads.write_jsonl(out_file, [samples[i] for i in order])
+    if ctx is not None:
+        ctx.barrier()
 
 
 def build_train_dataset(parquet_path, output_dir, scene_infos, qtype, desired_count, overlap_min, overlap_max, interval):
     """{qtype}_train.jsonl from the pair table (reference: :271-308)."""
-    out_samples = _build_samples(parquet_path, scene_infos, qtype, desired_count, overlap_min, overlap_max, interval, "Train")
-    random.shuffle(out_samples)
-    out_file = os.path.join(output_dir, f"{qtype}_train.jsonl")
-    print(f"[Train: {qtype}] writing {len(out_samples)} items to {out_file}")
-    heads.write_jsonl(out_file, out_samples)
+    samples, n, ctx = _build_samples(parquet_path, scene_infos, qtype, desired_count, overlap_min, overlap_max, interval, "Train")
+    _shuffle_and_write(samples, n, ctx, os.path.join(output_dir, f"{qtype}_train.jsonl"), "Train", qtype)
 
 
 def build_val_dataset(parquet_path, output_dir, scene_infos, qtype, desired_count, overlap_min, overlap_max, interval):
     """{qtype}_val.jsonl in the eval form (reference: :314-354)."""
-    out_samples = [convert_train_sample_to_eval_sample(s) for s in
-                   _build_samples(parquet_path, scene_infos, qtype, desired_count, overlap_min, overlap_max, interval, "Val")]
-    random.shuffle(out_samples)
-    out_file = os.path.join(output_dir, f"{qtype}_val.jsonl")
-    print(f"[Val: {qtype}] writing {len(out_samples)} items to {out_file}")
-    heads.write_jsonl(out_file, out_samples)
+    samples, n, ctx = _build_samples(parquet_path, scene_infos, qtype, desired_count, overlap_min, overlap_max, interval, "Val",
+                                     transform=convert_train_sample_to_eval_sample)
+    _shuffle_and_write(samples, n, ctx, os.path.join(output_dir, f"{qtype}_val.jsonl"), "Val", qtype)
 
 
 DEBUG = False

@@ -52,7 +52,7 @@ def _tracks():
 
 def _write_inputs(root):
     from mspa import synth
-    synth.write_scannet_layout(_scenes(), os.path.join(root, "data", "scannet"))
+    synth.write_scannet_layout(_scenes(), os.path.join(root, "data", "scannet"), jpeg_for_every_image=True)
     os.makedirs(os.path.join(root, "tapvid"), exist_ok=True)
     for tr in _tracks():
         H, W = tr.image_hw
@@ -81,6 +81,13 @@ def _run_everything(out_dir):
                            save_interval=3, timings=timings)
     vis = MVI.run_split(INFO, os.path.join(out_dir, "vis.parquet"), os.path.join(out_dir, "mvi_warn.txt"), num_workers=4)
     MVI.run_split(INFO, os.path.join(out_dir, "vis.pkl"), os.path.join(out_dir, "mvi_warn2.txt"), num_workers=2)
+    # the camera-movement dataset builders on the pair table just written: every rank draws, each formats its slice of the text
+    import spatial_engine.camera_movement.camera_movement_engine_train_val as CME
+    handler0 = SceneInfoHandler(INFO)
+    random.seed(3)
+    np.random.seed(3)
+    CME.build_train_dataset(os.path.join(out_dir, "pairs.parquet"), out_dir, handler0, "displacement_vector", 60, 1, 60, 1)
+    CME.build_val_dataset(os.path.join(out_dir, "pairs.parquet"), out_dir, handler0, "yaw_movement", 25, 1, 60, 1)
     eng = OM.TwoFrameVideoQAEngine("tapvid3d_total_distance", "adt")
     random.seed(11)
     eng.generate_qa_training_data([t.scene_id for t in _tracks()], "tapvid", out_dir, os.path.join(out_dir, "om_train.jsonl"),
@@ -166,6 +173,10 @@ def test_drop_in_entry_points_one_rank_vs_two_ranks_from_disk(tmp_path, monkeypa
     assert counts["camera_movement_total_distance"] > 0 and 0 < counts["depth_estimation_coor"] <= 2 * (N_SCENES - 1)
     assert counts["object_movement_tapvid3d_total_distance"] > 0
     assert pipe_t["records_bytes"] > 1000 and "rank0_replay_s" not in pipe_t
+    cm = [json.loads(line) for line in open(os.path.join(root, "one", "displacement_vector_train.jsonl"))]
+    assert len(cm) > 10 and {"id", "image", "conversations", "answer_values", "gt_value"} <= set(cm[0])
+    cmv = [json.loads(line) for line in open(os.path.join(root, "one", "yaw_movement_val.jsonl"))]
+    assert len(cmv) > 5 and "text" in cmv[0] and "conversations" not in cmv[0]
     om = [json.loads(line) for line in open(os.path.join(root, "one", "om_train.jsonl"))]
     assert len(om) > 5 and {"id", "conversations", "point_moving", "cam_moving"} <= set(om[0])
     # ---- two ranks, one GPU: the same bytes everywhere ----------------------------------------------------------------
