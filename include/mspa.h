@@ -361,6 +361,13 @@ int mspa_read_depth_png_host(const char *const *paths_host, int64_t n_files, int
                              int32_t n_threads, int32_t *status_host);
 int mspa_png_header_host(const char *path_host, int32_t *h, int32_t *w, int32_t *bit_depth, int32_t *color_type,
                          int32_t *interlace);
+/*
+ * The table-driven zlib decoder the two ingest entry points above try first (csrc/inflate_fast.h; the from-disk sweep is bound
+ * by the inflate of its depth frames -- zlib's own delivers ~155 MB/s per thread on them).  One whole zlib stream in host memory
+ * -> exactly dst_bytes of output.  Returns 0 when the stream was decoded (output size AND Adler-32 match), 1 when the decoder
+ * declines it (damaged or truncated stream, other output size, preset dictionary): the callers above then use zlib itself.
+ */
+int mspa_inflate_zlib_fast_host(const void *src_host, int64_t src_bytes, void *dst_host, int64_t dst_bytes);
 
 /*
  * K4 -- per-pair camera relations: the distance / yaw / pitch columns of CFR.process_scene's pair

@@ -13,6 +13,7 @@
 //   mspa_bits_transpose  64 x 64 bit tiles through ballots: lane r holds row r's word, ballot(bit b of my word) IS row b of
 //                        the transposed tile (lane b keeps it)
 #include "mspa_common.h"
+#include "inflate_fast.h"
 
 #include <atomic>
 #include <cstdio>
@@ -267,6 +268,10 @@ extern "C" int mspa_inflate_blocks_host(const void *const *src_blocks_host, cons
         for (;;) {
             const int64_t k = next.fetch_add(1);
             if (k >= n_blocks) return;
+            // first through the table-driven decoder (inflate_fast.h: exact size + Adler-32, or it declines), then zlib itself
+            if (inflate_zlib((const uint8_t *)src_blocks_host[k], (size_t)src_bytes_host[k], (uint8_t *)dst_host + k * block_bytes,
+                             (size_t)block_bytes))
+                continue;
             uLongf got = (uLongf)block_bytes;
             const int rc = uncompress((Bytef *)dst_host + k * block_bytes, &got, (const Bytef *)src_blocks_host[k],
                                       (uLong)src_bytes_host[k]);

@@ -10,6 +10,7 @@
 // uint16 array): PNG, 16-bit greyscale (colour type 0), non-interlaced, any zlib level, any mix of the five row
 // filters.  Anything else gets status 2 and the caller decodes that one frame with its general reader.
 #include "mspa_common.h"
+#include "inflate_fast.h"
 
 #include <atomic>
 #include <cstdio>
@@ -68,40 +69,55 @@ inline int paeth(int a, int b, int c) {
 
 // One 16-bit greyscale frame: file bytes -> dst[h * w] (host byte order).  `raw` is the thread's scratch buffer.
 // 0 ok, 2 not the native format / size, 3 corrupt.
-int decode_gray16(const unsigned char *buf, size_t n, int32_t h, int32_t w, uint16_t *dst, std::vector<unsigned char> &raw) {
+int decode_gray16(const unsigned char *buf, size_t n, int32_t h, int32_t w, uint16_t *dst, std::vector<unsigned char> &raw,
+                  std::vector<unsigned char> &idat) {
     PngHeader hd;
     if (int rc = parse_header(buf, n, hd)) return rc;
     if (hd.bit_depth != 16 || hd.color_type != 0 || hd.interlace != 0 || hd.w != (uint32_t)w || hd.h != (uint32_t)h) return 2;
     const size_t stride = (size_t)w * 2 + 1;
     raw.resize(stride * (size_t)h);
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (inflateInit(&zs) != Z_OK) return 3;
-    zs.next_out = raw.data();
-    zs.avail_out = (uInt)raw.size();
+    // The scanlines' zlib stream: the IDAT chunks' payloads back to back.  One chunk (what most writers emit for a frame of this
+    // size is several 8-64 KB chunks; a single one needs no copy) or several gathered into `idat`; first through the
+    // table-driven decoder (inflate_fast.h: exact output size + Adler-32 or it reports failure), then, for a stream it
+    // declines, through zlib itself.
     size_t pos = 33;                                  // past the signature and IHDR (8 + 4 + 4 + 13 + 4)
-    bool done = false, bad = false;
-    while (!done && !bad && pos + 12 <= n) {
+    const unsigned char *one = nullptr;
+    size_t one_len = 0;
+    int n_idat = 0;
+    bool bad = false;
+    idat.clear();
+    while (pos + 12 <= n) {
         const uint32_t len = be32(buf + pos);
         const unsigned char *type = buf + pos + 4;
         if ((size_t)len > n - pos - 12) { bad = true; break; }
         if (memcmp(type, "IDAT", 4) == 0) {
-            zs.next_in = const_cast<Bytef *>(buf + pos + 8);
-            zs.avail_in = len;
-            while (zs.avail_in > 0) {
-                const int rc = inflate(&zs, Z_NO_FLUSH);
-                if (rc == Z_STREAM_END) { done = true; break; }
-                if (rc != Z_OK) { bad = true; break; }
-                if (zs.avail_out == 0) { done = true; break; }   // all rows are out; only the stream's trailer can follow
+            if (n_idat == 0) { one = buf + pos + 8; one_len = len; }
+            else {
+                if (n_idat == 1) idat.assign(one, one + one_len);
+                idat.insert(idat.end(), buf + pos + 8, buf + pos + 8 + len);
             }
+            ++n_idat;
         } else if (memcmp(type, "IEND", 4) == 0) {
             break;
         }
         pos += 12 + (size_t)len;
     }
-    const bool full = zs.avail_out == 0;
-    inflateEnd(&zs);
-    if (bad || !full) return 3;
+    if (bad || n_idat == 0) return 3;
+    const unsigned char *zsrc = n_idat == 1 ? one : idat.data();
+    const size_t zlen = n_idat == 1 ? one_len : idat.size();
+    if (!inflate_zlib(zsrc, zlen, raw.data(), raw.size())) {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit(&zs) != Z_OK) return 3;
+        zs.next_out = raw.data();
+        zs.avail_out = (uInt)raw.size();
+        zs.next_in = const_cast<Bytef *>(zsrc);
+        zs.avail_in = (uInt)zlen;
+        const int rc = inflate(&zs, Z_FINISH);
+        const bool full = zs.avail_out == 0;
+        inflateEnd(&zs);
+        if (!full || (rc != Z_STREAM_END && rc != Z_OK && rc != Z_BUF_ERROR)) return 3;
+    }
     // undo the row filters in place (bytes per pixel = 2), then swap to host order
     const unsigned char *prior = nullptr;
     for (int32_t y = 0; y < h; ++y) {
@@ -162,6 +178,11 @@ extern "C" int mspa_png_header_host(const char *path_host, int32_t *h, int32_t *
     return MSPA_OK;
 }
 
+extern "C" int mspa_inflate_zlib_fast_host(const void *src_host, int64_t src_bytes, void *dst_host, int64_t dst_bytes) {
+    if (!src_host || !dst_host || src_bytes <= 0 || dst_bytes < 0) return fail(MSPA_EINVAL, "mspa_inflate_zlib_fast_host: bad argument");
+    return inflate_zlib((const uint8_t *)src_host, (size_t)src_bytes, (uint8_t *)dst_host, (size_t)dst_bytes) ? 0 : 1;
+}
+
 extern "C" int mspa_read_depth_png_host(const char *const *paths_host, int64_t n_files, int32_t h, int32_t w,
                                         uint16_t *dst_host, int32_t n_threads, int32_t *status_host) {
     if (n_files < 0 || h <= 0 || w <= 0 || (n_files > 0 && (!paths_host || !dst_host || !status_host)))
@@ -173,13 +194,13 @@ extern "C" int mspa_read_depth_png_host(const char *const *paths_host, int64_t n
     const size_t frame = (size_t)h * (size_t)w;
     std::atomic<int64_t> next{0};
     auto work = [&]() {
-        std::vector<unsigned char> file, raw;
+        std::vector<unsigned char> file, raw, idat;
         for (;;) {
             const int64_t k = next.fetch_add(1);
             if (k >= n_files) return;
             int st;
             try {
-                st = read_file(paths_host[k], file) ? decode_gray16(file.data(), file.size(), h, w, dst_host + (size_t)k * frame, raw)
+                st = read_file(paths_host[k], file) ? decode_gray16(file.data(), file.size(), h, w, dst_host + (size_t)k * frame, raw, idat)
                                                     : 1;
             } catch (...) {                           // allocation failure on a damaged length field
                 st = 3;

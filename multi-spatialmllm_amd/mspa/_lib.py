@@ -71,6 +71,7 @@ _SIGNATURES = {
     "mspa_gather_blocks_host": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int32]),
     "mspa_inflate_blocks_host": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32]),
     "mspa_read_depth_png_host": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "mspa_inflate_zlib_fast_host": (c_int, [c_void_p, c_int64, c_void_p, c_int64]),
     "mspa_png_header_host": (c_int, [c_char_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
                                      POINTER(c_int32)]),
     "mspa_check_visibility": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32,

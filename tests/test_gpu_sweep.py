@@ -219,3 +219,46 @@ def test_handler_host_scene_is_what_the_general_reader_gives(tmp_path, monkeypat
     torch.cuda.synchronize()
     assert torch.equal(pre.depth, direct.depth) and torch.equal(pre.xyz, direct.xyz) and torch.equal(pre.cam_mats, direct.cam_mats)
     assert pre.frames_relations_arrays()["overlap"].tolist() == direct.frames_relations_arrays()["overlap"].tolist()
+
+
+def test_reference_cli_unchanged_under_the_launcher(tmp_path):
+    """`python -m spatial_engine.camera_movement.calculate_frames_relations` and `python -m mspa.pipeline --scene-info ...`,
+    started the way a user starts a multi-GPU job (`torch.distributed.run`, one process per GPU; here two processes on the one
+    GPU, gloo), against the same commands started plain: the scripts' own `main()`s with their own fixed paths, nothing
+    handed to them but the environment the launcher sets."""
+    import shutil
+    import socket
+    import subprocess
+    from mspa import synth
+    root = str(tmp_path)
+    scenes = _scenes()
+    for run in ("one", "two"):
+        base = os.path.join(root, run, "data", "scannet")
+        synth.write_scannet_layout(scenes[:4], base, info_name="scenes_train_info_i_D5.pkl", jpeg_for_every_image=True)
+        synth.write_scannet_layout(scenes[4:], base, info_name="scenes_val_info_i_D5.pkl", jpeg_for_every_image=True)
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MSPA_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    plain = [sys.executable]
+    launched = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    for run, head in (("one", plain), ("two", launched)):
+        cwd = os.path.join(root, run)
+        for mod, extra in (("spatial_engine.camera_movement.calculate_frames_relations", []),
+                           ("mspa.pipeline", ["--scene-info", "data/scannet/scannet_instance_data/scenes_train_info_i_D5.pkl",
+                                              "--tracks", "2", "--out", "pipe_out"])):
+            out = subprocess.run(head + ["-m", mod] + extra, cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+            assert out.returncode == 0, (run, mod, out.stdout[-1500:], out.stderr[-3000:])
+    files = ["training_data/camera_movement/train_camera_info_D5.parquet", "training_data/camera_movement/train_camera_info_D5_nonzero.parquet",
+             "evaluation_data/camera_movement/val_camera_info_D5.parquet", "evaluation_data/camera_movement/val_warning_D5.txt"]
+    files += [os.path.join("pipe_out", n) for n in sorted(os.listdir(os.path.join(root, "one", "pipe_out")))]
+    assert len(files) >= 10
+    for n in files:
+        a, b = os.path.join(root, "one", n), os.path.join(root, "two", n)
+        assert os.path.exists(a) == os.path.exists(b), n
+        if os.path.exists(a):
+            assert open(a, "rb").read() == open(b, "rb").read(), n
+    shutil.rmtree(root, ignore_errors=True)

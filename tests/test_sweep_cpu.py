@@ -308,3 +308,64 @@ def test_windows_and_blob_framing():
     assert peak[0] <= 3
     with pytest.raises(ZeroDivisionError):
         list(sweep.SceneLoader(lambda k: 1 // (k - 2), range(5), lookahead=2))
+
+
+def test_table_driven_inflate_against_zlib():
+    """csrc/inflate_fast.h (what the PNG / .sens ingest tries before zlib itself): every compression level, strategy and window
+    size zlib offers, stored / fixed / dynamic blocks, long runs and overlapping copies -- decoded output identical; truncated,
+    padded or bit-flipped streams and wrong output sizes are DECLINED (never a wrong success: exact size + Adler-32)."""
+    import ctypes
+    from mspa import _lib
+    lib = _lib.load()
+
+    def fast(comp: bytes, n: int):
+        out = np.empty(max(n, 1), np.uint8)
+        src = np.frombuffer(comp, np.uint8)
+        rc = lib.mspa_inflate_zlib_fast_host(src.ctypes.data, len(comp), out.ctypes.data, n)
+        return rc, out[:n].tobytes()
+
+    rng = np.random.default_rng(7)
+    sc = synth.make_scene(1, n_points=16, n_frames=1, color_hw=(120, 160), depth_hw=(120, 160), with_color=False)
+    depth = sc.depth[sc.image_ids[0]]
+    scan = (np.diff(depth.astype(">u2").view(np.uint8).reshape(120, 320).astype(np.int16), axis=1, prepend=0) & 255).astype(np.uint8)
+    cases = {
+        "depth scanlines": scan.tobytes(), "depth raw": depth.tobytes(), "zeros": bytes(70000),
+        "random": rng.integers(0, 256, 50000, dtype=np.uint8).tobytes(), "text": b"the quick brown fox jumps over the lazy dog " * 3000,
+        "one byte": b"a", "empty": b"", "two symbols": rng.integers(0, 2, 40000, dtype=np.uint8).tobytes(),
+        "runs": np.repeat(rng.integers(0, 256, 1500, dtype=np.uint8), rng.integers(1, 300, 1500)).tobytes(),
+        "far matches": (rng.integers(0, 256, 30000, dtype=np.uint8).tobytes()) * 3,
+    }
+    n_streams = 0
+    for name, data in cases.items():
+        for level in (0, 1, 4, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
+                for wbits in (15, 9):
+                    co = zlib.compressobj(level, zlib.DEFLATED, wbits, 9, strategy)
+                    comp = co.compress(data) + co.flush()
+                    rc, out = fast(comp, len(data))
+                    assert rc == 0 and out == data, (name, level, strategy, wbits)
+                    n_streams += 1
+    assert n_streams == 500
+    # several deflate blocks in one stream (full flushes), as a writer that flushes per row band produces
+    co = zlib.compressobj(6)
+    data = cases["depth scanlines"]
+    comp = b"".join(co.compress(data[i:i + 5000]) + co.flush(zlib.Z_FULL_FLUSH) for i in range(0, len(data), 5000)) + co.flush()
+    assert fast(comp, len(data)) == (0, data)
+    # declined, never wrong: other output size, truncation, trailing garbage is fine (zlib ignores it too), bit flips
+    comp = zlib.compress(data, 6)
+    assert fast(comp, len(data) - 1)[0] == 1 and fast(comp, len(data) + 1)[0] == 1
+    for cut in (1, 2, 5, len(comp) // 2, len(comp) - 5, len(comp) - 1):
+        assert fast(comp[:cut], len(data))[0] == 1
+    assert fast(comp + b"\0\0\0\0", len(data)) == (0, data)
+    flips = 0
+    for _ in range(300):
+        bad = bytearray(comp)
+        k = int(rng.integers(0, len(bad)))
+        bad[k] ^= 1 << int(rng.integers(0, 8))
+        rc, out = fast(bytes(bad), len(data))
+        assert rc == 1 or out == data
+        flips += rc
+    assert flips > 250
+    # a stream with a preset dictionary is zlib's business
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_DEFAULT_STRATEGY, b"dictionary")
+    assert fast(co.compress(b"dictionary dictionary") + co.flush(), 21)[0] == 1
