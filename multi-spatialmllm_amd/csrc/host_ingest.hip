@@ -14,6 +14,7 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -105,7 +106,8 @@ int decode_gray16(const unsigned char *buf, size_t n, int32_t h, int32_t w, uint
     if (bad || n_idat == 0) return 3;
     const unsigned char *zsrc = n_idat == 1 ? one : idat.data();
     const size_t zlen = n_idat == 1 ? one_len : idat.size();
-    if (!inflate_zlib(zsrc, zlen, raw.data(), raw.size())) {
+    static const bool zlib_only = getenv("MSPA_INGEST_ZLIB") != nullptr;      // A/B switch: skip the table-driven decoder
+    if (zlib_only || !inflate_zlib(zsrc, zlen, raw.data(), raw.size())) {
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (inflateInit(&zs) != Z_OK) return 3;

@@ -52,7 +52,7 @@ def _build_samples(parquet_path, scene_infos, qtype, desired_count, overlap_min,
     df_sampled = sample_dataframe(df, all_overlap_samples=desired_count, non_overlap_samples=0, overlap_min=overlap_min,
                                   overlap_max=overlap_max, interval=interval)
     print(f"[{tag}: {qtype}] got {len(df_sampled)} sampled rows")
-    rows = [df_sampled.iloc[k] for k in range(len(df_sampled))]
+    rows = df_sampled.to_dict("records")          # plain dicts in row order (a pandas Series per row costs ~10 us: 30 s per 3 M rows)
     # one K4 launch for the relative poses of the rows a rank formats, then the records in row order
     samples = heads.camera_movement_dataset(rows, scene_infos.get_extrinsic_matrix_align, scene_infos.get_image_shape, qtype,
                                             TEMPLATE_SET, random, device=ctx.device if ctx is not None else "cuda", ctx=ctx,

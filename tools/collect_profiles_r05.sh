@@ -27,6 +27,7 @@ cpif gpurun_out/final_${T}/ab_k3.txt profiles/${T}_ab_k3.txt
 cpif gpurun_out/final_${T}/ab_k1.txt profiles/${T}_ab_k1.txt
 cpif gpurun_out/final_${T}/ab_scannet.txt profiles/${T}_ab_scannet.txt
 cpif gpurun_out/final_${T}/heads.md profiles/${T}_heads_throughput.md
+cpif gpurun_out/final_${T}/ingest_bench.txt profiles/${T}_ingest_bench.txt
 args=""
 for kv in corr:fast:vc=corr_vc corr:fast:low=corr_low corr:fast:high=corr_high compact:fast:vc=compact_vc compact:fast:low=compact_low compact:fast:high=compact_high dense_xyz:fast:vc=dense_xyz_vc minimal:fast:vc=minimal_vc; do
   key=${kv%%=*}; leg=${kv##*=}

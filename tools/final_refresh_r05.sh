@@ -40,5 +40,6 @@ python tools/ab_k3.py --sets corr,compact,minimal,dense_xyz,dense --steps 30 --r
 python tools/ab_k1.py > $O/ab_k1.txt 2>&1
 python tools/ab_scannet.py --steps 30 > $O/ab_scannet.txt 2>&1
 python tools/heads_bench.py > $O/heads.md 2> $O/heads.err
+{ python tools/ingest_bench.py; MSPA_INGEST_ZLIB=1 python tools/ingest_bench.py; } 2>&1 | grep -v "^Data from\|amdgpu" > $O/ingest_bench.txt
 cat $O/pytest_gpu.txt $O/smoke.txt $O/ab_k3.txt $O/ab_k1.txt $O/ab_scannet.txt
 tail -c 300 $O/bench_n1.json
