@@ -181,10 +181,15 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
     timings = timings or Timings()
     for w in wins:
         local_rows, local_blobs = [], []
+        failure: Optional[BaseException] = None
         for index in w[rank]:
-            item = next(items)
-            with timings.span("produce"):
-                records, blobs = produce(index, item)
+            try:
+                item = next(items)
+                with timings.span("produce"):
+                    records, blobs = produce(index, item)
+            except Exception as e:                         # a missing file, a bad pose: the other ranks must not be left
+                failure = e                                # waiting in the window's exchange (they would, until the timeout)
+                break
             if record_width is not None:
                 if records is None:
                     records = torch.zeros((0, record_width), dtype=torch.float64)
@@ -193,6 +198,16 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
                 tagged[:, 1:] = records
                 local_rows.append(tagged)
             local_blobs.append((index, list(blobs)))
+        if ctx is not None:                                # one int per window: did every rank get through its scenes?
+            import torch.distributed as dist
+            flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device=ctx.collective_device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ctx.group)
+            if int(flag.item()):
+                if failure is not None:
+                    raise failure
+                raise RuntimeError("sharded_sweep: another rank failed in this window (its own traceback says why)")
+        elif failure is not None:
+            raise failure
         # ---- the window's one exchange ---------------------------------------------------------------------------
         with timings.span("exchange"):
             rows_by_index: Dict[int, np.ndarray] = {}

@@ -218,6 +218,44 @@ def _rank_main(rank, world, port, root, out_dir, q):
     ctx.close()
 
 
+def _failing_rank_main(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), MSPA_DIST_BACKEND="gloo")
+    for p in (PKG, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    ctx = shard.context_from_env(torch.device("cpu"))
+
+    def produce(index, item):
+        if index == 5:
+            raise FileNotFoundError("scene 5 has no depth frames")
+        return None, [b"x"]
+    seen = []
+    try:
+        sweep.sharded_sweep([1.0] * 12, ctx, lambda idx: iter(idx), produce, lambda i, r, b: seen.append(i), per_rank=2)
+        q.put((rank, "finished", seen))
+    except Exception as e:
+        q.put((rank, type(e).__name__, seen))
+
+
+def test_a_failing_rank_stops_every_rank_at_the_window(tmp_path):
+    """One rank's scene fails to load: that rank raises its own error, the others raise too instead of waiting in the
+    window's collective until the communicator times out; windows before the failure were consumed."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_failing_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict((r, (kind, seen)) for r, kind, seen in (q.get(timeout=120) for _ in procs))
+    for p in procs:
+        p.join(timeout=60)
+    kinds = sorted(k for k, _ in results.values())
+    assert kinds == ["FileNotFoundError", "RuntimeError"], results
+    assert results[0][1] == [0, 1, 2, 3]                     # window 0 (items 0..3) was consumed on rank 0 before item 5 failed
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
