@@ -96,6 +96,9 @@ def parse_args():
                          "configs[2] (K1 + K2 + K4 over 8 ScanNet-sized scenes per GPU, pair-table rows collated over RCCL)")
     ap.add_argument("--scenes-per-gpu", type=int, default=8, help="--workload scenes: resident scenes per GPU")
     ap.add_argument("--no-dropin-sweep", action="store_true", help="skip the from-disk run_split leg")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not re-run the headline under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two short child runs) to "
+                         "measure `roofline.traffic` on THIS box; the committed profiles/traffic.json value is used instead")
     ap.add_argument("--variant", choices=sorted(VARIANTS), default="corr")
     ap.add_argument("--mode", choices=("fast", "exact"), default="fast",
                     help="fast: MSPA_PAIR_FAST (bit-exact integers via guarded composed matrices); exact: the "
@@ -865,6 +868,53 @@ def cpu_baseline(sc, base_pairs, budget_s, with_pool=True):
             "host_cores_available": os.cpu_count()}
 
 
+def live_traffic(args):
+    """`roofline.traffic` measured in THIS run on THIS box: the headline step re-run twice as a child process under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, kernel trace only -- never combined with
+    sys / hip / hsa traces), mean per dispatch of the K3 kernel, FETCH_SIZE doubled (gfx950 reports half of the streamed bytes:
+    profiles/r01_counter_calibration.md, MI355X_MICROARCH.md), both in KiB.  Returns (bytes per launch, kernel name, dispatches)
+    or None when rocprofv3 is missing or a pass fails -- the committed value is used then, and the line says which it was."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(tool):
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "1", "--pairs", str(args.pairs), "--frames",
+             str(args.frames), "--base-frames", str(args.base_frames), "--scene-points", str(args.scene_points), "--workload",
+             args.workload, "--variant", args.variant, "--mode", args.mode, "--stream", args.stream, "--walk-step", str(args.walk_step),
+             "--target-step", str(args.target_step), "--spinup-ms", "0", "--no-cpu-baseline", "--no-scene-legs", "--no-sweep",
+             "--also", "none", "--no-live-traffic"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MSPA_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    got = {}
+    kernel = None
+    out_dir = tempfile.mkdtemp(prefix="mspa_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out_dir, counter)
+            r = subprocess.run([tool, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "pair_" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        vals.append(float(row["Counter_Value"]))
+                        kernel = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            if r.returncode != 0 or not vals:
+                return None
+            got[counter] = (sum(vals) / len(vals), len(vals))
+        return int(got["FETCH_SIZE"][0] * 2048 + got["WRITE_SIZE"][0] * 1024), kernel, min(got["FETCH_SIZE"][1], got["WRITE_SIZE"][1])
+    except Exception as e:                                     # a profiler that cannot run here must not cost the line
+        print(f"[bench] live traffic measurement skipped: {type(e).__name__}: {e}", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+
 def committed_traffic(key):
     """PMC-measured HBM bytes per launch for a named leg, from the committed profiles/traffic.json (collected with
     tools/profile.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very command).  NOT measured in
@@ -1084,6 +1134,16 @@ def main():
         tkey = f"{args.variant}:{args.mode}:{args.workload}"
         t = committed_traffic(tkey) if args.pairs == 1000 else None
         traffic = t["hbm_bytes_per_launch"] if t else None
+        traffic_committed = traffic
+        traffic_source = (t["source"] + " -- committed PMC passes of this command, NOT measured in this run") if t else None
+        live = None
+        if world == 1 and not args.no_live_traffic and not os.environ.get("MSPA_BENCH_FORCE_DIST"):
+            live = live_traffic(args)
+        if live:
+            traffic = live[0]
+            traffic_source = (f"measured in this run on this box: two child runs of this command under rocprofv3 --kernel-trace --pmc "
+                              f"FETCH_SIZE / WRITE_SIZE (separate passes; mean of {live[2]} dispatches of {live[1]}; FETCH_SIZE x 2 KiB + "
+                              "WRITE_SIZE x 1 KiB)")
         info = dev_info
         ceilings = measured_hbm_ceilings(device) if (world == 1 and not args.no_scene_legs) else None
         tight = args.mode != "exact"
@@ -1116,8 +1176,8 @@ def main():
                        "collation_backend": dist_ctx.backend if dist_ctx is not None else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": (t["source"] + " -- committed PMC passes of this command, NOT measured in this run")
-                         if t else None,
+                         "traffic_source": traffic_source,
+                         "traffic_committed": traffic_committed,
                          "traffic_GBs": round(traffic / (kern_ms * 1e-3) / 1e9, 1) if traffic else None,
                          "traffic_frac": round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                          "kernel": "mspa::pair_fast_tight_kernel" if tight else "mspa::pair_exact_kernel",

@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--steps", "2", "--warmup", "1", "--pairs", "96", "--frames", "64", "--base-frames", "16", "--scene-points", "8192",
-         "--no-scene-legs", "--also", "none", "--cpu-seconds", "1"]
+         "--no-scene-legs", "--also", "none", "--cpu-seconds", "1", "--no-live-traffic"]
 
 
 def free_port():
@@ -66,6 +66,20 @@ def test_bench_n1_with_the_rccl_collation_forced():
     j = run([sys.executable, "bench.py", "--gpus", "1"] + SMALL, MSPA_BENCH_FORCE_DIST="1")
     check_line(j, 1)
     assert j["config"]["collation_backend"] == "nccl" and "RCCL" in j["config"]["collation"]
+
+
+def test_bench_measures_the_headline_traffic_in_the_run():
+    """Without --no-live-traffic the N = 1 line's `roofline.traffic` comes from two rocprofv3 --pmc child passes of the same
+    command on this box (FETCH_SIZE x 2 KiB + WRITE_SIZE x 1 KiB per launch of the K3 kernel), not from the committed file."""
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("no rocprofv3 on this box")
+    small = [a for a in SMALL if a != "--no-live-traffic"] + ["--no-sweep", "--no-cpu-baseline"]
+    j = run([sys.executable, "bench.py", "--gpus", "1"] + small)
+    r = j["roofline"]
+    assert r["traffic"] is not None and r["traffic_source"].startswith("measured in this run")
+    # 96 pairs of 640x480: the two depth frames in, bitset + index table out -- the measured bytes sit near the formula's
+    assert 0.5 < r["traffic"] / r["bytes_per_launch"] < 1.5 and r["traffic_frac"] > 0
 
 
 RCCL_WORLD1 = r"""
