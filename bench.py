@@ -1137,7 +1137,9 @@ def main():
         traffic_committed = traffic
         traffic_source = (t["source"] + " -- committed PMC passes of this command, NOT measured in this run") if t else None
         live = None
-        if world == 1 and not args.no_live_traffic and not os.environ.get("MSPA_BENCH_FORCE_DIST"):
+        under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or \
+            "rocprof" in os.environ.get("LD_PRELOAD", "")            # never a profiler inside a profiler
+        if world == 1 and not args.no_live_traffic and not under_profiler and not os.environ.get("MSPA_BENCH_FORCE_DIST"):
             live = live_traffic(args)
         if live:
             traffic = live[0]

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 cd /tmp
 for lib in $ROOT/tools/ab/libmspa_*.so $ROOT/multi-spatialmllm_amd/libmspa.so; do
   rm -rf /tmp/k2prof
-  MSPA_LIB=$lib timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k2prof -o p -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sweep --also none > /dev/null 2>&1
+  MSPA_LIB=$lib timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k2prof -o p -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic --no-sweep --also none > /dev/null 2>&1
   python - <<PY
 import csv, glob
 out = []

@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $ROOT
 for i in 1 2; do
   for lib in tools/ab/libmspa_*.so multi-spatialmllm_amd/libmspa.so; do
-    MSPA_LIB=$ROOT/$lib python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep --also none 2>/dev/null | tail -1 | python -c "
+    MSPA_LIB=$ROOT/$lib python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic --no-sweep --also none 2>/dev/null | tail -1 | python -c "
 import sys,json
 j=json.loads(sys.stdin.read())
 s=j['variants']['scene']

@@ -17,7 +17,7 @@ python bench.py --workload scenes --gpus 2 --steps 5 > $O/bench_scenes_n2.json 2
 bash tools/profile.sh ${T}_corr_vc > /dev/null 2>&1
 bash tools/profile.sh ${T}_compact_vc --variant compact > /dev/null 2>&1
 bash tools/profile.sh ${T}_minimal_vc --variant minimal > /dev/null 2>&1
-bash tools/pmc.sh ${T}_k3corr pair_fast_tight python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-scene-legs --also none --no-sweep > /dev/null 2>&1
+bash tools/pmc.sh ${T}_k3corr pair_fast_tight python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-live-traffic --no-scene-legs --also none --no-sweep > /dev/null 2>&1
 bash tools/pmc.sh ${T}_rect_minimal pair_fast_tight python $ROOT/tools/ab_scannet.py --legs minimal:rect --rounds 1 --steps 6 > /dev/null 2>&1
 bash tools/pmc.sh ${T}_rect_corr pair_fast_tight python $ROOT/tools/ab_scannet.py --legs corr:rect --rounds 1 --steps 6 > /dev/null 2>&1
 bash tools/profile_scene.sh > /dev/null 2>&1

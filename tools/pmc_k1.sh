@@ -6,7 +6,7 @@ cd /tmp
 for lib in $ROOT/tools/ab/libmspa_*.so $ROOT/multi-spatialmllm_amd/libmspa.so; do
   [ -f "$lib" ] || continue
   rm -rf /tmp/k1pmc
-  MSPA_LIB=$lib timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d /tmp/k1pmc -o p -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sweep --also none > /dev/null 2>&1
+  MSPA_LIB=$lib timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d /tmp/k1pmc -o p -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic --no-sweep --also none > /dev/null 2>&1
   python - <<PY
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-B="python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-scene-legs --also none --no-sweep $*"
+B="python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-live-traffic --no-scene-legs --also none --no-sweep $*"
 run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace "$@" --output-format csv -d $OUT/$name -o p -- $B > $OUT/$name.log 2>&1; }
 run stats --stats
 run sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY

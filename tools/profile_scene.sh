@@ -5,7 +5,7 @@ OUT=$ROOT/gpurun_out/prof_scene
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --also none --no-dropin-sweep > $OUT/stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic --also none --no-dropin-sweep > $OUT/stats.log 2>&1
 python - <<PY | tee $OUT/summary.md
 import csv, glob
 print("# rocprofv3 --kernel-trace --stats: scene-level kernels (bench.py informational legs, 320 images x 131072 vertices; 300 x 256 tracks)\n")

@@ -5,7 +5,7 @@ OUT=$ROOT/gpurun_out/prof_scene_pmc
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-B="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --also none --no-dropin-sweep"
+B="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-traffic --also none --no-dropin-sweep"
 run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace "$@" --output-format csv -d $OUT/$name -o p -- $B > $OUT/$name.log 2>&1; }
 run sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY
 run fetch --pmc FETCH_SIZE
