@@ -326,7 +326,8 @@ def visual_correspondence_records(scene, rows: Sequence[dict], image_hw, start_i
 
 
 def visual_correspondence_dataset(rows: Sequence, get_scene, get_bits=None, templates: T.TemplateSet = T.VISUAL_CORRESPONDENCE,
-                                  rng=_random, max_points_per_pair: int = 1, on_warn=None) -> List[Optional[dict]]:
+                                  rng=_random, max_points_per_pair: int = 1, on_warn=None, ctx=None,
+                                  transform=None) -> List[Optional[dict]]:
     """The record loop of VC_C.build_train_dataset (VC_C:424-429) for rows that may span many scenes.
 
     Pass 1 (per scene, GPU): size of the common visible set of every row (K2 on the scene's bitsets).
@@ -340,6 +341,14 @@ def visual_correspondence_dataset(rows: Sequence, get_scene, get_bits=None, temp
     ``get_scene(scene_id)`` -> resident ``SceneOnDevice`` (or None if the scene is unknown) and ``get_bits(scene_id, scene)``
     -> [F, n_words] bitsets in ``scene.ids`` order (default: K1 on the resident scene); or pass a ready backend
     (``GpuCorrespondenceBackend``-like object) as ``get_scene``.
+
+    With a communicator (``ctx``: one process per GPU) the SCENES are dealt over the ranks (longest-first by their number of
+    rows): a rank reads, uploads and runs passes 1 and 3 only for its own scenes; the sizes of pass 1 are summed over the ranks
+    (one all_reduce of an int64 [rows, 2] table: every row has exactly one owner), pass 2 -- all draws, microseconds per row --
+    runs identically on every rank (so the generator ends where a single process leaves it), each rank builds the records of its
+    scenes' rows (``transform`` applied) and ONE ``shard.gather_bytes`` brings the JSON lines to rank 0, which returns them in
+    row order as ``JsonLine``s (None where upstream returns None); the other ranks return a list of Nones.  A stale visibility
+    index (a drawn vertex fails the re-check: the rewind below) is a single-process affair and raises here.
     """
     backend = get_scene if hasattr(get_scene, "project") else GpuCorrespondenceBackend(get_scene, get_bits)
     warn = on_warn or (lambda message: None)
@@ -347,16 +356,35 @@ def visual_correspondence_dataset(rows: Sequence, get_scene, get_bits=None, temp
     for k, r in enumerate(rows):
         by_scene.setdefault(r["scene_id"], []).append(k)
     n = len(rows)
+    rank, world = (ctx.rank, ctx.world) if ctx is not None else (0, 1)
+    if ctx is not None:
+        from . import shard
+        names = list(by_scene)
+        bins = shard.lpt_assign([float(len(by_scene[s])) for s in names], world)
+        mine = {names[i] for i in bins[rank]}
+        if rank != 0:
+            warn = lambda message: None                                    # the warning file is rank 0's
+    else:
+        mine = set(by_scene)
     n_common = [0] * n
     known = [False] * n
     hw: Dict[str, Tuple[int, int]] = {}
     for scene_id, ks in by_scene.items():                                  # pass 1
+        if scene_id not in mine:
+            continue
         counts = backend.common_counts(scene_id, [(rows[k]["image_id1"], rows[k]["image_id2"]) for k in ks])
         if counts is None:
             continue
         hw[scene_id] = backend.image_hw(scene_id)
         for k, c in zip(ks, counts):
             known[k], n_common[k] = True, c
+    if ctx is not None and n:
+        import torch
+        import torch.distributed as dist
+        table = torch.tensor([[int(kn), int(c)] for kn, c in zip(known, n_common)], dtype=torch.int64, device=ctx.collective_device)
+        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=ctx.group)
+        table = table.cpu().numpy()
+        known, n_common = [bool(v) for v in table[:, 0]], [int(v) for v in table[:, 1]]
 
     hidden: Dict[int, set] = {}                                            # row -> slots whose vertex failed the re-check
     out: List[Optional[dict]] = [None] * n
@@ -378,6 +406,8 @@ def visual_correspondence_dataset(rows: Sequence, get_scene, get_bits=None, temp
             draws[k] = draw(k)
         proj: Dict[int, list] = {}
         for scene_id, ks in by_scene.items():                              # pass 3
+            if scene_id not in mine:
+                continue
             live = [k for k in ks if k >= start and draws[k] is not None]
             if not live:
                 continue
@@ -400,9 +430,15 @@ def visual_correspondence_dataset(rows: Sequence, get_scene, get_bits=None, temp
                     warn(f"[build_training_sample] Warning: No common visible points for scene {r['scene_id']} "
                          f"{r['image_id1']}, {r['image_id2']}\n")
                 continue
+            if r["scene_id"] not in mine:                                  # another rank's row: its record arrives as bytes
+                continue
             image1, image2 = (r["image_id2"], r["image_id1"]) if d["swap"] else (r["image_id1"], r["image_id2"])
             bad = {s for s, (_, _, _, ok1, ok2) in enumerate(proj[k]) if not (ok1 and ok2)}
             if bad - hidden.get(k, set()):
+                if ctx is not None:
+                    raise RuntimeError(f"visual_correspondence_dataset: vertex {proj[k][min(bad)][0]} of scene {r['scene_id']} failed the "
+                                       "visibility re-check (a visibility index that does not belong to these frames); the rewind that "
+                                       "reproduces upstream's draws for such rows runs in a single process only")
                 for s in sorted(bad):
                     vertex, _, _, ok1, ok2 = proj[k][s]
                     if not ok1:
@@ -426,7 +462,20 @@ def visual_correspondence_dataset(rows: Sequence, get_scene, get_bits=None, temp
             draw(j)
         hidden[k] = set(bad)
         start = k
-    return out
+    if transform is not None:
+        out = [None if rec is None else transform(rec) for rec in out]
+    if ctx is None:
+        return out
+    from . import shard
+    lines = "".join(f"{k}\t{json.dumps(rec)}\n" for k, rec in enumerate(out) if rec is not None).encode()
+    parts = shard.gather_bytes(lines, ctx, dst=0)
+    merged: List[Optional[dict]] = [None] * n
+    if rank == 0:
+        for p in parts:
+            for line in bytes(p).split(b"\n")[:-1]:
+                k, _, body = line.partition(b"\t")
+                merged[int(k)] = JsonLine(body)
+    return merged
 
 
 def _vc_dot_row_draws(n_common: int, known: bool, image_hw, templates: T.TemplateSet, rng, correct_point=None):

@@ -113,8 +113,13 @@ class _ResidentScenes:
 
 
 def _build_samples(parquet_path, scene_infos, desired_count, overlap_min, overlap_max, interval, visibility_info_path,
-                   warning_file, max_points_per_pair, tag):
+                   warning_file, max_points_per_pair, tag, transform=None):
+    """(records in row order -- rows without one dropped --, how many there are on every rank, communicator or None).  In a job
+    with one process per GPU the scenes of the sampled rows are dealt over the ranks: each reads and uploads only its own
+    (``heads.visual_correspondence_dataset``); upstream loops over the rows in one process (VC_C:424-429)."""
     import pandas as pd
+    from mspa import shard
+    ctx = shard.context_from_env()
     df = pd.read_parquet(parquet_path)
     print(f"[{tag}] Loaded DataFrame with {len(df)} rows from {parquet_path}")
     print(f"[{tag}] Sampling {desired_count} samples with overlap in [{overlap_min}, {overlap_max}]")
@@ -127,33 +132,46 @@ def _build_samples(parquet_path, scene_infos, desired_count, overlap_min, overla
         print(message.strip())
         with open(warning_file, "a") as wf:
             wf.write(message)
-    rows = [df_sampled.iloc[k] for k in range(len(df_sampled))]
+    rows = df_sampled.to_dict("records")
     samples = heads.visual_correspondence_dataset(rows, resident.get, resident.get_bits, TEMPLATE_SET, random,
-                                                  max_points_per_pair, warn)
-    return [s for s in samples if s]
+                                                  max_points_per_pair, warn, ctx=ctx, transform=transform)
+    if ctx is None:
+        kept = [s for s in samples if s]
+        return kept, len(kept), None
+    import torch.distributed as dist                          # every rank shuffles an index list of rank 0's length (the generator stays in step)
+    n_kept = torch.tensor([sum(1 for s in samples if s)], dtype=torch.int64, device=ctx.collective_device)
+    dist.broadcast(n_kept, src=0, group=ctx.group)
+    return [s for s in samples if s], int(n_kept.item()), ctx
+
+
+def _shuffle_and_write(samples, n_kept, ctx, out_file, tag):
+    """``random.shuffle(out_samples)`` + the JSONL (VC_C:430-433), the shuffle as an index permutation every rank computes."""
+    order = list(range(n_kept))
+    random.shuffle(order)
+    if ctx is not None and ctx.rank != 0:
+        ctx.barrier()
+        return
+    print(f"[{tag}] Writing {len(samples)} items to {out_file}")
+    heads.write_jsonl(out_file, [samples[i] for i in order])
+    if ctx is not None:
+        ctx.barrier()
 
 
 def build_train_dataset(parquet_path, output_dir, scene_infos, desired_count, overlap_min, overlap_max, interval,
                         visibility_info_path, warning_file, max_points_per_pair=1):
     """train_visual_correspondence_coor_2_coor.jsonl (reference: :401-433); all projections batched per scene."""
-    out_samples = _build_samples(parquet_path, scene_infos, desired_count, overlap_min, overlap_max, interval,
-                                 visibility_info_path, warning_file, max_points_per_pair, "Train")
-    random.shuffle(out_samples)
-    out_file = os.path.join(output_dir, "train_visual_correspondence_coor_2_coor.jsonl")
-    print(f"[Train] Writing {len(out_samples)} items to {out_file}")
-    heads.write_jsonl(out_file, out_samples)
+    samples, n, ctx = _build_samples(parquet_path, scene_infos, desired_count, overlap_min, overlap_max, interval,
+                                     visibility_info_path, warning_file, max_points_per_pair, "Train")
+    _shuffle_and_write(samples, n, ctx, os.path.join(output_dir, "train_visual_correspondence_coor_2_coor.jsonl"), "Train")
 
 
 def build_val_dataset(parquet_path, output_dir, scene_infos, desired_count, overlap_min, overlap_max, interval,
                       visibility_info_path, warning_file, max_points_per_pair=1):
     assert max_points_per_pair == 1, "[Val] max_points_per_pair should be 1."
-    out_samples = [convert_train_sample_to_eval_sample(s) for s in
-                   _build_samples(parquet_path, scene_infos, desired_count, overlap_min, overlap_max, interval,
-                                  visibility_info_path, warning_file, max_points_per_pair, "Val")]
-    random.shuffle(out_samples)
-    out_file = os.path.join(output_dir, "val_visual_correspondence_coor_2_coor.jsonl")
-    print(f"[Val] Writing {len(out_samples)} items to {out_file}")
-    heads.write_jsonl(out_file, out_samples)
+    samples, n, ctx = _build_samples(parquet_path, scene_infos, desired_count, overlap_min, overlap_max, interval,
+                                     visibility_info_path, warning_file, max_points_per_pair, "Val",
+                                     transform=convert_train_sample_to_eval_sample)
+    _shuffle_and_write(samples, n, ctx, os.path.join(output_dir, "val_visual_correspondence_coor_2_coor.jsonl"), "Val")
 
 
 DEBUG = False

@@ -88,6 +88,14 @@ def _run_everything(out_dir):
     np.random.seed(3)
     CME.build_train_dataset(os.path.join(out_dir, "pairs.parquet"), out_dir, handler0, "displacement_vector", 60, 1, 60, 1)
     CME.build_val_dataset(os.path.join(out_dir, "pairs.parquet"), out_dir, handler0, "yaw_movement", 25, 1, 60, 1)
+    # ... and the correspondence builder: scenes dealt over the ranks, sizes summed, draws replicated, records as bytes to rank 0
+    import spatial_engine.visual_correspondence.visual_correspondence_qa_engine_coor_2_coor as VC
+    random.seed(4)
+    np.random.seed(4)
+    VC.build_train_dataset(os.path.join(out_dir, "pairs.parquet"), out_dir, handler0, 50, 1, 60, 1, os.path.join(out_dir, "vis.pkl"),
+                           os.path.join(out_dir, "vc_warn.txt"))
+    VC.build_val_dataset(os.path.join(out_dir, "pairs.parquet"), out_dir, handler0, 20, 1, 60, 1, os.path.join(out_dir, "vis.pkl"),
+                         os.path.join(out_dir, "vc_warn_val.txt"))
     eng = OM.TwoFrameVideoQAEngine("tapvid3d_total_distance", "adt")
     random.seed(11)
     eng.generate_qa_training_data([t.scene_id for t in _tracks()], "tapvid", out_dir, os.path.join(out_dir, "om_train.jsonl"),
@@ -177,6 +185,8 @@ def test_drop_in_entry_points_one_rank_vs_two_ranks_from_disk(tmp_path, monkeypa
     assert len(cm) > 10 and {"id", "image", "conversations", "answer_values", "gt_value"} <= set(cm[0])
     cmv = [json.loads(line) for line in open(os.path.join(root, "one", "yaw_movement_val.jsonl"))]
     assert len(cmv) > 5 and "text" in cmv[0] and "conversations" not in cmv[0]
+    vc = [json.loads(line) for line in open(os.path.join(root, "one", "train_visual_correspondence_coor_2_coor.jsonl"))]
+    assert len(vc) > 10 and {"id", "image", "conversations", "p1_list", "p2_list", "gt_value"} <= set(vc[0])
     om = [json.loads(line) for line in open(os.path.join(root, "one", "om_train.jsonl"))]
     assert len(om) > 5 and {"id", "conversations", "point_moving", "cam_moving"} <= set(om[0])
     # ---- two ranks, one GPU: the same bytes everywhere ----------------------------------------------------------------
