@@ -14,6 +14,7 @@
 //                        the transposed tile (lane b keeps it)
 #include "mspa_common.h"
 #include "inflate_fast.h"
+#include "host_pool.h"
 
 #include <atomic>
 #include <cstdio>
@@ -234,19 +235,15 @@ extern "C" int mspa_gather_blocks_host(const void *const *src_blocks_host, int64
         if (block_bytes > 0 && !src_blocks_host[k]) return fail(MSPA_EINVAL, "mspa_gather_blocks_host: null block");
     if (n_blocks == 0 || block_bytes == 0) return MSPA_OK;
     const int64_t nt = n_threads < 1 ? 1 : (n_threads > n_blocks ? n_blocks : (int64_t)n_threads);
-    auto work = [&](int64_t t) {
-        const int64_t lo = n_blocks * t / nt, hi = n_blocks * (t + 1) / nt;
-        for (int64_t k = lo; k < hi; ++k) memcpy((char *)dst_host + k * block_bytes, src_blocks_host[k], (size_t)block_bytes);
+    std::atomic<int64_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int64_t k = next.fetch_add(1);
+            if (k >= n_blocks) return;
+            memcpy((char *)dst_host + k * block_bytes, src_blocks_host[k], (size_t)block_bytes);
+        }
     };
-    std::vector<std::thread> pool;
-    try {
-        for (int64_t t = 1; t < nt; ++t) pool.emplace_back(work, t);
-    } catch (...) {                      // thread creation refused: the blocks nobody took are copied here
-        const int64_t started = (int64_t)pool.size();
-        for (int64_t t = started + 1; t < nt; ++t) work(t);
-    }
-    work(0);
-    for (auto &th : pool) th.join();
+    HostPool::get().parallel((int)nt, work);                // persistent worker threads (host_pool.h); the caller copies too
     return MSPA_OK;
 }
 
@@ -281,13 +278,7 @@ extern "C" int mspa_inflate_blocks_host(const void *const *src_blocks_host, cons
             }
         }
     };
-    std::vector<std::thread> pool;
-    try {
-        for (int64_t t = 1; t < nt; ++t) pool.emplace_back(work);
-    } catch (...) {
-    }                                                    // fewer threads than asked for: the rest of the blocks go to those running
-    work();
-    for (auto &th : pool) th.join();
+    HostPool::get().parallel((int)nt, work);
     if (bad.load() >= 0) {
         char msg[128];
         snprintf(msg, sizeof msg, "mspa_inflate_blocks_host: block %lld is not a zlib stream of the expected size", (long long)bad.load());

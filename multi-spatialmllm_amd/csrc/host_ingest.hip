@@ -11,6 +11,7 @@
 // filters.  Anything else gets status 2 and the caller decodes that one frame with its general reader.
 #include "mspa_common.h"
 #include "inflate_fast.h"
+#include "host_pool.h"
 
 #include <atomic>
 #include <cstdio>
@@ -210,12 +211,6 @@ extern "C" int mspa_read_depth_png_host(const char *const *paths_host, int64_t n
             status_host[k] = st;
         }
     };
-    std::vector<std::thread> pool;
-    try {
-        for (int64_t t = 1; t < nt; ++t) pool.emplace_back(work);
-    } catch (...) {
-    }                                                 // fewer threads than asked for: the files go to those running
-    work();
-    for (auto &th : pool) th.join();
+    HostPool::get().parallel((int)nt, work);                // persistent worker threads (host_pool.h); the caller works too
     return MSPA_OK;
 }

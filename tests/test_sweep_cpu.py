@@ -407,3 +407,35 @@ def test_table_driven_inflate_against_zlib():
     # a stream with a preset dictionary is zlib's business
     co = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_DEFAULT_STRATEGY, b"dictionary")
     assert fast(co.compress(b"dictionary dictionary") + co.flush(), 21)[0] == 1
+
+
+def _forked_child_reads(paths, want_sum, q):
+    out = ingest.read_depth_frames(paths, 4)                # the parent's pool threads do not exist here: the pool is rebuilt
+    q.put(int(out.astype(np.int64).sum()) == want_sum)
+
+
+def test_ingest_pool_survives_fork_and_concurrent_callers(tmp_path):
+    """The ingest entry points share one persistent pool of native worker threads (csrc/host_pool.h): several Python threads
+    calling at once get their own results, and a FORKED child (the reference's scripts fork worker pools) is not left waiting
+    for threads that did not survive the fork."""
+    import multiprocessing as mp
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    frames = [rng.integers(0, 65536, (60, 80), dtype=np.uint16) for _ in range(12)]
+    paths = []
+    for k, f in enumerate(frames):
+        p = str(tmp_path / f"{k}.png")
+        Image.fromarray(f).save(p)
+        paths.append(p)
+    want = np.stack(frames)
+    with ThreadPoolExecutor(max_workers=6) as ex:            # six callers at once, three native threads each
+        outs = list(ex.map(lambda _: ingest.read_depth_frames(paths, 3), range(24)))
+    assert all(np.array_equal(o, want) for o in outs)
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    child = ctx.Process(target=_forked_child_reads, args=(paths, int(want.astype(np.int64).sum()), q))
+    child.start()
+    assert q.get(timeout=60) is True
+    child.join(timeout=30)
+    assert child.exitcode == 0
