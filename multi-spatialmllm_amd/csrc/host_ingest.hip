@@ -197,7 +197,8 @@ extern "C" int mspa_read_depth_png_host(const char *const *paths_host, int64_t n
     const size_t frame = (size_t)h * (size_t)w;
     std::atomic<int64_t> next{0};
     auto work = [&]() {
-        std::vector<unsigned char> file, raw, idat;
+        // scratch of the THREAD, not of the call: the pool's workers keep it (and its faulted-in pages) from scene to scene
+        static thread_local std::vector<unsigned char> file, raw, idat;
         for (;;) {
             const int64_t k = next.fetch_add(1);
             if (k >= n_files) return;

@@ -30,6 +30,13 @@ def main():
                 ingest.read_depth_frames(files, n)
             dt = (time.perf_counter() - t) / 5
             print(f"read_depth_frames threads {n:3d}: {dt * 1e3:7.2f} ms per scene, {dt / len(files) * 1e3 * min(n, len(files)):.2f} ms per frame and thread, {len(files) * 614400 / dt / 1e9:.2f} GB/s out")
+        buf = ingest.read_depth_frames(files, 8).copy()        # a destination that already has its pages: what a reused block costs
+        for n in (8, 25, 64):
+            t = time.perf_counter()
+            for _ in range(5):
+                ingest.read_depth_frames(files, n, out=buf)
+            dt = (time.perf_counter() - t) / 5
+            print(f"read_depth_frames threads {n:3d}, REUSED destination: {dt * 1e3:7.2f} ms per scene, {len(files) * 614400 / dt / 1e9:.2f} GB/s out")
         t = time.perf_counter()
         for _ in range(5):
             h.get_scene_points_align(sid)
