@@ -51,6 +51,9 @@ class BlockPool:
                 self._free.append(base)
 
 
+DEFAULT_POOL = BlockPool(max_free=8)      # one per process: destinations outlive a handler (a split's scenes, then the next split's)
+
+
 def png_header(path: str):
     """(h, w, bit_depth, colour_type, interlace) of a PNG file's IHDR."""
     v = [ctypes.c_int32(0) for _ in range(5)]

@@ -281,17 +281,16 @@ class SceneInfoHandler:
         ids = self.get_all_image_ids(scene_id)
         E = {i: self.infos[scene_id]["images_info"][i]["extrinsic_matrix"] for i in ids}
         valid = [i for i in ids if np.all(np.isfinite(E[i]))]
-        if getattr(self, "_block_pool", None) is None:
-            self._block_pool = ingest.BlockPool()         # reused destinations: no page faults under the decode threads
+        pool = ingest.DEFAULT_POOL                        # reused destinations: no page faults under the decode threads
         block = ingest.read_depth_frames([self.get_depth_image_path(scene_id, i) for i in valid], num_workers,
-                                         general_reader=_images.read_depth, memory=_images.MEMORY, pool=self._block_pool)
+                                         general_reader=_images.read_depth, memory=_images.MEMORY, pool=pool)
         pts = self.get_scene_points_align(scene_id)[:, :3] if with_points else None
         hs = HostScene(scene_id, self.get_intrinsic_matrix(scene_id), self.get_world_to_axis_align_matrix(scene_id), E,
                        {i: block[k] for k, i in enumerate(valid)}, tuple(self.get_image_shape(scene_id)), pts,
                        float(self.depth_value_scale))
         if len(valid):
             import weakref
-            weakref.finalize(hs, self._block_pool.give, block)       # the block goes back when nothing holds the scene any more
+            weakref.finalize(hs, pool.give, block)       # the block goes back when nothing holds the scene any more
         return hs
 
     def scene_on_device(self, scene_id, with_points=True, num_workers=8):
