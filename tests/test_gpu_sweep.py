@@ -246,6 +246,12 @@ def test_reference_cli_unchanged_under_the_launcher(tmp_path):
         base = os.path.join(root, run, "data", "scannet")
         synth.write_scannet_layout(scenes[:4], base, info_name="scenes_train_info_i_D5.pkl", jpeg_for_every_image=True)
         synth.write_scannet_layout(scenes[4:], base, info_name="scenes_val_info_i_D5.pkl", jpeg_for_every_image=True)
+        os.makedirs(os.path.join(root, run, "tapvid"), exist_ok=True)
+        for tr in _tracks()[:2]:                              # TAPVid-3D sample files for the pipeline's --tapvid-root
+            H, W = tr.image_hw
+            np.savez(os.path.join(root, run, "tapvid", f"{tr.scene_id}.npz"),
+                     images_jpeg_bytes=np.array([_fake_jpeg(H, W)] * tr.tracks_XYZ.shape[0], dtype=object), tracks_XYZ=tr.tracks_XYZ,
+                     visibility=tr.visibility, fx_fy_cx_cy=tr.fx_fy_cx_cy, extrinsics_w2c=tr.extrinsics_w2c)
     env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MSPA_DIST_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
@@ -259,7 +265,7 @@ def test_reference_cli_unchanged_under_the_launcher(tmp_path):
         cwd = os.path.join(root, run)
         for mod, extra in (("spatial_engine.camera_movement.calculate_frames_relations", []),
                            ("mspa.pipeline", ["--scene-info", "data/scannet/scannet_instance_data/scenes_train_info_i_D5.pkl",
-                                              "--tracks", "2", "--out", "pipe_out"])):
+                                              "--tapvid-root", "tapvid", "--out", "pipe_out"])):
             out = subprocess.run(head + ["-m", mod] + extra, cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
             assert out.returncode == 0, (run, mod, out.stdout[-1500:], out.stderr[-3000:])
     files = ["training_data/camera_movement/train_camera_info_D5.parquet", "training_data/camera_movement/train_camera_info_D5_nonzero.parquet",
