@@ -197,9 +197,10 @@ inline uint32_t adler32_of(const uint8_t *d, size_t n) {
 // *consumed (optional): bytes of src the stream occupied (rounded up to a whole byte).
 inline bool inflate_raw(const uint8_t *src, size_t n_src, uint8_t *dst, size_t n_dst, size_t *consumed = nullptr) {
     using namespace inflate_detail;
-    static thread_local Entry lit_table[kLitTableSize];
-    static thread_local Entry dist_table[kDistTableSize];
-    Bits br{src, src + n_src};
+    static thread_local Entry lit_table_tls[kLitTableSize];
+    static thread_local Entry dist_table_tls[kDistTableSize];
+    Entry *const lit_table = lit_table_tls, *const dist_table = dist_table_tls;     // the thread's tables: their address taken ONCE
+    Bits br{src, src + n_src};                                                       // (in a shared library every TLS access is a call)
     uint8_t *out = dst, *const out_end = dst + n_dst;
     bool last = false;
     while (!last) {
