@@ -668,7 +668,7 @@ def time_dropin_sweep(n_scenes=8, n_frames=64, n_points=131072, num_workers=None
             # passes warm the page cache, the upload slots, the decode threads -- and the allocator: glibc stops mapping and
             # unmapping its large blocks (every page faulted in again by 25 threads) only after a few of them have been freed;
             # a fresh process ran its first 3 passes at 88 scenes/s and every later 8-scene sweep at 190-240
-            # (tools/dropin_order_test.py).  A real split has hundreds of scenes: the steady state is what it runs at.
+            # (tools/dropin_order_check.py).  A real split has hundreds of scenes: the steady state is what it runs at.
             for rep in range(7):
                 tm = sweep.Timings()
                 with contextlib.redirect_stdout(io.StringIO()):
@@ -814,7 +814,7 @@ def _cpu_pair(job):
     depth, K, E, A, color = _CPU_SCENE
     a, b = job
     r = O.frame_pair(depth[a], depth[b], K, E[a], E[b], A, (H, W), color)
-    return r["n_vis"]
+    return r["n_valid"], r["n_vis"]
 
 
 def _cpu_worker_init(payload_path):
@@ -830,25 +830,54 @@ def _cpu_worker_init(payload_path):
     _CPU_SCENE = (z["depth"], z["K"], z["E"], z["A"], np.zeros((H, W, 3), dtype=np.uint8))
 
 
-def cpu_baseline(sc, base_pairs, budget_s, with_pool=True):
+def cpu_baseline(sc, base_pairs, budget_s, with_pool=True, timed=None):
     """Time the NumPy restatement of the reference path (oracle/np_oracle.frame_pair) on a bounded sample
     of the step's pairs: (i) one process, (ii) multiprocessing.Pool(min(25, cores)) -- the reference's own
-    worker count (CFR:280).  The oracle is used here as the thing timed BESIDE the product, never inside it."""
+    worker count (CFR:280).  The oracle is used here as the thing timed BESIDE the product, never inside it.
+
+    ``timed`` = (pairs [n, 2] frame indices of the timed launch, the resident depth tensor, the launch's `counts` [n, 2]):
+    the one-process leg then runs the oracle on the VERY frames the timed launch read (pair p's two replica frames, downloaded
+    outside the clock) and its (n_valid, n_vis) -- the sizes of the reference's validity and visibility masks, OPS:272-296 and
+    IH:375-386 -- are compared with what the timed launch wrote for the same pair: `parity_in_run`."""
     global _CPU_SCENE
     import multiprocessing as mp
     import tempfile
     ids = sc.valid_image_ids
     depth = np.stack([sc.depth[i] for i in ids])
     E = np.stack([sc.E[i] for i in ids])
-    _CPU_SCENE = (depth, sc.K, E, sc.A, np.zeros((H, W, 3), dtype=np.uint8))
+    color = np.zeros((H, W, 3), dtype=np.uint8)
+    _CPU_SCENE = (depth, sc.K, E, sc.A, color)
     jobs = [(int(p[0]), int(p[1])) for p in base_pairs]
-    n, t0 = 0, time.perf_counter()
+    parity = None
+    if timed is not None:
+        t_pairs, t_depth, t_counts = timed
+        gpu_counts = t_counts.detach().cpu().numpy().reshape(-1, 2)
+        parity = {"pairs": 0, "mismatches": 0, "first_mismatch": None,
+                  "what": "(n_valid, n_vis) of oracle/np_oracle.frame_pair on the frames the timed launch read (replica frames "
+                          "downloaded from HBM) == the `counts` the timed launch wrote for the same pairs"}
+    n, el = 0, 0.0
     while True:
-        _cpu_pair(jobs[n])
+        if timed is not None:                 # this pair's own two frames, as resident on the device (outside the clock)
+            fa, fb = int(t_pairs[n][0]), int(t_pairs[n][1])
+            pair_depth = t_depth[[fa, fb]].cpu().numpy().view(np.uint16)
+            _CPU_SCENE = (pair_depth, sc.K, np.stack([E[jobs[n][0]], E[jobs[n][1]]]), sc.A, color)
+            job = (0, 1)
+        else:
+            job = jobs[n]
+        t0 = time.perf_counter()
+        got = _cpu_pair(job)
+        el += time.perf_counter() - t0
+        if parity is not None:
+            parity["pairs"] += 1
+            want = (int(gpu_counts[n][0]), int(gpu_counts[n][1]))
+            if tuple(int(x) for x in got) != want:
+                parity["mismatches"] += 1
+                if parity["first_mismatch"] is None:
+                    parity["first_mismatch"] = {"pair": n, "frames": [fa, fb], "oracle": [int(got[0]), int(got[1])], "gpu": list(want)}
         n += 1
-        el = time.perf_counter() - t0
         if (el > budget_s / 2 and n >= 8) or n >= len(jobs):
             break
+    _CPU_SCENE = (depth, sc.K, E, sc.A, color)
     single = n / el
     workers = min(25, os.cpu_count() or 1)
     pool_rate, pool_jobs = None, []
@@ -871,7 +900,7 @@ def cpu_baseline(sc, base_pairs, budget_s, with_pool=True):
             "pool": None if pool_rate is None else {
                 "value": round(pool_rate, 2), "cores": workers,
                 "sample": f"{len(pool_jobs)} pairs over multiprocessing.Pool({workers}), 1 BLAS thread each"},
-            "host_cores_available": os.cpu_count()}
+            "host_cores_available": os.cpu_count(), "parity_in_run": parity}
 
 
 def live_traffic(args):
@@ -1134,7 +1163,8 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         # after the GPU legs (the pair list comes from K1 + K2); at N > 1 only the 1-process leg, with half the budget,
         # while the other ranks wait at the final barrier
-        cpu = cpu_baseline(sc, base_pairs, args.cpu_seconds if world == 1 else args.cpu_seconds / 2, with_pool=(world == 1))
+        cpu = cpu_baseline(sc, base_pairs, args.cpu_seconds if world == 1 else args.cpu_seconds / 2, with_pool=(world == 1),
+                           timed=(pairs_np, depth, out["counts"]))
 
     if rank == 0:
         tkey = f"{args.variant}:{args.mode}:{args.workload}"
@@ -1194,6 +1224,7 @@ def main():
                          "measured_ceilings_GBs": ceilings},
             "roofline_valu": valu_roofline(args.variant, args.mode, args.workload, kern_ms),
             "cpu_baseline": cpu,
+            "parity_in_run": cpu.pop("parity_in_run") if cpu else None,
             "cpu_baseline_pool": None if not cpu or not cpu.get("pool") else dict(
                 cpu["pool"], unit="frame-pairs/s", kind="port",
                 what="the same NumPy restatement over multiprocessing.Pool(min(25, cores)) -- the reference's own fan-out (CFR:280)"),
@@ -1223,6 +1254,8 @@ def main():
         except Exception:
             pass
         print(json.dumps(line), flush=True)
+        if (line.get("parity_in_run") or {}).get("mismatches"):
+            raise SystemExit(f"bench.py: the timed launch disagrees with the oracle: {line['parity_in_run']}")
 
 
 if __name__ == "__main__":

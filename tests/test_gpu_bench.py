@@ -38,6 +38,8 @@ def check_line(j, n):
     assert "traffic_source" in r
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
     assert "cpu_baseline_pool" in j and "roofline_valu" in j
+    # the timed launch's own counts against the oracle on the frames it read, inside the run
+    assert j["parity_in_run"]["pairs"] >= 8 and j["parity_in_run"]["mismatches"] == 0
     assert j["config"]["pairs"]["rule"].startswith("equal quotas over the overlap bins 6..35")
     assert 0 < j["config"]["visible_fraction"] < 1
 
