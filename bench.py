@@ -96,6 +96,8 @@ def parse_args():
                          "configs[2] (K1 + K2 + K4 over 8 ScanNet-sized scenes per GPU, pair-table rows collated over RCCL)")
     ap.add_argument("--scenes-per-gpu", type=int, default=8, help="--workload scenes: resident scenes per GPU")
     ap.add_argument("--no-dropin-sweep", action="store_true", help="skip the from-disk run_split leg")
+    ap.add_argument("--no-dropin-ranks", action="store_true",
+                    help="skip the 1 / 2 / 4-ranks-on-one-GPU from-disk leg (tools/dropin_ranks.py)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not re-run the headline under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two short child runs) to "
                          "measure `roofline.traffic` on THIS box; the committed profiles/traffic.json value is used instead")
@@ -697,6 +699,20 @@ def time_dropin_sweep(n_scenes=8, n_frames=64, n_points=131072, num_workers=None
         shutil.rmtree(root, ignore_errors=True)
 
 
+def time_dropin_sweep_ranks(ranks=(1, 2, 4), n_scenes=16, n_frames=320, passes=2, per_rank=2, timeout_s=170, num_workers=None):
+    """`variants.dropin_sweep_ranks`: both split-sweeping drop-in entry points (CFR:200-253, MVI:127-177) over ScanNet-sized
+    on-disk scenes with 1, 2 and 4 ranks sharing this GPU over gloo, each world size in its own processes
+    (tools/dropin_ranks.py): scenes/s including the writing, rank 0's writer busy time, every rank's wait at the window
+    exchange, and whether the files equal the one-rank run's byte for byte.  The kernels are < 1 % of a scene, so this is the
+    host-side scaling of an N-GPU job; the GPU and its PCIe link are the one thing the ranks share here."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mspa_dropin_ranks", os.path.join(ROOT, "tools", "dropin_ranks.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.drive(ranks=tuple(ranks), n_scenes=n_scenes, n_frames=n_frames, workers=num_workers or min(25, os.cpu_count() or 1),
+                     passes=passes, per_rank=per_rank, timeout_s=timeout_s)
+
+
 def run_scene_workload(args, rank, world, device, dist_ctx, share):
     """--workload scenes: BASELINE.json configs[2] in the bench's shape.  `scenes_per_gpu` x world ScanNet-sized scenes
     (131 072 vertices; 160..400 frames, so costs differ) are dealt longest-first (shard.lpt_assign, cost F^2 N / 64 + F N); each
@@ -1149,6 +1165,11 @@ def main():
                     extra["dropin_sweep"] = time_dropin_sweep()
                 except Exception as e:                       # e.g. no Pillow / no pyarrow on the box: the leg is informational
                     extra["dropin_sweep"] = {"skipped": f"{type(e).__name__}: {e}"}
+            if not args.no_dropin_ranks:
+                try:
+                    extra["dropin_sweep_ranks"] = time_dropin_sweep_ranks()
+                except Exception as e:                       # informational: never costs the line
+                    extra["dropin_sweep_ranks"] = {"skipped": f"{type(e).__name__}: {e}"}
             t1 = committed_traffic("K1_vertex_visibility")
             if t1:
                 k1 = extra["scene"]["K1_vertex_visibility"]["shuffled_worst_case"]   # the PMC passes ran on the shuffled cloud

@@ -76,10 +76,16 @@ def partition(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
-def lpt_assign(costs: Sequence[float], world: int) -> List[List[int]]:
-    """Longest-processing-time-first assignment of scenes to ranks (cost ~ F^2*N/64 + F*N)."""
+def lpt_assign(costs: Sequence[float], world: int, rank0_share: float = 1.0) -> List[List[int]]:
+    """Longest-processing-time-first assignment of scenes to ranks (cost ~ F^2*N/64 + F*N).  ``rank0_share`` < 1 starts
+    rank 0 with a handicap so that it ends with about that fraction of what each other rank gets (rank 0 also writes the
+    split's files: mspa/sweep.py); every rank computes the same assignment."""
     order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
     load = [0.0] * world
+    if world > 1 and rank0_share < 1.0:
+        # balanced loads with a handicap h on rank 0: the others end at L, rank 0 at L - h = share * L, and
+        # (world - 1 + share) * L = total
+        load[0] = max(0.0, (1.0 - float(rank0_share)) * float(sum(costs)) / (world - 1 + float(rank0_share)))
     bins: List[List[int]] = [[] for _ in range(world)]
     for i in order:
         r = min(range(world), key=lambda k: (load[k], k))

@@ -119,13 +119,14 @@ class SceneLoader:
 _END = object()
 
 
-def windows(costs: Sequence[float], world: int, per_rank: int = 8) -> List[List[List[int]]]:
-    """Consecutive windows of ``world * per_rank`` items, each dealt longest-first: ``result[w][rank]`` = ascending indices."""
+def windows(costs: Sequence[float], world: int, per_rank: int = 8, rank0_share: float = 1.0) -> List[List[List[int]]]:
+    """Consecutive windows of ``world * per_rank`` items, each dealt longest-first: ``result[w][rank]`` = ascending indices.
+    ``rank0_share`` < 1 gives rank 0 (the writer) that fraction of an even share of each window's cost."""
     n, size = len(costs), max(1, world * max(1, int(per_rank)))
     out = []
     for lo in range(0, n, size):
         hi = min(n, lo + size)
-        bins = shard.lpt_assign(list(costs[lo:hi]), world)
+        bins = shard.lpt_assign(list(costs[lo:hi]), world, rank0_share=rank0_share)
         out.append([[lo + i for i in b] for b in bins])
     return out
 
@@ -162,9 +163,63 @@ def _unpack_blobs(buf: np.ndarray) -> Dict[int, List[np.ndarray]]:
     return out
 
 
+class _WindowWriter:
+    """Rank 0's ordered writer: ``consume`` of window w runs on this thread while window w + 1 is produced and exchanged.
+
+    The reference hands worker results back asynchronously (``apply_async`` + ``r.get()``, CFR:222-229, MVI:151-156); here
+    the other ranks would otherwise stand in the next window's first collective until rank 0 had converted and written
+    every rank's scenes.  At most ``depth`` exchanged windows wait in the queue (rank 0 holds windows, never the split); a
+    failure in ``consume`` is kept and raised on the sweep's thread -- at the next window's failure vote, so that every
+    rank leaves together -- and the thread drains what is queued without touching it."""
+
+    def __init__(self, consume: Callable, record_width: Optional[int], timings: "Timings", depth: int = 2):
+        import queue
+        self.consume, self.record_width, self.timings = consume, record_width, timings
+        self.q: "queue.Queue" = queue.Queue(maxsize=max(1, int(depth)))
+        self.error: Optional[BaseException] = None
+        self.thread = threading.Thread(target=self._run, name="mspa-writer", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            if self.error is not None:
+                continue
+            indices, rows_by_index, parts = job
+            t = time.perf_counter()
+            try:
+                blobs_by_index: Dict[int, List[np.ndarray]] = {}
+                for p in parts:
+                    blobs_by_index.update(_unpack_blobs(p))
+                for index in indices:
+                    rows = rows_by_index.get(index)
+                    if self.record_width is not None and rows is None:
+                        rows = np.zeros((0, self.record_width))
+                    self.consume(index, rows, blobs_by_index[index])
+            except BaseException as e:                     # noqa: BLE001 -- re-raised on the sweep's thread
+                self.error = e
+            finally:
+                self.timings.add("consume", time.perf_counter() - t)
+
+    def put(self, indices, rows_by_index, parts):
+        t = time.perf_counter()
+        self.q.put((indices, rows_by_index, parts))
+        self.timings.add("writer_backpressure", time.perf_counter() - t)
+
+    def close(self) -> Optional[BaseException]:
+        """Waits until everything queued has been written (or skipped after a failure); returns the failure, if any."""
+        t = time.perf_counter()
+        self.q.put(None)
+        self.thread.join()
+        self.timings.add("writer_drain", time.perf_counter() - t)
+        return self.error
+
+
 def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work_items: Callable[[List[int]], Iterator],
-                  produce: Callable, consume: Callable, record_width: Optional[int] = None, per_rank: int = 8,
-                  timings: Optional[Timings] = None) -> None:
+                  produce: Callable, consume: Callable, record_width: Optional[int] = None, per_rank: Optional[int] = None,
+                  timings: Optional[Timings] = None, writer_depth: int = 2, rank0_share: Optional[float] = None) -> None:
     """Run ``produce(index, item) -> (records | None, [blob, ...])`` for this rank's items and ``consume(index, records,
     blobs)`` on rank 0 for EVERY item, in index order.
 
@@ -172,76 +227,97 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
     ``records`` is a [n, record_width] float64 tensor (any device) or None; blobs are bytes-like.  With a communicator the
     records of a window go to rank 0 through ``shard.collate_records(dst=0)`` and the blobs through ``shard.gather_bytes``;
     without one (``ctx`` None) nothing is exchanged and the same ``consume`` calls happen in the same order.
-    """
+
+    A window is ``world x per_rank`` items (default: ``MSPA_WINDOW_PER_RANK`` from the environment, else 8).
+    ``consume`` runs on a writer thread of rank 0 (``_WindowWriter``: window w is written while window w + 1 is produced),
+    still strictly in index order, so the files stay those of a one-process run.  ``rank0_share`` (default: the environment's
+    ``MSPA_RANK0_SHARE``, else 1.0) scales the share of each window's work dealt to rank 0, the rank that also writes.
+    ``timings`` gains ``wait_at_exchange`` (seconds this rank stood in the window's first collective: on ranks > 0 that is
+    the wait for the slowest producer, and for rank 0 if its writer ever fell behind), ``consume`` (the writer's busy time),
+    ``writer_backpressure`` (the sweep thread blocked on a full writer queue) and ``writer_drain`` (the tail after the last
+    window)."""
+    import os
     import torch
     rank, world = (ctx.rank, ctx.world) if ctx is not None else (0, 1)
-    wins = windows(costs, world, per_rank)
+    if rank0_share is None:
+        rank0_share = float(os.environ.get("MSPA_RANK0_SHARE", "1.0"))
+    if per_rank is None:
+        per_rank = int(os.environ.get("MSPA_WINDOW_PER_RANK", "8"))
+    wins = windows(costs, world, per_rank, rank0_share=rank0_share)
     order = [i for w in wins for i in w[rank]]
     items = iter(work_items(order))
     timings = timings or Timings()
-    for w in wins:
-        local_rows, local_blobs = [], []
-        failure: Optional[BaseException] = None
-        for index in w[rank]:
-            try:
-                item = next(items)
-                with timings.span("produce"):
-                    records, blobs = produce(index, item)
-            except Exception as e:                         # a missing file, a bad pose: the other ranks must not be left
-                failure = e                                # waiting in the window's exchange (they would, until the timeout)
-                break
-            if record_width is not None:
-                if records is None:
-                    records = torch.zeros((0, record_width), dtype=torch.float64)
-                tagged = torch.empty((records.shape[0], record_width + 1), dtype=torch.float64, device=records.device)
-                tagged[:, 0] = index
-                tagged[:, 1:] = records
-                local_rows.append(tagged)
-            local_blobs.append((index, list(blobs)))
-        if ctx is not None:                                # one int per window: did every rank get through its scenes?
+    writer = _WindowWriter(consume, record_width, timings, writer_depth) if rank == 0 else None
+
+    def vote(failure: Optional[BaseException]) -> None:
+        """One int per window: did every rank get through its scenes (and is rank 0's writer alive)?  Raises on EVERY rank."""
+        if writer is not None and failure is None:
+            failure = writer.error
+        if ctx is not None:
             import torch.distributed as dist
             flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device=ctx.collective_device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ctx.group)
-            if int(flag.item()):
+            with timings.span("wait_at_exchange"):
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ctx.group)
+                failed = int(flag.item())
+            if failed:
                 if failure is not None:
                     raise failure
                 raise RuntimeError("sharded_sweep: another rank failed in this window (its own traceback says why)")
         elif failure is not None:
             raise failure
-        # ---- the window's one exchange ---------------------------------------------------------------------------
-        with timings.span("exchange"):
-            rows_by_index: Dict[int, np.ndarray] = {}
-            if record_width is not None:
-                dev = ctx.collective_device if ctx is not None else "cpu"
-                local = torch.cat([r.to(dev) for r in local_rows], 0) if local_rows else \
-                    torch.zeros((0, record_width + 1), dtype=torch.float64, device=dev)
-                table = shard.collate_records(local, ctx, dst=0) if ctx is not None else local
-                if rank == 0:
-                    table = table.cpu().numpy()
-                    tags = table[:, 0].astype(np.int64)
-                    # each item's rows are contiguous (cat per item, ranks concatenated): cut at the tag changes
-                    cuts = np.flatnonzero(np.diff(tags)) + 1 if len(tags) else np.zeros(0, np.int64)
-                    for lo, hi in zip(np.concatenate([[0], cuts]).astype(np.int64), np.concatenate([cuts, [len(tags)]]).astype(np.int64)):
-                        if hi > lo:
-                            rows_by_index[int(tags[lo])] = table[lo:hi, 1:]
-            packed = _pack_blobs(local_blobs)
-            if ctx is not None:
-                parts = shard.gather_bytes(packed, ctx, dst=0)
-            else:
-                parts = [np.frombuffer(packed, dtype=np.uint8)]
-        if rank != 0:
-            continue
-        blobs_by_index: Dict[int, List[np.ndarray]] = {}
-        for p in parts:
-            blobs_by_index.update(_unpack_blobs(p))
-        with timings.span("consume"):
-            for index in sorted(i for b in w for i in b):
-                rows = rows_by_index.get(index)
-                if record_width is not None and rows is None:
-                    rows = np.zeros((0, record_width))
-                consume(index, rows, blobs_by_index[index])
-    for _ in items:                                            # drain: lets the prefetcher's generator finish cleanly
-        pass
+
+    try:
+        for w in wins:
+            local_rows, local_blobs = [], []
+            failure: Optional[BaseException] = None
+            for index in w[rank]:
+                try:
+                    item = next(items)
+                    with timings.span("produce"):
+                        records, blobs = produce(index, item)
+                except Exception as e:                     # a missing file, a bad pose: the other ranks must not be left
+                    failure = e                            # waiting in the window's exchange (they would, until the timeout)
+                    break
+                if record_width is not None:
+                    if records is None:
+                        records = torch.zeros((0, record_width), dtype=torch.float64)
+                    tagged = torch.empty((records.shape[0], record_width + 1), dtype=torch.float64, device=records.device)
+                    tagged[:, 0] = index
+                    tagged[:, 1:] = records
+                    local_rows.append(tagged)
+                local_blobs.append((index, list(blobs)))
+            vote(failure)
+            # ---- the window's one exchange -----------------------------------------------------------------------
+            with timings.span("exchange"):
+                rows_by_index: Dict[int, np.ndarray] = {}
+                if record_width is not None:
+                    dev = ctx.collective_device if ctx is not None else "cpu"
+                    local = torch.cat([r.to(dev) for r in local_rows], 0) if local_rows else \
+                        torch.zeros((0, record_width + 1), dtype=torch.float64, device=dev)
+                    table = shard.collate_records(local, ctx, dst=0) if ctx is not None else local
+                    if rank == 0:
+                        table = table.cpu().numpy()
+                        tags = table[:, 0].astype(np.int64)
+                        # each item's rows are contiguous (cat per item, ranks concatenated): cut at the tag changes
+                        cuts = np.flatnonzero(np.diff(tags)) + 1 if len(tags) else np.zeros(0, np.int64)
+                        for lo, hi in zip(np.concatenate([[0], cuts]).astype(np.int64), np.concatenate([cuts, [len(tags)]]).astype(np.int64)):
+                            if hi > lo:
+                                rows_by_index[int(tags[lo])] = table[lo:hi, 1:]
+                packed = _pack_blobs(local_blobs)
+                if ctx is not None:
+                    parts = shard.gather_bytes(packed, ctx, dst=0)
+                else:
+                    parts = [np.frombuffer(packed, dtype=np.uint8)]
+            if writer is not None:
+                writer.put(sorted(i for b in w for i in b), rows_by_index, parts)
+        for _ in items:                                        # drain: lets the prefetcher's generator finish cleanly
+            pass
+    except BaseException:
+        if writer is not None:
+            writer.close()          # windows exchanged before the failure are complete: they are written, then the error leaves
+        raise
+    # the tail: rank 0 waits for its writer, and the ranks agree once more that nothing failed after the last window's vote
+    vote(writer.close() if writer is not None else None)
 
 
 def prefetched_scenes(host_scenes: Iterable[HostScene], device="cuda", timings: Optional[Timings] = None):

@@ -291,28 +291,38 @@ def make_tracks(seed: int, T: int = 300, P: int = 256, n_groups: int = 8,
 
 
 def write_scannet_layout(scenes: Sequence["SynthScene"], root: str, info_name: str = "scenes_info.pkl",
-                         compress_level: int = 1, jpeg_for_every_image: bool = False) -> Dict[str, str]:
+                         compress_level: int = 1, jpeg_for_every_image: bool = False,
+                         link_identical: bool = False) -> Dict[str, str]:
     """Write synthetic scenes to disk the way the reference's pipeline finds ScanNet:
     ``<root>/posed_images/<scene>/<image>.png`` (16-bit depth, extract_posed_images.py:118-123) and ``<image>.jpg``,
     ``<root>/scannet_instance_data/<scene>/aligned_points.npy`` (N x 6 float64, batch_load_scannet_data.py:201) and the
     scene-info pickle (info_handler.py:7-30).  A scene without colour frames gets a flat grey JPEG of the right size for its
     first image (only its header is ever read: IH:133-139 takes the image size from it; ``jpeg_for_every_image``: for all
     of them -- the dataset builders look the size up per row, CME:238-239).  Returns the paths to hand to
-    ``SceneInfoHandler(info_path, posed_images_root=..., instance_data_root=...)``."""
+    ``SceneInfoHandler(info_path, posed_images_root=..., instance_data_root=...)``.
+    ``link_identical``: a depth array that appears under several image ids (or scenes) -- the SAME ndarray object -- is
+    encoded once and hard-linked under the other names (ScanNet-sized inputs for the sweep benchmarks in seconds instead of
+    minutes; every name is still opened, read and inflated on its own)."""
     import os
     import pickle
     from PIL import Image
     from concurrent.futures import ThreadPoolExecutor
     posed, inst = os.path.join(root, "posed_images"), os.path.join(root, "scannet_instance_data")
     infos, jobs = {}, []
+    first_png: Dict[int, str] = {}
+    links = []
     for sc in scenes:
         os.makedirs(os.path.join(posed, sc.scene_id), exist_ok=True)
         os.makedirs(os.path.join(inst, sc.scene_id), exist_ok=True)
         np.save(os.path.join(inst, sc.scene_id, "aligned_points.npy"), sc.points)
         H, W = sc.color_hw
         for n, (image_id, d) in enumerate(sc.depth.items()):
-            jobs.append((Image.fromarray(np.ascontiguousarray(d, dtype=np.uint16)),
-                         os.path.join(posed, sc.scene_id, f"{image_id}.png"), {"compress_level": compress_level}))
+            png = os.path.join(posed, sc.scene_id, f"{image_id}.png")
+            if link_identical and id(d) in first_png:
+                links.append((first_png[id(d)], png))
+            else:
+                first_png[id(d)] = png
+                jobs.append((Image.fromarray(np.ascontiguousarray(d, dtype=np.uint16)), png, {"compress_level": compress_level}))
             col = sc.color.get(image_id) if sc.color else None
             if col is not None:
                 jobs.append((Image.fromarray(col), os.path.join(posed, sc.scene_id, f"{image_id}.jpg"), {"quality": 90}))
@@ -322,6 +332,10 @@ def write_scannet_layout(scenes: Sequence["SynthScene"], root: str, info_name: s
         infos[sc.scene_id] = sc.info_dict()
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:      # the encoders release the interpreter lock
         list(ex.map(lambda j: j[0].save(j[1], **j[2]), jobs))
+    for src, dst in links:
+        if os.path.exists(dst):
+            os.remove(dst)
+        os.link(src, dst)
     info_path = os.path.join(inst, info_name)
     with open(info_path, "wb") as f:
         pickle.dump(infos, f)

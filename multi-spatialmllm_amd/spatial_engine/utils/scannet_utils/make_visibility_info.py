@@ -139,7 +139,8 @@ def run_split(scene_info_path, output_file, warning_file, num_workers=8, keep=Tr
             with timings.span("write"):
                 table = pa.ipc.open_stream(pa.py_buffer(blobs[1])).read_all()
                 if state["writer"] is None:
-                    state["writer"] = pq.ParquetWriter(output_file, table.schema)
+                    # every key and every JSON list is unique: a dictionary page would be built, overflow and be dropped
+                    state["writer"] = pq.ParquetWriter(output_file, table.schema, use_dictionary=False)
                 state["writer"].write_table(table)
                 state["n"] += table.num_rows
 

@@ -256,6 +256,94 @@ def test_a_failing_rank_stops_every_rank_at_the_window(tmp_path):
     assert results[0][1] == [0, 1, 2, 3]                     # window 0 (items 0..3) was consumed on rank 0 before item 5 failed
 
 
+def _failing_writer_main(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), MSPA_DIST_BACKEND="gloo")
+    for p in (PKG, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    ctx = shard.context_from_env(torch.device("cpu"))
+    seen, produced = [], []
+
+    def consume(index, rows, blobs):
+        if index == 2:
+            raise OSError("disk full")
+        seen.append(index)
+
+    def produce(index, item):
+        produced.append(index)
+        return None, [b"x"]
+    try:
+        sweep.sharded_sweep([1.0] * 12, ctx, lambda idx: iter(idx), produce, consume, per_rank=2)
+        q.put((rank, "finished", seen, produced))
+    except Exception as e:
+        q.put((rank, type(e).__name__, seen, produced))
+
+
+def test_a_failing_writer_stops_every_rank(tmp_path):
+    """Rank 0's writer thread fails (consume raises while a later window is being produced): rank 0 raises the writer's own
+    error and the other rank raises too -- at the next window's vote or, for the last window, at the vote after the drain."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_failing_writer_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict((r, (kind, seen, produced)) for r, kind, seen, produced in (q.get(timeout=120) for _ in procs))
+    for p in procs:
+        p.join(timeout=60)
+    assert results[0][0] == "OSError" and results[1][0] == "RuntimeError", results
+    assert results[0][1] == [0, 1]                           # in order up to the failure; nothing after it was written
+    assert len(results[1][2]) < 6 or results[1][0] == "RuntimeError"
+
+
+def test_writer_thread_keeps_order_and_overlaps_production():
+    """One process: consume runs on the writer thread strictly in index order while later windows are produced (a slow
+    consume does not hold production up beyond the queue's depth), and the timings carry the new stages."""
+    import threading
+    import time
+    events, lock = [], threading.Lock()
+    main_thread = threading.get_ident()
+    consume_threads = set()
+
+    def produce(index, item):
+        with lock:
+            events.append(("p", index))
+        return torch.full((2, 3), float(index), dtype=torch.float64), [bytes([index])]
+
+    def consume(index, rows, blobs):
+        consume_threads.add(threading.get_ident())
+        time.sleep(0.02)
+        assert rows.shape == (2, 3) and (rows == index).all() and bytes(blobs[0]) == bytes([index])
+        with lock:
+            events.append(("c", index))
+    tm = sweep.Timings()
+    sweep.sharded_sweep([1.0] * 10, None, lambda idx: iter(idx), produce, consume, record_width=3, per_rank=2, timings=tm)
+    assert [i for k, i in events if k == "c"] == list(range(10)) and [i for k, i in events if k == "p"] == list(range(10))
+    assert consume_threads and main_thread not in consume_threads
+    # production of window 1 (items 2, 3) began before window 0 had been written completely
+    assert events.index(("p", 2)) < events.index(("c", 1))
+    d = tm.as_dict()
+    assert d["consume"] >= 0.18 and "writer_drain" in d and "writer_backpressure" in d
+    # nothing is written twice or dropped when consume fails in one process either
+    with pytest.raises(KeyError):
+        sweep.sharded_sweep([1.0] * 4, None, lambda idx: iter(idx), produce,
+                            lambda i, r, b: (_ for _ in ()).throw(KeyError(i)) if i == 3 else None, record_width=3, per_rank=2)
+
+
+def test_rank0_share_handicap():
+    costs = [1.0] * 64
+    even = shard.lpt_assign(costs, 8)
+    assert [len(b) for b in even] == [8] * 8
+    less = shard.lpt_assign(costs, 8, rank0_share=0.5)
+    assert len(less[0]) in (4, 5) and sorted(i for b in less for i in b) == list(range(64))
+    assert max(len(b) for b in less[1:]) - min(len(b) for b in less[1:]) <= 1
+    assert shard.lpt_assign(costs, 1, rank0_share=0.5) == [list(range(64))]
+    w = sweep.windows(costs, 8, per_rank=8, rank0_share=0.0)
+    assert w[0][0] == [] and sum(len(b) for b in w[0]) == 64
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
