@@ -649,7 +649,9 @@ def time_dropin_sweep(n_scenes=8, n_frames=64, n_points=131072, num_workers=None
     from mspa import synth, sweep
     import spatial_engine.camera_movement.calculate_frames_relations as CFR
     from spatial_engine.utils.scannet_utils.handler import info_handler as IH
-    num_workers = num_workers or min(25, os.cpu_count() or 1)       # the reference's worker count (CFR:280)
+    from mspa import hostinfo
+    # the reference's worker count (CFR:280), cut to the CPUs this process may really use (cgroup quota: mspa/hostinfo.py)
+    num_workers = num_workers or min(25, hostinfo.effective_cpus())
     root = tempfile.mkdtemp(prefix="mspa_dropin_")
     try:
         t0 = time.perf_counter()
@@ -665,7 +667,7 @@ def time_dropin_sweep(n_scenes=8, n_frames=64, n_points=131072, num_workers=None
         try:
             import contextlib
             import io
-            runs = []
+            runs, throttled = [], []
             # Seven passes over the same 8 scenes; the median of the last three is reported, every pass's rate is kept.  The first
             # passes warm the page cache, the upload slots, the decode threads -- and the allocator: glibc stops mapping and
             # unmapping its large blocks (every page faulted in again by 25 threads) only after a few of them have been freed;
@@ -673,11 +675,14 @@ def time_dropin_sweep(n_scenes=8, n_frames=64, n_points=131072, num_workers=None
             # (tools/dropin_order_check.py).  A real split has hundreds of scenes: the steady state is what it runs at.
             for rep in range(7):
                 tm = sweep.Timings()
+                th0 = hostinfo.throttle_stats()
                 with contextlib.redirect_stdout(io.StringIO()):
                     t0 = time.perf_counter()
                     CFR.run_split(paths["info_path"], os.path.join(root, f"out{rep}", "pairs.parquet"),
                                   os.path.join(root, f"warn{rep}.txt"), num_workers=num_workers, keep=False, timings=tm)
                     dt = time.perf_counter() - t0
+                th1 = hostinfo.throttle_stats()
+                throttled.append({k: th1[k] - th0.get(k, 0) for k in th1})
                 runs.append((dt, tm.as_dict()))
         finally:
             IH.SceneInfoHandler.__init__ = orig_init
@@ -694,7 +699,13 @@ def time_dropin_sweep(n_scenes=8, n_frames=64, n_points=131072, num_workers=None
                                  "write (parquet only)": stages.get("write")},
                 "first_pass_seconds": round(runs[0][0], 4), "inputs_written_in_s": round(t_write_inputs, 2),
                 "png_bytes": int(png_bytes), "statistic": "median of the last three of seven passes over the same 8 scenes (page cache warm: disk is not what is measured)",
-                "passes_scenes_per_s": [round(n_scenes / r[0], 1) for r in runs]}
+                "passes_scenes_per_s": [round(n_scenes / r[0], 1) for r in runs],
+                "host_cpus": hostinfo.describe(),
+                "passes_cfs_throttling": throttled,
+                "throttling_note": "per pass: CFS periods in which this container's threads were frozen by its cgroup CPU quota "
+                                   "(`nr_throttled`) and for how long (`throttled_usec`, summed over CPUs) -- the cause of round "
+                                   "5's 2 x pass-to-pass alternation (25 threads x 4 scenes in flight against a 16-CPU quota); "
+                                   "thread counts now follow the quota (mspa/hostinfo.py, csrc/host_pool.h)"}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
@@ -709,8 +720,8 @@ def time_dropin_sweep_ranks(ranks=(1, 2, 4), n_scenes=16, n_frames=320, passes=2
     spec = importlib.util.spec_from_file_location("mspa_dropin_ranks", os.path.join(ROOT, "tools", "dropin_ranks.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.drive(ranks=tuple(ranks), n_scenes=n_scenes, n_frames=n_frames, workers=num_workers or min(25, os.cpu_count() or 1),
-                     passes=passes, per_rank=per_rank, timeout_s=timeout_s)
+    return mod.drive(ranks=tuple(ranks), n_scenes=n_scenes, n_frames=n_frames, workers=num_workers, passes=passes,
+                     per_rank=per_rank, timeout_s=timeout_s)
 
 
 def run_scene_workload(args, rank, world, device, dist_ctx, share):
@@ -895,7 +906,11 @@ def cpu_baseline(sc, base_pairs, budget_s, with_pool=True, timed=None):
             break
     _CPU_SCENE = (depth, sc.K, E, sc.A, color)
     single = n / el
+    from mspa import hostinfo
+    # the reference's Pool(25) (CFR:280); `cores` is what the pool can really burn: a container's cgroup quota may be far
+    # below os.cpu_count() (16 CPUs of 256 on the MI355X boxes), and 25 workers then share 16 CPUs' worth of time
     workers = min(25, os.cpu_count() or 1)
+    usable = min(workers, hostinfo.effective_cpus())
     pool_rate, pool_jobs = None, []
     if with_pool:
         pool_jobs = jobs[:max(workers * 4, int(single * workers * budget_s / 2))][:len(jobs)]
@@ -914,9 +929,10 @@ def cpu_baseline(sc, base_pairs, budget_s, with_pool=True, timed=None):
             "sample": f"{n} of the step's 640x480 pairs through oracle/np_oracle.frame_pair "
                       f"(NumPy {np.__version__}, 1 process, in-memory images) in {el:.1f} s",
             "pool": None if pool_rate is None else {
-                "value": round(pool_rate, 2), "cores": workers,
-                "sample": f"{len(pool_jobs)} pairs over multiprocessing.Pool({workers}), 1 BLAS thread each"},
-            "host_cores_available": os.cpu_count(), "parity_in_run": parity}
+                "value": round(pool_rate, 2), "cores": usable, "pool_processes": workers,
+                "sample": f"{len(pool_jobs)} pairs over multiprocessing.Pool({workers}), 1 BLAS thread each"
+                          + (f"; the container's CPU quota lets them use {usable} CPUs" if usable < workers else "")},
+            "host_cores_available": hostinfo.effective_cpus(), "host_cpus": hostinfo.describe(), "parity_in_run": parity}
 
 
 def live_traffic(args):

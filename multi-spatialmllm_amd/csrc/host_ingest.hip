@@ -119,7 +119,10 @@ int decode_gray16(const unsigned char *buf, size_t n, int32_t h, int32_t w, uint
         const int rc = inflate(&zs, Z_FINISH);
         const bool full = zs.avail_out == 0;
         inflateEnd(&zs);
-        if (!full || (rc != Z_STREAM_END && rc != Z_OK && rc != Z_BUF_ERROR)) return 3;
+        // Z_STREAM_END only: the stream ended where the scanlines end AND zlib checked its Adler-32 trailer.  Z_OK /
+        // Z_BUF_ERROR with a full output is a stream that is longer than h * (2 w + 1) bytes or was cut before its trailer --
+        // libpng (the reference's cv2.imread) rejects both, so does this reader (status 3).
+        if (!full || rc != Z_STREAM_END) return 3;
     }
     // undo the row filters in place (bytes per pixel = 2), then swap to host order
     const unsigned char *prior = nullptr;

@@ -4,8 +4,9 @@
 // a thread costs 50-100 us (stack mapping, TLS of the inflate tables): 64 threads for a 64-frame scene took longer to start than
 // a frame takes to decode (tools/ingest_bench.py, round 5: 6.7 ms per scene on 64 threads against 1.56 ms per frame), and the
 // loader keeps several scenes in flight, each with its own set.  The pool's threads are started once, on demand (never more
-// than the hardware has), and shared by all callers; a call hands the pool `n_threads - 1` helper tickets for its job and works
-// on the job itself, so it never waits for a helper to start: if the pool is busy the caller simply does more of the items.
+// than the process may use: affinity mask and cgroup CPU quota), and shared by all callers; a call hands the pool
+// `n_threads - 1` helper tickets for its job and works on the job itself, so it never waits for a helper to start: if the pool
+// is busy the caller simply does more of the items, and takes its unclaimed tickets back when it has run out of them.
 //
 // Not observable from outside: results, error strings and re-entrancy are those of the per-call threads.  The pool is leaked at
 // exit (no destructor ordering against the interpreter's teardown) and rebuilt in a forked child (threads do not survive fork).
@@ -16,7 +17,11 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <pthread.h>
+#include <sched.h>
 #include <thread>
 
 namespace mspa {
@@ -67,7 +72,23 @@ class HostPool {
         }
         cv_.notify_all();
         fn();
+        // The caller's share is done (the shared counter is exhausted): tickets nobody has claimed yet would only start copies
+        // that find nothing -- and would make this call wait for a worker to get round to them behind other callers' real
+        // work, or for ever if no worker thread could be started.  Take them back.
+        int unclaimed = 0;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            for (auto it = queue_.begin(); it != queue_.end();) {
+                if (it->get() == job.get()) {
+                    it = queue_.erase(it);
+                    ++unclaimed;
+                } else {
+                    ++it;
+                }
+            }
+        }
         std::unique_lock<std::mutex> lk(job->m);
+        job->pending -= unclaimed;
         job->cv.wait(lk, [&] { return job->pending == 0; });
     }
 
@@ -82,10 +103,48 @@ class HostPool {
         static std::atomic<HostPool *> p{nullptr};
         return p;
     }
-    HostPool() {
-        const unsigned hw = std::thread::hardware_concurrency();
-        cap_ = hw ? hw : 8;
+    // The CPUs this process may really use: the affinity mask, cut down to the cgroup's CFS quota (cpu.max) -- a container on
+    // a 256-thread host may hold 16 CPUs' worth of quota, and a pool that keeps more threads busy than that gets the WHOLE
+    // group frozen for the rest of each 100 ms period (decode, staging and the thread feeding the GPU alike).  MSPA_HOST_CPUS
+    // overrides.  mspa/hostinfo.py is the same rule on the Python side.
+    static size_t effective_cpus() {
+        if (const char *e = getenv("MSPA_HOST_CPUS")) {
+            const long v = atol(e);
+            if (v > 0) return (size_t)v;
+        }
+        size_t n = std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) {
+            const int c = CPU_COUNT(&set);
+            if (c > 0) n = (size_t)c;
+        }
+        if (!n) n = 8;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            double period = 0;
+            if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+                const double cpus = atof(q) / period;
+                if (cpus >= 1 && (size_t)cpus < n) n = (size_t)cpus;
+            }
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            double quota = 0, period = 0;
+            const bool ok = fscanf(g, "%lf", &quota) == 1;
+            fclose(g);
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (ok && fscanf(h, "%lf", &period) == 1 && quota > 0 && period > 0 && quota / period >= 1 &&
+                    (size_t)(quota / period) < n)
+                    n = (size_t)(quota / period);
+                fclose(h);
+            }
+        }
+        if (const char *e = getenv("LOCAL_WORLD_SIZE")) {       // the ranks of a node share its CPUs (torch.distributed.run)
+            const long w = atol(e);
+            if (w > 1) n = n / (size_t)w ? n / (size_t)w : 1;
+        }
+        return n;
     }
+    HostPool() { cap_ = effective_cpus(); }
     void worker() {
         for (;;) {
             std::shared_ptr<Job> job;

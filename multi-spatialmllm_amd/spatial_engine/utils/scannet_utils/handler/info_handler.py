@@ -312,10 +312,13 @@ class SceneInfoHandler:
     def prefetched_scenes(self, scene_ids, num_workers=8, device="cuda", timings=None, with_points=True, lookahead=None):
         """``scene_ids`` -> resident scenes, one after the other: scene n+1 is decoded by ``num_workers`` host threads and
         copied on the copy stream while the caller runs scene n's kernels (mspa/sweep.py, mspa/upload.py).  ``lookahead`` scenes
-        are in flight on the host at once (default: 2, more -- up to 4 -- when the host has cores to spare for them)."""
-        from mspa import sweep
+        are in flight on the host at once (default: 2, more -- up to 4 -- when the process has CPUs to spare for them: its
+        affinity mask and cgroup quota count, not the machine's ``os.cpu_count()``, mspa/hostinfo.py)."""
+        from mspa import hostinfo, sweep
+        if lookahead is None and os.environ.get("MSPA_LOOKAHEAD"):
+            lookahead = max(1, int(os.environ["MSPA_LOOKAHEAD"]))
         if lookahead is None:
-            lookahead = min(4, max(2, (os.cpu_count() or 1) // (2 * max(1, int(num_workers)))))
+            lookahead = min(4, max(2, hostinfo.effective_cpus() // (2 * max(1, int(num_workers)))))
         loader = sweep.SceneLoader(lambda sid: self.host_scene(sid, num_workers, with_points), list(scene_ids), lookahead,
                                    timings)
         return sweep.prefetched_scenes(loader, device, timings)

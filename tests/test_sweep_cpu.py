@@ -28,8 +28,9 @@ from mspa import ingest, shard, sweep, synth  # noqa: E402
 
 
 # ---- native PNG reader ---------------------------------------------------------------------------------------------
-def _png_gray16(a: np.ndarray, filters, level=6, idat_chunks=1) -> bytes:
-    """A 16-bit greyscale PNG of ``a`` with row y filtered by filters[y % len]: all five filter types on demand."""
+def _png_gray16(a: np.ndarray, filters, level=6, idat_chunks=1, mangle=None) -> bytes:
+    """A 16-bit greyscale PNG of ``a`` with row y filtered by filters[y % len]: all five filter types on demand.
+    ``mangle(z)`` rewrites the scanlines' zlib stream before it is chunked (chunk CRCs stay right)."""
     h, w = a.shape
     be = a.astype(">u2").view(np.uint8).reshape(h, 2 * w).astype(np.int32)
     prior = np.zeros(2 * w, np.int32)
@@ -55,6 +56,8 @@ def _png_gray16(a: np.ndarray, filters, level=6, idat_chunks=1) -> bytes:
         rows.append(bytes([ft]) + (f & 255).astype(np.uint8).tobytes())
         prior = x
     z = zlib.compress(b"".join(rows), level)
+    if mangle is not None:
+        z = mangle(z)
 
     def chunk(kind, data):
         return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data))
@@ -101,6 +104,18 @@ def test_native_png_reader_all_filters_and_errors(tmp_path):
         f.write(open(paths[5], "rb").read()[:300])
     with pytest.raises(ValueError, match="corrupt"):
         ingest.read_depth_frames([paths[0], cut], 2)
+    # a scanline stream whose every byte inflates but whose integrity cannot be confirmed is refused, as libpng refuses it:
+    # cut before / inside its Adler-32 trailer, a wrong trailer, a stream that goes on after h * (2 w + 1) bytes
+    longer = np.vstack([frames[1], frames[1][:3]])
+    for name, data in (("no_trailer", _png_gray16(frames[1], [1], mangle=lambda z: z[:-4])),
+                       ("half_trailer", _png_gray16(frames[1], [0], 0, mangle=lambda z: z[:-2])),
+                       ("bad_trailer", _png_gray16(frames[1], [2], mangle=lambda z: z[:-1] + bytes([z[-1] ^ 1]))),
+                       ("too_long", _png_gray16(longer, [1]).replace(struct.pack(">II", 53, 40), struct.pack(">II", 53, 37)))):
+        bad = str(tmp_path / f"{name}.png")
+        with open(bad, "wb") as f:
+            f.write(data)
+        with pytest.raises(ValueError, match="corrupt"):
+            ingest.read_depth_frames([paths[0], bad], 2)
     other = str(tmp_path / "other_size.png")
     with open(other, "wb") as f:
         f.write(_png_gray16(frames[0][:20], [1]))

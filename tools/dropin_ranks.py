@@ -8,7 +8,11 @@ Why this says something about an 8-GPU node: a 320-frame scene is ~0.2 ms of ker
 the per-window exchange towards rank 0, rank 0's writer -- and all of that is the real thing here; only the GPU and its PCIe
 link are shared (4 ranks x 20 scenes/s x 197 MB = 16 GB/s of a 57 GB/s link).
 
-    python tools/dropin_ranks.py [--ranks 1,2,4] [--scenes 32] [--frames 320] [--workers 25] [--passes 3] [--per-rank 2]
+    python tools/dropin_ranks.py [--ranks 1,2,4] [--scenes 32] [--frames 320] [--workers N] [--passes 3] [--per-rank 2]
+
+`--workers` (decode threads per scene in flight, per rank) is the SAME for every world size and defaults to what lets the largest
+world fit the container's CPU quota (16 CPUs on the MI355X boxes -> 2): the question is whether the job scales when every rank
+brings its own resources, as on an 8-GPU node; one rank with all the box's CPUs is already decode-bound at the quota.
 
 Driver mode (no RANK in the environment) writes the inputs once (rendered frames hard-linked under 320 image ids: every
 file is still opened and inflated on its own), starts each world size as `python -m torch.distributed.run` of this file, and
@@ -103,9 +107,17 @@ def worker(a):
         ctx.barrier()
 
 
-def drive(ranks=(1, 2, 4), n_scenes=32, n_frames=320, n_points=131072, workers=25, passes=3, per_rank=2, timeout_s=900,
+def drive(ranks=(1, 2, 4), n_scenes=32, n_frames=320, n_points=131072, workers=None, passes=3, per_rank=2, timeout_s=900,
           keep_root=None):
-    """Returns the leg's dict (see the module docstring)."""
+    """Returns the leg's dict (see the module docstring).  ``workers`` = decode threads per scene in flight PER RANK, the same
+    for every world size (an N-GPU node gives every rank its own cores: what is measured is whether the job scales when the
+    per-rank resources are fixed).  Default: the CPUs this container may use (cgroup quota, mspa/hostinfo.py) divided by the
+    largest world and by the 2 scenes a rank keeps in flight -- 16 CPUs / 4 ranks / 2 = 2 on the MI355X boxes -- so that the
+    largest world still fits inside the quota instead of being throttled by it."""
+    from mspa import hostinfo
+    eff = hostinfo.effective_cpus(per_rank=False)
+    if workers is None:
+        workers = max(1, min(25, eff // (2 * max(ranks))))
     root = keep_root or tempfile.mkdtemp(prefix="mspa_dropin_ranks_")
     try:
         t0 = time.perf_counter()
@@ -115,14 +127,16 @@ def drive(ranks=(1, 2, 4), n_scenes=32, n_frames=320, n_points=131072, workers=2
         out_dir = os.path.join(root, "out")
         os.makedirs(out_dir, exist_ok=True)
         res = {"scenes": n_scenes, "frames_per_scene": n_frames, "vertices": n_points, "num_workers_per_rank": workers,
-               "window_scenes_per_rank": per_rank, "passes": passes, "host_cores": os.cpu_count(),
+               "cpus_per_rank": max(1, eff // max(ranks)), "scenes_in_flight_per_rank": 2, "window_scenes_per_rank": per_rank, "passes": passes, "host_cpus": hostinfo.describe(),
                "inputs_written_in_s": round(t_inputs, 1),
                "what": "ranks share ONE GPU and its PCIe link (gloo); decode threads, exchange and rank 0's writer are the real "
                        "ones -- the host-side scaling an N-GPU node sees",
                "statistic": "best of the passes after the first (page cache, pools and pinned slots warm)", "worlds": {}}
         deadline = time.perf_counter() + timeout_s
         for world in ranks:
-            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MSPA_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+            # every rank of every world size gets the same resources: `eff // max(ranks)` CPUs for its native pool, 2 scenes in flight
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MSPA_DIST_BACKEND="gloo", OMP_NUM_THREADS="1",
+                       MSPA_HOST_CPUS=str(max(1, eff // max(ranks))), MSPA_LOOKAHEAD="2")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MSPA_BENCH_FORCE_DIST"):
                 env.pop(k, None)
             args = [os.path.abspath(__file__), "--worker", "--root", root, "--out", out_dir, "--workers", str(workers),
@@ -140,6 +154,7 @@ def drive(ranks=(1, 2, 4), n_scenes=32, n_frames=320, n_points=131072, workers=2
                 res["worlds"][str(world)] = {"skipped": "the leg's time budget was used up by the smaller worlds"}
                 continue
             # own session: on a timeout the launcher AND its ranks are ended by process group, never by name
+            th0 = hostinfo.throttle_stats()
             proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT,
                                     start_new_session=True)
             try:
@@ -169,6 +184,8 @@ def drive(ranks=(1, 2, 4), n_scenes=32, n_frames=320, n_points=131072, workers=2
                            "wait_at_exchange_s": [b.get("wait_at_exchange", 0.0) for b in busy],
                            "produce_s": [b.get("produce") for b in busy], "decode_busy_s": [b.get("decode") for b in busy],
                            "exchange_s": [b.get("exchange") for b in busy], "digests": legs[0]["digests"]}
+            th1 = hostinfo.throttle_stats()
+            w["cfs_throttling_whole_run"] = {k: th1[k] - th0.get(k, 0) for k in th1}
             res["worlds"][str(world)] = w
         base = res["worlds"].get(str(ranks[0]), {})
         for world in ranks:
@@ -196,7 +213,7 @@ def main():
     ap.add_argument("--scenes", type=int, default=32)
     ap.add_argument("--frames", type=int, default=320)
     ap.add_argument("--points", type=int, default=131072)
-    ap.add_argument("--workers", type=int, default=25)
+    ap.add_argument("--workers", type=int, default=None)
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--per-rank", type=int, default=2)
     ap.add_argument("--timeout", type=int, default=900)
