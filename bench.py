@@ -695,8 +695,9 @@ def time_dropin_sweep(n_scenes=8, n_frames=64, n_points=131072, num_workers=None
                 "stage_busy_s": {"decode (PNG read + inflate + np.load, loader threads)": stages.get("decode"),
                                  "stage (pinned staging + H2D enqueue, copy stream)": stages.get("stage"),
                                  "produce (K1 + K2 + K4 + the scene's small D2H)": stages.get("produce"),
-                                 "consume (arrow tables + parquet row groups)": stages.get("consume"),
-                                 "write (parquet only)": stages.get("write")},
+                                 "encode (owner rank: arrow table + parquet row group bytes, inside produce)": stages.get("encode"),
+                                 "consume (rank 0's writer thread: warnings + splice of the encoded row groups)": stages.get("consume"),
+                                 "write (splice only)": stages.get("write")},
                 "first_pass_seconds": round(runs[0][0], 4), "inputs_written_in_s": round(t_write_inputs, 2),
                 "png_bytes": int(png_bytes), "statistic": "median of the last three of seven passes over the same 8 scenes (page cache warm: disk is not what is measured)",
                 "passes_scenes_per_s": [round(n_scenes / r[0], 1) for r in runs],

@@ -168,15 +168,17 @@ def run_split(scene_info_path, output_parquet, warning_file, num_workers=15, sav
     The reference maps scenes over ``Pool(num_workers)`` (:222-229).  Here ``num_workers`` is the number of host threads that
     read and inflate the NEXT scene's depth PNGs while the current scene's kernels run (mspa/sweep.py), and the scenes are
     sharded over the GPUs of the job -- one process per GPU, ``RANK`` / ``WORLD_SIZE`` from the environment
-    (torch.distributed.run) or an explicit ``ctx`` (mspa.shard.DistContext): longest-first within windows of scenes, the
-    numeric rows of each window collated on rank 0 over RCCL (``shard.collate_records``), rank 0 writing the row groups in
-    the split's scene order.  The files are byte for byte those of a one-process run.
+    (torch.distributed.run) or an explicit ``ctx`` (mspa.shard.DistContext): longest-first within windows of scenes.  The
+    rank that OWNS a scene also encodes its two row groups (all pairs / nonzero overlap) as self-contained parquet bytes;
+    after each window these travel to rank 0 (``shard.gather_bytes``: RCCL), whose writer thread only splices them into the
+    two files in the split's scene order (mspa/parquet_splice.py) -- nothing is encoded, compressed or converted on rank 0,
+    and the files are byte for byte those of a one-process run.
 
     The tables stay columnar from the kernels to the parquet row groups -- ScanNet's 106.8 M pairs as a dict with one entry
     per pair would not fit in memory -- and both files are streamed, one row group per scene.  Returns {scene_id: PairTable}
-    on rank 0 ({} elsewhere); with ``keep=False`` each table is dropped once written and {} is returned."""
-    import pyarrow.parquet as pq
-    from mspa import shard, sweep
+    on rank 0 ({} elsewhere; the numeric rows then also cross the fabric, ``shard.collate_records``); with ``keep=False`` each
+    table is dropped once written and {} is returned."""
+    from mspa import parquet_splice, shard, sweep
     from spatial_engine.utils.scannet_utils.handler.info_handler import SceneInfoHandler
     scene_infos = SceneInfoHandler(scene_info_path)
     all_scene_ids = scene_infos.get_all_scene_ids()
@@ -194,7 +196,7 @@ def run_split(scene_info_path, output_parquet, warning_file, num_workers=15, sav
     timings = timings if timings is not None else sweep.Timings()
     costs = [scene_infos.scene_cost(s) for s in all_scene_ids]
     device = ctx.device if ctx is not None else "cuda"
-    tables, writers, totals = {}, [None, None], [0, 0]
+    tables, writers, paths = {}, [None, None], (output_parquet, nonzero_parquet)
 
     def work_items(indices):
         return scene_infos.prefetched_scenes([all_scene_ids[i] for i in indices], max(1, int(num_workers)), device, timings)
@@ -203,48 +205,58 @@ def run_split(scene_info_path, output_parquet, warning_file, num_workers=15, sav
         scene_id = all_scene_ids[index]
         print(f"Start processing {scene_id}.")
         lines = [f"{scene_id}: {image_id} has no in bound points\n" for image_id in _empty_frames(scene)]
-        rows = _device_rows(scene)
+        rows_dev = _device_rows(scene)
+        rows = rows_dev.cpu().numpy()
+        ids = list(scene_infos.get_all_extrinsic_valid_image_ids(scene_id))
+        arrays = _row_arrays(rows)
+        lines += _bad_value_lines(scene_id, ids, arrays)
+        with timings.span("encode"):
+            t = PairTable(scene_id, ids, arrays)
+            # dictionary pages for the three id columns only: on the float64 columns the encoder hashes every value, overflows
+            # its dictionary page and falls back to plain anyway -- 4 x the encoding time of a row group and a LARGER file
+            # (measured: 22.6 -> 5.9 ms, 1.92 -> 1.56 MB per 51 040-row scene); readers see the same table
+            blobs = ["".join(lines).encode()] + [parquet_splice.encode_row_group(t.to_arrow(nz), use_dictionary=_COLUMNS[:3])
+                                                 for nz in (False, True)]
         print(f"Finished scene {scene_id}.")
-        return rows, ["".join(lines).encode()]
+        return (rows_dev if keep else None), blobs
 
     def consume(index, rows, blobs):
         scene_id = all_scene_ids[index]
-        ids = scene_infos.get_all_extrinsic_valid_image_ids(scene_id)
-        arrays = {"i": rows[:, 0].astype(np.int32), "j": rows[:, 1].astype(np.int32),
-                  "overlap": np.ascontiguousarray(rows[:, 2]), "distance": np.ascontiguousarray(rows[:, 3]),
-                  "yaw": np.ascontiguousarray(rows[:, 4]), "pitch": np.ascontiguousarray(rows[:, 5])}
-        text = bytes(blobs[0]).decode() + "".join(_bad_value_lines(scene_id, ids, arrays))
-        if text:
+        if blobs[0].size:
             with open(warning_file, "a") as f:
-                f.write(text)
-        t = PairTable(scene_id, list(ids), arrays)
+                f.write(bytes(blobs[0]).decode())
         if keep:
-            tables[scene_id] = t
+            ids = scene_infos.get_all_extrinsic_valid_image_ids(scene_id)
+            tables[scene_id] = PairTable(scene_id, list(ids), _row_arrays(rows))
         with timings.span("write"):
-            for w, (path, nz) in enumerate(((output_parquet, False), (nonzero_parquet, True))):
-                arrow = t.to_arrow(nz)
+            for w in range(2):
                 if writers[w] is None:
-                    # dictionary pages for the three id columns only: on the float64 columns the encoder hashes every value,
-                    # overflows its dictionary page and falls back to plain anyway -- 4 x the encoding time of a row group and
-                    # a LARGER file (measured: 22.6 -> 5.9 ms, 1.92 -> 1.56 MB per 51 040-row scene); readers see the same table
-                    writers[w] = pq.ParquetWriter(path, arrow.schema, use_dictionary=_COLUMNS[:3])
-                writers[w].write_table(arrow)
-                totals[w] += arrow.num_rows
+                    writers[w] = parquet_splice.SplicedParquetWriter(paths[w])
+                writers[w].append(blobs[1 + w])
         if (index + 1) % save_interval == 0:
             print(f"[run_split] {index + 1} scenes written to {output_parquet}")
 
+    ok = False
     try:
-        sweep.sharded_sweep(costs, ctx, work_items, produce, consume, record_width=6, timings=timings)
+        sweep.sharded_sweep(costs, ctx, work_items, produce, consume, record_width=6 if keep else None, timings=timings)
+        ok = True
     finally:
         for w in writers:
             if w is not None:
-                w.close()
+                w.__exit__(None if ok else RuntimeError, None, None)      # the footer only for a sweep that got through
     if ctx is not None:
         ctx.barrier()
     if rank == 0:
-        print(f"[run_split] Total number of records: {totals[0]}")
-        print(f"[run_split] Total number of nonzero records: {totals[1]}")
+        print(f"[run_split] Total number of records: {writers[0].num_rows if writers[0] else 0}")
+        print(f"[run_split] Total number of nonzero records: {writers[1].num_rows if writers[1] else 0}")
     return tables
+
+
+def _row_arrays(rows):
+    """[n, 6] float64 rows (i, j, overlap, distance, yaw, pitch) -> PairTable's column dict."""
+    return {"i": rows[:, 0].astype(np.int32), "j": rows[:, 1].astype(np.int32),
+            "overlap": np.ascontiguousarray(rows[:, 2]), "distance": np.ascontiguousarray(rows[:, 3]),
+            "yaw": np.ascontiguousarray(rows[:, 4]), "pitch": np.ascontiguousarray(rows[:, 5])}
 
 
 def main():

@@ -73,12 +73,14 @@ def run_split(scene_info_path, output_file, warning_file, num_workers=8, keep=Tr
 
     ``num_workers`` = host threads that read and inflate the next scene's depth PNGs under the current scene's kernels; the
     scenes are sharded over the job's GPUs (one process per GPU: ``RANK`` / ``WORLD_SIZE`` from the environment, or ``ctx``).
-    Every rank turns its scenes' bitsets into CSR tables on its GPU and formats the JSON text itself; the finished arrow
-    buffers of a window of scenes go to rank 0 as bytes (``shard.gather_bytes``), which writes one row group per scene in the
-    split's order -- the file is byte for byte that of a one-process run.  ``keep=False`` drops each scene's index after it
+    Every rank turns its scenes' bitsets into CSR tables on its GPU, formats the JSON text itself AND encodes each scene's row
+    group as self-contained parquet bytes (81 MB of text per 320-frame scene: encoding + compression is the expensive part,
+    54 ms per scene when rank 0 alone did it); the finished bytes of a window of scenes go to rank 0 (``shard.gather_bytes``),
+    whose writer thread only splices them into the file in the split's order (mspa/parquet_splice.py) -- the file is byte for
+    byte that of a one-process run.  ``keep=False`` drops each scene's index after it
     has been written (parquet output), for splits that do not fit in memory; the dict comes back on rank 0 only."""
     import numpy as np
-    from mspa import shard, sweep, visindex
+    from mspa import parquet_splice, shard, sweep, visindex
     from spatial_engine.utils.scannet_utils.handler.info_handler import SceneInfoHandler
     scene_infos = SceneInfoHandler(scene_info_path)
     all_scene_ids = scene_infos.get_all_scene_ids()
@@ -103,7 +105,6 @@ def run_split(scene_info_path, output_file, warning_file, num_workers=8, keep=Tr
         return scene_infos.prefetched_scenes([all_scene_ids[i] for i in indices], max(1, int(num_workers)), device, timings)
 
     def produce(index, scene):
-        import pyarrow as pa
         scene_id = all_scene_ids[index]
         print(f"[process_scene] Start: {scene_id}")
         csr = _visibility_csr(scene)
@@ -111,20 +112,16 @@ def run_split(scene_info_path, output_file, warning_file, num_workers=8, keep=Tr
         blobs = ["".join(lines).encode()]
         if not as_pkl:
             # columns all the way: bitsets -> CSR on the device -> JSON text by libmspa's host formatters, straight into
-            # arrow's buffers; what leaves this rank is the finished table as one IPC stream
-            sink = pa.BufferOutputStream()
-            table = csr.to_arrow(scene_id)
-            with pa.ipc.new_stream(sink, table.schema) as w:
-                w.write_table(table)
-            blobs.append(sink.getvalue())
+            # arrow's buffers -> this scene's row group, encoded and compressed HERE; what leaves this rank is finished parquet
+            # bytes.  No dictionary pages: every key and every JSON list is unique, one would be built, overflow and be dropped.
+            with timings.span("encode"):
+                blobs.append(parquet_splice.encode_row_group(csr.to_arrow(scene_id), use_dictionary=False))
         if want_csr:
             blobs += [np.ascontiguousarray(getattr(csr, f)) for f in _CSR_FIELDS]
         print(f"[process_scene] Done: {scene_id}")
         return None, blobs
 
     def consume(index, _rows, blobs):
-        import pyarrow as pa
-        import pyarrow.parquet as pq
         scene_id = all_scene_ids[index]
         if blobs[0].size:
             with open(warning_file, "a") as f:
@@ -137,18 +134,17 @@ def run_split(scene_info_path, output_file, warning_file, num_workers=8, keep=Tr
             scene_visibility_dict[scene_id] = csr.to_dict()
         if not as_pkl:
             with timings.span("write"):
-                table = pa.ipc.open_stream(pa.py_buffer(blobs[1])).read_all()
                 if state["writer"] is None:
-                    # every key and every JSON list is unique: a dictionary page would be built, overflow and be dropped
-                    state["writer"] = pq.ParquetWriter(output_file, table.schema, use_dictionary=False)
-                state["writer"].write_table(table)
-                state["n"] += table.num_rows
+                    state["writer"] = parquet_splice.SplicedParquetWriter(output_file)
+                state["n"] += state["writer"].append(blobs[1])
 
+    ok = False
     try:
         sweep.sharded_sweep(costs, ctx, work_items, produce, consume, timings=timings)
+        ok = True
     finally:
         if state["writer"] is not None:
-            state["writer"].close()
+            state["writer"].__exit__(None if ok else RuntimeError, None, None)     # the footer only for a sweep that got through
     if as_pkl and rank == 0:
         with open(output_file, "wb") as f:
             pickle.dump(scene_visibility_dict, f)

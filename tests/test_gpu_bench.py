@@ -150,6 +150,6 @@ def test_bench_informational_legs_run_small():
     d = bench.time_dropin_sweep(n_scenes=3, n_frames=6, n_points=4096, num_workers=4)
     assert d["scenes"] == 3 and d["scenes_per_s"] > 0 and d["pair_rows_per_s"] > 0
     busy = d["stage_busy_s"]
-    assert all(v is not None and v >= 0 for v in busy.values()) and len(busy) == 5
+    assert all(v is not None and v >= 0 for v in busy.values()) and len(busy) == 6
     k5 = bench.time_track_geometry(torch.device("cuda", 0), T=60, P=32, n_scenes=4, reps=2)
     assert k5["batched"]["frames"] == 240 and k5["one_block"]["frac"] > 0

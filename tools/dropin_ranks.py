@@ -182,7 +182,7 @@ def drive(ranks=(1, 2, 4), n_scenes=32, n_frames=320, n_points=131072, workers=N
                            "rank0_consume_busy_s": busy[0].get("consume"), "rank0_writer_drain_s": busy[0].get("writer_drain"),
                            "rank0_writer_backpressure_s": busy[0].get("writer_backpressure"),
                            "wait_at_exchange_s": [b.get("wait_at_exchange", 0.0) for b in busy],
-                           "produce_s": [b.get("produce") for b in busy], "decode_busy_s": [b.get("decode") for b in busy],
+                           "produce_s": [b.get("produce") for b in busy], "encode_s": [b.get("encode") for b in busy], "decode_busy_s": [b.get("decode") for b in busy],
                            "exchange_s": [b.get("exchange") for b in busy], "digests": legs[0]["digests"]}
             th1 = hostinfo.throttle_stats()
             w["cfs_throttling_whole_run"] = {k: th1[k] - th0.get(k, 0) for k in th1}
