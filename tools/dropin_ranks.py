@@ -11,7 +11,7 @@ link are shared (4 ranks x 20 scenes/s x 197 MB = 16 GB/s of a 57 GB/s link).
     python tools/dropin_ranks.py [--ranks 1,2,4] [--scenes 32] [--frames 320] [--workers N] [--passes 3] [--per-rank 2]
 
 `--workers` (decode threads per scene in flight, per rank) is the SAME for every world size and defaults to what lets the largest
-world fit the container's CPU quota (16 CPUs on the MI355X boxes -> 2): the question is whether the job scales when every rank
+world fit the container's CPU quota (16 CPUs on the MI355X boxes -> 1): the question is whether the job scales when every rank
 brings its own resources, as on an 8-GPU node; one rank with all the box's CPUs is already decode-bound at the quota.
 
 Driver mode (no RANK in the environment) writes the inputs once (rendered frames hard-linked under 320 image ids: every
@@ -112,12 +112,14 @@ def drive(ranks=(1, 2, 4), n_scenes=32, n_frames=320, n_points=131072, workers=N
     """Returns the leg's dict (see the module docstring).  ``workers`` = decode threads per scene in flight PER RANK, the same
     for every world size (an N-GPU node gives every rank its own cores: what is measured is whether the job scales when the
     per-rank resources are fixed).  Default: the CPUs this container may use (cgroup quota, mspa/hostinfo.py) divided by the
-    largest world and by the 2 scenes a rank keeps in flight -- 16 CPUs / 4 ranks / 2 = 2 on the MI355X boxes -- so that the
-    largest world still fits inside the quota instead of being throttled by it."""
+    largest world, by the 2 scenes a rank keeps in flight and by 2 again (the other half of a rank's CPUs is for its main thread:
+    staging, JSON formatting, parquet encoding) -- 16 CPUs / 4 ranks / 2 / 2 = 1 on the MI355X boxes -- so that the largest world
+    still fits inside the quota instead of being throttled by it (with 2, the index sweep at 4 ranks spent 9.9 CPU-seconds frozen:
+    profiles/r06_dropin_ranks.md)."""
     from mspa import hostinfo
     eff = hostinfo.effective_cpus(per_rank=False)
     if workers is None:
-        workers = max(1, min(25, eff // (2 * max(ranks))))
+        workers = max(1, min(25, eff // (4 * max(ranks))))
     root = keep_root or tempfile.mkdtemp(prefix="mspa_dropin_ranks_")
     try:
         t0 = time.perf_counter()
