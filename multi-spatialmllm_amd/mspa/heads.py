@@ -175,6 +175,30 @@ def camera_movement_dataset(rows: Sequence, frame_pose, image_hw_of, question_ty
     if ctx is not None:                                        # all rows, every rank: ~4 generator calls per row
         draws = [camera_movement_draw(r, question_type, templates, rng) for r in rows]
     lo, hi = (0, n) if ctx is None else _partition(n, world, rank)
+    failure: Optional[BaseException] = None
+    mine: List[dict] = []
+    try:
+        mine = _camera_movement_slice(rows, lo, hi, frame_pose, image_hw_of, question_type, templates, rng, device, draws)
+        if transform is not None:
+            mine = [transform(rec) for rec in mine]
+    except Exception as e:                                     # the distance assert, a missing image, a backend error on THIS
+        if ctx is None:                                        # rank's slice: the other ranks must not be left in the gather
+            raise
+        failure = e
+    if ctx is None:
+        return mine
+    from . import shard
+    shard.raise_together(ctx, failure, "camera_movement_dataset")
+    parts = shard.gather_bytes("".join(json.dumps(rec) + "\n" for rec in mine).encode(), ctx, dst=0)
+    if rank != 0:
+        return []
+    return [JsonLine(line) for p in parts for line in bytes(p).split(b"\n")[:-1]]
+
+
+def _camera_movement_slice(rows, lo, hi, frame_pose, image_hw_of, question_type, templates, rng, device, draws) -> List[dict]:
+    """Records of rows [lo, hi): one K4 launch over a table of the slice's distinct frames, then the per-row formatting."""
+    import torch
+    from . import engine
     table: Dict[Tuple[str, str], int] = {}
     poses = []
     idx = np.empty((hi - lo, 2), dtype=np.int32)
@@ -187,27 +211,18 @@ def camera_movement_dataset(rows: Sequence, frame_pose, image_hw_of, question_ty
                 table[key] = len(poses)
                 poses.append(E)
             idx[k - lo, c] = table[key]
-    mine: List[dict] = []
-    if hi > lo:
-        E_all = np.stack(poses)
-        E_t = torch.from_numpy(E_all.reshape(-1, 16)).to(device)
-        Einv_t = torch.from_numpy(np.linalg.inv(E_all).reshape(-1, 16)).to(device)   # same LAPACK call as per frame
-        zeros = torch.zeros(len(poses), dtype=torch.float64, device=device)
-        both = torch.from_numpy(np.concatenate([idx, idx[:, ::-1]], axis=0).copy()).to(device)
-        out = engine.pair_pose(E_t, Einv_t, zeros, zeros, both).cpu().numpy()
-        m = hi - lo
-        mine = [camera_movement_record(rows[k], k, question_type, out[k - lo, 3:6], out[m + k - lo, 3:6],
-                                       image_hw_of(rows[k]["scene_id"], rows[k]["image_id1"]), templates, rng,
-                                       draw=None if draws is None else draws[k]) for k in range(lo, hi)]
-    if transform is not None:
-        mine = [transform(rec) for rec in mine]
-    if ctx is None:
-        return mine
-    from . import shard
-    parts = shard.gather_bytes("".join(json.dumps(rec) + "\n" for rec in mine).encode(), ctx, dst=0)
-    if rank != 0:
+    if hi <= lo:
         return []
-    return [JsonLine(line) for p in parts for line in bytes(p).split(b"\n")[:-1]]
+    E_all = np.stack(poses)
+    E_t = torch.from_numpy(E_all.reshape(-1, 16)).to(device)
+    Einv_t = torch.from_numpy(np.linalg.inv(E_all).reshape(-1, 16)).to(device)       # same LAPACK call as per frame
+    zeros = torch.zeros(len(poses), dtype=torch.float64, device=device)
+    both = torch.from_numpy(np.concatenate([idx, idx[:, ::-1]], axis=0).copy()).to(device)
+    out = engine.pair_pose(E_t, Einv_t, zeros, zeros, both).cpu().numpy()
+    m = hi - lo
+    return [camera_movement_record(rows[k], k, question_type, out[k - lo, 3:6], out[m + k - lo, 3:6],
+                                   image_hw_of(rows[k]["scene_id"], rows[k]["image_id1"]), templates, rng,
+                                   draw=None if draws is None else draws[k]) for k in range(lo, hi)]
 
 
 def _partition(n_items: int, world: int, rank: int) -> Tuple[int, int]:
@@ -369,15 +384,24 @@ def visual_correspondence_dataset(rows: Sequence, get_scene, get_bits=None, temp
     n_common = [0] * n
     known = [False] * n
     hw: Dict[str, Tuple[int, int]] = {}
-    for scene_id, ks in by_scene.items():                                  # pass 1
-        if scene_id not in mine:
-            continue
-        counts = backend.common_counts(scene_id, [(rows[k]["image_id1"], rows[k]["image_id2"]) for k in ks])
-        if counts is None:
-            continue
-        hw[scene_id] = backend.image_hw(scene_id)
-        for k, c in zip(ks, counts):
-            known[k], n_common[k] = True, c
+    failure: Optional[BaseException] = None
+    try:
+        for scene_id, ks in by_scene.items():                              # pass 1
+            if scene_id not in mine:
+                continue
+            counts = backend.common_counts(scene_id, [(rows[k]["image_id1"], rows[k]["image_id2"]) for k in ks])
+            if counts is None:
+                continue
+            hw[scene_id] = backend.image_hw(scene_id)
+            for k, c in zip(ks, counts):
+                known[k], n_common[k] = True, c
+    except Exception as e:                                                 # a rank-local failure (a missing frame, a backend
+        if ctx is None:                                                    # error) must reach EVERY rank before the collective
+            raise
+        failure = e
+    if ctx is not None:
+        from . import shard
+        shard.raise_together(ctx, failure, "visual_correspondence_dataset (pass 1)")
     if ctx is not None and n:
         import torch
         import torch.distributed as dist
@@ -396,77 +420,85 @@ def visual_correspondence_dataset(rows: Sequence, get_scene, get_bits=None, temp
             return None
         return visual_correspondence_draws([rows[k]], [n_common[k]], templates, rng, max_points_per_pair, [hidden.get(k)])[0]
 
-    start = 0
-    while start < n:
-        draws: Dict[int, Optional[dict]] = {}
-        checkpoints: Dict[int, tuple] = {}
-        for k in range(start, n):                                          # pass 2
-            if (k - start) % STRIDE == 0:
-                checkpoints[k] = rng.getstate()
-            draws[k] = draw(k)
-        proj: Dict[int, list] = {}
-        for scene_id, ks in by_scene.items():                              # pass 3
-            if scene_id not in mine:
-                continue
-            live = [k for k in ks if k >= start and draws[k] is not None]
-            if not live:
-                continue
-            jobs, owner = [], []
-            for k in live:
+    try:
+        start = 0
+        while start < n:
+            draws: Dict[int, Optional[dict]] = {}
+            checkpoints: Dict[int, tuple] = {}
+            for k in range(start, n):                                          # pass 2
+                if (k - start) % STRIDE == 0:
+                    checkpoints[k] = rng.getstate()
+                draws[k] = draw(k)
+            proj: Dict[int, list] = {}
+            for scene_id, ks in by_scene.items():                              # pass 3
+                if scene_id not in mine:
+                    continue
+                live = [k for k in ks if k >= start and draws[k] is not None]
+                if not live:
+                    continue
+                jobs, owner = [], []
+                for k in live:
+                    r, d = rows[k], draws[k]
+                    i1, i2 = (r["image_id2"], r["image_id1"]) if d["swap"] else (r["image_id1"], r["image_id2"])
+                    for j in d["positions"]:
+                        jobs.append((i1, i2, j))
+                        owner.append(k)
+                for k, res in zip(owner, backend.project(scene_id, jobs)):
+                    proj.setdefault(k, []).append(res)
+            redo = None
+            for k in range(start, n):                                          # records, until a row needs its draws corrected
                 r, d = rows[k], draws[k]
-                i1, i2 = (r["image_id2"], r["image_id1"]) if d["swap"] else (r["image_id1"], r["image_id2"])
-                for j in d["positions"]:
-                    jobs.append((i1, i2, j))
-                    owner.append(k)
-            for k, res in zip(owner, backend.project(scene_id, jobs)):
-                proj.setdefault(k, []).append(res)
-        redo = None
-        for k in range(start, n):                                          # records, until a row needs its draws corrected
-            r, d = rows[k], draws[k]
-            if d is None:
-                if not known[k]:
-                    warn(f"[build_training_sample] Warning: Visibility info not found for scene {r['scene_id']}\n")
-                else:
-                    warn(f"[build_training_sample] Warning: No common visible points for scene {r['scene_id']} "
-                         f"{r['image_id1']}, {r['image_id2']}\n")
-                continue
-            if r["scene_id"] not in mine:                                  # another rank's row: its record arrives as bytes
-                continue
-            image1, image2 = (r["image_id2"], r["image_id1"]) if d["swap"] else (r["image_id1"], r["image_id2"])
-            bad = {s for s, (_, _, _, ok1, ok2) in enumerate(proj[k]) if not (ok1 and ok2)}
-            if bad - hidden.get(k, set()):
-                if ctx is not None:
-                    raise RuntimeError(f"visual_correspondence_dataset: vertex {proj[k][min(bad)][0]} of scene {r['scene_id']} failed the "
-                                       "visibility re-check (a visibility index that does not belong to these frames); the rewind that "
-                                       "reproduces upstream's draws for such rows runs in a single process only")
-                for s in sorted(bad):
-                    vertex, _, _, ok1, ok2 = proj[k][s]
-                    if not ok1:
-                        warn(f"Warning: Point {vertex} is not visible in image {image1} in scene {r['scene_id']}.\n")
-                    if not ok2:
-                        warn(f"Warning: Point {vertex} is not visible in image {image2} in scene {r['scene_id']}.\n")
-                redo = (k, bad)
+                if d is None:
+                    if not known[k]:
+                        warn(f"[build_training_sample] Warning: Visibility info not found for scene {r['scene_id']}\n")
+                    else:
+                        warn(f"[build_training_sample] Warning: No common visible points for scene {r['scene_id']} "
+                             f"{r['image_id1']}, {r['image_id2']}\n")
+                    continue
+                image1, image2 = (r["image_id2"], r["image_id1"]) if d["swap"] else (r["image_id1"], r["image_id2"])
+                if r["scene_id"] not in mine:                                  # another rank's row: its record arrives as bytes;
+                    if all(p is None for p in d["picks"]):                     # its warning line is rank 0's to write (the picks
+                        warn(f"[build_training_sample] Warning: No conversation for scene {r['scene_id']} {image1}, {image2}\n")
+                    continue                                                   # come from the replicated draws: known here)
+                bad = {s for s, (_, _, _, ok1, ok2) in enumerate(proj[k]) if not (ok1 and ok2)}
+                if bad - hidden.get(k, set()):
+                    if ctx is not None:
+                        raise RuntimeError(f"visual_correspondence_dataset: vertex {proj[k][min(bad)][0]} of scene {r['scene_id']} failed the "
+                                           "visibility re-check (a visibility index that does not belong to these frames); the rewind that "
+                                           "reproduces upstream's draws for such rows runs in a single process only")
+                    for s in sorted(bad):
+                        vertex, _, _, ok1, ok2 = proj[k][s]
+                        if not ok1:
+                            warn(f"Warning: Point {vertex} is not visible in image {image1} in scene {r['scene_id']}.\n")
+                        if not ok2:
+                            warn(f"Warning: Point {vertex} is not visible in image {image2} in scene {r['scene_id']}.\n")
+                    redo = (k, bad)
+                    break
+                if all(p is None for p in d["picks"]):                         # VC_C:373-378
+                    warn(f"[build_training_sample] Warning: No conversation for scene {r['scene_id']} {image1}, {image2}\n")
+                    continue
+                uv1 = np.stack([res[1] for res in proj[k]])
+                uv2 = np.stack([res[2] for res in proj[k]])
+                out[k] = visual_correspondence_record(r, k, d, uv1, uv2, hw[r["scene_id"]], templates)
+            if redo is None:
                 break
-            if all(p is None for p in d["picks"]):                         # VC_C:373-378
-                warn(f"[build_training_sample] Warning: No conversation for scene {r['scene_id']} {image1}, {image2}\n")
-                continue
-            uv1 = np.stack([res[1] for res in proj[k]])
-            uv2 = np.stack([res[2] for res in proj[k]])
-            out[k] = visual_correspondence_record(r, k, d, uv1, uv2, hw[r["scene_id"]], templates)
-        if redo is None:
-            break
-        k, bad = redo                                                      # take the generator back to the start of row k
-        base = max(c for c in checkpoints if c <= k)
-        rng.setstate(checkpoints[base])
-        for j in range(base, k):
-            draw(j)
-        hidden[k] = set(bad)
-        start = k
-    if transform is not None:
-        out = [None if rec is None else transform(rec) for rec in out]
+            k, bad = redo                                                      # take the generator back to the start of row k
+            base = max(c for c in checkpoints if c <= k)
+            rng.setstate(checkpoints[base])
+            for j in range(base, k):
+                draw(j)
+            hidden[k] = set(bad)
+            start = k
+        if transform is not None:
+            out = [None if rec is None else transform(rec) for rec in out]
+    except Exception as e:                                                 # e.g. the stale-index error of ONE rank's rows
+        if ctx is None:
+            raise
+        failure = e
     if ctx is None:
         return out
     from . import shard
+    shard.raise_together(ctx, failure, "visual_correspondence_dataset (passes 2-3)")
     lines = "".join(f"{k}\t{json.dumps(rec)}\n" for k, rec in enumerate(out) if rec is not None).encode()
     parts = shard.gather_bytes(lines, ctx, dst=0)
     merged: List[Optional[dict]] = [None] * n

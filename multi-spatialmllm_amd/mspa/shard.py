@@ -182,6 +182,32 @@ def gather_bytes(payload, ctx: DistContext, dst: int = 0):
     return [parts[r][:c].cpu().numpy() for r, c in enumerate(counts)]
 
 
+def raise_together(ctx: "DistContext | None", failure: "BaseException | None", what: str = "a sharded step"):
+    """One int over the ranks: did ANY rank fail in the step that just ended?  The failing rank raises its own exception,
+    every other rank a RuntimeError -- instead of walking into the next collective and standing there until the
+    communicator times out.  Call it on every rank where a rank-local step ends and a collective begins."""
+    if ctx is None:
+        if failure is not None:
+            raise failure
+        return
+    flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device=ctx.collective_device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ctx.group)
+    if int(flag.item()):
+        if failure is not None:
+            raise failure
+        raise RuntimeError(f"{what}: another rank failed (its own traceback says why)")
+
+
+def broadcast_object(obj, ctx: "DistContext | None", src: int = 0):
+    """``obj`` of rank ``src`` on every rank (pickled; a few hundred bytes to a few KB: generator states, counts).  With no
+    communicator the object itself."""
+    if ctx is None:
+        return obj
+    box = [obj if ctx.rank == src else None]
+    dist.broadcast_object_list(box, src=src, group=ctx.group, device=ctx.collective_device)
+    return box[0]
+
+
 def context_from_env(device=None) -> "DistContext | None":
     """The communicator of a job launched with one process per GPU (RANK / WORLD_SIZE / LOCAL_RANK in the environment, as
     torch.distributed.run sets them), or None for a plain single-process run: what the drop-in entry points

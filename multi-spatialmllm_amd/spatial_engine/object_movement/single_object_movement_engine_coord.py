@@ -162,6 +162,16 @@ class TwoFrameVideoQAEngine:
             ctx.barrier()
         return ctx is None or ctx.rank == 0
 
+    def _sync_generator(self):
+        """Every rank leaves a dataset call with rank 0's ``random`` state.  Only the writer runs ``random.sample`` /
+        ``random.shuffle`` on the collected records, and the NEXT call's scenes start from ``random.getstate()`` on whichever
+        rank owns them (``_all_scenes``): without this the second call of a job (main() makes eight) would depend on the
+        world size.  One pickled generator state (2.5 KB) per call."""
+        from mspa import shard
+        ctx = getattr(self, "_ctx", None)
+        if ctx is not None:
+            random.setstate(shard.broadcast_object(random.getstate(), ctx, src=0))
+
     @staticmethod
     def _report(kind, output_file, data):
         still = sum(1 for e in data if e["point_moving"] == 0)
@@ -174,13 +184,13 @@ class TwoFrameVideoQAEngine:
                                   npoints_per_group, npairs_per_bin, augment, augment_ratio=1.0, max_samples=-1, num_workers=20):
         data = self._all_scenes(scene_id_list, source_data_root, img_output_dir, npoints_per_group, npairs_per_bin, augment,
                                 augment_ratio, num_workers)
-        if not self._is_writer():
-            return
-        if max_samples > 0 and len(data) > max_samples:
-            data = random.sample(data, max_samples)
-        random.shuffle(data)
-        heads.write_jsonl(output_file, data)
-        self._report("Training", output_file, data)
+        if self._is_writer():
+            if max_samples > 0 and len(data) > max_samples:
+                data = random.sample(data, max_samples)
+            random.shuffle(data)
+            heads.write_jsonl(output_file, data)
+            self._report("Training", output_file, data)
+        self._sync_generator()
 
     def format_eval_sample(self, training_sample):
         training_sample["text"] = training_sample["conversations"][0]["value"]
@@ -190,12 +200,12 @@ class TwoFrameVideoQAEngine:
                               npoints_per_group, npairs_per_bin, augment, augment_ratio=0.3, max_samples=300, num_workers=20):
         data = self._all_scenes(scene_id_list, source_data_root, img_output_dir, npoints_per_group, npairs_per_bin, augment,
                                 augment_ratio, num_workers)
-        if not self._is_writer():
-            return
-        if max_samples > 0 and len(data) > max_samples:
-            data = random.sample(data, max_samples)
-        heads.write_jsonl(output_file, [self.format_eval_sample(s) for s in data])
-        self._report("Evaluation", output_file, data)
+        if self._is_writer():
+            if max_samples > 0 and len(data) > max_samples:
+                data = random.sample(data, max_samples)
+            heads.write_jsonl(output_file, [self.format_eval_sample(s) for s in data])
+            self._report("Evaluation", output_file, data)
+        self._sync_generator()
 
 
 def jpeg_size(data: bytes):

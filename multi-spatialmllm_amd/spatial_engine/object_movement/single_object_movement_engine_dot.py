@@ -110,27 +110,27 @@ class TwoFrameVideoQAEngineDot(TwoFrameVideoQAEngine):
                                   npoints_per_group, npairs_per_bin, augment, augment_ratio=1.0, max_samples=-1, num_workers=20):
         data = self._all_scenes_dot(scene_id_list, source_data_root, base_img_dir, img_output_dir, npoints_per_group,
                                     npairs_per_bin, augment, augment_ratio, num_workers)
-        if not self._is_writer():
-            return
-        if max_samples > 0 and len(data) > max_samples:
-            data = random.sample(data, max_samples)
-        random.shuffle(data)
-        heads.write_jsonl(output_file, data)
-        self._report("Training", output_file, data)
+        if self._is_writer():
+            if max_samples > 0 and len(data) > max_samples:
+                data = random.sample(data, max_samples)
+            random.shuffle(data)
+            heads.write_jsonl(output_file, data)
+            self._report("Training", output_file, data)
+        self._sync_generator()
 
     def generate_qa_eval_data(self, scene_id_list, source_data_root, base_img_dir, output_dir, output_file, img_output_dir,
                               npoints_per_group, npairs_per_bin, augment, augment_ratio=0.3, max_samples=300, num_workers=20):
         """Writes ``*_orig.jsonl`` (everything) and the subsampled file (reference: :640-683)."""
         data = self._all_scenes_dot(scene_id_list, source_data_root, base_img_dir, img_output_dir, npoints_per_group,
                                     npairs_per_bin, augment, augment_ratio, num_workers)
-        if not self._is_writer():
-            return
-        eval_data = [self.format_eval_sample(s) for s in data]
-        heads.write_jsonl(output_file.replace(".jsonl", "_orig.jsonl"), eval_data)
-        subsampled = random.sample(eval_data, max_samples) if max_samples > 0 and len(eval_data) > max_samples else eval_data
-        heads.write_jsonl(output_file, subsampled)
-        self._report("Original evaluation", output_file.replace(".jsonl", "_orig.jsonl"), data)
-        self._report("Subsampled evaluation", output_file, subsampled)
+        if self._is_writer():
+            eval_data = [self.format_eval_sample(s) for s in data]
+            heads.write_jsonl(output_file.replace(".jsonl", "_orig.jsonl"), eval_data)
+            subsampled = random.sample(eval_data, max_samples) if max_samples > 0 and len(eval_data) > max_samples else eval_data
+            heads.write_jsonl(output_file, subsampled)
+            self._report("Original evaluation", output_file.replace(".jsonl", "_orig.jsonl"), data)
+            self._report("Subsampled evaluation", output_file, subsampled)
+        self._sync_generator()
 
 
 if __name__ == "__main__":

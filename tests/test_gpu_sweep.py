@@ -100,6 +100,15 @@ def _run_everything(out_dir):
     random.seed(11)
     eng.generate_qa_training_data([t.scene_id for t in _tracks()], "tapvid", out_dir, os.path.join(out_dir, "om_train.jsonl"),
                                   os.path.join(out_dir, f"img_rank{os.environ.get('RANK', '0')}"), 4, 3, True, 0.5, num_workers=3)
+    # a second and a third call WITHOUT reseeding (upstream's main makes eight in a row): the writer's sample / shuffle of the
+    # first call moved rank 0's generator only -- every rank must start the next call's scenes from the same state
+    eng.generate_qa_eval_data([t.scene_id for t in _tracks()], "tapvid", out_dir, os.path.join(out_dir, "om_val.jsonl"),
+                              os.path.join(out_dir, f"img_rank{os.environ.get('RANK', '0')}"), 2, 2, True, 0.5, max_samples=7,
+                              num_workers=3)
+    eng2 = OM.TwoFrameVideoQAEngine("tapvid3d_displacement_vector", "adt")
+    eng2.generate_qa_training_data([t.scene_id for t in _tracks()], "tapvid", out_dir, os.path.join(out_dir, "om_train2.jsonl"),
+                                   os.path.join(out_dir, f"img_rank{os.environ.get('RANK', '0')}"), 3, 2, True, 0.5, max_samples=40,
+                                   num_workers=3)
     ctx = shard.context_from_env()
     handler = SceneInfoHandler(INFO)
     # (not the scene with frames that see nothing: the depth heads draw two visible points per sampled image and, like the

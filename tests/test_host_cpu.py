@@ -220,8 +220,21 @@ def _worker(rank, world, port, q):
         for p in parts:
             PL._unpack_outputs(p, merged)
         got = {name: sorted((k, ln.decode()) for k, ln in v) for name, v in merged.items()}
+    # a generator state from rank 0 to everybody (the object-movement builders' writer keeps the ranks' `random` in step)
+    import random
+    random.seed(100 + rank)
+    random.setstate(S.broadcast_object(random.getstate(), ctx, src=0))
+    drawn = random.random()
+    # a rank-local failure reaches every rank before the next collective: the failing rank raises its own error
+    raised = []
+    for failing in (None, 1):
+        try:
+            S.raise_together(ctx, KeyError("frame 00015") if rank == failing else None, "pass 1")
+            raised.append(None)
+        except Exception as e:
+            raised.append(type(e).__name__)
     ctx.barrier()
-    q.put((rank, full.numpy().tolist(), t, got))
+    q.put((rank, full.numpy().tolist(), t, got, drawn, raised))
     ctx.close()
 
 
@@ -247,9 +260,13 @@ def test_shard_and_collate_gloo_world2():
     for (i, j) in all_pairs:
         r = O.frame_pair(sc.depth[ids[i]], sc.depth[ids[j]], sc.K, sc.E[ids[i]], sc.E[ids[j]], sc.A, (24, 32), col)
         expect.append([i, j, r["n_valid"], r["n_vis"]])
-    for rank, full, t, tapes in results:
+    import random
+    random.seed(100)
+    want_draw = random.random()
+    for rank, full, t, tapes, drawn, raised in results:
         assert full == expect, f"rank {rank}: collated records differ from the single-process table"
-        assert t == 2.0
+        assert t == 2.0 and drawn == want_draw
+        assert raised == [None, "KeyError" if rank == 1 else "RuntimeError"]
         if rank == 0:
             import json
             want_a = sorted((f"a{r}_{k}", json.dumps({"id": f"a{r}_{k}", "v": [r, k, 0.1 * k]})) for r in range(2) for k in range(2 + r))
