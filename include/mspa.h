@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MSPA_VERSION 150            /* 0.5.0: host-side depth-PNG ingest (mspa_read_depth_png_host); 0.4.0: frame records carry
+#define MSPA_VERSION 160            /* 0.6.0: depth-frame decode on the device (mspa_inflate_blocks_device, mspa_png_unfilter_device); 0.5.0: host-side depth-PNG ingest (mspa_read_depth_png_host); 0.4.0: frame records carry
                                        guard-bound coefficients (slot MSPA_MAT_BOUNDS, MSPA_FRAME_MATS 7 -> 8) */
 
 #define MSPA_OK 0
@@ -368,6 +368,38 @@ int mspa_png_header_host(const char *path_host, int32_t *h, int32_t *w, int32_t 
  * declines it (damaged or truncated stream, other output size, preset dictionary): the callers above then use zlib itself.
  */
 int mspa_inflate_zlib_fast_host(const void *src_host, int64_t src_bytes, void *dst_host, int64_t dst_bytes);
+
+/*
+ * Depth-frame decode ON THE DEVICE (csrc/device_ingest.hip): the same two reference stages -- `cv2.imread(depth_png, -1)` per
+ * frame (info_handler.py:149-155) and `zlib.decompress` per .sens frame (extract_posed_images.py:49-57) -- with the COMPRESSED
+ * bytes crossing PCIe and the frames landing in HBM as the [F, h, w] uint16 block K1 / K3 read.
+ *
+ * mspa_inflate_blocks_device   n_blocks zlib streams (RFC 1950 / 1951: stored, fixed and dynamic blocks, 32 K window), stream k =
+ *   src_bytes_dev[k] bytes at src_dev + src_offsets_dev[k] (offsets multiples of 8; the buffer src_dev .. + src_capacity must
+ *   hold every stream and may be read up to the 8-byte unit a stream ends in), each inflated by ONE wave into dst_dev + k *
+ *   dst_pitch.  status_dev[k] (int32, written for every k): 0 the stream inflated to EXACTLY block_bytes, ended inside its
+ *   input and the Adler-32 of the output equals its trailer; 1 not a valid / supported stream or another size; 2 checksum
+ *   mismatch.  A block with a non-zero status holds garbage: decode that frame on the host (mspa_inflate_blocks_host /
+ *   mspa_read_depth_png_host) -- the same "accept only what verifies, hand the rest on" contract as csrc/inflate_fast.h.
+ *   work_dev: n_blocks uint32 of scratch.  src_dev, dst_dev, dst_pitch 16-byte aligned; block_bytes <= 64 MiB.
+ * mspa_png_unfilter_device     n_images inflated scanline blocks (h rows of 1 filter byte + 2 w sample bytes, image k at raw_dev +
+ *   k * raw_pitch) -> out_dev[k, h, w] uint16 in host byte order: the five PNG row filters (None / Sub / Up / Average / Paeth)
+ *   undone, big-endian samples swapped.  Images whose status_dev[k] is non-zero on entry are skipped; an image with a filter
+ *   byte > 4 gets status 3.
+ * mspa_png_pack_idat_host      the host half: the n_files 16-bit greyscale non-interlaced h x w PNG files are read by up to
+ *   n_threads threads and the payloads of their IDAT chunks -- the scanlines' zlib stream -- packed into dst_host (pinned memory
+ *   the H2D copy reads) at offsets_host[k] (multiples of 16), bytes_host[k] long.  Call with dst_host == NULL first: only the
+ *   files' sizes are looked up and *capacity_needed is set (offsets are assigned from the file sizes, so both calls agree).
+ *   status_host[k]: 0 packed; 1 unreadable; 2 another pixel format or size; 3 corrupt chunk structure.
+ */
+int mspa_inflate_blocks_device(const void *src_dev, const int64_t *src_offsets_dev, const int64_t *src_bytes_dev,
+                               int64_t src_capacity, int64_t n_blocks, int64_t block_bytes, void *dst_dev, int64_t dst_pitch,
+                               int32_t *status_dev, uint32_t *work_dev, void *stream);
+int mspa_png_unfilter_device(const void *raw_dev, int64_t raw_pitch, int64_t n_images, int32_t h, int32_t w, uint16_t *out_dev,
+                             int32_t *status_dev, void *stream);
+int mspa_png_pack_idat_host(const char *const *paths_host, int64_t n_files, int32_t h, int32_t w, void *dst_host,
+                            int64_t dst_capacity, int64_t *offsets_host, int64_t *bytes_host, int32_t *status_host,
+                            int64_t *capacity_needed, int32_t n_threads);
 
 /*
  * K4 -- per-pair camera relations: the distance / yaw / pitch columns of CFR.process_scene's pair

@@ -1,0 +1,615 @@
+// Depth-frame decode ON the MI355X: DEFLATE (RFC 1951) / zlib (RFC 1950) streams inflated by one wave each, Adler-32 checked,
+// PNG scanline filters undone -- compressed frames cross PCIe (half the bytes) and land as the [F, h, w] uint16 block K1 / K3 read.
+//
+// What it replaces: the per-frame `cv2.imread(depth_png, -1)` of SceneInfoHandler.get_depth_image (info_handler.py:149-155) and
+// the per-frame `zlib.decompress` of the .sens reader (extract_posed_images.py:49-57), i.e. the stage that bounds every from-disk
+// sweep: 16 CPUs' worth of container quota inflate ~10 k frames/s (profiles/r06_ingest_scaling.txt) while the kernels downstream
+// take 3 M images/s.  DEFLATE is serial inside a stream, so the parallelism is ACROSS streams: a scene has 320 of them, the
+// loader keeps several scenes in flight, the chip has room for 3 840 such waves.
+//
+// mspa::dinf::inflate_kernel -- one 64-lane workgroup (one wave) per stream:
+//   * everything that steers the decode is WAVE-UNIFORM and lives in SGPRs: the 64-bit bit buffer, the bit count, the input
+//     word index, the output position.  Branches are scalar branches; the vector unit only moves bytes.
+//   * input: the wave holds 512 B of the compressed stream in two VGPRs (8 B per lane, one coalesced load) with the next 512 B
+//     in flight; a refill is `v_readlane_b32` with a scalar lane index -- no memory latency on the decode's critical path.
+//   * tables: a 10-bit literal/length table and an 8-bit distance table in LDS, read at a uniform address (LDS broadcast) and
+//     brought to an SGPR with `v_readfirstlane_b32`.  Codes longer than the table index (p < 2^-10 each) take the canonical
+//     first-code walk over the length-sorted symbol list -- no sub-tables to build.  The tables of a dynamic block are built by
+//     all 64 lanes (ballot ranks -> canonical codes -> replicated entries).
+//   * output: a 4 KB ring in LDS takes every byte; whole 256-byte lines leave for HBM as one coalesced dword store per lane.
+//     A match whose distance fits the ring (<= 3 838: every filter-row distance of a 640-pixel image, 1 281) is copied LDS to
+//     LDS by the lanes, 64 bytes per step; a farther one reads the flushed bytes back from global memory behind a
+//     workgroup-scope fence.
+//   * a stream is ACCEPTED only if it ends exactly at the expected size, stays inside its input, and (second kernel,
+//     adler32_kernel) the Adler-32 of the output equals the stream's trailer -- the contract of csrc/inflate_fast.h.  Anything
+//     else is reported per block and the caller decodes that frame on the host.
+// mspa::dinf::png_unfilter_kernel -- one wave per image, 64 rows at a time on a skewed pipeline (lane y works on column t - y at
+//   step t, so the left, upper and upper-left neighbours of Sub / Up / Average / Paeth are a register, the lane above's previous
+//   output via DPP, and the one before that), writing host-order uint16 pixels.
+#include "mspa_common.h"
+
+namespace mspa {
+namespace dinf {
+
+constexpr int kLitBits = 10, kDistBits = 8;
+constexpr int kRing = 4096, kRingMask = kRing - 1;
+constexpr int kRingNear = kRing - 258;          // a match at most this far back never reads a ring slot it is overwriting
+constexpr int kLitSyms = 288, kDistSyms = 32;
+
+// entry: bits 0..7 code length, 8..10 kind, 11..15 extra-bit count, 16..31 payload
+//   kind 0 literal (payload = byte) / code-length symbol; 1 length or distance (payload = base); 2 end of block;
+//   3 a code longer than the table index (canonical walk); 4 invalid
+__device__ __forceinline__ uint32_t pack(uint32_t len, uint32_t kind, uint32_t extra, uint32_t payload) {
+    return len | (kind << 8) | (extra << 11) | (payload << 16);
+}
+constexpr uint32_t kInvalid = 1u | (4u << 8);
+
+__constant__ uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t kPreOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct __align__(16) WaveLds {
+    uint32_t lit[1 << kLitBits];        // 4 096 B
+    uint32_t dist[1 << kDistBits];      // 1 024 B
+    uint8_t ring[kRing];                // 4 096 B
+    uint32_t pre[128];                  //   512 B  code-length code, 7-bit index
+    uint16_t sorted[kLitSyms + kDistSyms];   // 640 B  symbols by (code length, symbol), literal/length then distance alphabet
+    uint8_t lens[kLitSyms + kDistSyms];      // 320 B
+    // per alphabet (0 literal/length, 1 distance, 2 code-length code) and code length: first canonical code, symbol count,
+    // offset of the length's first symbol in `sorted`
+    uint32_t first[3][16], count[3][16], offs[3][16];
+};
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// The wave-uniform decode state.  Members are only ever assigned wave-uniform values (readlane / readfirstlane results, kernel
+// arguments, arithmetic on those), so the compiler keeps them in SGPRs.
+struct Reader {
+    const uint2 *src;            // 8-byte aligned start of the stream
+    uint32_t n_words;            // 32-bit words the stream's bytes span (rounded up)
+    uint32_t n_chunks_ok;        // 8-byte units that may be loaded
+    uint2 cur, nxt;              // per lane: 8 bytes of the current / next 512-byte chunk
+    uint32_t widx;               // next 32-bit word of the stream to enter the bit buffer
+    uint64_t buf;
+    int cnt;
+
+    __device__ __forceinline__ uint2 load_chunk(uint32_t chunk, int lane) const {
+        const uint32_t unit = chunk * 64u + (uint32_t)lane;
+        uint2 v = make_uint2(0u, 0u);
+        if (unit < n_chunks_ok) v = src[unit];
+        return v;
+    }
+    __device__ __forceinline__ void seek(uint32_t byte_off, int lane) {
+        widx = byte_off >> 2;
+        const uint32_t chunk = widx >> 7;
+        cur = load_chunk(chunk, lane);
+        nxt = load_chunk(chunk + 1, lane);
+        buf = 0;
+        cnt = 0;
+        refill();
+        const int skip = (int)(byte_off & 3u) * 8;
+        buf >>= skip;
+        cnt -= skip;
+    }
+    __device__ __forceinline__ uint32_t next_word(int lane) {
+        const int l = (int)((widx >> 1) & 63u);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)cur.x, l);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)cur.y, l);
+        const uint32_t w = (widx & 1u) ? hi : lo;
+        ++widx;
+        if ((widx & 127u) == 0u) {                          // the chunk is used up: the prefetched one takes its place
+            cur = nxt;
+            nxt = load_chunk((widx >> 7) + 1u, lane);
+        }
+        return w;
+    }
+    int lane_;
+    __device__ __forceinline__ void refill() {              // >= 32 valid bits afterwards (zeros beyond the stream's end)
+        if (cnt <= 32) {
+            buf |= (uint64_t)next_word(lane_) << cnt;
+            cnt += 32;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)buf & ((1u << k) - 1u); }
+    __device__ __forceinline__ void drop(int k) {
+        buf >>= k;
+        cnt -= k;
+    }
+    __device__ __forceinline__ uint32_t take(int k) {
+        const uint32_t v = peek(k);
+        drop(k);
+        return v;
+    }
+    // bytes of the stream consumed so far, whole bytes still in the bit buffer given back
+    __device__ __forceinline__ int64_t consumed_bytes() const { return (int64_t)widx * 4 - (int64_t)(cnt >> 3); }
+};
+
+__device__ __forceinline__ uint32_t brev(uint32_t v, int len) { return __builtin_bitreverse32(v) >> (32 - len); }
+
+// Canonical Huffman tables of one alphabet from its code lengths, by all 64 lanes.  lens[0 .. n_syms) in LDS; `table` has
+// 1 << bits entries; `sorted` receives the symbols ordered by (length, symbol).  `kind`: 0 literal/length alphabet, 1 distance,
+// 2 code-length code.  Returns false (wave-uniform) for an over-subscribed set.
+__device__ bool build_table(WaveLds &L, int alpha, const uint8_t *lens, int n_syms, uint32_t *table, int bits, uint16_t *sorted,
+                            int lane) {
+    // 1. symbols per code length (ballots over chunks of 64 symbols)
+    uint32_t cnt[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) cnt[l] = 0;
+    for (int base = 0; base < n_syms; base += 64) {
+        const int s = base + lane;
+        const int len = s < n_syms ? (int)lens[s] : 0;
+#pragma unroll
+        for (int l = 1; l < 16; ++l) cnt[l] += (uint32_t)__builtin_popcountll(__ballot(len == l));
+    }
+    // 2. first canonical code and offset into `sorted` per length; Kraft check
+    uint32_t first[16], offs[16];
+    uint32_t code = 0, off = 0;
+    int left = 1;
+    bool ok = true;
+    first[0] = offs[0] = 0;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) {
+        left = (left << 1) - (int)cnt[l];
+        ok = ok && left >= 0;
+        code = (code + cnt[l - 1]) << 1;
+        first[l] = code;
+        offs[l] = off;
+        off += cnt[l];
+    }
+    if (!ok) return false;
+    if (lane < 16) {
+        uint32_t f = 0, c = 0, o = 0;
+#pragma unroll
+        for (int l = 1; l < 16; ++l)
+            if (lane == l) { f = first[l]; c = cnt[l]; o = offs[l]; }
+        L.first[alpha][lane] = f;
+        L.count[alpha][lane] = c;
+        L.offs[alpha][lane] = o;
+    }
+    for (int i = lane; i < (1 << bits); i += 64) table[i] = kInvalid;
+    wave_lds_fence();
+    // 3. every symbol: its rank among the symbols of its length (in symbol order) -> canonical code -> entries
+    uint32_t seen[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) seen[l] = 0;
+    for (int base = 0; base < n_syms; base += 64) {
+        const int s = base + lane;
+        const int len = s < n_syms ? (int)lens[s] : 0;
+        uint32_t rank = 0, fcode = 0, so = 0;
+#pragma unroll
+        for (int l = 1; l < 16; ++l) {
+            const uint64_t b = __ballot(len == l);
+            if (len == l) {
+                rank = seen[l] + (uint32_t)__builtin_popcountll(b & ((1ull << lane) - 1ull));
+                fcode = first[l];
+                so = offs[l];
+            }
+            seen[l] += (uint32_t)__builtin_popcountll(b);
+        }
+        if (len > 0) {
+            sorted[so + rank] = (uint16_t)s;
+            const uint32_t rev = brev(fcode + rank, len);
+            if (len <= bits) {
+                uint32_t e;
+                if (alpha == 0) {
+                    if (s < 256) e = pack((uint32_t)len, 0, 0, (uint32_t)s);
+                    else if (s == 256) e = pack((uint32_t)len, 2, 0, 0);
+                    else if (s > 285) e = pack((uint32_t)len, 4, 0, 0);
+                    else e = pack((uint32_t)len, 1, kLenExtra[s - 257], kLenBase[s - 257]);
+                } else if (alpha == 1) {
+                    e = s > 29 ? pack((uint32_t)len, 4, 0, 0) : pack((uint32_t)len, 1, kDistExtra[s], kDistBase[s]);
+                } else {
+                    e = pack((uint32_t)len, 0, 0, (uint32_t)s);
+                }
+                for (uint32_t i = rev; i < (1u << bits); i += 1u << len) table[i] = e;
+            } else {
+                table[rev & ((1u << bits) - 1u)] = pack((uint32_t)bits, 3, 0, 0);      // a longer code starts with these bits
+            }
+        }
+    }
+    wave_lds_fence();
+    return true;
+}
+
+// A code longer than the table index: walk the lengths above it (first-code test on the bit-reversed prefix).  Returns the
+// symbol and its length, or len = 0 when no code matches (an incomplete set's unused pattern).  All wave-uniform.
+__device__ __forceinline__ uint32_t long_code(const WaveLds &L, int alpha, int bits, const uint16_t *sorted, uint32_t peek16,
+                                              int &len_out) {
+    for (int l = bits + 1; l <= 15; ++l) {
+        const uint32_t code = brev(peek16 & ((1u << l) - 1u), l);
+        const uint32_t f = uni(L.first[alpha][l]), c = uni(L.count[alpha][l]);
+        if (code - f < c) {                                     // unsigned: code >= f and code < f + c
+            len_out = l;
+            return uni((uint32_t)sorted[uni(L.offs[alpha][l]) + (code - f)]);
+        }
+    }
+    len_out = 0;
+    return 0;
+}
+
+// status codes of a block (int32): 0 accepted; 1 not a valid / supported stream or wrong size; (2 set by the Adler pass: checksum)
+__global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__ src_base, const int64_t *__restrict__ src_offsets,
+                                                     const int64_t *__restrict__ src_bytes, int64_t src_capacity, uint8_t *__restrict__ dst_base, int64_t dst_pitch,
+                                                     int64_t block_bytes, int32_t *__restrict__ status,
+                                                     uint32_t *__restrict__ adler_expected) {
+    __shared__ WaveLds L;
+    const int lane = (int)threadIdx.x;
+    const int64_t k = blockIdx.x;
+    const int64_t s0 = src_offsets[k], nb = src_bytes[k];
+    uint8_t *const dst = dst_base + k * dst_pitch;
+    // a stream must lie inside the buffer, start on an 8-byte unit and be shorter than 2 GiB
+    bool good = nb >= 6 && nb < (1ll << 31) && s0 >= 0 && (s0 & 7) == 0 && s0 + nb <= src_capacity;
+    const uint32_t n_src = good ? (uint32_t)nb : 0u;
+    // zlib header: CM = 8, window <= 32 K, FCHECK, no preset dictionary
+    if (good) {
+        const uint32_t cmf = src_base[s0], flg = src_base[s0 + 1];
+        good = (cmf & 0x0Fu) == 8u && (cmf >> 4) <= 7u && ((cmf << 8) | flg) % 31u == 0u && !(flg & 0x20u);
+    }
+    Reader r;
+    r.lane_ = lane;
+    r.src = (const uint2 *)(src_base + s0);
+    r.n_words = (n_src + 3u) >> 2;
+    {   // 8-byte units that lie inside the buffer (the stream's last unit may reach up to 7 bytes past its end)
+        const int64_t room = src_capacity - s0;
+        const int64_t units = (((int64_t)n_src + 7) >> 3);
+        r.n_chunks_ok = (uint32_t)(units * 8 <= room ? units : room >> 3);
+    }
+    uint32_t pos = 0, flushed = 0;
+    const uint32_t out_n = (uint32_t)block_bytes;
+    if (good) r.seek(2, lane);
+    bool last = false;
+    while (good && !last) {
+        if (r.widx > r.n_words + 2u) { good = false; break; }   // ran past the stream's end (zeros decode to nothing useful)
+        r.refill();
+        last = r.take(1) != 0;
+        const uint32_t type = r.take(2);
+        if (type == 3) { good = false; break; }
+        if (type == 0) {
+            // ---- stored block: LEN, NLEN at the next byte boundary, then LEN raw bytes ------------------------------------------
+            r.drop(r.cnt & 7);
+            r.refill();
+            const uint32_t len = r.take(16);
+            r.refill();
+            const uint32_t nlen = r.take(16);
+            const int64_t at = r.consumed_bytes();
+            if ((len ^ nlen) != 0xFFFFu || at + (int64_t)len > (int64_t)n_src || (uint64_t)pos + len > out_n) { good = false; break; }
+            const uint8_t *q = src_base + s0 + at;
+            for (uint32_t done = 0; done < len; done += 64) {
+                const uint32_t i = done + (uint32_t)lane;
+                if (i < len) L.ring[(pos + i) & kRingMask] = q[i];
+                const uint32_t step = len - done < 64u ? len - done : 64u;
+                wave_lds_fence();
+                // flush as we go: a stored block can be longer than the ring
+                const uint32_t npos = pos + done + step;
+                while (npos - flushed >= 256u) {
+                    const uint32_t v = *(const uint32_t *)&L.ring[(flushed + 4u * (uint32_t)lane) & kRingMask];
+                    *(uint32_t *)(dst + flushed + 4u * (uint32_t)lane) = v;
+                    flushed += 256u;
+                }
+                wave_lds_fence();
+            }
+            pos += len;
+            r.seek((uint32_t)(at + len), lane);
+            continue;
+        }
+        // ---- code lengths of the block's two alphabets into L.lens[0 .. 288) and L.lens[288 .. 320) -----------------------------
+        if (type == 1) {
+            for (int i = lane; i < kLitSyms + kDistSyms; i += 64)
+                L.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
+            wave_lds_fence();
+        } else {
+            r.refill();
+            const int n_lit = (int)r.take(5) + 257, n_dist = (int)r.take(5) + 1, n_pre = (int)r.take(4) + 4;
+            if (n_lit > 286 || n_dist > 30) { good = false; break; }
+            // the code-length code's own lengths: 3 bits each, in the fixed permuted order
+            uint32_t mine = 0;                                   // lane s (< 19) ends up with the length of code-length symbol s
+            for (int i = 0; i < n_pre; ++i) {
+                r.refill();
+                const uint32_t v = r.take(3);
+                if (lane == (int)kPreOrder[i]) mine = v;
+            }
+            if (lane < 19) L.lens[lane] = (uint8_t)mine;
+            wave_lds_fence();
+            if (!build_table(L, 2, L.lens, 19, L.pre, 7, L.sorted, lane)) { good = false; break; }
+            // the run-length coded lengths, decoded into VGPR-free LDS bytes: lens2 lives behind the two alphabets' final place,
+            // so decode into a scratch area of the ring's far side?  No: the ring holds live output.  Decode straight into
+            // L.lens (both alphabets back to back), then move the distance lengths to offset 288.
+            int i = 0;
+            const int total = n_lit + n_dist;
+            uint32_t prev = 0;
+            bool bad = false;
+            // the 19 lengths at L.lens[0 .. 19) have served their purpose (the table is built)
+            while (i < total) {
+                r.refill();
+                const uint32_t e = uni(L.pre[r.peek(7)]);
+                if (((e >> 8) & 7u) != 0u) { bad = true; break; }
+                r.drop((int)(e & 0xFFu));
+                const uint32_t sym = e >> 16;
+                if (sym < 16) {
+                    if (lane == 0) L.lens[i] = (uint8_t)sym;
+                    prev = sym;
+                    ++i;
+                    continue;
+                }
+                uint32_t rep, val = 0;
+                if (sym == 16) {
+                    if (i == 0) { bad = true; break; }
+                    val = prev;
+                    rep = 3 + r.take(2);
+                } else if (sym == 17) {
+                    rep = 3 + r.take(3);
+                } else {
+                    rep = 11 + r.take(7);
+                }
+                if (i + (int)rep > total) { bad = true; break; }
+                for (uint32_t j = (uint32_t)lane; j < rep; j += 64) L.lens[i + (int)j] = (uint8_t)val;
+                prev = val;
+                i += (int)rep;
+            }
+            if (bad) { good = false; break; }
+            wave_lds_fence();
+            // distance lengths to their fixed place, the unused tails zeroed
+            uint8_t dl = 0;
+            if (lane < kDistSyms && lane < n_dist) dl = L.lens[n_lit + lane];
+            wave_lds_fence();
+            for (int j = n_lit + lane; j < kLitSyms; j += 64) L.lens[j] = 0;
+            if (lane < kDistSyms) L.lens[kLitSyms + lane] = dl;
+            wave_lds_fence();
+            if (uni((uint32_t)L.lens[256]) == 0u) { good = false; break; }       // no end-of-block code
+        }
+        if (!build_table(L, 0, L.lens, kLitSyms, L.lit, kLitBits, L.sorted, lane)) { good = false; break; }
+        if (!build_table(L, 1, L.lens + kLitSyms, kDistSyms, L.dist, kDistBits, L.sorted + kLitSyms, lane)) { good = false; break; }
+
+        // ---- the block's symbols ---------------------------------------------------------------------------------------------
+        for (;;) {
+            r.refill();                                          // >= 32 bits: a literal/length code (<= 15) + its extra bits (<= 5)
+            uint32_t e = uni(L.lit[r.peek(kLitBits)]);
+            uint32_t kind = (e >> 8) & 7u;
+            if (kind == 3u) {
+                int len;
+                const uint32_t s = long_code(L, 0, kLitBits, L.sorted, (uint32_t)r.buf & 0xFFFFu, len);
+                if (len == 0) { good = false; break; }
+                if (s < 256u) e = pack((uint32_t)len, 0, 0, s);
+                else if (s == 256u) e = pack((uint32_t)len, 2, 0, 0);
+                else if (s > 285u) e = pack((uint32_t)len, 4, 0, 0);
+                else e = pack((uint32_t)len, 1, kLenExtra[s - 257u], kLenBase[s - 257u]);
+                kind = (e >> 8) & 7u;
+            }
+            r.drop((int)(e & 0xFFu));
+            if (kind == 0u) {                                    // literal
+                if (pos >= out_n) { good = false; break; }
+                if (lane == 0) L.ring[pos & kRingMask] = (uint8_t)(e >> 16);
+                ++pos;
+            } else if (kind == 1u) {                             // length + distance
+                const uint32_t length = (e >> 16) + r.take((int)((e >> 11) & 31u));
+                r.refill();                                      // a distance code (<= 15) + its extra bits (<= 13)
+                uint32_t d = uni(L.dist[r.peek(kDistBits)]);
+                if (((d >> 8) & 7u) == 3u) {
+                    int len;
+                    const uint32_t s = long_code(L, 1, kDistBits, L.sorted + kLitSyms, (uint32_t)r.buf & 0xFFFFu, len);
+                    if (len == 0 || s > 29u) { good = false; break; }
+                    d = pack((uint32_t)len, 1, kDistExtra[s], kDistBase[s]);
+                }
+                if (((d >> 8) & 7u) != 1u) { good = false; break; }
+                r.drop((int)(d & 0xFFu));
+                const uint32_t dist = (d >> 16) + r.take((int)((d >> 11) & 31u));
+                if (dist > pos || (uint64_t)pos + length > out_n) { good = false; break; }
+                if (dist <= (uint32_t)kRingNear) {
+                    if (dist >= 64u) {                           // 64 bytes per step; a step's sources were written by earlier steps
+                        for (uint32_t done = 0; done < length; done += 64) {
+                            const uint32_t i = done + (uint32_t)lane;
+                            uint8_t b = 0;
+                            if (i < length) b = L.ring[(pos - dist + i) & kRingMask];
+                            wave_lds_fence();
+                            if (i < length) L.ring[(pos + i) & kRingMask] = b;
+                            wave_lds_fence();
+                        }
+                    } else {                                     // overlapping (run-like) copy: byte i repeats byte i mod dist
+                        const float inv = 1.0f / (float)dist;
+                        for (uint32_t done = 0; done < length; done += 64) {
+                            const uint32_t i = done + (uint32_t)lane;
+                            uint32_t q = (uint32_t)((float)i * inv);
+                            int rem = (int)i - (int)(q * dist);
+                            rem = rem < 0 ? rem + (int)dist : (rem >= (int)dist ? rem - (int)dist : rem);
+                            uint8_t b = 0;
+                            if (i < length) b = L.ring[(pos - dist + (uint32_t)rem) & kRingMask];
+                            wave_lds_fence();
+                            if (i < length) L.ring[(pos + i) & kRingMask] = b;
+                            wave_lds_fence();
+                        }
+                    }
+                } else {                                         // beyond the ring: the bytes are in HBM (flushed long ago)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    for (uint32_t done = 0; done < length; done += 64) {
+                        const uint32_t i = done + (uint32_t)lane;
+                        if (i < length) L.ring[(pos + i) & kRingMask] = dst[pos - dist + i];
+                    }
+                    wave_lds_fence();
+                }
+                pos += length;
+            } else if (kind == 2u) {
+                break;                                           // end of block
+            } else {
+                good = false;
+                break;
+            }
+            while (pos - flushed >= 256u) {                      // whole 256-byte lines leave the ring: one dword per lane
+                wave_lds_fence();
+                const uint32_t v = *(const uint32_t *)&L.ring[(flushed + 4u * (uint32_t)lane) & kRingMask];
+                *(uint32_t *)(dst + flushed + 4u * (uint32_t)lane) = v;
+                flushed += 256u;
+            }
+        }
+    }
+    // the tail of the ring, byte by byte
+    wave_lds_fence();
+    if (good) {
+        for (uint32_t i = flushed + (uint32_t)lane; i < pos; i += 64) dst[i] = L.ring[i & kRingMask];
+    }
+    const int64_t used = r.consumed_bytes();
+    good = good && pos == out_n && used >= 2 && used + 4 <= (int64_t)n_src;
+    if (lane == 0) {
+        uint32_t want = 0;
+        if (good) {
+            const uint8_t *t = src_base + s0 + used;
+            want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | (uint32_t)t[3];
+        }
+        status[k] = good ? 0 : 1;
+        adler_expected[k] = want;
+    }
+}
+
+// Adler-32 of every accepted block against its stream's trailer: a = 1 + sum d_j, b = N + sum (N - j) d_j (mod 65521).
+// One 256-thread workgroup per block, coalesced dword reads; 64-bit sums (block_bytes <= 2^26 keeps sum j d_j below 2^63).
+__global__ __launch_bounds__(256) void adler32_kernel(const uint8_t *__restrict__ dst_base, int64_t dst_pitch, int64_t block_bytes,
+                                                      int32_t *__restrict__ status, const uint32_t *__restrict__ adler_expected) {
+    const int64_t k = blockIdx.x;
+    if (status[k] != 0) return;
+    const uint8_t *d = dst_base + k * dst_pitch;
+    const int64_t n_words = block_bytes >> 2;
+    uint64_t A = 0, W = 0;
+    for (int64_t w = threadIdx.x; w < n_words; w += 256) {
+        const uint32_t v = ((const uint32_t *)d)[w];
+        const uint64_t b0 = v & 0xFFu, b1 = (v >> 8) & 0xFFu, b2 = (v >> 16) & 0xFFu, b3 = v >> 24;
+        const uint64_t j = (uint64_t)w * 4;
+        A += b0 + b1 + b2 + b3;
+        W += j * (b0 + b1 + b2 + b3) + b1 + 2 * b2 + 3 * b3;
+    }
+    for (int64_t j = n_words * 4 + threadIdx.x; j < block_bytes; j += 256) {
+        A += d[j];
+        W += (uint64_t)j * d[j];
+    }
+    __shared__ uint64_t sA[256], sW[256];
+    sA[threadIdx.x] = A;
+    sW[threadIdx.x] = W;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sA[threadIdx.x] += sA[threadIdx.x + s];
+            sW[threadIdx.x] += sW[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint64_t N = (uint64_t)block_bytes, M = 65521u;
+        const uint64_t a = (1 + sA[0]) % M;
+        // b = N + N * A - W, each term reduced first (N * A < 2^26 * 2^34 fits; W <= N * A)
+        const uint64_t b = (N % M + ((N % M) * (sA[0] % M)) % M + M - sW[0] % M) % M;
+        const uint32_t got = (uint32_t)((b << 16) | a);
+        if (got != adler_expected[k]) status[k] = 2;
+    }
+}
+
+// ---- PNG scanline filters (PNG spec 9.2; bytes per pixel = 2) -----------------------------------------------------------
+__device__ __forceinline__ int paeth(int a, int b, int c) {
+    const int p = a + b - c;
+    const int pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+// value of lane - 1 (lane 0 receives `fill`)
+__device__ __forceinline__ int from_lane_above(int v, int fill, int lane) {
+    const int got = __shfl_up(v, 1, 64);
+    return lane == 0 ? fill : got;
+}
+
+__global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t *__restrict__ raw_base, int64_t raw_pitch, int32_t h, int32_t w,
+                                                          uint16_t *__restrict__ out_base, int32_t *__restrict__ status) {
+    const int64_t k = blockIdx.x;
+    if (status[k] != 0) return;
+    const int lane = (int)threadIdx.x;
+    const uint8_t *raw = raw_base + k * raw_pitch;
+    uint16_t *out = out_base + k * (int64_t)h * w;
+    const int64_t stride = (int64_t)w * 2 + 1;
+    bool bad = false;
+    for (int y0 = 0; y0 < h; y0 += 64) {
+        const int y = y0 + lane;
+        const bool row = y < h;
+        const uint8_t *rp = raw + (int64_t)(row ? y : 0) * stride;
+        const int ft = row ? (int)rp[0] : 0;
+        bad = bad || ft > 4;
+        uint16_t *op = out + (int64_t)(row ? y : 0) * w;
+        const uint16_t *up = y0 > 0 ? out + (int64_t)(y0 - 1) * w : nullptr;      // the row above the band (lane 0's neighbour)
+        if (y0 > 0) {                                                              // written by this wave in the previous band
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        int a_hi = 0, a_lo = 0;              // left pixel of this row
+        int x_hi = 0, x_lo = 0;              // this lane's most recent output (what the lane below reads as "up")
+        int b_hi = 0, b_lo = 0;              // up pixel received at the previous step = upper-left of the current one
+        const int steps = w + 63;
+        for (int t = 0; t < steps; ++t) {
+            const int col = t - lane;
+            const bool on = row && col >= 0 && col < w;
+            // the lane above worked on this very column one step ago: its latest output is our "up"
+            int top_hi = 0, top_lo = 0;
+            if (up != nullptr && t < w) {                                          // lane 0: column t of the row above the band
+                const uint16_t v = up[t];
+                top_hi = v >> 8;
+                top_lo = v & 0xFF;
+            }
+            const int nb_hi = from_lane_above(x_hi, top_hi, lane), nb_lo = from_lane_above(x_lo, top_lo, lane);
+            const int c_hi = b_hi, c_lo = b_lo;                                    // received one step earlier: column col - 1
+            const bool has_up = y > 0;
+            const int ub_hi = has_up ? nb_hi : 0, ub_lo = has_up ? nb_lo : 0;
+            const int uc_hi = (has_up && col > 0) ? c_hi : 0, uc_lo = (has_up && col > 0) ? c_lo : 0;
+            if (on) {
+                const int r_hi = rp[1 + 2 * col], r_lo = rp[2 + 2 * col];
+                int p_hi, p_lo;
+                if (ft == 0) { p_hi = 0; p_lo = 0; }
+                else if (ft == 1) { p_hi = a_hi; p_lo = a_lo; }
+                else if (ft == 2) { p_hi = ub_hi; p_lo = ub_lo; }
+                else if (ft == 3) { p_hi = (a_hi + ub_hi) >> 1; p_lo = (a_lo + ub_lo) >> 1; }
+                else { p_hi = paeth(a_hi, ub_hi, uc_hi); p_lo = paeth(a_lo, ub_lo, uc_lo); }
+                x_hi = (r_hi + p_hi) & 0xFF;
+                x_lo = (r_lo + p_lo) & 0xFF;
+                a_hi = x_hi;
+                a_lo = x_lo;
+                op[col] = (uint16_t)((x_hi << 8) | x_lo);
+            }
+            b_hi = nb_hi;
+            b_lo = nb_lo;
+        }
+    }
+    if (__any(bad) && lane == 0) status[k] = 3;
+}
+
+}  // namespace dinf
+}  // namespace mspa
+
+using namespace mspa;
+
+extern "C" int mspa_inflate_blocks_device(const void *src_dev, const int64_t *src_offsets_dev, const int64_t *src_bytes_dev,
+                                          int64_t src_capacity, int64_t n_blocks, int64_t block_bytes, void *dst_dev,
+                                          int64_t dst_pitch, int32_t *status_dev, uint32_t *work_dev, void *stream) {
+    if (n_blocks < 0 || block_bytes <= 0 || dst_pitch < block_bytes || src_capacity < 0)
+        return fail(MSPA_EINVAL, "mspa_inflate_blocks_device: bad size");
+    if (n_blocks == 0) return MSPA_OK;
+    if (!src_dev || !src_offsets_dev || !src_bytes_dev || !dst_dev || !status_dev || !work_dev)
+        return fail(MSPA_EINVAL, "mspa_inflate_blocks_device: null pointer");
+    if (block_bytes > (1ll << 26)) return fail(MSPA_EINVAL, "mspa_inflate_blocks_device: block larger than 64 MiB");
+    if (n_blocks > 0x7fffffffll) return fail(MSPA_EINVAL, "mspa_inflate_blocks_device: too many blocks");
+    if (((uintptr_t)src_dev & 15u) || ((uintptr_t)dst_dev & 15u) || (dst_pitch & 15))
+        return fail(MSPA_EINVAL, "mspa_inflate_blocks_device: src, dst and dst_pitch must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dinf::inflate_kernel, dim3((unsigned)n_blocks), dim3(64), 0, st, (const uint8_t *)src_dev, src_offsets_dev,
+                       src_bytes_dev, src_capacity, (uint8_t *)dst_dev, dst_pitch, block_bytes, status_dev, work_dev);
+    hipLaunchKernelGGL(dinf::adler32_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, (const uint8_t *)dst_dev, dst_pitch, block_bytes,
+                       status_dev, (const uint32_t *)work_dev);
+    return check_hip(hipGetLastError(), "mspa_inflate_blocks_device");
+}
+
+extern "C" int mspa_png_unfilter_device(const void *raw_dev, int64_t raw_pitch, int64_t n_images, int32_t h, int32_t w,
+                                        uint16_t *out_dev, int32_t *status_dev, void *stream) {
+    if (n_images < 0 || h <= 0 || w <= 0 || raw_pitch < (int64_t)h * ((int64_t)w * 2 + 1))
+        return fail(MSPA_EINVAL, "mspa_png_unfilter_device: bad size");
+    if (n_images == 0) return MSPA_OK;
+    if (!raw_dev || !out_dev || !status_dev) return fail(MSPA_EINVAL, "mspa_png_unfilter_device: null pointer");
+    if (n_images > 0x7fffffffll) return fail(MSPA_EINVAL, "mspa_png_unfilter_device: too many images");
+    hipLaunchKernelGGL(dinf::png_unfilter_kernel, dim3((unsigned)n_images), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)raw_dev,
+                       raw_pitch, h, w, out_dev, status_dev);
+    return check_hip(hipGetLastError(), "mspa_png_unfilter_device");
+}

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sys/stat.h>
 #include <thread>
 #include <vector>
 #include <zlib.h>
@@ -216,5 +217,83 @@ extern "C" int mspa_read_depth_png_host(const char *const *paths_host, int64_t n
         }
     };
     HostPool::get().parallel((int)nt, work);                // persistent worker threads (host_pool.h); the caller works too
+    return MSPA_OK;
+}
+
+
+// The host half of the on-device decode (csrc/device_ingest.hip): file bytes -> the scanlines' zlib stream, packed for ONE H2D copy.
+extern "C" int mspa_png_pack_idat_host(const char *const *paths_host, int64_t n_files, int32_t h, int32_t w, void *dst_host,
+                                       int64_t dst_capacity, int64_t *offsets_host, int64_t *bytes_host, int32_t *status_host,
+                                       int64_t *capacity_needed, int32_t n_threads) {
+    if (n_files < 0 || h <= 0 || w <= 0 || (n_files > 0 && (!paths_host || !offsets_host || !bytes_host || !status_host)))
+        return fail(MSPA_EINVAL, "mspa_png_pack_idat_host: bad argument");
+    for (int64_t k = 0; k < n_files; ++k)
+        if (!paths_host[k]) return fail(MSPA_EINVAL, "mspa_png_pack_idat_host: null path");
+    // slot k = the file's size rounded up to 16 bytes (+ 16: the device reader may touch the 8-byte unit a stream ends in); the
+    // file is read INTO its slot and the IDAT payloads are then moved to the slot's front, so nothing is copied twice
+    int64_t need = 0;
+    std::vector<int64_t> fsize((size_t)n_files, -1);
+    for (int64_t k = 0; k < n_files; ++k) {
+        struct stat st;
+        offsets_host[k] = need;
+        if (stat(paths_host[k], &st) == 0 && S_ISREG(st.st_mode)) {
+            fsize[(size_t)k] = (int64_t)st.st_size;
+            need += (((int64_t)st.st_size + 15) & ~(int64_t)15) + 16;
+        } else {
+            need += 16;
+        }
+    }
+    if (capacity_needed) *capacity_needed = need;
+    if (!dst_host) return MSPA_OK;
+    if (dst_capacity < need) return fail(MSPA_EINVAL, "mspa_png_pack_idat_host: destination smaller than capacity_needed");
+    if (n_files == 0) return MSPA_OK;
+    const int64_t nt = n_threads < 1 ? 1 : (n_threads > n_files ? n_files : (int64_t)n_threads);
+    std::atomic<int64_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int64_t k = next.fetch_add(1);
+            if (k >= n_files) return;
+            bytes_host[k] = 0;
+            unsigned char *slot = (unsigned char *)dst_host + offsets_host[k];
+            const int64_t sz = fsize[(size_t)k];
+            int st = 1;
+            if (sz >= 0) {
+                FILE *f = fopen(paths_host[k], "rb");
+                if (f) {
+                    const bool got = sz == 0 || fread(slot, 1, (size_t)sz, f) == (size_t)sz;
+                    fclose(f);
+                    if (got) {
+                        PngHeader hd;
+                        if (parse_header(slot, (size_t)sz, hd)) st = 3;
+                        else if (hd.bit_depth != 16 || hd.color_type != 0 || hd.interlace != 0 || hd.w != (uint32_t)w || hd.h != (uint32_t)h) st = 2;
+                        else {
+                            size_t pos = 33, out = 0;
+                            bool bad = false, any = false;
+                            while (pos + 12 <= (size_t)sz) {
+                                const uint32_t len = be32(slot + pos);
+                                const unsigned char *type = slot + pos + 4;
+                                if ((size_t)len > (size_t)sz - pos - 12) { bad = true; break; }
+                                if (memcmp(type, "IDAT", 4) == 0) {
+                                    memmove(slot + out, slot + pos + 8, len);      // always towards the front: out < pos + 8
+                                    out += len;
+                                    any = true;
+                                } else if (memcmp(type, "IEND", 4) == 0) {
+                                    break;
+                                }
+                                pos += 12 + (size_t)len;
+                            }
+                            if (bad || !any) st = 3;
+                            else {
+                                st = 0;
+                                bytes_host[k] = (int64_t)out;
+                            }
+                        }
+                    }
+                }
+            }
+            status_host[k] = st;
+        }
+    };
+    HostPool::get().parallel((int)nt, work);
     return MSPA_OK;
 }

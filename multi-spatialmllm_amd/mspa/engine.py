@@ -161,6 +161,49 @@ def gather_blocks_host(blocks, dst: np.ndarray, n_threads: int = 4) -> None:
     _lib.check(_lib.load().mspa_gather_blocks_host(ptrs, n, block_bytes, dst.ctypes.data, int(n_threads)))
 
 
+def inflate_blocks_device(src: torch.Tensor, offsets: torch.Tensor, nbytes: torch.Tensor, block_bytes: int,
+                          out: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None):
+    """``len(offsets)`` zlib streams resident on the device -- stream k = ``src[offsets[k] : offsets[k] + nbytes[k]]`` (uint8;
+    offsets multiples of 8) -- inflated by one wave each into ``out[k, :block_bytes]`` (mspa_inflate_blocks_device; replaces
+    the per-frame zlib.decompress / cv2.imread of the reference, extract_posed_images.py:49-57, info_handler.py:149-155).
+    Returns (out [n, pitch] uint8, status [n] int32): status 0 = inflated to exactly ``block_bytes`` with a matching
+    Adler-32; anything else = decode that block on the host.  Only enqueues; read ``status`` after a synchronisation."""
+    _require_gpu()
+    n = int(offsets.shape[0])
+    _require(src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous() and src.dim() == 1, "src: a flat uint8 device tensor")
+    _require(offsets.is_cuda and offsets.dtype == torch.int64 and nbytes.is_cuda and nbytes.dtype == torch.int64
+             and nbytes.shape[0] == n, "offsets / nbytes: int64 device tensors of one length")
+    pitch = (int(block_bytes) + 15) // 16 * 16
+    if out is None:
+        out = torch.empty((n, pitch), dtype=torch.uint8, device=src.device)
+    _require(out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and out.dim() == 2 and out.shape[0] >= n
+             and out.shape[1] >= block_bytes and out.shape[1] % 16 == 0, "out: [n, pitch] uint8 with a pitch that is a multiple of 16")
+    if status is None:
+        status = torch.empty((n,), dtype=torch.int32, device=src.device)
+    work = torch.empty((max(n, 1),), dtype=torch.int32, device=src.device)
+    _lib.check(_lib.load().mspa_inflate_blocks_device(_ptr(src), _ptr(offsets), _ptr(nbytes), int(src.numel()), n, int(block_bytes),
+                                                      _ptr(out), int(out.shape[1]), _ptr(status), _ptr(work), _stream_ptr()))
+    return out, status
+
+
+def png_unfilter_device(raw: torch.Tensor, h: int, w: int, status: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``raw[k, : h * (2 w + 1)]`` -- the inflated scanlines of n 16-bit greyscale PNG images -- to ``out[k, h, w]`` (int16
+    storage of the uint16 depth values, like every depth tensor here): the five PNG row filters undone on the device
+    (mspa_png_unfilter_device).  Images with ``status[k] != 0`` are skipped; a filter byte > 4 sets status 3."""
+    _require_gpu()
+    n = int(raw.shape[0])
+    _require(raw.is_cuda and raw.dtype == torch.uint8 and raw.dim() == 2 and raw.is_contiguous()
+             and raw.shape[1] >= h * (2 * w + 1), "raw: [n, pitch] uint8 with pitch >= h * (2 w + 1)")
+    _require(status.is_cuda and status.dtype == torch.int32 and status.shape[0] >= n, "status: int32 [n] on the device")
+    if out is None:
+        out = torch.empty((n, h, w), dtype=torch.int16, device=raw.device)
+    _require(out.is_cuda and out.dtype == torch.int16 and out.is_contiguous() and tuple(out.shape[-2:]) == (h, w)
+             and out.shape[0] >= n, "out: [n, h, w] int16 on the device")
+    _lib.check(_lib.load().mspa_png_unfilter_device(_ptr(raw), int(raw.shape[1]), n, int(h), int(w), _ptr(out), _ptr(status),
+                                                    _stream_ptr()))
+    return out
+
+
 def _require_pinhole(mats: torch.Tensor):
     """MSPA_PAIR_FAST reads the camera-2 depth off the third image row: K's third row must be 0 0 1 0 in EVERY frame record
     (include/mspa.h).  The records live on the device, so the check is one read-back of all frames' rows the first time a

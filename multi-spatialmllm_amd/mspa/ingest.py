@@ -128,3 +128,57 @@ def read_depth_frames(paths: Sequence[str], n_threads: int = 8, general_reader: 
             else:
                 raise ValueError(f"{paths[k]}: corrupt PNG stream")
     return out
+
+
+def pack_depth_pngs(paths: Sequence[str], h: int, w: int, n_threads: int = 8, out=None):
+    """The scanline zlib streams of the 16-bit greyscale ``h x w`` PNG files at ``paths``, packed into ONE host buffer for one
+    H2D copy (mspa_png_pack_idat_host: files read into their slots by native threads, IDAT payloads moved to the slot's
+    front).  ``out``: a uint8 NumPy array to pack into (e.g. a view of pinned memory), grown by the caller when the returned
+    capacity exceeds it.  Returns (buffer, offsets int64 [F], nbytes int64 [F], status int32 [F], capacity)."""
+    paths = list(paths)
+    F = len(paths)
+    enc = [p.encode() for p in paths]
+    arr = (ctypes.c_char_p * max(F, 1))(*enc)
+    offsets, nbytes = np.zeros(F, dtype=np.int64), np.zeros(F, dtype=np.int64)
+    status = np.zeros(F, dtype=np.int32)
+    need = ctypes.c_int64(0)
+    lib = _lib.load()
+    _lib.check(lib.mspa_png_pack_idat_host(arr, F, int(h), int(w), None, 0, offsets.ctypes.data, nbytes.ctypes.data,
+                                           status.ctypes.data, ctypes.byref(need), int(n_threads)))
+    cap = int(need.value)
+    if out is None or out.nbytes < cap:
+        out = np.empty(max(cap, 16), dtype=np.uint8)
+    _lib.check(lib.mspa_png_pack_idat_host(arr, F, int(h), int(w), out.ctypes.data, int(out.nbytes), offsets.ctypes.data,
+                                           nbytes.ctypes.data, status.ctypes.data, ctypes.byref(need), int(max(1, n_threads))))
+    return out, offsets, nbytes, status, cap
+
+
+def read_depth_frames_device(paths: Sequence[str], device="cuda", n_threads: int = 8, out=None,
+                             general_reader: Optional[Callable[[str], np.ndarray]] = None, hw=None):
+    """[F, h, w] int16 device tensor (the uint16 depth values): the depth PNGs at ``paths`` DECODED ON THE DEVICE -- the host only
+    reads the files and packs their compressed scanline streams (``pack_depth_pngs``), one H2D copy carries them, one wave per
+    frame inflates (mspa_inflate_blocks_device), one wave per frame undoes the row filters (mspa_png_unfilter_device).  A
+    frame the device declines (another pixel format, a damaged stream, a failed checksum) is decoded by the host path
+    (``read_depth_frames``) and uploaded on its own, so the result is the host path's result for every input.  Synchronises
+    once (the per-frame status has to be read)."""
+    import torch
+    from . import engine
+    paths = list(paths)
+    F = len(paths)
+    if F == 0:
+        return torch.zeros((0, 0, 0), dtype=torch.int16, device=device)
+    if hw is None:
+        h, w, bits, ctype, lace = png_header(paths[0])
+    else:
+        h, w = hw
+    buf, offsets, nbytes, st_host, cap = pack_depth_pngs(paths, h, w, n_threads)
+    src = torch.from_numpy(buf[:max(cap, 16)]).to(device, non_blocking=False)
+    off_d = torch.from_numpy(offsets).to(device)
+    nb_d = torch.from_numpy(np.where(st_host == 0, nbytes, 0)).to(device)          # a frame the packer declined: an empty stream
+    raw, status = engine.inflate_blocks_device(src, off_d, nb_d, h * (2 * w + 1))
+    frames = engine.png_unfilter_device(raw, h, w, status, out)
+    bad = np.nonzero(status.cpu().numpy())[0]
+    if len(bad):
+        host = read_depth_frames([paths[int(k)] for k in bad], n_threads, general_reader=general_reader)
+        frames[torch.from_numpy(bad).to(device)] = torch.from_numpy(host.view(np.int16)).to(device)
+    return frames[:F]

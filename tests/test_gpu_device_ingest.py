@@ -1,0 +1,216 @@
+"""Depth-frame decode on the MI355X (csrc/device_ingest.hip) against zlib and against the host PNG reader, bit for bit:
+mspa_inflate_blocks_device on streams of every compression level / strategy / window (stored, fixed and dynamic blocks, run-like
+and far matches), its refusal of damaged streams, mspa_png_unfilter_device on all five row filters, and the composed reader on
+640 x 480 depth PNGs as Pillow writes them (what the reference's cv2.imread decodes, info_handler.py:149-155)."""
+import os
+import struct
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _upload(streams):
+    import torch
+    offs, pos = [], 0
+    for s in streams:
+        offs.append(pos)
+        pos += (len(s) + 15) // 16 * 16 + 16
+    buf = np.zeros(pos, dtype=np.uint8)
+    for o, s in zip(offs, streams):
+        buf[o:o + len(s)] = np.frombuffer(s, dtype=np.uint8)
+    return (torch.from_numpy(buf).cuda(), torch.tensor(offs, dtype=torch.int64).cuda(),
+            torch.tensor([len(s) for s in streams], dtype=torch.int64).cuda())
+
+
+def _payloads(n, rng):
+    """Byte strings of length n that exercise different parts of the decoder."""
+    depth_like = (np.cumsum(rng.integers(-3, 4, n // 2)) % 4000 + 500).astype(">u2").tobytes()
+    block = rng.integers(0, 256, 33000, dtype=np.uint8).tobytes()
+    return {
+        "random": rng.integers(0, 256, n, dtype=np.uint8).tobytes(),                       # literals only, long codes
+        "zeros": bytes(n),                                                                 # distance 1, length 258 chains
+        "period3": (b"abc" * n)[:n],                                                       # overlapping copies, dist < 64
+        "period100": (bytes(range(100)) * n)[:n],                                          # dist >= 64 inside the ring
+        "far": (block * (n // len(block) + 1))[:n],                                        # distance 33 000 > the 32 K window: literals;
+        "far_window": ((block[:20000]) * (n // 20000 + 1))[:n],                            # distance 20 000: beyond the ring, from HBM
+        "depth_like": (depth_like + bytes(n))[:n],
+        "text": (b"the quick brown fox jumps over the lazy dog. " * (n // 40 + 1))[:n],
+        "skewed": rng.choice(np.arange(256, dtype=np.uint8), n, p=np.r_[[0.5], np.full(255, 0.5 / 255)]).tobytes(),
+        "mixed": (rng.integers(0, 4, n // 3, dtype=np.uint8).tobytes() + block[:n // 3] + bytes(n))[:n],
+    }
+
+
+def test_inflate_matches_zlib_on_every_kind_of_stream():
+    import torch
+    from mspa import engine
+    rng = np.random.default_rng(7)
+    N = 70001                                                   # not a multiple of 4: the tail of the ring leaves byte by byte
+    cases, streams = [], []
+    for name, data in _payloads(N, rng).items():
+        for level in (0, 1, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
+                for wbits in (9, 15):
+                    c = zlib.compressobj(level, zlib.DEFLATED, wbits, 9, strategy)
+                    streams.append(c.compress(data) + c.flush())
+                    cases.append((name, level, strategy, wbits, data))
+    src, off, nb = _upload(streams)
+    out, status = engine.inflate_blocks_device(src, off, nb, N)
+    torch.cuda.synchronize()
+    st = status.cpu().numpy()
+    got = out.cpu().numpy()
+    wrong = [(c[:4], int(s)) for c, s in zip(cases, st) if s != 0]
+    assert wrong == [], wrong[:10]
+    for k, c in enumerate(cases):
+        assert got[k, :N].tobytes() == c[4], c[:4]
+    assert len(streams) == 400
+
+
+def test_inflate_refuses_what_it_cannot_verify():
+    import torch
+    from mspa import engine
+    rng = np.random.default_rng(8)
+    N = 50000
+    data = _payloads(N, rng)["depth_like"]
+    good = zlib.compress(data, 6)
+    streams = [good]
+    kinds = ["good"]
+    for cut in (1, 4, 5, 100, len(good) // 2):                 # truncated: inside the trailer, inside the data
+        streams.append(good[:-cut])
+        kinds.append(f"cut{cut}")
+    streams.append(good[:-1] + bytes([good[-1] ^ 1]))          # wrong Adler-32
+    kinds.append("adler")
+    streams.append(zlib.compress(data + b"x", 6))              # inflates to N + 1
+    kinds.append("longer")
+    streams.append(zlib.compress(data[:-1], 6))                # inflates to N - 1
+    kinds.append("shorter")
+    streams.append(b"\x78\x9c" + bytes(40))                    # stored block with LEN = NLEN = 0
+    kinds.append("zeros")
+    streams.append(bytes([0x78, 0xBB]) + good[2:])             # FDICT set / bad FCHECK
+    kinds.append("header")
+    streams.append(b"\x78\x9c\x07" + bytes(20))                # block type 3
+    kinds.append("type3")
+    streams.append(b"")                                        # nothing at all
+    kinds.append("empty")
+    flips = []
+    for _ in range(150):                                       # single-bit damage anywhere in the stream
+        b = bytearray(good)
+        pos = int(rng.integers(0, len(b) * 8))
+        b[pos >> 3] ^= 1 << (pos & 7)
+        flips.append(bytes(b))
+    streams += flips
+    kinds += ["flip"] * len(flips)
+    src, off, nb = _upload(streams)
+    out, status = engine.inflate_blocks_device(src, off, nb, N)
+    torch.cuda.synchronize()
+    st, got = status.cpu().numpy(), out.cpu().numpy()
+    assert st[0] == 0 and got[0, :N].tobytes() == data
+    for k in range(1, len(kinds)):
+        if kinds[k] == "flip":                                  # damage is either detected or did not change the output
+            assert st[k] != 0 or got[k, :N].tobytes() == data, k
+        else:
+            assert st[k] != 0, kinds[k]
+    assert (st[len(kinds) - len(flips):] != 0).sum() >= len(flips) - 5
+    # what zlib itself says about the same streams: it accepts none of the named ones either
+    for k in range(1, len(kinds) - len(flips)):
+        try:
+            ok = zlib.decompress(streams[k]) == data
+        except zlib.error:
+            ok = False
+        assert not ok, kinds[k]
+
+
+def test_argument_checks():
+    import torch
+    from mspa import _lib, engine
+    src, off, nb = _upload([zlib.compress(b"abc" * 100)])
+    with pytest.raises(_lib.MspaError):
+        engine.inflate_blocks_device(src[1:].contiguous()[0:16].clone()[1:], off, nb, 300)      # misaligned source
+    out, status = engine.inflate_blocks_device(src, off + 1, nb, 300)                           # a stream off its 8-byte unit
+    torch.cuda.synchronize()
+    assert int(status[0]) == 1
+    out, status = engine.inflate_blocks_device(src, off, nb + 10_000, 300)                      # a stream reaching past the buffer
+    torch.cuda.synchronize()
+    assert int(status[0]) == 1
+    out, status = engine.inflate_blocks_device(src, off[:0], nb[:0], 300)
+    assert tuple(status.shape) == (0,)
+
+
+def _png_rows(a, filters, level=6):
+    from test_sweep_cpu import _png_gray16
+    return _png_gray16(a, filters, level)
+
+
+def test_unfilter_all_five_filters_and_the_composed_reader(tmp_path):
+    import torch
+    from PIL import Image
+    from mspa import ingest
+    rng = np.random.default_rng(3)
+    frames, paths = [], []
+    shapes = [(37, 53), (37, 53), (37, 53), (37, 53), (37, 53), (37, 53), (37, 53)]
+    for k, filters in enumerate([[0], [1], [2], [3], [4], [0, 1, 2, 3, 4], [4, 3, 2, 1]]):
+        a = rng.integers(0, 65536, shapes[k], dtype=np.uint16) if k % 2 else \
+            (np.add.outer(np.arange(37), np.arange(53)) * 419 % 65536).astype(np.uint16)
+        p = str(tmp_path / f"f{k}.png")
+        open(p, "wb").write(_png_rows(a, filters))
+        frames.append(a)
+        paths.append(p)
+    got = ingest.read_depth_frames_device(paths, "cuda", 3)
+    torch.cuda.synchronize()
+    assert got.dtype == torch.int16 and tuple(got.shape) == (7, 37, 53)
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), np.stack(frames))
+    # taller than one 64-row band, wider than a ring line; every filter, Pillow's own adaptive choice, and frames the device must
+    # hand to the host path: another bit depth, a truncated file, a stream with a damaged trailer
+    big = [(rng.integers(0, 4000, (150, 200)) + np.add.outer(np.arange(150), np.arange(200)) * 3).astype(np.uint16) for _ in range(4)]
+    bp = []
+    for k, a in enumerate(big):
+        p = str(tmp_path / f"big{k}.png")
+        if k < 2:
+            open(p, "wb").write(_png_rows(a, [[4, 3, 1, 2, 0], [3, 4]][k], level=[1, 9][k]))
+        else:
+            Image.fromarray(a).save(p, compress_level=[1, 6][k - 2])
+        bp.append(p)
+    p8 = str(tmp_path / "eight.png")
+    Image.fromarray((big[0] >> 8).astype(np.uint8)).save(p8)
+    damaged = str(tmp_path / "damaged.png")
+    raw = bytearray(open(bp[3], "rb").read())
+    idat = raw.rfind(b"IEND") - 4 - 4 - 1                       # last byte of the last IDAT payload = the Adler-32's last byte
+    raw[idat] ^= 0x40
+    open(damaged, "wb").write(bytes(raw))
+    host = ingest.read_depth_frames(bp, 2)
+    dev = ingest.read_depth_frames_device(bp, "cuda", 2)
+    assert np.array_equal(dev.cpu().numpy().view(np.uint16), host) and np.array_equal(host, np.stack(big))
+    mixed = ingest.read_depth_frames_device([bp[0], p8, bp[2]], "cuda", 2, general_reader=lambda p: np.array(Image.open(p)), hw=(150, 200))
+    assert np.array_equal(mixed[1].cpu().numpy().view(np.uint16), big[0] >> 8) and np.array_equal(mixed[2].cpu().numpy().view(np.uint16), big[2])
+    with pytest.raises(ValueError, match="corrupt"):            # the host path's verdict on the damaged file, not garbage pixels
+        ingest.read_depth_frames_device([bp[0], damaged], "cuda", 2)
+
+
+def test_full_size_depth_frames_as_the_dataset_stores_them(tmp_path):
+    """640 x 480 depth frames of the synthetic room (5 mm noise, 7 % invalid pixels) written by Pillow at three
+    compression levels: the device decode equals the host decode on every pixel, and no frame needed the host."""
+    import torch
+    from PIL import Image
+    from mspa import engine, ingest, synth
+    sc = synth.make_scene(77, n_points=2048, n_frames=6, color_hw=(480, 640), depth_hw=(480, 640), invalid_pose_frac=0.0, with_color=False)
+    paths = []
+    for k, image_id in enumerate(sc.valid_image_ids):
+        p = str(tmp_path / f"{image_id}.png")
+        Image.fromarray(sc.depth[image_id]).save(p, compress_level=[1, 6, 9][k % 3])
+        paths.append(p)
+    host = ingest.read_depth_frames(paths, 4)
+    buf, offsets, nbytes, st, cap = ingest.pack_depth_pngs(paths, 480, 640, 4)
+    assert (st == 0).all() and (offsets % 16 == 0).all()
+    for k in range(len(paths)):                                 # the packed bytes ARE the scanlines' zlib stream
+        assert len(zlib.decompress(buf[offsets[k]:offsets[k] + nbytes[k]].tobytes())) == 480 * 1281
+    src = torch.from_numpy(buf[:cap]).cuda()
+    raw, status = engine.inflate_blocks_device(src, torch.from_numpy(offsets).cuda(), torch.from_numpy(nbytes).cuda(), 480 * 1281)
+    out = engine.png_unfilter_device(raw, 480, 640, status)
+    torch.cuda.synchronize()
+    assert status.cpu().numpy().tolist() == [0] * len(paths)
+    assert np.array_equal(out.cpu().numpy().view(np.uint16), host)
+    assert np.array_equal(host, np.stack([sc.depth[i] for i in sc.valid_image_ids]))
