@@ -381,7 +381,7 @@ int mspa_inflate_zlib_fast_host(const void *src_host, int64_t src_bytes, void *d
  *   input and the Adler-32 of the output equals its trailer; 1 not a valid / supported stream or another size; 2 checksum
  *   mismatch.  A block with a non-zero status holds garbage: decode that frame on the host (mspa_inflate_blocks_host /
  *   mspa_read_depth_png_host) -- the same "accept only what verifies, hand the rest on" contract as csrc/inflate_fast.h.
- *   work_dev: n_blocks uint32 of scratch.  src_dev, dst_dev, dst_pitch 16-byte aligned; block_bytes <= 64 MiB.
+ *   work_dev: n_blocks uint32 of scratch.  src_dev 16-byte, dst_dev and dst_pitch 256-byte aligned; block_bytes <= 64 MiB.
  * mspa_png_unfilter_device     n_images inflated scanline blocks (h rows of 1 filter byte + 2 w sample bytes, image k at raw_dev +
  *   k * raw_pitch) -> out_dev[k, h, w] uint16 in host byte order: the five PNG row filters (None / Sub / Up / Average / Paeth)
  *   undone, big-endian samples swapped.  Images whose status_dev[k] is non-zero on entry are skipped; an image with a filter

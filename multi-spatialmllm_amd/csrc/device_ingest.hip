@@ -23,9 +23,11 @@
 //   * a stream is ACCEPTED only if it ends exactly at the expected size, stays inside its input, and (second kernel,
 //     adler32_kernel) the Adler-32 of the output equals the stream's trailer -- the contract of csrc/inflate_fast.h.  Anything
 //     else is reported per block and the caller decodes that frame on the host.
-// mspa::dinf::png_unfilter_kernel -- one wave per image, 64 rows at a time on a skewed pipeline (lane y works on column t - y at
-//   step t, so the left, upper and upper-left neighbours of Sub / Up / Average / Paeth are a register, the lane above's previous
-//   output via DPP, and the one before that), writing host-order uint16 pixels.
+// mspa::dinf::png_unfilter_kernel -- one wave per image.  Images whose rows use only None / Sub / Up (what adaptive writers choose
+//   for depth maps) go row by row with the lanes along the row: coalesced dword loads, bytewise SWAR adds, Sub as a wave-wide
+//   prefix sum.  An image with an Average or Paeth row takes the skewed pipeline: 64 rows at a time, lane y works on column t - y
+//   at step t, so the left, upper and upper-left neighbours are a register, the lane above's previous output via DPP, and the one
+//   before that.  Both write host-order uint16 pixels.
 #include "mspa_common.h"
 
 namespace mspa {
@@ -72,8 +74,9 @@ struct Reader {
     uint32_t n_chunks_ok;        // 8-byte units that may be loaded
     uint2 cur, nxt;              // per lane: 8 bytes of the current / next 512-byte chunk
     uint32_t widx;               // next 32-bit word of the stream to enter the bit buffer
-    uint64_t buf;
-    int cnt;
+    uint64_t lo, hi;             // 128-bit bit buffer: the next bit of the stream is bit 0 of `lo`
+    int cnt;                     // valid bits in (hi : lo)
+    int lane_;
 
     __device__ __forceinline__ uint2 load_chunk(uint32_t chunk, int lane) const {
         const uint32_t unit = chunk * 64u + (uint32_t)lane;
@@ -86,18 +89,16 @@ struct Reader {
         const uint32_t chunk = widx >> 7;
         cur = load_chunk(chunk, lane);
         nxt = load_chunk(chunk + 1, lane);
-        buf = 0;
+        lo = hi = 0;
         cnt = 0;
         refill();
-        const int skip = (int)(byte_off & 3u) * 8;
-        buf >>= skip;
-        cnt -= skip;
+        drop((int)(byte_off & 3u) * 8);
     }
     __device__ __forceinline__ uint32_t next_word(int lane) {
         const int l = (int)((widx >> 1) & 63u);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)cur.x, l);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)cur.y, l);
-        const uint32_t w = (widx & 1u) ? hi : lo;
+        const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)cur.x, l);
+        const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)cur.y, l);
+        const uint32_t w = (widx & 1u) ? whi : wlo;
         ++widx;
         if ((widx & 127u) == 0u) {                          // the chunk is used up: the prefetched one takes its place
             cur = nxt;
@@ -105,17 +106,26 @@ struct Reader {
         }
         return w;
     }
-    int lane_;
-    __device__ __forceinline__ void refill() {              // >= 32 valid bits afterwards (zeros beyond the stream's end)
-        if (cnt <= 32) {
-            buf |= (uint64_t)next_word(lane_) << cnt;
+    // > 96 valid bits afterwards (zeros beyond the stream's end): what one batch of the symbol walk may consume
+    __device__ __forceinline__ void refill() {
+        while (cnt <= 96) {
+            const uint64_t w = next_word(lane_);
+            if (cnt < 64) {
+                lo |= w << cnt;
+                if (cnt > 32) hi |= w >> (64 - cnt);
+            } else {
+                hi |= w << (cnt - 64);
+            }
             cnt += 32;
         }
     }
-    __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)buf & ((1u << k) - 1u); }
-    __device__ __forceinline__ void drop(int k) {
-        buf >>= k;
-        cnt -= k;
+    __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)lo & ((1u << k) - 1u); }
+    __device__ __forceinline__ void drop(int k) {           // 0 <= k < 64
+        if (k) {
+            lo = (lo >> k) | (hi << (64 - k));
+            hi >>= k;
+            cnt -= k;
+        }
     }
     __device__ __forceinline__ uint32_t take(int k) {
         const uint32_t v = peek(k);
@@ -131,7 +141,7 @@ __device__ __forceinline__ uint32_t brev(uint32_t v, int len) { return __builtin
 // Canonical Huffman tables of one alphabet from its code lengths, by all 64 lanes.  lens[0 .. n_syms) in LDS; `table` has
 // 1 << bits entries; `sorted` receives the symbols ordered by (length, symbol).  `kind`: 0 literal/length alphabet, 1 distance,
 // 2 code-length code.  Returns false (wave-uniform) for an over-subscribed set.
-__device__ bool build_table(WaveLds &L, int alpha, const uint8_t *lens, int n_syms, uint32_t *table, int bits, uint16_t *sorted,
+__device__ __attribute__((noinline)) bool build_table(WaveLds &L, int alpha, const uint8_t *lens, int n_syms, uint32_t *table, int bits, uint16_t *sorted,
                             int lane) {
     // 1. symbols per code length (ballots over chunks of 64 symbols)
     uint32_t cnt[16];
@@ -213,20 +223,70 @@ __device__ bool build_table(WaveLds &L, int alpha, const uint8_t *lens, int n_sy
     return true;
 }
 
-// A code longer than the table index: walk the lengths above it (first-code test on the bit-reversed prefix).  Returns the
-// symbol and its length, or len = 0 when no code matches (an incomplete set's unused pattern).  All wave-uniform.
-__device__ __forceinline__ uint32_t long_code(const WaveLds &L, int alpha, int bits, const uint16_t *sorted, uint32_t peek16,
-                                              int &len_out) {
+// A code longer than the table index: walk the lengths above it (first-code test on the bit-reversed prefix).  Returns
+// symbol | length << 16, length 0 when no code matches (an incomplete set's unused pattern).  All wave-uniform.
+__device__ __forceinline__ uint32_t long_code(const WaveLds &L, int alpha, int bits, const uint16_t *sorted, uint32_t peek16) {
     for (int l = bits + 1; l <= 15; ++l) {
         const uint32_t code = brev(peek16 & ((1u << l) - 1u), l);
         const uint32_t f = uni(L.first[alpha][l]), c = uni(L.count[alpha][l]);
-        if (code - f < c) {                                     // unsigned: code >= f and code < f + c
-            len_out = l;
-            return uni((uint32_t)sorted[uni(L.offs[alpha][l]) + (code - f)]);
+        if (code - f < c)                                       // unsigned: code >= f and code < f + c
+            return uni((uint32_t)sorted[uni(L.offs[alpha][l]) + (code - f)]) | ((uint32_t)l << 16);
+    }
+    return 0;
+}
+
+// Whole 256-byte lines leave the ring: one coalesced dword store per lane and line.  Returns the new `flushed`.
+__device__ __forceinline__ uint32_t flush_lines(WaveLds &L, uint8_t *dst, uint32_t pos, uint32_t flushed, int lane) {
+    const uint32_t lines = (pos - flushed) >> 8;
+    for (uint32_t n = 0; n < lines; ++n) {
+        const uint32_t v = *(const uint32_t *)&L.ring[(flushed + 4u * (uint32_t)lane) & kRingMask];
+        *(uint32_t *)(dst + flushed + 4u * (uint32_t)lane) = v;
+        flushed += 256u;
+    }
+    return flushed;
+}
+
+// A match copied by the lanes: ring to ring when the source is within kRingNear, else (a long match far back) from the flushed
+// bytes in HBM behind a workgroup-scope fence.  `pos` is the output position the match starts at.
+__device__ __forceinline__ void copy_match(WaveLds &L, const uint8_t *dst, uint32_t pos, uint32_t length, uint32_t dist, int lane) {
+    if (dist <= (uint32_t)kRingNear) {
+        if (length <= 64u && dist >= length) {                   // the common case: one step, source and destination apart
+            uint8_t b = 0;
+            if ((uint32_t)lane < length) b = L.ring[(pos - dist + (uint32_t)lane) & kRingMask];
+            wave_lds_fence();
+            if ((uint32_t)lane < length) L.ring[(pos + (uint32_t)lane) & kRingMask] = b;
+        } else if (dist >= 64u) {                                // 64 bytes per step; a step's sources were written by earlier steps
+            for (uint32_t done = 0; done < length; done += 64) {
+                const uint32_t i = done + (uint32_t)lane;
+                uint8_t b = 0;
+                if (i < length) b = L.ring[(pos - dist + i) & kRingMask];
+                wave_lds_fence();
+                if (i < length) L.ring[(pos + i) & kRingMask] = b;
+                wave_lds_fence();
+            }
+        } else {                                                 // overlapping (run-like) copy: byte i repeats byte i mod dist
+            const float inv = 1.0f / (float)dist;
+            for (uint32_t done = 0; done < length; done += 64) {
+                const uint32_t i = done + (uint32_t)lane;
+                uint32_t q = (uint32_t)((float)i * inv);
+                int rem = (int)i - (int)(q * dist);
+                rem = rem < 0 ? rem + (int)dist : (rem >= (int)dist ? rem - (int)dist : rem);
+                uint8_t b = 0;
+                if (i < length) b = L.ring[(pos - dist + (uint32_t)rem) & kRingMask];
+                wave_lds_fence();
+                if (i < length) L.ring[(pos + i) & kRingMask] = b;
+                wave_lds_fence();
+            }
+        }
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (uint32_t done = 0; done < length; done += 64) {
+            const uint32_t i = done + (uint32_t)lane;
+            if (i < length) L.ring[(pos + i) & kRingMask] = dst[pos - dist + i];
         }
     }
-    len_out = 0;
-    return 0;
+    wave_lds_fence();
 }
 
 // status codes of a block (int32): 0 accepted; 1 not a valid / supported stream or wrong size; (2 set by the Adler pass: checksum)
@@ -257,11 +317,12 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
         r.n_chunks_ok = (uint32_t)(units * 8 <= room ? units : room >> 3);
     }
     uint32_t pos = 0, flushed = 0;
+    uint32_t far_v = 0, far_pos = 0, far_len = 0;       // a far match whose bytes are still on their way from HBM (per lane: byte `lane`)
     const uint32_t out_n = (uint32_t)block_bytes;
     if (good) r.seek(2, lane);
     bool last = false;
     while (good && !last) {
-        if (r.widx > r.n_words + 2u) { good = false; break; }   // ran past the stream's end (zeros decode to nothing useful)
+        if (r.widx > r.n_words + 6u) { good = false; break; }   // ran past the stream's end (zeros decode to nothing useful)
         r.refill();
         last = r.take(1) != 0;
         const uint32_t type = r.take(2);
@@ -312,7 +373,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
             }
             if (lane < 19) L.lens[lane] = (uint8_t)mine;
             wave_lds_fence();
-            if (!build_table(L, 2, L.lens, 19, L.pre, 7, L.sorted, lane)) { good = false; break; }
+            if (!uni(build_table(L, 2, L.lens, 19, L.pre, 7, L.sorted, lane))) { good = false; break; }
             // the run-length coded lengths, decoded into VGPR-free LDS bytes: lens2 lives behind the two alphabets' final place,
             // so decode into a scratch area of the ring's far side?  No: the ring holds live output.  Decode straight into
             // L.lens (both alphabets back to back), then move the distance lengths to offset 288.
@@ -359,90 +420,163 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
             wave_lds_fence();
             if (uni((uint32_t)L.lens[256]) == 0u) { good = false; break; }       // no end-of-block code
         }
-        if (!build_table(L, 0, L.lens, kLitSyms, L.lit, kLitBits, L.sorted, lane)) { good = false; break; }
-        if (!build_table(L, 1, L.lens + kLitSyms, kDistSyms, L.dist, kDistBits, L.sorted + kLitSyms, lane)) { good = false; break; }
+        if (!uni(build_table(L, 0, L.lens, kLitSyms, L.lit, kLitBits, L.sorted, lane))) { good = false; break; }
+        if (!uni(build_table(L, 1, L.lens + kLitSyms, kDistSyms, L.dist, kDistBits, L.sorted + kLitSyms, lane))) { good = false; break; }
 
         // ---- the block's symbols ---------------------------------------------------------------------------------------------
-        for (;;) {
-            r.refill();                                          // >= 32 bits: a literal/length code (<= 15) + its extra bits (<= 5)
+        // In batches.  Every lane DECODES THE WHOLE SYMBOL that would start at the bit offset equal to its lane number -- the
+        // literal/length entry (an LDS gather), for a length its extra bits, the distance entry at the offset behind them (a
+        // second gather) and its extra bits -- and packs the symbol's total bit count, match length and distance into one word.
+        // All of that is vector work on 64 hypotheses at once.  The serial part, the thing DEFLATE forces, is reduced to
+        // following the chain from offset 0: for a literal one `v_readlane_b32`, a compare, a bit set and an add.  The literals
+        // of a run are then stored by their own lanes in ONE instruction (rank = `v_mbcnt` of the run's lane mask).  Symbols the
+        // vector path cannot finish -- a code longer than the table index, end of block, an invalid pattern -- take the scalar
+        // one-symbol path; the scalar bit buffer is brought up to date once per batch.
+        bool block_done = false;
+        while (good && !block_done) {
+            r.refill();                                          // > 96 valid bits
+            uint32_t E, P;
+            {
+                const uint32_t w0 = (uint32_t)r.lo, w1 = (uint32_t)(r.lo >> 32), w2 = (uint32_t)r.hi, w3 = (uint32_t)(r.hi >> 32);
+                const uint32_t win = __builtin_amdgcn_alignbit(lane < 32 ? w1 : w2, lane < 32 ? w0 : w1, (uint32_t)lane & 31u);
+                E = L.lit[win & ((1u << kLitBits) - 1u)];        // stream bits [lane, lane + 32) -> the symbol starting there
+                const uint32_t kE = (E >> 8) & 7u, clen = E & 0xFFu, lx = (E >> 11) & 31u;
+                const uint32_t len = (E >> 16) + ((win >> clen) & ((1u << lx) - 1u));
+                const uint32_t off2 = (uint32_t)lane + clen + lx;      // where the distance code would start (<= 63 + 20)
+                const uint32_t d2 = off2 >> 5;
+                const uint32_t a2 = d2 == 0u ? w0 : d2 == 1u ? w1 : w2, b2 = d2 == 0u ? w1 : d2 == 1u ? w2 : w3;
+                const uint32_t win2 = __builtin_amdgcn_alignbit(b2, a2, off2 & 31u);
+                const uint32_t D = L.dist[win2 & ((1u << kDistBits) - 1u)];
+                const uint32_t kD = (D >> 8) & 7u, dlen = D & 0xFFu, dx = (D >> 11) & 31u;
+                const uint32_t dist = (D >> 16) + ((win2 >> dlen) & ((1u << dx) - 1u));
+                const uint32_t total = kE == 0u ? clen : clen + lx + dlen + dx;
+                // a literal: its code length (1 .. 15); a match: total bits (7) | length (9) << 7 | distance (16) << 16;
+                // 0: not decodable here (long code, end of block, invalid); ~0: the symbol reaches beyond the bits in the buffer
+                // (a code is decided by its own bits -- prefix property -- so "fits the valid bits" is the whole condition)
+                P = kE == 0u ? clen : (kE == 1u && kD == 1u) ? (total | (len << 7) | (dist << 16)) : 0u;
+                if (P != 0u && (uint32_t)lane + total > (uint32_t)r.cnt) P = ~0u;
+            }
+            int off = 0;                                         // bits consumed since the gathers (wave-uniform)
+            uint64_t run = 0;                                    // lanes (= bit offsets) of the pending literal run
+            bool slow = false;
+            for (;;) {
+                // ---- the literal chain: the hot loop ----
+                uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)P, off);
+                while (p - 1u < 15u) {                           // a literal: p is its code length
+                    run |= 1ull << off;
+                    off += (int)p;
+                    if (off > 63) { p = ~0u; break; }
+                    p = (uint32_t)__builtin_amdgcn_readlane((int)P, off);
+                }
+                if (run) {                                       // every literal of the run by its own lane, ranks from the mask
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(run >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)run, 0u));
+                    if ((run >> lane) & 1ull) L.ring[(pos + rank) & kRingMask] = (uint8_t)(E >> 16);
+                    pos += (uint32_t)__builtin_popcountll(run);
+                    run = 0;
+                }
+                if (p == ~0u) break;                             // out of lanes or out of bits: next batch
+                if (p == 0u) { slow = true; break; }
+                // ---- a match ----
+                const uint32_t length = (p >> 7) & 0x1FFu, dist = p >> 16;
+                if (dist > pos || (uint64_t)pos + length > out_n) { good = false; break; }
+                if (far_len) {                                   // the bytes of the previous far match must be in the ring first
+                    if ((uint32_t)lane < far_len) L.ring[(far_pos + (uint32_t)lane) & kRingMask] = (uint8_t)far_v;
+                    far_len = 0;
+                    wave_lds_fence();
+                }
+                if (dist <= (uint32_t)kRingNear || length > 64u) {
+                    copy_match(L, dst, pos, length, dist, lane);
+                } else {
+                    // beyond the ring: the bytes left for HBM at least 12 lines ago.  vmcnt counts a wave's vector memory
+                    // operations in issue order, so "at most 8 outstanding" means those stores have completed; the load's
+                    // result goes to the ring only when the next match (or the next line leaving the ring) needs it.
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    far_v = (uint32_t)lane < length ? (uint32_t)dst[pos - dist + (uint32_t)lane] : 0u;
+                    far_pos = pos;
+                    far_len = length;
+                }
+                pos += length;
+                off += (int)(p & 0x7Fu);
+                if (pos - flushed >= 256u) {
+                    if (far_len) {
+                        if ((uint32_t)lane < far_len) L.ring[(far_pos + (uint32_t)lane) & kRingMask] = (uint8_t)far_v;
+                        far_len = 0;
+                    }
+                    wave_lds_fence();
+                    flushed = flush_lines(L, dst, pos, flushed, lane);
+                }
+                if (off > 63) break;
+            }
+            if (!good) break;
+            if (pos > out_n) { good = false; break; }            // before anything of it leaves the ring
+            if (off >= 64) {                                     // bring the scalar bit buffer up to the walk (off <= 63 + 48)
+                r.drop(32);
+                r.drop(32);
+                off -= 64;
+            }
+            r.drop(off);
+            if (pos - flushed >= 256u) {
+                if (far_len) {
+                    if ((uint32_t)lane < far_len) L.ring[(far_pos + (uint32_t)lane) & kRingMask] = (uint8_t)far_v;
+                    far_len = 0;
+                }
+                wave_lds_fence();
+                flushed = flush_lines(L, dst, pos, flushed, lane);
+            }
+            if (!slow) continue;
+            // ---- one symbol on the scalar path: a long code, end of block, or an invalid pattern ---------------------------------
+            if (far_len) {
+                if ((uint32_t)lane < far_len) L.ring[(far_pos + (uint32_t)lane) & kRingMask] = (uint8_t)far_v;
+                far_len = 0;
+                wave_lds_fence();
+            }
+            r.refill();
             uint32_t e = uni(L.lit[r.peek(kLitBits)]);
             uint32_t kind = (e >> 8) & 7u;
             if (kind == 3u) {
-                int len;
-                const uint32_t s = long_code(L, 0, kLitBits, L.sorted, (uint32_t)r.buf & 0xFFFFu, len);
-                if (len == 0) { good = false; break; }
-                if (s < 256u) e = pack((uint32_t)len, 0, 0, s);
-                else if (s == 256u) e = pack((uint32_t)len, 2, 0, 0);
-                else if (s > 285u) e = pack((uint32_t)len, 4, 0, 0);
-                else e = pack((uint32_t)len, 1, kLenExtra[s - 257u], kLenBase[s - 257u]);
+                const uint32_t lc = uni(long_code(L, 0, kLitBits, L.sorted, (uint32_t)r.lo & 0xFFFFu));
+                const uint32_t sym = lc & 0xFFFFu;
+                const uint32_t len = lc >> 16;
+                if (len == 0u) { good = false; break; }
+                if (sym < 256u) e = pack(len, 0, 0, sym);
+                else if (sym == 256u) e = pack(len, 2, 0, 0);
+                else if (sym > 285u) e = pack(len, 4, 0, 0);
+                else e = pack(len, 1, kLenExtra[sym - 257u], kLenBase[sym - 257u]);
                 kind = (e >> 8) & 7u;
             }
             r.drop((int)(e & 0xFFu));
-            if (kind == 0u) {                                    // literal
+            if (kind == 0u) {
                 if (pos >= out_n) { good = false; break; }
                 if (lane == 0) L.ring[pos & kRingMask] = (uint8_t)(e >> 16);
                 ++pos;
-            } else if (kind == 1u) {                             // length + distance
+            } else if (kind == 2u) {
+                block_done = true;
+            } else if (kind == 1u) {
                 const uint32_t length = (e >> 16) + r.take((int)((e >> 11) & 31u));
-                r.refill();                                      // a distance code (<= 15) + its extra bits (<= 13)
                 uint32_t d = uni(L.dist[r.peek(kDistBits)]);
                 if (((d >> 8) & 7u) == 3u) {
-                    int len;
-                    const uint32_t s = long_code(L, 1, kDistBits, L.sorted + kLitSyms, (uint32_t)r.buf & 0xFFFFu, len);
-                    if (len == 0 || s > 29u) { good = false; break; }
-                    d = pack((uint32_t)len, 1, kDistExtra[s], kDistBase[s]);
+                    const uint32_t lc = uni(long_code(L, 1, kDistBits, L.sorted + kLitSyms, (uint32_t)r.lo & 0xFFFFu));
+                    const uint32_t sym = lc & 0xFFFFu;
+                    if ((lc >> 16) == 0u || sym > 29u) { good = false; break; }
+                    d = pack(lc >> 16, 1, kDistExtra[sym], kDistBase[sym]);
                 }
                 if (((d >> 8) & 7u) != 1u) { good = false; break; }
                 r.drop((int)(d & 0xFFu));
                 const uint32_t dist = (d >> 16) + r.take((int)((d >> 11) & 31u));
                 if (dist > pos || (uint64_t)pos + length > out_n) { good = false; break; }
-                if (dist <= (uint32_t)kRingNear) {
-                    if (dist >= 64u) {                           // 64 bytes per step; a step's sources were written by earlier steps
-                        for (uint32_t done = 0; done < length; done += 64) {
-                            const uint32_t i = done + (uint32_t)lane;
-                            uint8_t b = 0;
-                            if (i < length) b = L.ring[(pos - dist + i) & kRingMask];
-                            wave_lds_fence();
-                            if (i < length) L.ring[(pos + i) & kRingMask] = b;
-                            wave_lds_fence();
-                        }
-                    } else {                                     // overlapping (run-like) copy: byte i repeats byte i mod dist
-                        const float inv = 1.0f / (float)dist;
-                        for (uint32_t done = 0; done < length; done += 64) {
-                            const uint32_t i = done + (uint32_t)lane;
-                            uint32_t q = (uint32_t)((float)i * inv);
-                            int rem = (int)i - (int)(q * dist);
-                            rem = rem < 0 ? rem + (int)dist : (rem >= (int)dist ? rem - (int)dist : rem);
-                            uint8_t b = 0;
-                            if (i < length) b = L.ring[(pos - dist + (uint32_t)rem) & kRingMask];
-                            wave_lds_fence();
-                            if (i < length) L.ring[(pos + i) & kRingMask] = b;
-                            wave_lds_fence();
-                        }
-                    }
-                } else {                                         // beyond the ring: the bytes are in HBM (flushed long ago)
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    for (uint32_t done = 0; done < length; done += 64) {
-                        const uint32_t i = done + (uint32_t)lane;
-                        if (i < length) L.ring[(pos + i) & kRingMask] = dst[pos - dist + i];
-                    }
-                    wave_lds_fence();
-                }
+                copy_match(L, dst, pos, length, dist, lane);
                 pos += length;
-            } else if (kind == 2u) {
-                break;                                           // end of block
             } else {
                 good = false;
                 break;
             }
-            while (pos - flushed >= 256u) {                      // whole 256-byte lines leave the ring: one dword per lane
-                wave_lds_fence();
-                const uint32_t v = *(const uint32_t *)&L.ring[(flushed + 4u * (uint32_t)lane) & kRingMask];
-                *(uint32_t *)(dst + flushed + 4u * (uint32_t)lane) = v;
-                flushed += 256u;
-            }
+            wave_lds_fence();
+            if (pos - flushed >= 256u) flushed = flush_lines(L, dst, pos, flushed, lane);
         }
+    }
+    if (far_len) {
+        if ((uint32_t)lane < far_len) L.ring[(far_pos + (uint32_t)lane) & kRingMask] = (uint8_t)far_v;
+        far_len = 0;
     }
     // the tail of the ring, byte by byte
     wave_lds_fence();
@@ -516,6 +650,82 @@ __device__ __forceinline__ int from_lane_above(int v, int fill, int lane) {
     return lane == 0 ? fill : got;
 }
 
+// bytewise a + b (mod 256 per byte) on four bytes at once
+__device__ __forceinline__ uint32_t add_bytes(uint32_t a, uint32_t b) {
+    return ((a & 0x7F7F7F7Fu) + (b & 0x7F7F7F7Fu)) ^ ((a ^ b) & 0x80808080u);
+}
+
+// Images whose rows use only None / Sub / Up (what an adaptive writer picks for depth maps almost always): row by row with the
+// lanes ALONG the row.  Lane l owns 4 nd consecutive bytes (2 nd pixels) of every row: coalesced dword loads re-aligned by the
+// row's byte phase, bytewise SWAR arithmetic, Up against the previous output row held in registers, Sub as a prefix sum -- in the
+// lane, then an exclusive scan of the lanes' totals over the wave -- and coalesced dword stores of the byte-swapped samples.
+// nd <= 8 (w <= 1 024), w even.
+__device__ void unfilter_rows(const uint8_t *__restrict__ raw, int64_t raw_pitch, int64_t stride, int32_t h, int32_t w,
+                              uint16_t *__restrict__ out, int lane, int nd) {
+    uint32_t prior[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) prior[d] = 0u;
+    const int64_t last = (raw_pitch - 4) & ~(int64_t)3;          // no load past the image's own block
+    uint32_t v[9], vn[9];
+    auto load_row = [&](int y, uint32_t *dstv) {
+        const int64_t a0 = (int64_t)y * stride + 1;
+        const int64_t base = (a0 & ~(int64_t)3) + 4 * (int64_t)nd * lane;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) {
+            if (d <= nd) {
+                int64_t o = base + 4 * d;
+                o = o < last ? o : last;
+                dstv[d] = *(const uint32_t *)(raw + o);
+            }
+        }
+    };
+    load_row(0, v);
+    for (int y = 0; y < h; ++y) {
+        if (y + 1 < h) load_row(y + 1, vn);                      // the next row is on its way while this one is worked on
+        const int64_t a0 = (int64_t)y * stride + 1;
+        const uint32_t ft = raw[a0 - 1];                         // wave-uniform
+        const uint32_t sh = (uint32_t)(a0 & 3);
+        uint32_t x[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) x[d] = d < nd ? __builtin_amdgcn_alignbyte(v[d + 1], v[d], sh) : 0u;
+        if (ft == 2u) {
+#pragma unroll
+            for (int d = 0; d < 8; ++d) x[d] = add_bytes(x[d], prior[d]);
+        } else if (ft == 1u) {
+            uint32_t acc = 0;                                    // two byte channels in the low half
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                if (d < nd) {
+                    acc = add_bytes(acc, x[d] & 0xFFFFu) & 0xFFFFu;
+                    const uint32_t lo = acc;
+                    acc = add_bytes(acc, x[d] >> 16) & 0xFFFFu;
+                    x[d] = lo | (acc << 16);
+                }
+            }
+            uint32_t incl = acc;                                 // inclusive scan of the lanes' totals, bytewise
+#pragma unroll
+            for (int sft = 1; sft < 64; sft <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, sft, 64);
+                if (lane >= sft) incl = add_bytes(incl, t) & 0xFFFFu;
+            }
+            uint32_t excl = (uint32_t)__shfl_up((int)incl, 1, 64);
+            excl = lane == 0 ? 0u : excl;
+            const uint32_t both = excl | (excl << 16);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) x[d] = add_bytes(x[d], both);
+        }
+        uint32_t *orow = (uint32_t *)(out + (int64_t)y * w);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            prior[d] = x[d];
+            if (d < nd && 2 * (nd * lane + d) < w)
+                orow[nd * lane + d] = ((x[d] & 0x00FF00FFu) << 8) | ((x[d] >> 8) & 0x00FF00FFu);     // big-endian samples -> host order
+        }
+#pragma unroll
+        for (int d = 0; d < 9; ++d) v[d] = vn[d];
+    }
+}
+
 __global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t *__restrict__ raw_base, int64_t raw_pitch, int32_t h, int32_t w,
                                                           uint16_t *__restrict__ out_base, int32_t *__restrict__ status) {
     const int64_t k = blockIdx.x;
@@ -524,13 +734,27 @@ __global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t *__restr
     const uint8_t *raw = raw_base + k * raw_pitch;
     uint16_t *out = out_base + k * (int64_t)h * w;
     const int64_t stride = (int64_t)w * 2 + 1;
-    bool bad = false;
+    // the rows' filter types: anything above Paeth is not PNG; Average / Paeth anywhere sends the image down the skewed pipeline
+    bool bad = false, hard = false;
+    for (int y = lane; y < h; y += 64) {
+        const int ft = raw[(int64_t)y * stride];
+        bad = bad || ft > 4;
+        hard = hard || ft > 2;
+    }
+    if (__any(bad)) {
+        if (lane == 0) status[k] = 3;
+        return;
+    }
+    const int nd = (w + 127) / 128;
+    if (!__any(hard) && (w & 1) == 0 && nd <= 8 && (((uintptr_t)out) & 3u) == 0) {
+        unfilter_rows(raw, raw_pitch, stride, h, w, out, lane, nd);
+        return;
+    }
     for (int y0 = 0; y0 < h; y0 += 64) {
         const int y = y0 + lane;
         const bool row = y < h;
         const uint8_t *rp = raw + (int64_t)(row ? y : 0) * stride;
         const int ft = row ? (int)rp[0] : 0;
-        bad = bad || ft > 4;
         uint16_t *op = out + (int64_t)(row ? y : 0) * w;
         const uint16_t *up = y0 > 0 ? out + (int64_t)(y0 - 1) * w : nullptr;      // the row above the band (lane 0's neighbour)
         if (y0 > 0) {                                                              // written by this wave in the previous band
@@ -574,7 +798,6 @@ __global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t *__restr
             b_lo = nb_lo;
         }
     }
-    if (__any(bad) && lane == 0) status[k] = 3;
 }
 
 }  // namespace dinf
@@ -592,8 +815,9 @@ extern "C" int mspa_inflate_blocks_device(const void *src_dev, const int64_t *sr
         return fail(MSPA_EINVAL, "mspa_inflate_blocks_device: null pointer");
     if (block_bytes > (1ll << 26)) return fail(MSPA_EINVAL, "mspa_inflate_blocks_device: block larger than 64 MiB");
     if (n_blocks > 0x7fffffffll) return fail(MSPA_EINVAL, "mspa_inflate_blocks_device: too many blocks");
-    if (((uintptr_t)src_dev & 15u) || ((uintptr_t)dst_dev & 15u) || (dst_pitch & 15))
-        return fail(MSPA_EINVAL, "mspa_inflate_blocks_device: src, dst and dst_pitch must be 16-byte aligned");
+    // dst: lines of 256 bytes leave the ring whole, and a cache line must never hold bytes from both sides of that frontier
+    if (((uintptr_t)src_dev & 15u) || ((uintptr_t)dst_dev & 255u) || (dst_pitch & 255))
+        return fail(MSPA_EINVAL, "mspa_inflate_blocks_device: src must be 16-byte, dst and dst_pitch 256-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(dinf::inflate_kernel, dim3((unsigned)n_blocks), dim3(64), 0, st, (const uint8_t *)src_dev, src_offsets_dev,
                        src_bytes_dev, src_capacity, (uint8_t *)dst_dev, dst_pitch, block_bytes, status_dev, work_dev);

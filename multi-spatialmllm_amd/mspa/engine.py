@@ -173,11 +173,11 @@ def inflate_blocks_device(src: torch.Tensor, offsets: torch.Tensor, nbytes: torc
     _require(src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous() and src.dim() == 1, "src: a flat uint8 device tensor")
     _require(offsets.is_cuda and offsets.dtype == torch.int64 and nbytes.is_cuda and nbytes.dtype == torch.int64
              and nbytes.shape[0] == n, "offsets / nbytes: int64 device tensors of one length")
-    pitch = (int(block_bytes) + 15) // 16 * 16
+    pitch = (int(block_bytes) + 255) // 256 * 256
     if out is None:
         out = torch.empty((n, pitch), dtype=torch.uint8, device=src.device)
     _require(out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and out.dim() == 2 and out.shape[0] >= n
-             and out.shape[1] >= block_bytes and out.shape[1] % 16 == 0, "out: [n, pitch] uint8 with a pitch that is a multiple of 16")
+             and out.shape[1] >= block_bytes and out.shape[1] % 256 == 0, "out: [n, pitch] uint8 with a pitch that is a multiple of 256")
     if status is None:
         status = torch.empty((n,), dtype=torch.int32, device=src.device)
     work = torch.empty((max(n, 1),), dtype=torch.int32, device=src.device)

@@ -190,6 +190,27 @@ def test_unfilter_all_five_filters_and_the_composed_reader(tmp_path):
         ingest.read_depth_frames_device([bp[0], damaged], "cuda", 2)
 
 
+@pytest.mark.parametrize("h,w", [(5, 2), (70, 130), (33, 640), (9, 1024), (9, 1026), (3, 254), (66, 126)])
+def test_unfilter_row_parallel_path_shapes(h, w, tmp_path):
+    """Images with None / Sub / Up rows only take the row-parallel path (lanes along the row, Sub as a wave-wide prefix sum);
+    widths that leave lanes partly or wholly idle, more than 8 dwords per lane (back to the skewed pipeline), heights past one
+    64-row band -- every pixel against the host reader."""
+    import torch
+    from mspa import ingest
+    rng = np.random.default_rng(h * 10007 + w)
+    frames, paths = [], []
+    for k, filters in enumerate([[1], [2], [0, 1, 2], [2, 1, 1, 0], [1, 2, 4]]):      # the last one: a Paeth row -> skewed pipeline
+        a = rng.integers(0, 65536, (h, w), dtype=np.uint16)
+        p = str(tmp_path / f"r{k}.png")
+        open(p, "wb").write(_png_rows(a, filters, level=1))
+        frames.append(a)
+        paths.append(p)
+    got = ingest.read_depth_frames_device(paths, "cuda", 2)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), np.stack(frames))
+    assert np.array_equal(ingest.read_depth_frames(paths, 2), np.stack(frames))
+
+
 def test_full_size_depth_frames_as_the_dataset_stores_them(tmp_path):
     """640 x 480 depth frames of the synthetic room (5 mm noise, 7 % invalid pixels) written by Pillow at three
     compression levels: the device decode equals the host decode on every pixel, and no frame needed the host."""

@@ -58,7 +58,7 @@ def main():
         off = torch.from_numpy(np.concatenate([offsets + r * stride for r in range(reps)])).to(dev)
         nb = torch.from_numpy(np.tile(nbytes, reps)).to(dev)
         block = H * (2 * W + 1)
-        pitch = (block + 15) // 16 * 16
+        pitch = (block + 255) // 256 * 256
         raw = torch.empty((n, pitch), dtype=torch.uint8, device=dev)
         status = torch.empty((n,), dtype=torch.int32, device=dev)
         out = torch.empty((n, H, W), dtype=torch.int16, device=dev)
