@@ -130,6 +130,87 @@ def read_depth_frames(paths: Sequence[str], n_threads: int = 8, general_reader: 
     return out
 
 
+class PinnedBytesPool:
+    """Reusable page-locked byte buffers for the packed compressed frames of a scene (what the H2D copy reads).  Pinning 100 MB
+    costs tens of milliseconds, so buffers are kept; sized in 16 MB steps; ``take`` returns a flat uint8 torch tensor."""
+    STEP = 16 << 20
+
+    def __init__(self, max_free: int = 12):
+        import threading
+        self._free, self._lock, self.max_free = [], threading.Lock(), max_free
+
+    def take(self, nbytes: int):
+        import torch
+        with self._lock:
+            fit = [b for b in self._free if b.numel() >= nbytes]
+            if fit:
+                buf = min(fit, key=lambda b: b.numel())
+                self._free = [b for b in self._free if b is not buf]
+                return buf
+        n = max(self.STEP, -(-int(nbytes) // self.STEP) * self.STEP)
+        t = torch.empty(n, dtype=torch.uint8)
+        try:
+            return t.pin_memory()
+        except RuntimeError:                                # no GPU in this process (CPU tests): pageable memory works too
+            return t
+
+    def give(self, buf):
+        with self._lock:
+            if len(self._free) < self.max_free and all(b is not buf for b in self._free):
+                self._free.append(buf)
+
+
+PINNED_POOL = PinnedBytesPool()
+
+
+class PackedDepth:
+    """A scene's depth frames as they sit on disk, packed for ONE H2D copy: ``buf`` (flat uint8, page-locked) holds frame k's
+    scanline zlib stream at ``offsets[k]``, ``nbytes[k]`` long; ``status[k]`` != 0 marks a file the packer declined (the
+    device decode then reports it and the host reader takes that frame).  ``release()`` hands the buffer back to its pool."""
+
+    def __init__(self, paths, hw, buf, offsets, nbytes, status, capacity, pool=None):
+        self.paths, self.hw, self.buf, self.offsets, self.nbytes, self.status, self.capacity = \
+            list(paths), tuple(hw), buf, offsets, nbytes, status, int(capacity)
+        self._pool = pool
+
+    def __len__(self):
+        return len(self.paths)
+
+    def release(self):
+        if self._pool is not None and self.buf is not None:
+            self._pool.give(self.buf)
+        self.buf = None
+
+
+def pack_scene_depth(paths: Sequence[str], n_threads: int = 8, pool: Optional[PinnedBytesPool] = None) -> Optional[PackedDepth]:
+    """``PackedDepth`` of the 16-bit greyscale PNG files at ``paths`` (sized by the first one), or None when the first file is
+    not such a PNG -- the caller then reads the scene with ``read_depth_frames``."""
+    paths = list(paths)
+    if not paths:
+        return None
+    try:
+        h, w, bits, ctype, lace = png_header(paths[0])
+    except _lib.MspaError:
+        return None
+    if bits != 16 or ctype != 0 or lace != 0:
+        return None
+    pool = pool or PINNED_POOL
+    F = len(paths)
+    enc = [q.encode() for q in paths]
+    arr = (ctypes.c_char_p * F)(*enc)
+    offsets, nbytes = np.zeros(F, dtype=np.int64), np.zeros(F, dtype=np.int64)
+    status = np.zeros(F, dtype=np.int32)
+    need = ctypes.c_int64(0)
+    lib = _lib.load()
+    _lib.check(lib.mspa_png_pack_idat_host(arr, F, int(h), int(w), None, 0, offsets.ctypes.data, nbytes.ctypes.data,
+                                           status.ctypes.data, ctypes.byref(need), 1))
+    cap = max(int(need.value), 16)
+    buf = pool.take(cap)
+    _lib.check(lib.mspa_png_pack_idat_host(arr, F, int(h), int(w), buf.data_ptr(), int(buf.numel()), offsets.ctypes.data,
+                                           nbytes.ctypes.data, status.ctypes.data, ctypes.byref(need), int(max(1, n_threads))))
+    return PackedDepth(paths, (h, w), buf, offsets, nbytes, status, cap, pool)
+
+
 def pack_depth_pngs(paths: Sequence[str], h: int, w: int, n_threads: int = 8, out=None):
     """The scanline zlib streams of the 16-bit greyscale ``h x w`` PNG files at ``paths``, packed into ONE host buffer for one
     H2D copy (mspa_png_pack_idat_host: files read into their slots by native threads, IDAT payloads moved to the slot's

@@ -43,6 +43,9 @@ class HostScene:
     points: Optional[np.ndarray] = None    # [N, >=3] float64
     depth_scale: float = 0.001
     load_s: float = 0.0                    # wall time the loader spent on this scene (decode + np.load)
+    packed: object = None                  # ingest.PackedDepth: the frames still compressed (decoded on the device); then
+    #                                        ``depth`` is empty and ``depth_ids`` names the frames ``packed`` holds, in order
+    depth_ids: Optional[List[str]] = None
 
 
 class Timings:
@@ -320,8 +323,10 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
     vote(writer.close() if writer is not None else None)
 
 
-def prefetched_scenes(host_scenes: Iterable[HostScene], device="cuda", timings: Optional[Timings] = None):
+def prefetched_scenes(host_scenes: Iterable[HostScene], device="cuda", timings: Optional[Timings] = None,
+                      decode_on_device: bool = False):
     """HostScenes -> resident ``SceneOnDevice`` objects through pinned staging on a copy stream (upload.ScenePrefetcher);
-    a yielded scene stays valid until the next one is asked for."""
+    a yielded scene stays valid until the next one is asked for.  ``decode_on_device``: the scenes carry compressed frames
+    (``HostScene.packed``) -- more upload slots, so that several scenes' decode kernels run side by side."""
     from .upload import ScenePrefetcher
-    yield from ScenePrefetcher(host_scenes, device=device, timings=timings)
+    yield from ScenePrefetcher(host_scenes, device=device, timings=timings, decode_on_device=decode_on_device)

@@ -24,6 +24,11 @@ from .scene import SceneOnDevice, valid_image_ids
 # Three slots, not two: with two, the producer cannot start staging scene n+2 before the consumer has released scene n, and
 # staging (3 ms), H2D (4 ms) and the consumer's kernels + download (1.2 ms) run back to back instead of side by side.
 UPLOAD_SLOTS = int(os.environ.get("MSPA_UPLOAD_SLOTS", "3"))
+# Scenes whose depth frames are decoded ON the device need many of them in flight: one wave inflates one frame and a lone wave
+# takes ~70 ms for a 640 x 480 frame, so a 320-frame scene alone keeps 320 of the chip's ~3 600 such waves busy; ten scenes side by
+# side (each on its own stream) run at 30 k frames/s (profiles/r06_device_ingest.md).  Slots cost HBM, not host time: depth +
+# scanline scratch + compressed bytes = 0.5 GB per 320-frame scene.
+DECODE_SLOTS = int(os.environ.get("MSPA_DECODE_SLOTS", "10"))
 STAGE_THREADS = int(os.environ.get("MSPA_STAGE_THREADS", "4"))           # native copy threads per staged chunk
 STAGE_CHUNK_FRAMES = int(os.environ.get("MSPA_STAGE_CHUNK_FRAMES", "160"))  # frames per chunk (98 MB at 640 x 480)
 
@@ -39,14 +44,19 @@ class UploadSlot:
         self.h_fmats = self.d_fmats = self.h_cmats = self.d_cmats = self.h_pose = self.d_pose = None
         self.ready = torch.cuda.Event()          # recorded on the copy stream when the scene's tensors are resident
         self.free = None                         # recorded on the consumer's stream when it is done with them
+        # on-device decode of compressed frames (ingest.PackedDepth): the slot's own stream, scanline scratch, per-frame status
+        self.stream = None
+        self.d_comp = self.d_raw = self.d_status = self.d_off = self.d_nb = None
+        self.h_status = self.h_off = self.h_nb = None
+        self.pending_decode = None               # (PackedDepth, F): status still to be looked at (ScenePrefetcher._consume)
 
-    def _ensure(self, n_frames, depth_hw, n_points, copy_stream):
+    def _ensure(self, n_frames, depth_hw, n_points, copy_stream, host_depth=True):
         grown = False
         if n_frames > self.cap_frames or depth_hw != self.depth_hw:
             grown = True
             self.cap_frames, self.depth_hw = max(n_frames, self.cap_frames), depth_hw
             shape = (self.cap_frames,) + tuple(depth_hw)
-            self.h_depth = torch.empty(shape, dtype=torch.int16).pin_memory()
+            self.h_depth = None                  # pinned staging of DECODED frames: only for scenes that arrive decoded
             self.d_depth = torch.empty(shape, dtype=torch.int16, device=self.device)
             self.h_fmats = torch.empty((self.cap_frames, engine._lib.FRAME_MATS, 16), dtype=torch.float64).pin_memory()
             self.d_fmats = torch.empty_like(self.h_fmats, device=self.device)
@@ -54,6 +64,8 @@ class UploadSlot:
             self.d_cmats = torch.empty_like(self.h_cmats, device=self.device)
             self.h_pose = torch.empty((self.cap_frames * 18,), dtype=torch.float64).pin_memory()   # A @ E, yaw, pitch (K4)
             self.d_pose = torch.empty_like(self.h_pose, device=self.device)
+        if host_depth and (self.h_depth is None or tuple(self.h_depth.shape) != tuple(self.d_depth.shape)):
+            self.h_depth = torch.empty(tuple(self.d_depth.shape), dtype=torch.int16).pin_memory()
         if n_points > self.cap_points:
             grown = True
             self.cap_points = n_points
@@ -65,28 +77,94 @@ class UploadSlot:
             # copies below run on `copy_stream`: order them behind everything already enqueued on the allocation stream.
             copy_stream.wait_stream(torch.cuda.current_stream(self.device))
 
+    def _ensure_decode(self, n_frames, depth_hw, comp_bytes):
+        h, w = depth_hw
+        pitch = (h * (2 * w + 1) + 255) // 256 * 256
+        if self.d_raw is None or self.d_raw.shape[0] < n_frames or self.d_raw.shape[1] != pitch:
+            self.d_raw = torch.empty((max(n_frames, self.cap_frames), pitch), dtype=torch.uint8, device=self.device)
+            self.d_status = torch.zeros((self.d_raw.shape[0],), dtype=torch.int32, device=self.device)
+            self.d_off = torch.zeros((self.d_raw.shape[0],), dtype=torch.int64, device=self.device)
+            self.d_nb = torch.zeros_like(self.d_off)
+            self.h_status = torch.zeros((self.d_raw.shape[0],), dtype=torch.int32).pin_memory()
+            self.h_off = torch.zeros((self.d_raw.shape[0],), dtype=torch.int64).pin_memory()
+            self.h_nb = torch.zeros_like(self.h_off).pin_memory()
+        if self.d_comp is None or self.d_comp.numel() < comp_bytes:
+            self.d_comp = torch.empty(((int(comp_bytes) + (16 << 20) - 1) // (16 << 20) * (16 << 20),), dtype=torch.uint8,
+                                      device=self.device)
+
+    def _upload_and_decode(self, packed, F, stream):
+        """The compressed frames -> ``d_depth[:F]`` on ``stream``: one H2D copy of the packed bytes, one wave per frame inflates
+        (mspa_inflate_blocks_device), one wave per frame undoes the row filters (mspa_png_unfilter_device).  The per-frame
+        status comes back asynchronously; ``finish_decode`` looks at it once ``ready`` has passed."""
+        h, w = packed.hw
+        grown = self.d_raw is None or self.d_raw.shape[0] < F or self.d_comp is None or self.d_comp.numel() < packed.capacity
+        self._ensure_decode(F, (h, w), packed.capacity)
+        if grown:                                    # fresh blocks of the caching allocator: behind whatever the allocating
+            stream.wait_stream(torch.cuda.current_stream(self.device))      # thread's stream still has queued on them
+        self.h_off[:F] = torch.from_numpy(packed.offsets)
+        self.h_nb[:F] = torch.from_numpy(np.where(packed.status == 0, packed.nbytes, 0))    # a declined file: an empty stream
+        with torch.cuda.stream(stream):
+            self.d_comp[:packed.capacity].copy_(packed.buf[:packed.capacity], non_blocking=True)
+            self.d_off[:F].copy_(self.h_off[:F], non_blocking=True)
+            self.d_nb[:F].copy_(self.h_nb[:F], non_blocking=True)
+            engine.inflate_blocks_device(self.d_comp, self.d_off[:F], self.d_nb[:F], h * (2 * w + 1), self.d_raw, self.d_status)
+            engine.png_unfilter_device(self.d_raw[:F], h, w, self.d_status, self.d_depth[:F])
+            self.h_status[:F].copy_(self.d_status[:F], non_blocking=True)
+        self.pending_decode = (packed, F)
+
+    def finish_decode(self):
+        """After ``ready``: frames the device declined (another pixel format, a damaged stream, a failed checksum) are decoded
+        by the host reader and copied in on the current stream -- the result is the host path's for every input.  Hands the
+        packed buffer back to its pool."""
+        if self.pending_decode is None:
+            return
+        packed, F = self.pending_decode
+        self.pending_decode = None
+        self.ready.synchronize()
+        bad = np.nonzero(self.h_status[:F].numpy())[0]
+        if len(bad):
+            from . import ingest
+            from spatial_engine.utils.scannet_utils.handler import _images
+            host = ingest.read_depth_frames([packed.paths[int(k)] for k in bad], 4, general_reader=_images.read_depth)
+            self.d_depth[torch.from_numpy(bad).to(self.device)] = torch.from_numpy(host.view(np.int16)).to(self.device)
+        packed.release()
+
     def stage_and_upload(self, sc, copy_stream) -> SceneOnDevice:
-        """Fill the pinned buffers from ``sc`` (K, A, E, depth, color_hw, points) and enqueue the copies on ``copy_stream``."""
+        """Fill the pinned buffers from ``sc`` (K, A, E, depth, color_hw, points) and enqueue the copies on ``copy_stream``.
+        A scene that carries ``packed`` compressed frames (``sweep.HostScene.packed``) is decoded on the device instead, on
+        the slot's own stream, so that several scenes' decodes run side by side."""
         ids = valid_image_ids(sc.E)
         F = len(ids)
+        packed = getattr(sc, "packed", None)
+        if packed is not None:
+            if self.stream is None:
+                self.stream = torch.cuda.Stream(device=self.device)
+            copy_stream = self.stream
         # a scene without depth frames is an empty scene (as SceneOnDevice treats it), not a StopIteration
-        first_shape = tuple(next(iter(sc.depth.values())).shape) if len(sc.depth) else (self.depth_hw or tuple(sc.color_hw))
+        first_shape = tuple(packed.hw) if packed is not None else \
+            tuple(next(iter(sc.depth.values())).shape) if len(sc.depth) else (self.depth_hw or tuple(sc.color_hw))
         points = getattr(sc, "points", None)
         N = 0 if points is None else int(points.shape[0])
         if self.free is not None:
             self.free.synchronize()              # the previous user of this slot has finished (host-side wait: we overwrite
-        self._ensure(max(F, 1), first_shape, max(N, 1), copy_stream)  # pinned memory the earlier copy may still be reading)
+        self._ensure(max(F, 1), first_shape, max(N, 1), copy_stream, host_depth=packed is None)  # pinned memory the earlier copy may still be reading)
         # Depth frames: straight into pinned memory (no np.stack temporary), a chunk of frames at a time by native copy
         # threads, each chunk's H2D enqueued as soon as it is staged -- the link is busy while the next chunk is gathered
         # and while the matrices below are prepared.
-        hd = self.h_depth.numpy().view(np.uint16)
+        hd = self.h_depth.numpy().view(np.uint16) if packed is None else None
         frames = []
-        for i in ids:
+        for i in (ids if packed is None else ()):
             f = sc.depth[i]
             if f.dtype != np.uint16 or not f.flags.c_contiguous:
                 f = np.ascontiguousarray(f, dtype=np.uint16)
             frames.append(f)
-        def depth_job():                                # on a helper thread: the gather holds no interpreter lock, so the matrix
+        def depth_job():
+            if packed is not None:                      # compressed frames: H2D + decode kernels on the slot's stream
+                torch.cuda.set_device(copy_stream.device)
+                if list(sc.depth_ids) != list(ids):
+                    raise ValueError("stage_and_upload: the packed frames are not the scene's valid frames")
+                self._upload_and_decode(packed, F, copy_stream)
+                return                                # on a helper thread: the gather holds no interpreter lock, so the matrix
             torch.cuda.set_device(copy_stream.device)   # preparation below runs beside it
             with torch.cuda.stream(copy_stream):
                 for lo in range(0, F, STAGE_CHUNK_FRAMES):
@@ -162,9 +240,12 @@ class ScenePrefetcher:
     resident (the consumer's stream waits on the upload event, the host does not), while the next scene is being staged and
     copied.  A yielded scene is valid until the next iteration step (its slot is recycled two scenes later)."""
 
-    def __init__(self, scenes: Iterable, device="cuda", slots: int = UPLOAD_SLOTS, threaded: bool = True, timings=None):
+    def __init__(self, scenes: Iterable, device="cuda", slots: Optional[int] = None, threaded: bool = True, timings=None,
+                 decode_on_device: bool = False):
         self.scenes = scenes
         self.device = torch.device(device)
+        if slots is None:
+            slots = DECODE_SLOTS if decode_on_device else UPLOAD_SLOTS
         self.n_slots = max(2, int(slots))
         self.threaded = threaded
         self.timings = timings                        # mspa.sweep.Timings: "stage" = pinned staging + H2D enqueue, per scene
@@ -251,6 +332,7 @@ class ScenePrefetcher:
         scene, slot = item
         cur = torch.cuda.current_stream()
         cur.wait_event(slot.ready)                      # device-side dependency; the host does not block
+        slot.finish_decode()                            # frames decoded on the device: their status, the host reader for the rest
         yield scene
         slot.free = torch.cuda.Event()
         slot.free.record(torch.cuda.current_stream())

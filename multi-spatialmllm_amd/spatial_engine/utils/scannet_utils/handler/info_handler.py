@@ -272,19 +272,33 @@ class SceneInfoHandler:
         return np.where(mask_image == target_id + 1, 1, 0)
 
     # ---- resident scene (what the per-scene scripts use) -----------------------------------------
-    def host_scene(self, scene_id, num_workers=8, with_points=True):
-        """The scene in host memory (``mspa.sweep.HostScene``): poses, the depth frames of the frames with a finite pose --
-        read and inflated by ``num_workers`` native threads (``mspa.ingest``; one ``cv2.imread`` per frame upstream,
-        IH:149-155) into one [F, h, w] block -- and the axis-aligned vertices."""
+    def host_scene(self, scene_id, num_workers=8, with_points=True, decode=None):
+        """The scene in host memory (``mspa.sweep.HostScene``): poses, the axis-aligned vertices and the depth frames of the
+        frames with a finite pose (one ``cv2.imread`` per frame upstream, IH:149-155).
+
+        ``decode="device"``: the frames stay COMPRESSED -- ``num_workers`` native threads read the PNG files and pack their
+        scanline zlib streams into one page-locked buffer (``mspa.ingest.pack_scene_depth``); the upload stage copies that
+        (half the bytes of the decoded frames) and the MI355X inflates and un-filters them (csrc/device_ingest.hip).
+        ``decode="host"``: read and inflated here by the native threads (``mspa.ingest.read_depth_frames``) into one
+        [F, h, w] block.  Default: the environment's ``MSPA_DEPTH_DECODE``, else "host" (the streaming sweeps ask for "device").
+        Frames the device path cannot take (registered in memory, another pixel format) make the whole scene use the host path."""
         from mspa import ingest
         from mspa.sweep import HostScene
         ids = self.get_all_image_ids(scene_id)
         E = {i: self.infos[scene_id]["images_info"][i]["extrinsic_matrix"] for i in ids}
         valid = [i for i in ids if np.all(np.isfinite(E[i]))]
-        pool = ingest.DEFAULT_POOL                        # reused destinations: no page faults under the decode threads
-        block = ingest.read_depth_frames([self.get_depth_image_path(scene_id, i) for i in valid], num_workers,
-                                         general_reader=_images.read_depth, memory=_images.MEMORY, pool=pool)
+        paths = [self.get_depth_image_path(scene_id, i) for i in valid]
+        decode = decode or os.environ.get("MSPA_DEPTH_DECODE", "host")
+        packed = None
+        if decode == "device" and paths and not any(q in _images.MEMORY for q in paths):
+            packed = ingest.pack_scene_depth(paths, num_workers)
         pts = self.get_scene_points_align(scene_id)[:, :3] if with_points else None
+        if packed is not None:
+            return HostScene(scene_id, self.get_intrinsic_matrix(scene_id), self.get_world_to_axis_align_matrix(scene_id), E, {},
+                             tuple(self.get_image_shape(scene_id)), pts, float(self.depth_value_scale), packed=packed,
+                             depth_ids=valid)
+        pool = ingest.DEFAULT_POOL                        # reused destinations: no page faults under the decode threads
+        block = ingest.read_depth_frames(paths, num_workers, general_reader=_images.read_depth, memory=_images.MEMORY, pool=pool)
         hs = HostScene(scene_id, self.get_intrinsic_matrix(scene_id), self.get_world_to_axis_align_matrix(scene_id), E,
                        {i: block[k] for k, i in enumerate(valid)}, tuple(self.get_image_shape(scene_id)), pts,
                        float(self.depth_value_scale))
@@ -295,7 +309,7 @@ class SceneInfoHandler:
 
     def scene_on_device(self, scene_id, with_points=True, num_workers=8):
         from mspa.scene import SceneOnDevice
-        hs = self.host_scene(scene_id, num_workers, with_points)
+        hs = self.host_scene(scene_id, num_workers, with_points, decode="host")
         return SceneOnDevice(hs.K, hs.A, hs.E, hs.depth, hs.color_hw, hs.points, depth_scale=self.depth_value_scale)
 
     def scene_cost(self, scene_id):
@@ -309,7 +323,8 @@ class SceneInfoHandler:
             N = 1
         return shard.scene_cost(F, N)
 
-    def prefetched_scenes(self, scene_ids, num_workers=8, device="cuda", timings=None, with_points=True, lookahead=None):
+    def prefetched_scenes(self, scene_ids, num_workers=8, device="cuda", timings=None, with_points=True, lookahead=None,
+                          decode=None):
         """``scene_ids`` -> resident scenes, one after the other: scene n+1 is decoded by ``num_workers`` host threads and
         copied on the copy stream while the caller runs scene n's kernels (mspa/sweep.py, mspa/upload.py).  ``lookahead`` scenes
         are in flight on the host at once (default: 2, more -- up to 4 -- when the process has CPUs to spare for them: its
@@ -319,9 +334,11 @@ class SceneInfoHandler:
             lookahead = max(1, int(os.environ["MSPA_LOOKAHEAD"]))
         if lookahead is None:
             lookahead = min(4, max(2, hostinfo.effective_cpus() // (2 * max(1, int(num_workers)))))
-        loader = sweep.SceneLoader(lambda sid: self.host_scene(sid, num_workers, with_points), list(scene_ids), lookahead,
+        # the streaming sweeps decode the depth frames on the MI355X unless told otherwise (MSPA_DEPTH_DECODE=host)
+        decode = decode or os.environ.get("MSPA_DEPTH_DECODE", "device")
+        loader = sweep.SceneLoader(lambda sid: self.host_scene(sid, num_workers, with_points, decode), list(scene_ids), lookahead,
                                    timings)
-        return sweep.prefetched_scenes(loader, device, timings)
+        return sweep.prefetched_scenes(loader, device, timings, decode_on_device=(decode == "device"))
 
 
 class VisibilityInfoHandler:

@@ -240,6 +240,48 @@ def test_handler_host_scene_is_what_the_general_reader_gives(tmp_path, monkeypat
     assert pre.frames_relations_arrays()["overlap"].tolist() == direct.frames_relations_arrays()["overlap"].tolist()
 
 
+def test_device_decode_of_the_sweeps_equals_the_host_decode(tmp_path, monkeypatch):
+    """The streaming sweeps decode the depth PNGs on the MI355X (compressed bytes over PCIe, csrc/device_ingest.hip); with
+    MSPA_DEPTH_DECODE=host the native host threads do.  Same resident tensors, same parquet bytes -- also for a scene that holds
+    a frame the device has to hand to the host reader (an 8-bit PNG) -- and ten scenes in flight at once."""
+    import torch
+    from PIL import Image
+    from test_gpu_facade import facade
+    from mspa import sweep
+    SceneInfoHandler = facade().IH.SceneInfoHandler
+    import spatial_engine.camera_movement.calculate_frames_relations as CFR
+    root = str(tmp_path)
+    _write_inputs(root)
+    monkeypatch.chdir(root)
+    for stub in ("mmengine", "cv2"):
+        if getattr(sys.modules.get(stub), "__file__", None) is None:
+            monkeypatch.delitem(sys.modules, stub, raising=False)
+    h = SceneInfoHandler(INFO)
+    sids = h.get_all_scene_ids()
+    odd = h.get_depth_image_path(sids[2], h.get_all_extrinsic_valid_image_ids(sids[2])[1])
+    a = np.array(Image.open(odd))
+    Image.fromarray((a >> 4).astype(np.uint8)).save(odd)                   # an 8-bit frame in the middle of a scene
+    resident = {}
+    for mode in ("device", "host"):
+        got = []
+        for sc in h.prefetched_scenes(sids * 2, num_workers=3, decode=mode):   # 14 scenes: more than the decode slots
+            got.append((sc.depth.clone(), sc.cam_mats.clone()))
+        torch.cuda.synchronize()
+        resident[mode] = got
+    assert len(resident["device"]) == 14
+    for (d1, c1), (d2, c2) in zip(resident["device"], resident["host"]):
+        assert torch.equal(d1, d2) and torch.equal(c1, c2)
+    assert int(resident["device"][2][0][1].max()) < 4096                   # the 8-bit frame came through the host reader
+    digests = {}
+    for mode in ("device", "host"):
+        monkeypatch.setenv("MSPA_DEPTH_DECODE", mode)
+        tm = sweep.Timings()
+        CFR.run_split(INFO, os.path.join(root, mode, "pairs.parquet"), os.path.join(root, mode, "warn.txt"), num_workers=3, keep=False,
+                      timings=tm)
+        digests[mode] = _digest_tree(os.path.join(root, mode))
+    assert digests["device"] == digests["host"] and len(digests["device"]) == 3
+
+
 def test_reference_cli_unchanged_under_the_launcher(tmp_path):
     """`python -m spatial_engine.camera_movement.calculate_frames_relations` and `python -m mspa.pipeline --scene-info ...`,
     started the way a user starts a multi-GPU job (`torch.distributed.run`, one process per GPU; here two processes on the one

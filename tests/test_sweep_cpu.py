@@ -156,7 +156,9 @@ def _install_oracle_standins():
         sys.path.insert(0, PKG)
     import spatial_engine.camera_movement.calculate_frames_relations as CFR
     import spatial_engine.utils.scannet_utils.make_visibility_info as MVI
-    sweep.prefetched_scenes = lambda host_scenes, device="cuda", timings=None: iter(host_scenes)
+    # no device here: the scenes arrive decoded by the host reader (the streaming sweeps' default is the on-device decode)
+    os.environ["MSPA_DEPTH_DECODE"] = "host"
+    sweep.prefetched_scenes = lambda host_scenes, device="cuda", timings=None, **kw: iter(host_scenes)
 
     def masks(hs):
         return O.scene_visibility_masks(hs.points[:, :3], hs.K, hs.A, hs.E, hs.depth, hs.color_hw)
