@@ -37,6 +37,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(ROOT, "multi-spatialmllm_amd"), ROOT]
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # before the first HIP call: the from-disk legs overlap ten decode streams (mspa/__init__.py)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
 H, W = 480, 640
@@ -695,7 +696,7 @@ def time_dropin_sweep(n_scenes=8, n_frames=64, n_points=131072, num_workers=None
                 "stage_busy_s": {"decode (PNG read + inflate + np.load, loader threads)": stages.get("decode"),
                                  "stage (pinned staging + H2D enqueue, copy stream)": stages.get("stage"),
                                  "produce (K1 + K2 + K4 + the scene's small D2H)": stages.get("produce"),
-                                 "encode (owner rank: arrow table + parquet row group bytes, inside produce)": stages.get("encode"),
+                                 "encode (owner rank: arrow table + parquet row group bytes, on the sweep's encoder threads)": stages.get("encode_deferred"),
                                  "consume (rank 0's writer thread: warnings + splice of the encoded row groups)": stages.get("consume"),
                                  "write (splice only)": stages.get("write")},
                 "first_pass_seconds": round(runs[0][0], 4), "inputs_written_in_s": round(t_write_inputs, 2),

@@ -392,6 +392,15 @@ int mspa_inflate_zlib_fast_host(const void *src_host, int64_t src_bytes, void *d
  *   files' sizes are looked up and *capacity_needed is set (offsets are assigned from the file sizes, so both calls agree).
  *   status_host[k]: 0 packed; 1 unreadable; 2 another pixel format or size; 3 corrupt chunk structure.
  */
+/*
+ * A stream for long-running background kernels (the depth decode above) that leaves `reserve_cus` compute units alone, spread
+ * over the device (every (n_cu / reserve_cus)-th unit; hipExtStreamCreateWithCUMask): kernels launched on other streams always
+ * find free LDS and wave slots there instead of waiting for a 100 ms decode wave to retire.  reserve_cus = 0: a plain
+ * non-blocking stream.  *stream_out is a hipStream_t; release it with mspa_stream_destroy.
+ */
+int mspa_stream_create_reserving(int32_t reserve_cus, void **stream_out);
+int mspa_stream_destroy(void *stream);
+
 int mspa_inflate_blocks_device(const void *src_dev, const int64_t *src_offsets_dev, const int64_t *src_bytes_dev,
                                int64_t src_capacity, int64_t n_blocks, int64_t block_bytes, void *dst_dev, int64_t dst_pitch,
                                int32_t *status_dev, uint32_t *work_dev, void *stream);

@@ -58,6 +58,46 @@ extern "C" int mspa_device_info(int device, int *n_cu, int *wave_size, int64_t *
     return MSPA_OK;
 }
 
+// A stream whose kernels stay off `reserve_cus` of the device's compute units (every (n_cu / reserve_cus)-th one, so the reserved
+// units are spread over the XCDs).  The on-device depth decode keeps ~3 600 waves resident for ~100 ms each and fills every CU's
+// LDS; geometry kernels launched beside it (K1 needs 13.4 KB of LDS per workgroup) would wait milliseconds for a wave to retire.
+// Decode streams made here never touch the reserved units, so those kernels always find room.
+extern "C" int mspa_stream_create_reserving(int32_t reserve_cus, void **stream_out) {
+    if (!stream_out) return fail(MSPA_EINVAL, "mspa_stream_create_reserving: null output");
+    int dev = 0;
+    hipDeviceProp_t prop;
+    int rc = check_hip(hipGetDevice(&dev), "hipGetDevice");
+    if (rc) return rc;
+    rc = check_hip(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties");
+    if (rc) return rc;
+    const int n_cu = prop.multiProcessorCount;
+    if (reserve_cus < 0 || reserve_cus >= n_cu) return fail(MSPA_EINVAL, "mspa_stream_create_reserving: reserve_cus out of range");
+    hipStream_t st = nullptr;
+    if (reserve_cus == 0) {
+        rc = check_hip(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+    } else {
+        const int words = (n_cu + 31) / 32;
+        uint32_t mask[64] = {0};
+        if (words > 64) return fail(MSPA_EUNSUPPORTED, "mspa_stream_create_reserving: more than 2 048 compute units");
+        const int every = n_cu / reserve_cus;
+        int reserved = 0;
+        for (int cu = 0; cu < n_cu; ++cu) {
+            const bool hold = (cu % every == every - 1) && reserved < reserve_cus;
+            if (hold) ++reserved;
+            else mask[cu >> 5] |= 1u << (cu & 31);
+        }
+        rc = check_hip(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask), "hipExtStreamCreateWithCUMask");
+    }
+    if (rc) return rc;
+    *stream_out = (void *)st;
+    return MSPA_OK;
+}
+
+extern "C" int mspa_stream_destroy(void *stream) {
+    if (!stream) return MSPA_OK;
+    return check_hip(hipStreamDestroy((hipStream_t)stream), "hipStreamDestroy");
+}
+
 // Slot MSPA_MAT_BOUNDS of the frame records (include/mspa.h): magnitudes of the two halves of the pair pipe's matrix chain,
 // from which the fast kernels derive their guard band per tile.  Products of non-negative numbers: no cancellation, the few
 // roundings of this function itself are covered by MSPA_GUARD_C's slack.

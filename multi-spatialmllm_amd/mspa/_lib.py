@@ -74,6 +74,8 @@ _SIGNATURES = {
     "mspa_inflate_zlib_fast_host": (c_int, [c_void_p, c_int64, c_void_p, c_int64]),
     "mspa_png_header_host": (c_int, [c_char_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32),
                                      POINTER(c_int32)]),
+    "mspa_stream_create_reserving": (c_int, [c_int32, POINTER(c_void_p)]),
+    "mspa_stream_destroy": (c_int, [c_void_p]),
     "mspa_inflate_blocks_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p,
                                            c_void_p, c_void_p]),
     "mspa_png_unfilter_device": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

@@ -232,6 +232,9 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
     without one (``ctx`` None) nothing is exchanged and the same ``consume`` calls happen in the same order.
 
     A window is ``world x per_rank`` items (default: ``MSPA_WINDOW_PER_RANK`` from the environment, else 8).
+    A blob may be a CALLABLE returning the bytes: it runs on a small encoder pool (``MSPA_ENCODE_THREADS``, default 3) while the
+    sweep thread goes on to the next item, and is waited for at the window's exchange -- formatting and compressing a scene's text
+    (63 ms for a visibility index) then overlaps the next scenes' kernels instead of standing between them.
     ``consume`` runs on a writer thread of rank 0 (``_WindowWriter``: window w is written while window w + 1 is produced),
     still strictly in index order, so the files stay those of a one-process run.  ``rank0_share`` (default: the environment's
     ``MSPA_RANK0_SHARE``, else 1.0) scales the share of each window's work dealt to rank 0, the rank that also writes.
@@ -251,6 +254,11 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
     items = iter(work_items(order))
     timings = timings or Timings()
     writer = _WindowWriter(consume, record_width, timings, writer_depth) if rank == 0 else None
+    encoders = ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("MSPA_ENCODE_THREADS", "3"))), thread_name_prefix="mspa-encode")
+
+    def timed_encode(fn):
+        with timings.span("encode_deferred"):
+            return fn()
 
     def vote(failure: Optional[BaseException]) -> None:
         """One int per window: did every rank get through its scenes (and is rank 0's writer alive)?  Raises on EVERY rank."""
@@ -288,7 +296,15 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
                     tagged[:, 0] = index
                     tagged[:, 1:] = records
                     local_rows.append(tagged)
-                local_blobs.append((index, list(blobs)))
+                local_blobs.append((index, [encoders.submit(timed_encode, b) if callable(b) else b for b in blobs]))
+            if failure is None:                            # the deferred blobs of this window: wait, a failure there counts too
+                with timings.span("encode_wait"):
+                    for n, (index, blobs) in enumerate(local_blobs):
+                        try:
+                            local_blobs[n] = (index, [b.result() if hasattr(b, "result") else b for b in blobs])
+                        except Exception as e:
+                            failure = e
+                            break
             vote(failure)
             # ---- the window's one exchange -----------------------------------------------------------------------
             with timings.span("exchange"):
@@ -316,9 +332,11 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
         for _ in items:                                        # drain: lets the prefetcher's generator finish cleanly
             pass
     except BaseException:
+        encoders.shutdown(wait=True)
         if writer is not None:
             writer.close()          # windows exchanged before the failure are complete: they are written, then the error leaves
         raise
+    encoders.shutdown(wait=True)
     # the tail: rank 0 waits for its writer, and the ranks agree once more that nothing failed after the last window's vote
     vote(writer.close() if writer is not None else None)
 

@@ -29,6 +29,22 @@ UPLOAD_SLOTS = int(os.environ.get("MSPA_UPLOAD_SLOTS", "3"))
 # side (each on its own stream) run at 30 k frames/s (profiles/r06_device_ingest.md).  Slots cost HBM, not host time: depth +
 # scanline scratch + compressed bytes = 0.5 GB per 320-frame scene.
 DECODE_SLOTS = int(os.environ.get("MSPA_DECODE_SLOTS", "10"))
+# ... and those long-lived waves fill every compute unit's LDS, so the geometry kernels of the scene being consumed (K1: 13.4 KB
+# of LDS per workgroup) would wait milliseconds for one to retire: the decode streams leave this many compute units alone
+# (mspa_stream_create_reserving: spread over the XCDs), 1/8 of an MI355X by default.
+DECODE_RESERVED_CUS = int(os.environ.get("MSPA_DECODE_RESERVED_CUS", "32"))
+
+
+def _decode_stream(device) -> "torch.cuda.Stream":
+    """A stream for the on-device decode: CU-masked so that DECODE_RESERVED_CUS compute units stay free for other kernels."""
+    import ctypes
+    from . import _lib
+    ptr = ctypes.c_void_p(0)
+    with torch.cuda.device(device):
+        info = _lib.device_info(torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device())
+        reserve = DECODE_RESERVED_CUS if info["n_cu"] >= 4 * max(1, DECODE_RESERVED_CUS) else 0
+        _lib.check(_lib.load().mspa_stream_create_reserving(int(reserve), ctypes.byref(ptr)))
+    return torch.cuda.ExternalStream(ptr.value, device=device)
 STAGE_THREADS = int(os.environ.get("MSPA_STAGE_THREADS", "4"))           # native copy threads per staged chunk
 STAGE_CHUNK_FRAMES = int(os.environ.get("MSPA_STAGE_CHUNK_FRAMES", "160"))  # frames per chunk (98 MB at 640 x 480)
 
@@ -138,7 +154,7 @@ class UploadSlot:
         packed = getattr(sc, "packed", None)
         if packed is not None:
             if self.stream is None:
-                self.stream = torch.cuda.Stream(device=self.device)
+                self.stream = _decode_stream(self.device)       # lives as long as the slot (slots are pooled per process)
             copy_stream = self.stream
         # a scene without depth frames is an empty scene (as SceneOnDevice treats it), not a StopIteration
         first_shape = tuple(packed.hw) if packed is not None else \

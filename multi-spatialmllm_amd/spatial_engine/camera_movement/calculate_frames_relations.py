@@ -210,13 +210,13 @@ def run_split(scene_info_path, output_parquet, warning_file, num_workers=15, sav
         ids = list(scene_infos.get_all_extrinsic_valid_image_ids(scene_id))
         arrays = _row_arrays(rows)
         lines += _bad_value_lines(scene_id, ids, arrays)
-        with timings.span("encode"):
-            t = PairTable(scene_id, ids, arrays)
-            # dictionary pages for the three id columns only: on the float64 columns the encoder hashes every value, overflows
-            # its dictionary page and falls back to plain anyway -- 4 x the encoding time of a row group and a LARGER file
-            # (measured: 22.6 -> 5.9 ms, 1.92 -> 1.56 MB per 51 040-row scene); readers see the same table
-            blobs = ["".join(lines).encode()] + [parquet_splice.encode_row_group(t.to_arrow(nz), use_dictionary=_COLUMNS[:3])
-                                                 for nz in (False, True)]
+        t = PairTable(scene_id, ids, arrays)
+        # The two row groups are encoded on the sweep's encoder threads (callable blobs).  Dictionary pages for the three id
+        # columns only: on the float64 columns the encoder hashes every value, overflows its dictionary page and falls back to
+        # plain anyway -- 4 x the encoding time of a row group and a LARGER file (measured: 22.6 -> 5.9 ms, 1.92 -> 1.56 MB per
+        # 51 040-row scene); readers see the same table
+        blobs = ["".join(lines).encode()] + [
+            (lambda nz=nz: parquet_splice.encode_row_group(t.to_arrow(nz), use_dictionary=_COLUMNS[:3])) for nz in (False, True)]
         print(f"Finished scene {scene_id}.")
         return (rows_dev if keep else None), blobs
 

@@ -114,8 +114,8 @@ def run_split(scene_info_path, output_file, warning_file, num_workers=8, keep=Tr
             # columns all the way: bitsets -> CSR on the device -> JSON text by libmspa's host formatters, straight into
             # arrow's buffers -> this scene's row group, encoded and compressed HERE; what leaves this rank is finished parquet
             # bytes.  No dictionary pages: every key and every JSON list is unique, one would be built, overflow and be dropped.
-            with timings.span("encode"):
-                blobs.append(parquet_splice.encode_row_group(csr.to_arrow(scene_id), use_dictionary=False))
+            # ... on the sweep's encoder threads (a callable blob): 63 ms of formatting + compression per 320-frame scene
+            blobs.append(lambda csr=csr, scene_id=scene_id: parquet_splice.encode_row_group(csr.to_arrow(scene_id), use_dictionary=False))
         if want_csr:
             blobs += [np.ascontiguousarray(getattr(csr, f)) for f in _CSR_FIELDS]
         print(f"[process_scene] Done: {scene_id}")

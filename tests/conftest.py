@@ -10,6 +10,10 @@ for p in (PKG_ROOT, ROOT):
         sys.path.insert(0, p)
 
 
+# before the first HIP call of the session (the GPU probe below): see mspa/__init__.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")

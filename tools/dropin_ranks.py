@@ -108,7 +108,7 @@ def worker(a):
 
 
 def drive(ranks=(1, 2, 4), n_scenes=32, n_frames=320, n_points=131072, workers=None, passes=3, per_rank=2, timeout_s=900,
-          keep_root=None):
+          keep_root=None, decode=None):
     """Returns the leg's dict (see the module docstring).  ``workers`` = decode threads per scene in flight PER RANK, the same
     for every world size (an N-GPU node gives every rank its own cores: what is measured is whether the job scales when the
     per-rank resources are fixed).  Default: the CPUs this container may use (cgroup quota, mspa/hostinfo.py) divided by the
@@ -129,7 +129,7 @@ def drive(ranks=(1, 2, 4), n_scenes=32, n_frames=320, n_points=131072, workers=N
         out_dir = os.path.join(root, "out")
         os.makedirs(out_dir, exist_ok=True)
         res = {"scenes": n_scenes, "frames_per_scene": n_frames, "vertices": n_points, "num_workers_per_rank": workers,
-               "cpus_per_rank": max(1, eff // max(ranks)), "scenes_in_flight_per_rank": 2, "window_scenes_per_rank": per_rank, "passes": passes, "host_cpus": hostinfo.describe(),
+               "depth_decode": decode or os.environ.get("MSPA_DEPTH_DECODE", "device"), "cpus_per_rank": max(1, eff // max(ranks)), "scenes_in_flight_per_rank": 2, "window_scenes_per_rank": per_rank, "passes": passes, "host_cpus": hostinfo.describe(),
                "inputs_written_in_s": round(t_inputs, 1),
                "what": "ranks share ONE GPU and its PCIe link (gloo); decode threads, exchange and rank 0's writer are the real "
                        "ones -- the host-side scaling an N-GPU node sees",
@@ -139,6 +139,8 @@ def drive(ranks=(1, 2, 4), n_scenes=32, n_frames=320, n_points=131072, workers=N
             # every rank of every world size gets the same resources: `eff // max(ranks)` CPUs for its native pool, 2 scenes in flight
             env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MSPA_DIST_BACKEND="gloo", OMP_NUM_THREADS="1",
                        MSPA_HOST_CPUS=str(max(1, eff // max(ranks))), MSPA_LOOKAHEAD="2")
+            if decode:
+                env["MSPA_DEPTH_DECODE"] = decode
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MSPA_BENCH_FORCE_DIST"):
                 env.pop(k, None)
             args = [os.path.abspath(__file__), "--worker", "--root", root, "--out", out_dir, "--workers", str(workers),
@@ -184,7 +186,8 @@ def drive(ranks=(1, 2, 4), n_scenes=32, n_frames=320, n_points=131072, workers=N
                            "rank0_consume_busy_s": busy[0].get("consume"), "rank0_writer_drain_s": busy[0].get("writer_drain"),
                            "rank0_writer_backpressure_s": busy[0].get("writer_backpressure"),
                            "wait_at_exchange_s": [b.get("wait_at_exchange", 0.0) for b in busy],
-                           "produce_s": [b.get("produce") for b in busy], "encode_s": [b.get("encode") for b in busy], "decode_busy_s": [b.get("decode") for b in busy],
+                           "produce_s": [b.get("produce") for b in busy], "encode_s": [b.get("encode_deferred", b.get("encode")) for b in busy],
+                           "encode_wait_s": [b.get("encode_wait") for b in busy], "stage_s": [b.get("stage") for b in busy], "decode_busy_s": [b.get("decode") for b in busy],
                            "exchange_s": [b.get("exchange") for b in busy], "digests": legs[0]["digests"]}
             th1 = hostinfo.throttle_stats()
             w["cfs_throttling_whole_run"] = {k: th1[k] - th0.get(k, 0) for k in th1}
@@ -219,11 +222,12 @@ def main():
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--per-rank", type=int, default=2)
     ap.add_argument("--timeout", type=int, default=900)
+    ap.add_argument("--decode", default=None, help="device | host (default: the sweeps' default, device)")
     a = ap.parse_args()
     if a.worker:
         worker(a)
         return
-    res = drive(tuple(int(x) for x in a.ranks.split(",")), a.scenes, a.frames, a.points, a.workers, a.passes, a.per_rank, a.timeout)
+    res = drive(tuple(int(x) for x in a.ranks.split(",")), a.scenes, a.frames, a.points, a.workers, a.passes, a.per_rank, a.timeout, decode=a.decode)
     print(json.dumps(res))
 
 
