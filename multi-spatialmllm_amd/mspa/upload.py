@@ -12,6 +12,7 @@ from __future__ import annotations
 import os
 import queue
 import threading
+import time
 from typing import Iterable, Iterator, Optional
 
 import numpy as np
@@ -25,20 +26,26 @@ from .scene import SceneOnDevice, valid_image_ids
 # staging (3 ms), H2D (4 ms) and the consumer's kernels + download (1.2 ms) run back to back instead of side by side.
 UPLOAD_SLOTS = int(os.environ.get("MSPA_UPLOAD_SLOTS", "3"))
 # Scenes whose depth frames are decoded ON the device need many of them in flight: one wave inflates one frame and a lone wave
-# takes ~70 ms for a 640 x 480 frame, so a 320-frame scene alone keeps 320 of the chip's ~3 600 such waves busy; ten scenes side by
-# side (each on its own stream) run at 30 k frames/s (profiles/r06_device_ingest.md).  Slots cost HBM, not host time: depth +
-# scanline scratch + compressed bytes = 0.5 GB per 320-frame scene.
-DECODE_SLOTS = int(os.environ.get("MSPA_DECODE_SLOTS", "10"))
-# ... and those long-lived waves fill every compute unit's LDS, so the geometry kernels of the scene being consumed (K1: 13.4 KB
-# of LDS per workgroup) would wait milliseconds for one to retire: the decode streams leave this many compute units alone
-# (mspa_stream_create_reserving: spread over the XCDs), 1/8 of an MI355X by default.
-DECODE_RESERVED_CUS = int(os.environ.get("MSPA_DECODE_RESERVED_CUS", "32"))
+# takes ~70 ms for a 640 x 480 frame, so a 320-frame scene alone keeps 320 of the chip's ~3 600 such waves busy; eight scenes side
+# by side (each on its own stream) run at 27 k frames/s (profiles/r06_device_ingest.md).  Slots cost HBM, not host time: depth +
+# scanline scratch + compressed bytes = 0.5 GB per 320-frame scene.  The FRAMES in flight are capped as well: a decode wave owns
+# 11 KB of its compute unit's LDS for its whole life, 14 of them leave nothing for the geometry kernels of the scene being
+# consumed (K1: 13.4 KB per workgroup), which then wait milliseconds for a wave to retire (measured: 16 ms per scene with 3 200
+# frames in flight); at 2 560 (10 per unit) a third of every unit's LDS stays free.
+DECODE_SLOTS = int(os.environ.get("MSPA_DECODE_SLOTS", "8"))
+DECODE_MAX_FRAMES = int(os.environ.get("MSPA_DECODE_MAX_FRAMES", "2560"))
+# Tried and dropped as the default: decode streams that leave 32 compute units alone (mspa_stream_create_reserving, a CU mask).
+# Every masked stream is a hardware queue of its own; ten of them next to the process's other queues oversubscribe the queue
+# slots and the firmware time-slices them: 47 -> 12.5 scenes/s (profiles/r06_dropin_decode.md).  0 = plain streams.
+DECODE_RESERVED_CUS = int(os.environ.get("MSPA_DECODE_RESERVED_CUS", "0"))
 
 
 def _decode_stream(device) -> "torch.cuda.Stream":
     """A stream for the on-device decode: CU-masked so that DECODE_RESERVED_CUS compute units stay free for other kernels."""
     import ctypes
     from . import _lib
+    if DECODE_RESERVED_CUS <= 0:
+        return torch.cuda.Stream(device=device)
     ptr = ctypes.c_void_p(0)
     with torch.cuda.device(device):
         info = _lib.device_info(torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device())
@@ -291,16 +298,28 @@ class ScenePrefetcher:
                     pass
             return False
 
+        in_flight = {"frames": 0}
+        in_flight_lock = threading.Lock()
+
         def producer():
             try:
                 torch.cuda.set_device(dev_index)
                 for sc in self.scenes:
+                    n_packed = len(sc.packed) if getattr(sc, "packed", None) is not None else 0
+                    while n_packed and not stop.is_set():       # frames being decoded on the device: capped (see DECODE_MAX_FRAMES)
+                        with in_flight_lock:
+                            if in_flight["frames"] == 0 or in_flight["frames"] + n_packed <= DECODE_MAX_FRAMES:
+                                in_flight["frames"] += n_packed
+                                break
+                        time.sleep(0.0005)
                     slot = None
                     while slot is None and not stop.is_set():
                         try:
                             slot = free_slots.get(timeout=0.05)
                         except queue.Empty:
                             pass
+                    if slot is not None:
+                        slot.in_flight_frames = n_packed
                     if slot is None or not put((self._stage(slot, sc, copy_stream), slot, None)):
                         return
             except BaseException as e:                 # surfaces in the consumer
@@ -335,6 +354,12 @@ class ScenePrefetcher:
                     raise err
                 if scene is None:
                     break
+                cur = torch.cuda.current_stream()
+                cur.wait_event(slot.ready)
+                slot.finish_decode()                    # (host wait for this scene's decode) -> its frames leave the in-flight count
+                with in_flight_lock:
+                    in_flight["frames"] -= getattr(slot, "in_flight_frames", 0)
+                    slot.in_flight_frames = 0
                 yield from self._consume((scene, slot), free_slots)
         finally:
             stop.set()                                  # an abandoned iteration: the producer leaves at its next queue poll
