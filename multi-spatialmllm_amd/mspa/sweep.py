@@ -232,7 +232,7 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
     without one (``ctx`` None) nothing is exchanged and the same ``consume`` calls happen in the same order.
 
     A window is ``world x per_rank`` items (default: ``MSPA_WINDOW_PER_RANK`` from the environment, else 8).
-    A blob may be a CALLABLE returning the bytes: it runs on a small encoder pool (``MSPA_ENCODE_THREADS``, default 3) while the
+    A blob may be a CALLABLE returning the bytes: it runs on a small encoder pool (``MSPA_ENCODE_THREADS``, default: half of the CPUs this rank may use, 2 .. 8) while the
     sweep thread goes on to the next item, and is waited for at the window's exchange -- formatting and compressing a scene's text
     (63 ms for a visibility index) then overlaps the next scenes' kernels instead of standing between them.
     ``consume`` runs on a writer thread of rank 0 (``_WindowWriter``: window w is written while window w + 1 is produced),
@@ -254,7 +254,9 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
     items = iter(work_items(order))
     timings = timings or Timings()
     writer = _WindowWriter(consume, record_width, timings, writer_depth) if rank == 0 else None
-    encoders = ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("MSPA_ENCODE_THREADS", "3"))), thread_name_prefix="mspa-encode")
+    from . import hostinfo
+    n_enc = int(os.environ.get("MSPA_ENCODE_THREADS", "0")) or max(2, min(8, hostinfo.effective_cpus() // 2))
+    encoders = ThreadPoolExecutor(max_workers=n_enc, thread_name_prefix="mspa-encode")
 
     def timed_encode(fn):
         with timings.span("encode_deferred"):
