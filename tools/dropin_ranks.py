@@ -108,14 +108,16 @@ def worker(a):
 
 
 def drive(ranks=(1, 2, 4), n_scenes=32, n_frames=320, n_points=131072, workers=None, passes=3, per_rank=2, timeout_s=900,
-          keep_root=None, decode=None):
+          keep_root=None, decode="host"):
     """Returns the leg's dict (see the module docstring).  ``workers`` = decode threads per scene in flight PER RANK, the same
     for every world size (an N-GPU node gives every rank its own cores: what is measured is whether the job scales when the
     per-rank resources are fixed).  Default: the CPUs this container may use (cgroup quota, mspa/hostinfo.py) divided by the
     largest world, by the 2 scenes a rank keeps in flight and by 2 again (the other half of a rank's CPUs is for its main thread:
     staging, JSON formatting, parquet encoding) -- 16 CPUs / 4 ranks / 2 / 2 = 1 on the MI355X boxes -- so that the largest world
     still fits inside the quota instead of being throttled by it (with 2, the index sweep at 4 ranks spent 9.9 CPU-seconds frozen:
-    profiles/r06_dropin_ranks.md)."""
+    profiles/r06_dropin_ranks.md).  ``decode`` = "host" by default HERE: the ranks of this leg share one GPU, and with the depth
+    decode on the device (the sweeps' default at these sizes) that one GPU is what all of them wait for -- 4 ranks x 2 560 frames in
+    flight on a chip that holds 3 584 decode waves -- which says nothing about a node where every rank has its own."""
     from mspa import hostinfo
     eff = hostinfo.effective_cpus(per_rank=False)
     if workers is None:
@@ -222,7 +224,7 @@ def main():
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--per-rank", type=int, default=2)
     ap.add_argument("--timeout", type=int, default=900)
-    ap.add_argument("--decode", default=None, help="device | host (default: the sweeps' default, device)")
+    ap.add_argument("--decode", default="host", help="host (default: the ranks share one GPU) | device")
     a = ap.parse_args()
     if a.worker:
         worker(a)
