@@ -71,6 +71,26 @@ class DiskScene:
         return idx, bbox, cat
 
 
+class TrackFile:
+    """A TAPVid-3D sample file (``<scene>.npz``; keys as OM_C:441-444) known by name and size only: priced for the longest-first
+    assignment without being opened, read -- ``load()`` -- by the rank that owns it alone (a 1 956-file split opened completely,
+    JPEG payloads included, by every rank before sharding is what this replaces)."""
+
+    def __init__(self, path: str):
+        self.path = path
+        self.scene_id = os.path.splitext(os.path.basename(path))[0]
+        self.cost = float(os.path.getsize(path))
+
+    def load(self):
+        from spatial_engine.object_movement.single_object_movement_engine_coord import jpeg_size
+        from . import synth
+        with np.load(self.path, allow_pickle=True) as gt:
+            xyz = np.asarray(gt["tracks_XYZ"], np.float64)
+            w2c = gt["extrinsics_w2c"] if "extrinsics_w2c" in gt.files else np.repeat(np.eye(4)[None], xyz.shape[0], 0)
+            return synth.SynthTracks(self.scene_id, xyz, gt["visibility"], w2c, gt["fx_fy_cx_cy"],
+                                     jpeg_size(bytes(gt["images_jpeg_bytes"][0])))      # only the first payload is touched
+
+
 def _n_points(sc) -> int:
     return int(sc.n_points) if hasattr(sc, "n_points") else int(sc.points.shape[0])
 
@@ -129,162 +149,178 @@ def _unpack_outputs(buf, into: Dict[str, list]):
         into.setdefault(name, []).extend(zip(keys, lines))
 
 
+class RecordSpill:
+    """Rank 0's collector of finished records: (sort key, JSON line) pairs per output file, held in memory up to
+    ``limit_bytes`` per file and in sorted run files on disk beyond that.  ``finish(name, rng)`` yields the lines in the
+    pipeline's final order -- canonical order (key, then the line: independent of who produced what and when), then the seeded
+    shuffle -- as an external merge, so what rank 0 holds is bounded by the limit, not by the 27 M records of a full
+    regeneration.  Both routes give the same bytes (tests/test_pipeline_spill.py)."""
+
+    def __init__(self, directory: str, limit_bytes: int):
+        self.dir, self.limit = directory, max(1, int(limit_bytes))
+        self.mem: Dict[str, list] = {}
+        self.mem_bytes: Dict[str, int] = {}
+        self.runs: Dict[str, List[str]] = {}
+        self.counts: Dict[str, int] = {}
+        self.total_bytes = 0
+        self.runs_written = 0
+
+    def names(self):
+        return sorted(set(self.mem) | set(self.runs) | set(self.counts))
+
+    def touch(self, name: str):
+        self.counts.setdefault(name, 0)
+
+    def add_packed(self, buf):
+        got: Dict[str, list] = {}
+        _unpack_outputs(buf, got)
+        for name, pairs in got.items():
+            self.counts[name] = self.counts.get(name, 0) + len(pairs)
+            self.mem.setdefault(name, []).extend(pairs)
+            n = sum(len(k) + len(ln) + 2 for k, ln in pairs)
+            self.mem_bytes[name] = self.mem_bytes.get(name, 0) + n
+            self.total_bytes += n
+            if self.mem_bytes[name] > self.limit:
+                self._spill(name)
+
+    @staticmethod
+    def _write_run(path, pairs):
+        with open(path, "wb") as f:
+            for k, ln in pairs:
+                kb = k.encode()
+                f.write(struct.pack("<ii", len(kb), len(ln)))
+                f.write(kb)
+                f.write(ln)
+
+    @staticmethod
+    def _read_run(path):
+        with open(path, "rb") as f:
+            while True:
+                head = f.read(8)
+                if len(head) < 8:
+                    return
+                nk, nl = struct.unpack("<ii", head)
+                yield f.read(nk).decode(), f.read(nl)
+
+    def _spill(self, name):
+        pairs = self.mem.pop(name, [])
+        self.mem_bytes[name] = 0
+        if not pairs:
+            return
+        pairs.sort()
+        os.makedirs(self.dir, exist_ok=True)
+        path = os.path.join(self.dir, f"{name}.run{len(self.runs.get(name, []))}")
+        self._write_run(path, pairs)
+        self.runs_written += 1
+        self.runs.setdefault(name, []).append(path)
+
+    def finish(self, name: str, rng: random.Random):
+        """The file's lines in final order; the run files of ``name`` are removed."""
+        import heapq
+        n = self.counts.get(name, 0)
+        if not self.runs.get(name):                           # everything in memory: sort, shuffle
+            pairs = self.mem.pop(name, [])
+            pairs.sort()
+            rng.shuffle(pairs)
+            for _k, ln in pairs:
+                yield ln
+            return
+        self._spill(name)                                     # the remainder becomes the last run
+        runs = self.runs.pop(name)
+        # the seeded shuffle of the canonical order, as a permutation: after `shuffle`, position j holds element perm[j]
+        from array import array
+        perm = array("q", range(n))
+        rng.shuffle(perm)
+        dest = array("q", bytes(8 * n))
+        for j in range(n):
+            dest[perm[j]] = j
+        del perm
+        # second external sort, by destination: chunks of the canonical stream, each sorted by where its lines go
+        chunk, size, second = [], 0, []
+        def flush_chunk():
+            nonlocal chunk, size
+            if chunk:
+                chunk.sort()
+                path = os.path.join(self.dir, f"{name}.dst{len(second)}")
+                with open(path, "wb") as f:
+                    for d, ln in chunk:
+                        f.write(struct.pack("<qi", d, len(ln)))
+                        f.write(ln)
+                second.append(path)
+                chunk, size = [], 0
+        for i, (_k, ln) in enumerate(heapq.merge(*[self._read_run(p) for p in runs])):
+            chunk.append((dest[i], ln))
+            size += len(ln) + 16
+            if size > self.limit:
+                flush_chunk()
+        flush_chunk()
+        for pth in runs:
+            os.remove(pth)
+
+        def read_dst(path):
+            with open(path, "rb") as f:
+                while True:
+                    head = f.read(12)
+                    if len(head) < 12:
+                        return
+                    d, nl = struct.unpack("<qi", head)
+                    yield d, f.read(nl)
+        for _d, ln in heapq.merge(*[read_dst(pth) for pth in second]):
+            yield ln
+        for pth in second:
+            os.remove(pth)
+
+
 def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None, device="cuda", seed: int = 0,
         n_camera: int = 64, n_correspondence: int = 64, depth_images_per_scene: int = 4,
         overlap_range=(6, 35), question_types: Sequence[str] = ("total_distance", "displacement_vector"),
-        object_perception: bool = True, tracks: Sequence = (), loader_threads: int = 2) -> Dict[str, int]:
+        object_perception: bool = True, tracks: Sequence = (), loader_threads: int = 2,
+        spill_bytes: Optional[int] = None) -> Dict[str, int]:
     """Run the ScanNet-side heads over ``scenes`` -- in-memory scenes (K, A, E, depth, points, color_hw, scene_id,
-    valid_image_ids; ``mspa.synth``) or ``DiskScene`` objects -- and the object-movement family over ``tracks``.
-    Returns {jsonl name: record count} on rank 0 (empty dict elsewhere)."""
+    valid_image_ids; ``mspa.synth``) or ``DiskScene`` objects -- and the object-movement family over ``tracks`` (arrays or
+    ``TrackFile``s).  Returns {jsonl name: record count} on rank 0 (empty dict elsewhere).
+
+    Streamed: no rank keeps more scenes resident than its upload slots, and rank 0 holds a window of records, not the job's.
+      pass 1  every scene once, sharded in windows (``sweep.sharded_sweep``: longest-first, prefetched -- depth PNGs decoded
+              on the device for on-disk scenes): its pair-table rows (K1 + K2 + K4) AND the heads that need nothing but the
+              scene itself (depth estimation / comparison, object perception) while it is resident; rows and finished record
+              bytes go to rank 0 per window (``collate_records(dst=0)`` + ``gather_bytes``: RCCL);
+      sample  rank 0 draws the camera-movement and correspondence rows from the whole table (seeded, the reference's
+              overlap-binned sampler) and broadcasts the few sampled rows;
+      pass 2  the scenes that own sampled rows once more, sharded the same way: camera movement (K4) and correspondences
+              (K2 + K6), text built by the owner;
+      tracks  the TAPVid blocks, sharded by file size, read by their owners on loader threads;
+      write   rank 0 puts every file into canonical order and applies its seeded shuffle -- in memory, or as an external merge
+              over sorted run files once a file's records exceed ``spill_bytes`` (``RecordSpill``)."""
     import pandas as pd
+    import resource
     import torch
     from . import sweep
     from .scene import SceneOnDevice
 
     rank, world = (ctx.rank, ctx.world) if ctx is not None else (0, 1)
     LAST_TIMINGS.clear()
-    t_phase = time.perf_counter()
-    costs = [shard.scene_cost(len(sc.valid_image_ids), _n_points(sc)) for sc in scenes]
-    scene_bins = shard.lpt_assign(costs, world)
-    scene_owner = {k: r for r, b in enumerate(scene_bins) for k in b}
-    mine = scene_bins[rank]
+    if spill_bytes is None:
+        spill_bytes = int(os.environ.get("MSPA_PIPELINE_SPILL_MB", "512")) << 20
+    os.makedirs(out_dir, exist_ok=True)
+    spill = RecordSpill(os.path.join(out_dir, ".spill"), spill_bytes) if rank == 0 else None
+    timings = sweep.Timings()
 
-    # ---- my scenes: read (loader threads decode the next scene while this one is uploaded), keep resident ----------------
-    def load(k):
-        return scenes[k].load() if hasattr(scenes[k], "load") else scenes[k]
-    resident = {}
-    for k, hs in zip(mine, sweep.SceneLoader(load, mine, lookahead=max(1, int(loader_threads)))):
-        resident[k] = SceneOnDevice(hs.K, hs.A, hs.E, hs.depth, hs.color_hw, hs.points, device,
-                                    depth_scale=getattr(hs, "depth_scale", 0.001))
-    LAST_TIMINGS["load_s"] = time.perf_counter() - t_phase
-    t_phase = time.perf_counter()
-
-    # ---- geometry of my scenes; pair table collation --------------------------------------------
-    local = [pair_table_rows(k, resident[k]) for k in mine]
-    local = torch.cat(local, 0) if local else torch.zeros((0, 7), dtype=torch.float64, device=device)
-    table = shard.collate_records(local, ctx) if ctx is not None else local
-    table = table.cpu().numpy()
-    order = np.lexsort((table[:, 2], table[:, 1], table[:, 0]))          # rank-independent row order
-    table = table[order]
-    # id columns by fancy indexing (no Python object per row: ScanNet's table has 10^8 of them)
-    frame_ids = [list(scenes[k].valid_image_ids) for k in range(len(scenes))]
-    first = np.concatenate([[0], np.cumsum([len(f) for f in frame_ids])]).astype(np.int64)
-    flat_ids = np.array([i for f in frame_ids for i in f] or [""], dtype=object)
-    scene_col = table[:, 0].astype(np.int64)
-    df = pd.DataFrame({
-        "scene_id": np.array([sc.scene_id for sc in scenes] or [""], dtype=object)[scene_col],
-        "image_id1": flat_ids[first[scene_col] + table[:, 1].astype(np.int64)],
-        "image_id2": flat_ids[first[scene_col] + table[:, 2].astype(np.int64)],
-        "overlap": table[:, 3], "distance": table[:, 4], "yaw": table[:, 5], "pitch": table[:, 6],
-        "_scene": scene_col,
-    })
-
-    # ---- the heads as units of work: (collation name, unit key, fn(scene) -> records or {name: records}) ----------------
-    # A unit is one scene (or one track block) of one head; its generator is seeded per unit, so what it produces does not
-    # depend on which rank runs it.
-    from . import engine
-    LAST_TIMINGS["pair_table_s"] = time.perf_counter() - t_phase
-    t_phase = time.perf_counter()
-    units: Dict[str, List] = {}
-
-    def rows_by_scene(sampled):
-        by: Dict[int, List] = {}
-        for k in range(len(sampled)):
-            row = sampled.iloc[k].to_dict()
-            by.setdefault(int(row["_scene"]), []).append((k, row))
-        return by
-
-    # camera movement (seed as upstream: CME:17-18)
-    for qt in question_types:
-        np.random.seed(seed)
-        random.seed(seed)
-        sampled = sampling.sample_dataframe(df, n_camera, 0, overlap_range[0], overlap_range[1], 1)
-        for s, items in sorted(rows_by_scene(sampled).items()):
-            def cm_unit(scene, s=s, items=items, qt=qt):
-                rng = random.Random(f"{seed}:{qt}:{s}")             # per-scene stream: result independent of the sharding
-                t12, t21 = heads.camera_movement_numeric(scene, [r for _, r in items])
-                return [heads.camera_movement_record(row, k, qt, t12[n], t21[n], scenes[s].color_hw, T.CAMERA_MOVEMENT, rng)
-                        for n, (k, row) in enumerate(items)]
-            units.setdefault(f"camera_movement_{qt}", []).append((s, cm_unit))
-
-    # visual correspondence (VC_C:11-12 seeds 1)
-    np.random.seed(seed + 1)
-    sampled = sampling.sample_dataframe(df, n_correspondence, 0, overlap_range[0], overlap_range[1], 1)
-    units["visual_correspondence_coor_2_coor"] = []
-    for s, items in sorted(rows_by_scene(sampled).items()):
-        def vc_unit(scene, s=s, items=items):
-            rng = random.Random(f"{seed}:vc:{s}")
-            return heads.visual_correspondence_records(scene, [r for _, r in items], scenes[s].color_hw, 0,
-                                                       T.VISUAL_CORRESPONDENCE, rng)
-        units["visual_correspondence_coor_2_coor"].append((s, vc_unit))
-
-    # depth estimation / comparison: every scene
-    units["depth_estimation_coor"], units["depth_comparison_coor"] = [], []
-    for s in range(len(scenes)):
-        def de_unit(scene, s=s):
-            return heads.depth_estimation_records(scene, scenes[s].scene_id, scenes[s].color_hw, depth_images_per_scene,
-                                                  T.DEPTH_ESTIMATION, random.Random(f"{seed}:depth:{s}"))
-
-        def dc_unit(scene, s=s):
-            return heads.depth_comparison_records_gpu(scene, scenes[s].scene_id, scenes[s].color_hw, depth_images_per_scene,
-                                                      T.DEPTH_COMPARISON, random.Random(f"{seed}:depthcmp:{s}"))
-        units["depth_estimation_coor"].append((s, de_unit))
-        units["depth_comparison_coor"].append((s, dc_unit))
-
-    # object perception: visibility + coverage + records, per scene (COVIS / COV / OPE); one unit yields several files
-    if object_perception:
-        units["object_perception"] = []
-        for s in range(len(scenes)):
-            if not hasattr(scenes[s], "objects") or (isinstance(scenes[s], DiskScene) and not scenes[s].has_objects()):
-                continue
-
-            def op_unit(scene, s=s):
-                idx, bbox, cat = scenes[s].objects()
-                rng = random.Random(f"{seed}:op:{s}")
-                cov, _ = scene.object_coverage(idx, bbox, rng=rng)
-                by_name: Dict[str, List[dict]] = {}
-                for dim in ("height", "length", "width"):
-                    table = {scenes[s].scene_id: {o: res[dim] for o, res in cov.items()}}
-                    size = {"height": lambda o: bbox[o][5], "length": lambda o: max(bbox[o][3], bbox[o][4]),
-                            "width": lambda o: min(bbox[o][3], bbox[o][4])}[dim]
-                    by_k = heads.object_perception_records(table, dim, lambda _s, o: size(o), lambda _s, o: cat[o],
-                                                           scenes[s].color_hw, 6, T.OBJECT_PERCEPTION, rng)
-                    for k, recs in by_k.items():
-                        if recs:
-                            by_name.setdefault(f"object_perception_{dim}_k{k}", []).extend(recs)
-                return by_name
-            units["object_perception"].append((s, op_unit))
-
-    # object movement on TAPVid-style track blocks (OM_C): blocks sharded like scenes; a block is its own "scene"
-    track_owner = {}
-    if tracks:
-        from scipy.cluster.hierarchy import fcluster, linkage
-        from scipy.spatial.distance import squareform
-        bins = shard.lpt_assign([float(t.tracks_XYZ.shape[0]) * t.tracks_XYZ.shape[1] ** 2 for t in tracks], world)
-        track_owner = {k: r for r, b in enumerate(bins) for k in b}
-        for qt in T.OBJECT_MOVEMENT_TYPES:
-            units[f"object_movement_{qt}"] = []
-            for k in range(len(tracks)):
-                def om_unit(_scene, k=k, qt=qt):
-                    import torch
-                    from . import engine as E
-                    tr = tracks[k]
-                    rng = random.Random(f"{seed}:om:{qt}:{k}")
-                    xyz = np.ascontiguousarray(tr.tracks_XYZ, dtype=np.float64)
-                    dev_tracks = torch.from_numpy(xyz).to(device)
-                    loss = E.track_rigidity_loss(dev_tracks).cpu().numpy()                              # K7
-                    labels = fcluster(linkage(squareform(loss, checks=False), method="average"), 0.1, criterion="distance")
-                    groups = [g for g in (np.where(labels == i)[0].tolist() for i in range(1, max(labels) + 1)) if len(g) > 5]
-                    c2w = torch.from_numpy(np.linalg.inv(tr.extrinsics_w2c).reshape(-1, 16)).to(device)
-                    world_xyz = E.track_to_world(dev_tracks, c2w, tr.fx_fy_cx_cy, tr.image_hw, ("world",))["world"]   # K5a
-                    pairs_k = heads.object_movement_mine_pairs(                                       # K5c
-                        tr.visibility, groups, lambda p, f: E.track_pair_distances(world_xyz, p, f), 5, 3, True, 0.05, rng)
-                    return heads.object_movement_records(tr.scene_id, xyz, tr.extrinsics_w2c, tr.fx_fy_cx_cy, tr.image_hw,
-                                                         pairs_k, qt, T.OBJECT_MOVEMENT, rng, device)   # K5a + K5b
-                units[f"object_movement_{qt}"].append((k, om_unit))
-
-    def owner_of(name, key):
-        return track_owner[key] if name.startswith("object_movement_") else scene_owner[key]
+    def scene_items(indices):
+        """Resident scenes for ``indices``, in order: prefetched from disk (a DiskScene's handler streams them: native loader
+        threads, pinned staging, on-device decode) or uploaded from the arrays of an in-memory scene."""
+        indices = list(indices)
+        if indices and all(isinstance(scenes[k], DiskScene) for k in indices) and len({id(scenes[k].handler) for k in indices}) == 1:
+            h = scenes[indices[0]].handler
+            it = h.prefetched_scenes([scenes[k].scene_id for k in indices], scenes[indices[0]].num_workers, device, timings)
+        else:
+            def gen():
+                for k in indices:
+                    hs = scenes[k].load() if hasattr(scenes[k], "load") else scenes[k]
+                    yield SceneOnDevice(hs.K, hs.A, hs.E, hs.depth, hs.color_hw, hs.points, device,
+                                        depth_scale=getattr(hs, "depth_scale", 0.001))
+            it = gen()
+        yield from it
 
     def merge(outputs, name, produced):
         if isinstance(produced, dict):
@@ -293,39 +329,184 @@ def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None,
         else:
             outputs.setdefault(name, []).extend(produced)
 
-    # ---- run the units this rank owns: numbers AND text, here ------------------------------------------------------
-    outputs: Dict[str, List[dict]] = {}
-    for name in sorted(units):
-        if name != "object_perception":
-            outputs.setdefault(name, [])
-        for key, fn in units[name]:
-            if owner_of(name, key) == rank:
-                merge(outputs, name, fn(resident.get(key)))
+    def op_records(scene, s):
+        idx, bbox, cat = scenes[s].objects()
+        rng = random.Random(f"{seed}:op:{s}")
+        cov, _ = scene.object_coverage(idx, bbox, rng=rng)
+        by_name: Dict[str, List[dict]] = {}
+        for dim in ("height", "length", "width"):
+            table = {scenes[s].scene_id: {o: res[dim] for o, res in cov.items()}}
+            size = {"height": lambda o: bbox[o][5], "length": lambda o: max(bbox[o][3], bbox[o][4]),
+                    "width": lambda o: min(bbox[o][3], bbox[o][4])}[dim]
+            by_k = heads.object_perception_records(table, dim, lambda _s, o: size(o), lambda _s, o: cat[o],
+                                                   scenes[s].color_hw, 6, T.OBJECT_PERCEPTION, rng)
+            for k, recs in by_k.items():
+                if recs:
+                    by_name.setdefault(f"object_perception_{dim}_k{k}", []).extend(recs)
+        return by_name
+
+    # ---- pass 1: pair-table rows + the scene-local heads -----------------------------------------------------------------
+    t_phase = time.perf_counter()
+    costs = [shard.scene_cost(len(sc.valid_image_ids), _n_points(sc)) for sc in scenes]
+    table_parts: List[np.ndarray] = []
+    records_bytes = [0]
+
+    def produce1(s, scene):
+        rows = pair_table_rows(s, scene)
+        outputs: Dict[str, List[dict]] = {}
+        # a unit is one scene of one head, its generator seeded per unit: what it produces does not depend on who runs it
+        merge(outputs, "depth_estimation_coor",
+              heads.depth_estimation_records(scene, scenes[s].scene_id, scenes[s].color_hw, depth_images_per_scene,
+                                             T.DEPTH_ESTIMATION, random.Random(f"{seed}:depth:{s}")))
+        merge(outputs, "depth_comparison_coor",
+              heads.depth_comparison_records_gpu(scene, scenes[s].scene_id, scenes[s].color_hw, depth_images_per_scene,
+                                                 T.DEPTH_COMPARISON, random.Random(f"{seed}:depthcmp:{s}")))
+        if object_perception and hasattr(scenes[s], "objects") and \
+                not (isinstance(scenes[s], DiskScene) and not scenes[s].has_objects()):
+            merge(outputs, "object_perception", op_records(scene, s))
+        packed = _pack_outputs(outputs)
+        records_bytes[0] += len(packed)
+        return rows, [packed]
+
+    def consume_records(_index, rows, blobs):
+        if rows is not None and len(rows):
+            table_parts.append(np.array(rows, copy=True))
+        spill.add_packed(blobs[0])
+
+    sweep.sharded_sweep(costs, ctx, scene_items, produce1, consume_records, record_width=7, timings=timings)
+    LAST_TIMINGS["load_s"] = timings.as_dict().get("decode", 0.0)
+    LAST_TIMINGS["pair_table_s"] = time.perf_counter() - t_phase
+    t_phase = time.perf_counter()
+
+    # ---- sample on rank 0, broadcast the sampled rows --------------------------------------------------------------------
+    plan = None
+    if rank == 0:
+        table = np.concatenate(table_parts, 0) if table_parts else np.zeros((0, 7))
+        del table_parts
+        order = np.lexsort((table[:, 2], table[:, 1], table[:, 0]))      # rank-independent row order
+        table = table[order]
+        # id columns by fancy indexing (no Python object per row: ScanNet's table has 10^8 of them)
+        frame_ids = [list(scenes[k].valid_image_ids) for k in range(len(scenes))]
+        first = np.concatenate([[0], np.cumsum([len(f) for f in frame_ids])]).astype(np.int64)
+        flat_ids = np.array([i for f in frame_ids for i in f] or [""], dtype=object)
+        scene_col = table[:, 0].astype(np.int64)
+        df = pd.DataFrame({
+            "scene_id": np.array([sc.scene_id for sc in scenes] or [""], dtype=object)[scene_col],
+            "image_id1": flat_ids[first[scene_col] + table[:, 1].astype(np.int64)],
+            "image_id2": flat_ids[first[scene_col] + table[:, 2].astype(np.int64)],
+            "overlap": table[:, 3], "distance": table[:, 4], "yaw": table[:, 5], "pitch": table[:, 6],
+            "_scene": scene_col,
+        })
+
+        def rows_by_scene(sampled):
+            by: Dict[int, List] = {}
+            for k in range(len(sampled)):
+                row = sampled.iloc[k].to_dict()
+                by.setdefault(int(row["_scene"]), []).append((k, {c: (v.item() if hasattr(v, "item") else v) for c, v in row.items()}))
+            return by
+        plan = {"cm": {}, "vc": {}}
+        for qt in question_types:                                  # camera movement (seed as upstream: CME:17-18)
+            np.random.seed(seed)
+            random.seed(seed)
+            plan["cm"][qt] = rows_by_scene(sampling.sample_dataframe(df, n_camera, 0, overlap_range[0], overlap_range[1], 1))
+        np.random.seed(seed + 1)                                   # visual correspondence (VC_C:11-12 seeds 1)
+        plan["vc"] = rows_by_scene(sampling.sample_dataframe(df, n_correspondence, 0, overlap_range[0], overlap_range[1], 1))
+        LAST_TIMINGS["pair_table_rows"] = float(len(df))
+        del df, table
+    plan = shard.broadcast_object(plan, ctx, src=0)
+
+    # ---- pass 2: the scenes that own sampled rows ------------------------------------------------------------------------
+    wanted = sorted({s for qt in plan["cm"] for s in plan["cm"][qt]} | set(plan["vc"]))
+
+    def produce2(pos, scene):
+        s = wanted[pos]
+        outputs: Dict[str, List[dict]] = {}
+        for qt in question_types:
+            items = plan["cm"][qt].get(s)
+            if items:
+                rng = random.Random(f"{seed}:{qt}:{s}")          # per-scene stream: result independent of the sharding
+                t12, t21 = heads.camera_movement_numeric(scene, [r for _, r in items])
+                merge(outputs, f"camera_movement_{qt}",
+                      [heads.camera_movement_record(row, k, qt, t12[n], t21[n], scenes[s].color_hw, T.CAMERA_MOVEMENT, rng)
+                       for n, (k, row) in enumerate(items)])
+        items = plan["vc"].get(s)
+        if items:
+            merge(outputs, "visual_correspondence_coor_2_coor",
+                  heads.visual_correspondence_records(scene, [r for _, r in items], scenes[s].color_hw, 0,
+                                                      T.VISUAL_CORRESPONDENCE, random.Random(f"{seed}:vc:{s}")))
+        packed = _pack_outputs(outputs)
+        records_bytes[0] += len(packed)
+        return None, [packed]
+
+    n_rows = [float(sum(len(plan["cm"][qt].get(s, ())) for qt in plan["cm"]) + len(plan["vc"].get(s, ()))) for s in wanted]
+    sweep.sharded_sweep(n_rows, ctx, lambda positions: scene_items([wanted[p] for p in positions]), produce2, consume_records,
+                        timings=timings)
     LAST_TIMINGS["heads_s"] = time.perf_counter() - t_phase
     t_phase = time.perf_counter()
 
-    # ---- the one exchange of finished records: bytes to rank 0 -------------------------------------------------------
-    packed = _pack_outputs(outputs)
-    LAST_TIMINGS["records_bytes"] = float(len(packed))
-    parts = shard.gather_bytes(packed, ctx, dst=0) if ctx is not None else [np.frombuffer(packed, dtype=np.uint8)]
-    LAST_TIMINGS["exchange_s"] = time.perf_counter() - t_phase
+    # ---- object movement on TAPVid-style track blocks (OM_C): sharded by size, read by their owners ----------------------
+    if tracks:
+        from scipy.cluster.hierarchy import fcluster, linkage
+        from scipy.spatial.distance import squareform
+        from . import engine as E
+        tcosts = [t.cost if hasattr(t, "cost") else float(t.tracks_XYZ.shape[0]) * t.tracks_XYZ.shape[1] ** 2 for t in tracks]
+
+        def track_items(indices):
+            return sweep.SceneLoader(lambda k: tracks[k].load() if hasattr(tracks[k], "load") else tracks[k], list(indices),
+                                     lookahead=max(1, int(loader_threads)), timings=timings)
+
+        def produce_tracks(k, tr):
+            outputs: Dict[str, List[dict]] = {}
+            xyz = np.ascontiguousarray(tr.tracks_XYZ, dtype=np.float64)
+            dev_tracks = torch.from_numpy(xyz).to(device)
+            loss = E.track_rigidity_loss(dev_tracks).cpu().numpy()                                  # K7
+            labels = fcluster(linkage(squareform(loss, checks=False), method="average"), 0.1, criterion="distance")
+            groups = [g for g in (np.where(labels == i)[0].tolist() for i in range(1, max(labels) + 1)) if len(g) > 5]
+            c2w = torch.from_numpy(np.linalg.inv(tr.extrinsics_w2c).reshape(-1, 16)).to(device)
+            world_xyz = E.track_to_world(dev_tracks, c2w, tr.fx_fy_cx_cy, tr.image_hw, ("world",))["world"]       # K5a
+            for qt in T.OBJECT_MOVEMENT_TYPES:
+                rng = random.Random(f"{seed}:om:{qt}:{k}")
+                pairs_k = heads.object_movement_mine_pairs(                                           # K5c
+                    tr.visibility, groups, lambda p, f: E.track_pair_distances(world_xyz, p, f), 5, 3, True, 0.05, rng)
+                merge(outputs, f"object_movement_{qt}",
+                      heads.object_movement_records(tr.scene_id, xyz, tr.extrinsics_w2c, tr.fx_fy_cx_cy, tr.image_hw,
+                                                    pairs_k, qt, T.OBJECT_MOVEMENT, rng, device))        # K5a + K5b
+            packed = _pack_outputs(outputs)
+            records_bytes[0] += len(packed)
+            return None, [packed]
+        sweep.sharded_sweep(tcosts, ctx, track_items, produce_tracks, consume_records, timings=timings)
+    LAST_TIMINGS["tracks_s"] = time.perf_counter() - t_phase
+    LAST_TIMINGS["exchange_s"] = timings.as_dict().get("exchange", 0.0)
+    LAST_TIMINGS["records_bytes"] = float(records_bytes[0])
     t_phase = time.perf_counter()
 
-    # ---- rank 0: canonical order, seeded shuffle, JSONL ------------------------------------------------------
+    # ---- rank 0: canonical order, seeded shuffle, JSONL ------------------------------------------------------------------
     counts: Dict[str, int] = {}
-    os.makedirs(out_dir, exist_ok=True)
     if rank == 0:
-        merged: Dict[str, list] = {}
-        for p in parts:
-            _unpack_outputs(p, merged)
-        for name in sorted(merged):
-            allrecs = merged[name]
-            allrecs.sort()                                      # canonical order first: (str(id), line) -- sharding-independent
-            random.Random(f"{seed}:{name}").shuffle(allrecs)
+        for qt in question_types:
+            spill.touch(f"camera_movement_{qt}")
+        for name in ("visual_correspondence_coor_2_coor", "depth_estimation_coor", "depth_comparison_coor"):
+            spill.touch(name)
+        if tracks:
+            for qt in T.OBJECT_MOVEMENT_TYPES:
+                spill.touch(f"object_movement_{qt}")
+        for name in spill.names():
+            n = 0
             with open(os.path.join(out_dir, f"{name}.jsonl"), "wb") as f:
-                f.writelines(line + b"\n" for _, line in allrecs)
-            counts[name] = len(allrecs)
+                for line in spill.finish(name, random.Random(f"{seed}:{name}")):
+                    f.write(line + b"\n")
+                    n += 1
+            counts[name] = n
+        if os.path.isdir(spill.dir) and not os.listdir(spill.dir):
+            os.rmdir(spill.dir)
         LAST_TIMINGS["write_s"] = time.perf_counter() - t_phase
+        LAST_TIMINGS["spill_runs"] = float(spill.runs_written)
+    from . import upload
+    # what a rank keeps resident at once: the prefetcher's upload slots for on-disk scenes (3, or DECODE_SLOTS when the depth
+    # frames are decoded on the device), one scene for in-memory ones -- never the split
+    LAST_TIMINGS["max_resident_scenes"] = float(max(upload.UPLOAD_SLOTS, upload.DECODE_SLOTS)
+                                                if any(isinstance(sc, DiskScene) for sc in scenes) else 1)
+    LAST_TIMINGS["peak_rss_mb"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
     return counts
 
 
@@ -359,14 +540,7 @@ def main():
         scenes = [synth.make_scene(7000 + k, n_points=args.points, n_frames=args.frames + 3 * (k % 3),
                                    color_hw=(480, 640), with_color=False) for k in range(args.scenes)]
     if args.tapvid_root:
-        from spatial_engine.object_movement.single_object_movement_engine_coord import jpeg_size, load_tapvid_sample
-        tracks = []
-        for name in sorted(n for n in os.listdir(args.tapvid_root) if n.endswith(".npz")):
-            gt = load_tapvid_sample(os.path.join(args.tapvid_root, name))
-            n_frames = gt["tracks_XYZ"].shape[0]
-            w2c = gt["extrinsics_w2c"] if "extrinsics_w2c" in gt else np.repeat(np.eye(4)[None], n_frames, 0)
-            tracks.append(synth.SynthTracks(os.path.splitext(name)[0], np.asarray(gt["tracks_XYZ"], np.float64), gt["visibility"],
-                                            w2c, gt["fx_fy_cx_cy"], jpeg_size(bytes(gt["images_jpeg_bytes"][0]))))
+        tracks = [TrackFile(os.path.join(args.tapvid_root, name)) for name in sorted(os.listdir(args.tapvid_root)) if name.endswith(".npz")]
     else:
         tracks = [synth.make_tracks(300 + k, T=120, P=96, n_groups=4) for k in range(args.tracks)]
     counts = run(scenes, args.out, ctx, device, args.seed, tracks=tracks)

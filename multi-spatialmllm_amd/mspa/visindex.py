@@ -124,3 +124,49 @@ def from_bits(bits, image_ids: List[str], n_points: int) -> VisibilityCSR:
     t = engine.bits_transpose(bits)                      # [n_words * 64, ceil(F / 64)]; rows >= N are padding (all zero)
     o2, i2 = engine.bitset_csr(t[:n_points].contiguous() if t.shape[0] != n_points else t)
     return VisibilityCSR(list(image_ids), n_points, o1.cpu().numpy(), i1.cpu().numpy(), o2.cpu().numpy(), i2.cpu().numpy())
+
+
+class SceneRowGroups:
+    """Scene-addressable reader of the visibility-index parquet (columns ``key`` = "scene:kind:item", ``values`` = JSON text;
+    MVI:38-73): which row groups hold which scene is read off the ``key`` column's min / max statistics in the footer, so a rank
+    of a sharded job loads the rows of ITS scenes only -- the reference loads the whole table (13 GB for the train split) into a
+    dict in every process (COVIS:60-70, IH:486-500).  A row group whose keys span several scenes (files written with pandas'
+    default 1 M-row groups) is read once and kept.  ``scene_dict(scene_id)`` -> {key: JSON text} of that scene."""
+
+    def __init__(self, parquet_file: str):
+        import pyarrow.parquet as pq
+        self.file = pq.ParquetFile(parquet_file)
+        md = self.file.metadata
+        key_col = self.file.schema_arrow.get_field_index("key")
+        self._by_scene: Dict[str, List[int]] = {}
+        self._mixed: List[tuple] = []                       # (row group, first scene, last scene)
+        self._cache: Dict[int, Dict[str, Dict[str, str]]] = {}
+        for g in range(md.num_row_groups):
+            st = md.row_group(g).column(key_col).statistics
+            if st is None or not st.has_min_max:
+                self._mixed.append((g, "", "\U0010ffff"))
+                continue
+            lo, hi = str(st.min).split(":", 1)[0], str(st.max).split(":", 1)[0]
+            if lo == hi:
+                self._by_scene.setdefault(lo, []).append(g)
+            else:
+                self._mixed.append((g, lo, hi))
+
+    def _split_group(self, g: int) -> Dict[str, Dict[str, str]]:
+        if g not in self._cache:
+            t = self.file.read_row_group(g, columns=["key", "values"])
+            per: Dict[str, Dict[str, str]] = {}
+            for k, v in zip(t.column("key").to_pylist(), t.column("values").to_pylist()):
+                per.setdefault(k.split(":", 1)[0], {})[k] = v
+            self._cache[g] = per
+        return self._cache[g]
+
+    def scene_dict(self, scene_id: str) -> Dict[str, str]:
+        out: Dict[str, str] = {}
+        for g in self._by_scene.get(scene_id, []):
+            t = self.file.read_row_group(g, columns=["key", "values"])
+            out.update(zip(t.column("key").to_pylist(), t.column("values").to_pylist()))
+        for g, lo, hi in self._mixed:
+            if lo <= scene_id <= hi:
+                out.update(self._split_group(g).get(scene_id, {}))
+        return out

@@ -52,7 +52,22 @@ def _tracks():
 
 def _write_inputs(root):
     from mspa import synth
-    synth.write_scannet_layout(_scenes(), os.path.join(root, "data", "scannet"), jpeg_for_every_image=True)
+    scenes = _scenes()
+    paths = synth.write_scannet_layout(scenes, os.path.join(root, "data", "scannet"), jpeg_for_every_image=True)
+    # labelled objects (the furniture boxes) for the object-visibility sweep: instance masks + categories in the info record
+    with open(paths["info_path"], "rb") as f:
+        infos = pickle.load(f)
+    for sc in scenes:
+        idx, _bbox, cat = sc.objects()
+        mask = np.zeros(sc.points.shape[0], dtype=np.int64)
+        for o, pts in idx.items():
+            mask[pts] = o + 1
+        np.save(os.path.join(paths["instance_data_root"], sc.scene_id, "instance_mask.npy"), mask)
+        infos[sc.scene_id]["num_objects"] = 8
+        for o in range(8):
+            infos[sc.scene_id][o] = {"raw_category": "wall" if o == 7 else cat.get(o, f"thing{o}")}
+    with open(paths["info_path"], "wb") as f:
+        pickle.dump(infos, f)
     os.makedirs(os.path.join(root, "tapvid"), exist_ok=True)
     for tr in _tracks():
         H, W = tr.image_hw
@@ -81,6 +96,9 @@ def _run_everything(out_dir):
                            save_interval=3, timings=timings)
     vis = MVI.run_split(INFO, os.path.join(out_dir, "vis.parquet"), os.path.join(out_dir, "mvi_warn.txt"), num_workers=4)
     MVI.run_split(INFO, os.path.join(out_dir, "vis.pkl"), os.path.join(out_dir, "mvi_warn2.txt"), num_workers=2)
+    # object visibility from the index just written: scenes dealt over the ranks, each reading only its scenes' row groups
+    import spatial_engine.object_perception.compute_object_visibility as COV
+    COV.process_split("val", INFO, os.path.join(out_dir, "vis.parquet"), os.path.join(out_dir, "covis"))
     # the camera-movement dataset builders on the pair table just written: every rank draws, each formats its slice of the text
     import spatial_engine.camera_movement.camera_movement_engine_train_val as CME
     handler0 = SceneInfoHandler(INFO)
@@ -117,7 +135,20 @@ def _run_everything(out_dir):
     dev = ctx.device if ctx is not None else torch.device("cuda", 0)
     counts = pipeline.run(scenes, os.path.join(out_dir, "pipe"), ctx, dev, seed=5, n_camera=20, n_correspondence=20,
                           depth_images_per_scene=2, tracks=_tracks()[:3])
-    return tables, vis, timings, counts, dict(pipeline.LAST_TIMINGS)
+    pipe_timings = dict(pipeline.LAST_TIMINGS)
+    if ctx is None:
+        # the same job with rank 0's record collector forced through run files and the external merge, and the track blocks as
+        # files priced by size and read by their owner: the same bytes
+        track_files = [pipeline.TrackFile(os.path.join("tapvid", f"{t.scene_id}.npz")) for t in _tracks()[:3]]
+        spilled = pipeline.run(scenes, os.path.join(out_dir, "pipe_spilled"), ctx, dev, seed=5, n_camera=20, n_correspondence=20,
+                               depth_images_per_scene=2, tracks=track_files, spill_bytes=1500)
+        assert spilled == counts and pipeline.LAST_TIMINGS["spill_runs"] > 5
+        for name in counts:
+            assert open(os.path.join(out_dir, "pipe", f"{name}.jsonl"), "rb").read() == \
+                open(os.path.join(out_dir, "pipe_spilled", f"{name}.jsonl"), "rb").read(), name
+        import shutil
+        shutil.rmtree(os.path.join(out_dir, "pipe_spilled"))
+    return tables, vis, timings, counts, pipe_timings
 
 
 def _rank_main(rank, world, port, root, out_dir):
@@ -190,12 +221,23 @@ def test_drop_in_entry_points_one_rank_vs_two_ranks_from_disk(tmp_path, monkeypa
     assert counts["camera_movement_total_distance"] > 0 and 0 < counts["depth_estimation_coor"] <= 2 * (N_SCENES - 1)
     assert counts["object_movement_tapvid3d_total_distance"] > 0
     assert pipe_t["records_bytes"] > 1000 and "rank0_replay_s" not in pipe_t
+    assert pipe_t["max_resident_scenes"] <= 10 and pipe_t["peak_rss_mb"] > 0 and pipe_t["pair_table_rows"] > 50
     cm = [json.loads(line) for line in open(os.path.join(root, "one", "displacement_vector_train.jsonl"))]
     assert len(cm) > 10 and {"id", "image", "conversations", "answer_values", "gt_value"} <= set(cm[0])
     cmv = [json.loads(line) for line in open(os.path.join(root, "one", "yaw_movement_val.jsonl"))]
     assert len(cmv) > 5 and "text" in cmv[0] and "conversations" not in cmv[0]
     vc = [json.loads(line) for line in open(os.path.join(root, "one", "train_visual_correspondence_coor_2_coor.jsonl"))]
     assert len(vc) > 10 and {"id", "image", "conversations", "p1_list", "p2_list", "gt_value"} <= set(vc[0])
+    with open(os.path.join(root, "one", "covis", "object_visibility.pkl"), "rb") as f:
+        covis = pickle.load(f)
+    assert list(covis) == [s.scene_id for s in scenes]
+    sc0 = scenes[0]
+    idx0, _, _ = sc0.objects()
+    masks0 = O.scene_visibility_masks(sc0.points[:, :3], sc0.K, sc0.A, sc0.E, sc0.depth, sc0.color_hw)
+    for o, entries in covis[sc0.scene_id]["object_to_images"].items():                      # counts = |object & image| of the oracle's masks
+        for e in entries:
+            assert e["intersection_count"] == int(masks0[e["image_id"]][idx0[o]].sum()) >= max(1, int(0.05 * len(idx0[o])))
+    assert 7 not in covis[sc0.scene_id]["object_to_images"] and len(covis[sc0.scene_id]["object_to_images"]) >= 3
     om = [json.loads(line) for line in open(os.path.join(root, "one", "om_train.jsonl"))]
     assert len(om) > 5 and {"id", "conversations", "point_moving", "cam_moving"} <= set(om[0])
     # ---- two ranks, one GPU: the same bytes everywhere ----------------------------------------------------------------

@@ -47,3 +47,29 @@ def test_empty_scene_index():
     assert csr.to_dict() == {"image_to_points": {}, "point_to_images": {v: [] for v in range(5)}}
     t = csr.to_arrow("s").to_pandas()
     assert t["values"].tolist() == ["[]"] * 5 and t["key"][0] == "s:point_to_images:0"
+
+
+def test_scene_row_groups_reads_only_what_a_scene_needs(tmp_path):
+    """visindex.SceneRowGroups on the two layouts of the index file: one row group per scene (what make_visibility_info.run_split
+    streams) and pandas' single big row group spanning all scenes; an unknown scene is an empty dict."""
+    import pandas as pd
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from mspa import visindex
+    rows = {}
+    for s in range(5):
+        sid = f"scene{s:04d}_00"
+        rows[sid] = {f"{sid}:image_to_points:{5 * k:05d}": json.dumps(list(range(s, s + k))) for k in range(4)}
+        rows[sid].update({f"{sid}:point_to_images:{v}": json.dumps([f"{5 * k:05d}" for k in range(v % 3)]) for v in range(6)})
+    per_scene = str(tmp_path / "per_scene.parquet")
+    with pq.ParquetWriter(per_scene, pa.schema([("key", pa.string()), ("values", pa.string())])) as w:
+        for sid in rows:
+            w.write_table(pa.table({"key": list(rows[sid]), "values": list(rows[sid].values())}))
+    one_group = str(tmp_path / "one_group.parquet")
+    pd.DataFrame({"key": [k for d in rows.values() for k in d], "values": [v for d in rows.values() for v in d.values()]}).to_parquet(one_group)
+    for path, groups_of_scene in ((per_scene, 1), (one_group, 0)):
+        idx = visindex.SceneRowGroups(path)
+        assert all(len(idx._by_scene.get(sid, [])) == groups_of_scene for sid in rows)
+        for sid in rows:
+            assert idx.scene_dict(sid) == rows[sid]
+        assert idx.scene_dict("scene9999_00") == {}
