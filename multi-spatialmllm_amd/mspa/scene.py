@@ -70,13 +70,21 @@ class SceneOnDevice:
         self.depth, self.frame_mats, self.cam_mats, self.xyz = depth, frame_mats, cam_mats, xyz
         self.rgb = None
         self._vis = None
-        self._pose = None if pose_tables is None else (pose_tables[0], cam_mats[:, 0, :].contiguous(), pose_tables[1],
-                                                       pose_tables[2])
+        # Nothing may be COMPUTED from the resident tensors here: this runs on the uploader's thread while the copies are still
+        # queued on the copy stream, and a kernel launched now (e.g. ``cam_mats[:, 0, :].contiguous()`` for K4's inverse table)
+        # would read the slot's previous scene.  The inverse table is cut out by ``pose_tables()``, on the consumer's stream,
+        # which waits for the upload event.  (Round 5 built it here: the pair table never reads it, the camera-movement head
+        # does -- found when the pipeline's heads moved onto prefetched scenes.)
+        self._pose = None
+        self._staged_pose = pose_tables
         return self
 
     def pose_tables(self):
         """K4's per-frame inputs on the device: (A @ E [F,16], inv(A @ E) [F,16], yaw [F], pitch [F]); the angles are the
         reference's own host arithmetic (engine.extract_yaw_pitch_host), uploaded once per scene."""
+        if getattr(self, "_pose", None) is None and getattr(self, "_staged_pose", None) is not None:
+            e, yaw, pitch = self._staged_pose
+            self._pose = (e, self.cam_mats[:, 0, :].contiguous(), yaw, pitch)
         if getattr(self, "_pose", None) is None:
             F = len(self.ids)
             yaw, pitch = engine.extract_yaw_pitch_host(self.E_aligned)

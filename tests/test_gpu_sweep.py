@@ -311,6 +311,9 @@ def test_device_decode_of_the_sweeps_equals_the_host_decode(tmp_path, monkeypatc
         got = []
         for sc in h.prefetched_scenes(sids * 2, num_workers=3, decode=mode):   # 14 scenes: more than the decode slots
             got.append((sc.depth.clone(), sc.cam_mats.clone()))
+            # K4's inverse-pose table is cut out of the resident camera records on the CONSUMER's stream (built on the uploader's
+            # thread it raced the copy and held the slot's previous scene: round 6)
+            assert torch.equal(sc.pose_tables()[1], sc.cam_mats[:, 0, :]) and sc.pose_tables()[0].shape[0] == len(sc.ids)
         torch.cuda.synchronize()
         resident[mode] = got
     assert len(resident["device"]) == 14
