@@ -588,7 +588,7 @@ class GpuCorrespondenceBackend:
 
 
 def visual_correspondence_dot_dataset(rows: Sequence, backend, templates: T.TemplateSet = None, rng=_random, on_warn=None,
-                                      on_mark=None) -> List[Optional[dict]]:
+                                      on_mark=None, ctx=None, transform=None) -> List[Optional[dict]]:
     """Record loop of the multiple-choice correspondence head (visual_correspondence_qa_engine_dot_2_multichoice.py
     :279-433, VC_D) for rows that may span scenes.  ``backend``: ``GpuCorrespondenceBackend`` (or anything with its
     three methods).
@@ -599,109 +599,197 @@ def visual_correspondence_dot_dataset(rows: Sequence, backend, templates: T.Temp
     and checked afterwards; at the first row where one did occur the generator is taken back to that row (replayed from
     a checkpoint kept every 1024 rows), the row is redrawn with the rejection applied, and the passes resume behind it.
     ``on_mark(row_index, scene_id, first_image, second_image, vertex, p1_pixel, colour1, labelled_points, colours)``.
-    """
+
+    With a communicator (``ctx``: one process per GPU) the SCENES are dealt over the ranks (longest-first by rows), as in
+    ``visual_correspondence_dataset``: passes 1 and 3, the records and -- the expensive part of this head -- the two annotated
+    JPEGs per record (``on_mark``) only for a rank's own scenes; the sizes of pass 1 summed over the ranks; all draws on every
+    rank.  A coincidence is expected a handful of times in the 500 K-row train set, so it is handled, not refused: the ranks
+    agree on the FIRST row where one occurred (one all_reduce(MIN) of row << 32 | x << 16 | y), every rank rewinds to it with the
+    owner's pixel, and records and images are only produced for rows in front of it -- the files of a sharded run are those of
+    one process.  The finished JSON lines (``transform`` applied) travel to rank 0 in one ``shard.gather_bytes``; the other
+    ranks get Nones.  Only a stale visibility index (a drawn vertex that fails the depth test) stays a one-process affair."""
     templates = templates or T.VISUAL_CORRESPONDENCE_DOT
     warn = on_warn or (lambda message: None)
     by_scene: Dict[str, List[int]] = {}
     for k, r in enumerate(rows):
         by_scene.setdefault(r["scene_id"], []).append(k)
     n = len(rows)
+    rank, world = (ctx.rank, ctx.world) if ctx is not None else (0, 1)
+    if ctx is not None:
+        from . import shard
+        names = list(by_scene)
+        bins = shard.lpt_assign([float(len(by_scene[s_])) for s_ in names], world)
+        mine = {names[i] for i in bins[rank]}
+        if rank != 0:
+            warn = lambda message: None                                    # noqa: E731 -- the warning file is rank 0's
+    else:
+        mine = set(by_scene)
     n_common = [0] * n
     known = [False] * n
     hw: Dict[str, Tuple[int, int]] = {}
-    for scene_id, ks in by_scene.items():                                  # pass 1
-        counts = backend.common_counts(scene_id, [(rows[k]["image_id1"], rows[k]["image_id2"]) for k in ks])
-        if counts is None:
-            continue
-        hw[scene_id] = backend.image_hw(scene_id)
-        for k, c in zip(ks, counts):
-            known[k], n_common[k] = True, c
+    failure: Optional[BaseException] = None
+    try:
+        for scene_id, ks in by_scene.items():                              # pass 1
+            if scene_id not in mine:
+                continue
+            counts = backend.common_counts(scene_id, [(rows[k]["image_id1"], rows[k]["image_id2"]) for k in ks])
+            if counts is None:
+                continue
+            hw[scene_id] = backend.image_hw(scene_id)
+            for k, c in zip(ks, counts):
+                known[k], n_common[k] = True, c
+    except Exception as e:
+        if ctx is None:
+            raise
+        failure = e
+    if ctx is not None:
+        import torch
+        import torch.distributed as dist
+        shard.raise_together(ctx, failure, "visual_correspondence_dot_dataset (pass 1)")
+        if n:
+            # known, size, and the image size the distractors are drawn inside (H, W): every row has exactly one owner
+            table = torch.tensor([[int(kn), int(c), hw.get(rows[k]["scene_id"], (0, 0))[0] if kn else 0,
+                                   hw.get(rows[k]["scene_id"], (0, 0))[1] if kn else 0]
+                                  for k, (kn, c) in enumerate(zip(known, n_common))], dtype=torch.int64, device=ctx.collective_device)
+            dist.all_reduce(table, op=dist.ReduceOp.SUM, group=ctx.group)
+            table = table.cpu().numpy()
+            known, n_common = [bool(v) for v in table[:, 0]], [int(v) for v in table[:, 1]]
+            for k in range(n):
+                if known[k]:
+                    hw.setdefault(rows[k]["scene_id"], (int(table[k, 2]), int(table[k, 3])))
 
     out: List[Optional[dict]] = [None] * n
     start = 0
     forced: Dict[int, Tuple[int, int]] = {}                                # row -> correct pixel where the rejection applies
     STRIDE = 1024
+    NONE = (1 << 62)
 
     def draw(k):
         return _vc_dot_row_draws(n_common[k], known[k], hw.get(rows[k]["scene_id"], (0, 0)), templates, rng, forced.get(k))
 
-    while start < n:
-        draws: Dict[int, dict] = {}
-        checkpoints: Dict[int, tuple] = {}
-        for k in range(start, n):                                          # pass 2
-            if (k - start) % STRIDE == 0:
-                checkpoints[k] = rng.getstate()
-            draws[k] = draw(k)
-        proj: Dict[int, tuple] = {}
-        for scene_id, ks in by_scene.items():                              # pass 3
-            live = [k for k in ks if k >= start and not draws[k]["dead"]]
-            if not live:
-                continue
-            jobs = []
-            for k in live:
+    try:
+        while start < n:
+            draws: Dict[int, dict] = {}
+            checkpoints: Dict[int, tuple] = {}
+            for k in range(start, n):                                      # pass 2
+                if (k - start) % STRIDE == 0:
+                    checkpoints[k] = rng.getstate()
+                draws[k] = draw(k)
+            proj: Dict[int, tuple] = {}
+            for scene_id, ks in by_scene.items():                          # pass 3
+                if scene_id not in mine:
+                    continue
+                live = [k for k in ks if k >= start and not draws[k]["dead"]]
+                if not live:
+                    continue
+                jobs = []
+                for k in live:
+                    r, d = rows[k], draws[k]
+                    i1, i2 = (r["image_id2"], r["image_id1"]) if d["swap"] else (r["image_id1"], r["image_id2"])
+                    jobs.append((i1, i2, d["pos"]))
+                for k, res in zip(live, backend.project(scene_id, jobs)):
+                    proj[k] = res
+            # the first row (of mine) where the assumption behind the draws fails; nothing is written before the ranks agree
+            local = NONE
+            for k in range(start, n):
+                if k not in proj:
+                    continue
+                vertex, uv1, uv2, ok1, ok2 = proj[k]
+                if not (ok1 and ok2):
+                    local = (k << 32) | (0xFFFF << 16) | 0xFFFF
+                    break
+                correct = (int(uv2[0]), int(uv2[1]))
+                if k not in forced and correct in draws[k]["wrong"]:
+                    local = (k << 32) | ((correct[0] & 0xFFFF) << 16) | (correct[1] & 0xFFFF)
+                    break
+            first = local
+            if ctx is not None:
+                import torch
+                import torch.distributed as dist
+                t = torch.tensor([local], dtype=torch.int64, device=ctx.collective_device)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=ctx.group)
+                first = int(t.item())
+            stop = n if first == NONE else first >> 32
+            clash = None
+            if first != NONE:
+                cx, cy = (first >> 16) & 0xFFFF, first & 0xFFFF
+                clash = (stop, "invisible" if (cx, cy) == (0xFFFF, 0xFFFF) else (cx, cy))
+            for k in range(start, min(n, stop + (1 if clash and clash[1] == "invisible" else 0))):     # records in front of it
                 r, d = rows[k], draws[k]
-                i1, i2 = (r["image_id2"], r["image_id1"]) if d["swap"] else (r["image_id1"], r["image_id2"])
-                jobs.append((i1, i2, d["pos"]))
-            for k, res in zip(live, backend.project(scene_id, jobs)):
-                proj[k] = res
-        clash = None
-        for k in range(start, n):                                          # records, until a distractor hits the correct pixel
-            r, d = rows[k], draws[k]
-            image1, image2 = (r["image_id2"], r["image_id1"]) if d["swap"] else (r["image_id1"], r["image_id2"])
-            if d["dead"]:
-                if d.get("invisible"):
-                    pass                                                   # warned when the failure was found
-                elif not known[k]:
-                    warn(f"[build_training_sample] Warning: Visibility info not found for scene {r['scene_id']}\n")
-                else:
-                    warn(f"[build_training_sample] Warning: No common visible points for scene {r['scene_id']} {image1}, {image2}\n")
-                continue
-            vertex, uv1, uv2, ok1, ok2 = proj[k]
-            if not (ok1 and ok2):
-                # the index and the depth test disagree (a stale visibility file): upstream warns and returns before any
-                # further draw (VC_D:339-351) -- rewind to this row and redraw it that way
-                if not ok1:
-                    warn(f"Warning: Point {vertex} is not visible in image {image1} in scene {r['scene_id']}.\n")
-                if not ok2:
-                    warn(f"Warning: Point {vertex} is not visible in image {image2} in scene {r['scene_id']}.\n")
-                clash = (k, "invisible")
+                image1, image2 = (r["image_id2"], r["image_id1"]) if d["swap"] else (r["image_id1"], r["image_id2"])
+                if d["dead"]:
+                    if d.get("invisible"):
+                        pass                                               # warned when the failure was found
+                    elif not known[k]:
+                        warn(f"[build_training_sample] Warning: Visibility info not found for scene {r['scene_id']}\n")
+                    else:
+                        warn(f"[build_training_sample] Warning: No common visible points for scene {r['scene_id']} {image1}, {image2}\n")
+                    continue
+                if k not in proj:                                          # another rank's row: its record arrives as bytes
+                    continue
+                vertex, uv1, uv2, ok1, ok2 = proj[k]
+                if not (ok1 and ok2):
+                    # the index and the depth test disagree (a stale visibility file): upstream warns and returns before any
+                    # further draw (VC_D:339-351) -- rewind to this row and redraw it that way
+                    if ctx is not None:
+                        raise RuntimeError(f"visual_correspondence_dot_dataset: vertex {vertex} of scene {r['scene_id']} failed the "
+                                           "visibility re-check (a visibility index that does not belong to these frames); the rewind "
+                                           "that reproduces upstream's draws for such rows runs in a single process only")
+                    if not ok1:
+                        warn(f"Warning: Point {vertex} is not visible in image {image1} in scene {r['scene_id']}.\n")
+                    if not ok2:
+                        warn(f"Warning: Point {vertex} is not visible in image {image2} in scene {r['scene_id']}.\n")
+                    break
+                correct = (int(uv2[0]), int(uv2[1]))
+                H, W = hw[r["scene_id"]]
+                points = [correct] + d["wrong"]
+                labeled = dict(zip(d["labels"], [points[j] for j in d["order"]]))
+                correct_label = [lab for lab, p in labeled.items() if p == correct][0]
+                ti, qi, ai = d["picks"]
+                p1_pixel = (int(uv1[0]), int(uv1[1]))
+                if on_mark is not None:
+                    on_mark(k, r["scene_id"], image1, image2, vertex, p1_pixel, d["color1"], labeled,
+                            {lab: d["colors"][j] for j, lab in enumerate(d["labels"])})
+                out[k] = {
+                    "id": f"{k}_p{vertex}",
+                    "image": [os.path.join(r["scene_id"], f"{k}_point{vertex}_{image1}_{image2}_img1.jpg"),
+                              os.path.join(r["scene_id"], f"{k}_point{vertex}_{image1}_{image2}_img2.jpg")],
+                    "conversations": [{"from": "human", "value": f"{templates.task_description[ti]}\n{templates.questions['default'][qi]}"},
+                                      {"from": "gpt", "value": templates.answers["default"][ai].format(correct_label=correct_label)}],
+                    "height_list": [H] * 2,
+                    "width_list": [W] * 2,
+                    "question_type": "visual_correspondence_multiple_choice",
+                    "gt_value": correct_label,
+                    "p1_list": [p1_pixel[0], p1_pixel[1]],
+                    "p2_list": [correct] + d["wrong"],
+                }
+            if clash is None:
                 break
-            correct = (int(uv2[0]), int(uv2[1]))
-            if k not in forced and correct in d["wrong"]:
-                clash = (k, correct)
-                break
-            H, W = hw[r["scene_id"]]
-            points = [correct] + d["wrong"]
-            labeled = dict(zip(d["labels"], [points[j] for j in d["order"]]))
-            correct_label = [lab for lab, p in labeled.items() if p == correct][0]
-            ti, qi, ai = d["picks"]
-            p1_pixel = (int(uv1[0]), int(uv1[1]))
-            if on_mark is not None:
-                on_mark(k, r["scene_id"], image1, image2, vertex, p1_pixel, d["color1"], labeled,
-                        {lab: d["colors"][j] for j, lab in enumerate(d["labels"])})
-            out[k] = {
-                "id": f"{k}_p{vertex}",
-                "image": [os.path.join(r["scene_id"], f"{k}_point{vertex}_{image1}_{image2}_img1.jpg"),
-                          os.path.join(r["scene_id"], f"{k}_point{vertex}_{image1}_{image2}_img2.jpg")],
-                "conversations": [{"from": "human", "value": f"{templates.task_description[ti]}\n{templates.questions['default'][qi]}"},
-                                  {"from": "gpt", "value": templates.answers["default"][ai].format(correct_label=correct_label)}],
-                "height_list": [H] * 2,
-                "width_list": [W] * 2,
-                "question_type": "visual_correspondence_multiple_choice",
-                "gt_value": correct_label,
-                "p1_list": [p1_pixel[0], p1_pixel[1]],
-                "p2_list": [correct] + d["wrong"],
-            }
-        if clash is None:
-            break
-        k, correct = clash                                                 # take the generator back to the start of row k
-        base = max(c for c in checkpoints if c <= k)
-        rng.setstate(checkpoints[base])
-        for j in range(base, k):
-            draw(j)
-        forced[k] = correct
-        start = k
-    return out
+            k, correct = clash                                             # take the generator back to the start of row k
+            base = max(c for c in checkpoints if c <= k)
+            rng.setstate(checkpoints[base])
+            for j in range(base, k):
+                draw(j)
+            forced[k] = correct
+            start = k
+        if transform is not None:
+            out = [None if rec is None else transform(rec) for rec in out]
+    except Exception as e:
+        if ctx is None:
+            raise
+        failure = e
+    if ctx is None:
+        return out
+    shard.raise_together(ctx, failure, "visual_correspondence_dot_dataset (passes 2-3)")
+    lines = "".join(f"{k}\t{json.dumps(rec)}\n" for k, rec in enumerate(out) if rec is not None).encode()
+    parts = shard.gather_bytes(lines, ctx, dst=0)
+    merged: List[Optional[dict]] = [None] * n
+    if rank == 0:
+        for p in parts:
+            for line in bytes(p).split(b"\n")[:-1]:
+                k, _, body = line.partition(b"\t")
+                merged[int(k)] = JsonLine(body)
+    return merged
 
 
 # --------------------------------------------------------------------------------------------

@@ -12,7 +12,8 @@ from mspa import heads
 from mspa import templates as T
 from mspa.annotate import Mark
 from mspa.sampling import sample_dataframe  # noqa: F401
-from spatial_engine.visual_correspondence.visual_correspondence_qa_engine_coor_2_coor import _ResidentScenes, _load_visibility
+from spatial_engine.visual_correspondence.visual_correspondence_qa_engine_coor_2_coor import (_ResidentScenes, _load_visibility,
+                                                                                               _shuffle_and_write)
 
 random.seed(2)
 np.random.seed(2)
@@ -45,7 +46,7 @@ def _marker(scene_infos, image_output_dir):
     return on_mark
 
 
-def _records(rows, scene_infos, visibility_info_dict, warning_file, image_output_dir, resident=None):
+def _records(rows, scene_infos, visibility_info_dict, warning_file, image_output_dir, resident=None, ctx=None, transform=None):
     resident = resident or _ResidentScenes(scene_infos, visibility_info_dict)
 
     def warn(message):
@@ -53,7 +54,8 @@ def _records(rows, scene_infos, visibility_info_dict, warning_file, image_output
         with open(warning_file, "a") as wf:
             wf.write(message)
     backend = heads.GpuCorrespondenceBackend(resident.get, resident.get_bits)
-    return heads.visual_correspondence_dot_dataset(rows, backend, TEMPLATE_SET, random, warn, _marker(scene_infos, image_output_dir))
+    return heads.visual_correspondence_dot_dataset(rows, backend, TEMPLATE_SET, random, warn, _marker(scene_infos, image_output_dir),
+                                                   ctx=ctx, transform=transform)
 
 
 def build_training_sample(scene_infos, row, idx: int, visibility_info_dict, warning_file, max_points_per_pair=1,
@@ -79,8 +81,15 @@ def convert_train_sample_to_eval_sample(train_sample):
 
 
 def _build(parquet_path, output_dir, scene_infos, desired_count, overlap_min, overlap_max, interval, visibility_info_path,
-           warning_file, tag):
+           warning_file, tag, transform=None):
+    """(records in row order -- rows without one dropped --, how many there are on every rank, communicator or None).  In a job
+    with one process per GPU the scenes of the sampled rows are dealt over the ranks (``heads.visual_correspondence_dot_dataset``):
+    each rank reads and uploads its own scenes and draws the two annotated JPEGs of its own records -- the expensive part of
+    this head; upstream loops over the rows in one process (VC_D:455-466)."""
     import pandas as pd
+    import torch
+    from mspa import shard
+    ctx = shard.context_from_env()
     df = pd.read_parquet(parquet_path)
     print(f"[{tag}] Loaded DataFrame with {len(df)} rows from {parquet_path}")
     print(f"[{tag}] Sampling {desired_count} samples with overlap in [{overlap_min}, {overlap_max}]")
@@ -90,29 +99,30 @@ def _build(parquet_path, output_dir, scene_infos, desired_count, overlap_min, ov
     image_output_dir = os.path.join(output_dir, "images")
     os.makedirs(image_output_dir, exist_ok=True)
     rows = [df_sampled.iloc[k] for k in range(len(df_sampled))]
-    return [s for s in _records(rows, scene_infos, _load_visibility(visibility_info_path), warning_file, image_output_dir) if s]
+    samples = _records(rows, scene_infos, _load_visibility(visibility_info_path), warning_file, image_output_dir, ctx=ctx,
+                       transform=transform)
+    kept = [s for s in samples if s]
+    if ctx is None:
+        return kept, len(kept), None
+    import torch.distributed as dist                          # every rank shuffles an index list of rank 0's length (the generator stays in step)
+    n_kept = torch.tensor([len(kept)], dtype=torch.int64, device=ctx.collective_device)
+    dist.broadcast(n_kept, src=0, group=ctx.group)
+    return kept, int(n_kept.item()), ctx
 
 
 def build_train_dataset(parquet_path, output_dir, scene_infos, desired_count, overlap_min, overlap_max, interval,
                         visibility_info_path, warning_file, max_points_per_pair=1):
-    out_samples = _build(parquet_path, output_dir, scene_infos, desired_count, overlap_min, overlap_max, interval,
-                         visibility_info_path, warning_file, "Train")
-    random.shuffle(out_samples)
-    out_file = os.path.join(output_dir, "train_visual_correspondence_dot_2_multichoice.jsonl")
-    print(f"[Train] Writing {len(out_samples)} items to {out_file}")
-    heads.write_jsonl(out_file, out_samples)
+    samples, n, ctx = _build(parquet_path, output_dir, scene_infos, desired_count, overlap_min, overlap_max, interval,
+                             visibility_info_path, warning_file, "Train")
+    _shuffle_and_write(samples, n, ctx, os.path.join(output_dir, "train_visual_correspondence_dot_2_multichoice.jsonl"), "Train")
 
 
 def build_val_dataset(parquet_path, output_dir, scene_infos, desired_count, overlap_min, overlap_max, interval,
                       visibility_info_path, warning_file, max_points_per_pair=1):
     assert max_points_per_pair == 1, "[Val] max_points_per_pair should be 1."
-    out_samples = [convert_train_sample_to_eval_sample(s) for s in
-                   _build(parquet_path, output_dir, scene_infos, desired_count, overlap_min, overlap_max, interval,
-                          visibility_info_path, warning_file, "Val")]
-    random.shuffle(out_samples)
-    out_file = os.path.join(output_dir, "val_visual_correspondence_dot_2_multichoice.jsonl")
-    print(f"[Val] Writing {len(out_samples)} items to {out_file}")
-    heads.write_jsonl(out_file, out_samples)
+    samples, n, ctx = _build(parquet_path, output_dir, scene_infos, desired_count, overlap_min, overlap_max, interval,
+                             visibility_info_path, warning_file, "Val", transform=convert_train_sample_to_eval_sample)
+    _shuffle_and_write(samples, n, ctx, os.path.join(output_dir, "val_visual_correspondence_dot_2_multichoice.jsonl"), "Val")
 
 
 def main():

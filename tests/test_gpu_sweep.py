@@ -116,6 +116,13 @@ def _run_everything(out_dir):
                            os.path.join(out_dir, "vc_warn.txt"))
     VC.build_val_dataset(os.path.join(out_dir, "pairs.parquet"), out_dir, handler0, 20, 1, 60, 1, os.path.join(out_dir, "vis.pkl"),
                          os.path.join(out_dir, "vc_warn_val.txt"))
+    # ... and the multiple-choice builder: the same sharding, plus the two annotated JPEGs per record drawn by the owner rank
+    import spatial_engine.visual_correspondence.visual_correspondence_qa_engine_dot_2_multichoice as VCD
+    random.seed(6)
+    np.random.seed(6)
+    os.makedirs(os.path.join(out_dir, "vcd"), exist_ok=True)
+    VCD.build_train_dataset(os.path.join(out_dir, "pairs.parquet"), os.path.join(out_dir, "vcd"), handler0, 30, 1, 60, 1,
+                            os.path.join(out_dir, "vis.pkl"), os.path.join(out_dir, "vcd_warn.txt"))
     eng = OM.TwoFrameVideoQAEngine("tapvid3d_total_distance", "adt")
     random.seed(11)
     eng.generate_qa_training_data([t.scene_id for t in _tracks()], "tapvid", out_dir, os.path.join(out_dir, "om_train.jsonl"),
@@ -241,6 +248,8 @@ def test_drop_in_entry_points_one_rank_vs_two_ranks_from_disk(tmp_path, monkeypa
             assert e["intersection_count"] == int(masks0[e["image_id"]][idx0[o]].sum()) >= max(1, int(0.05 * len(idx0[o])))
     assert all(7 not in covis[s]["object_to_images"] for s in covis)                        # the "wall" is not asked about
     assert len(covis[sc0.scene_id]["object_to_images"]) >= 1 and sum(len(v["object_to_images"]) for v in covis.values()) >= 6
+    vcd = [json.loads(line) for line in open(os.path.join(root, "one", "vcd", "train_visual_correspondence_dot_2_multichoice.jsonl"))]
+    assert len(vcd) > 8 and all(os.path.exists(os.path.join(root, "one", "vcd", "images", p)) for r in vcd for p in r["image"])
     om = [json.loads(line) for line in open(os.path.join(root, "one", "om_train.jsonl"))]
     assert len(om) > 5 and {"id", "conversations", "point_moving", "cam_moving"} <= set(om[0])
     # ---- two ranks, one GPU: the same bytes everywhere ----------------------------------------------------------------
