@@ -846,11 +846,14 @@ def depth_estimation_record(scene_id: str, image_id: str, vertex: int, uv_row, d
 def depth_estimation_records_fn(scene_id: str, image_ids: Sequence[str], n_visible, numeric_fn, image_hw,
                                 max_samples: int = -1, templates: T.TemplateSet = T.DEPTH_ESTIMATION, rng=_random,
                                 max_n_points_per_image: int = 1, on_skip=None, dot: bool = False,
-                                on_mark=None) -> List[dict]:
+                                on_mark=None, draws=None) -> List[dict]:
     """DE_C / DE_D.generate_qa_training_single_scene with the numerics behind ``numeric_fn`` (see
     ``depth_comparison_records``); ``n_visible`` is only indexed for the images that get sampled.  In ``dot`` mode
-    ``on_mark(scene_id, image_id, vertex, (px, py), colour)`` receives the disc to draw for every record."""
-    draws = depth_estimation_draws(image_ids, n_visible, max_samples, templates, rng, max_n_points_per_image, dot)
+    ``on_mark(scene_id, image_id, vertex, (px, py), colour)`` receives the disc to draw for every record.
+    ``draws``: the scene's random decisions when they were made ahead (``depth_estimation_draws`` -- they depend on nothing the
+    kernels compute, so a sharded builder makes them for ALL scenes on every rank and builds records only for its own)."""
+    if draws is None:
+        draws = depth_estimation_draws(image_ids, n_visible, max_samples, templates, rng, max_n_points_per_image, dot)
     numerics = numeric_fn([(d["image_id"], j) for d in draws for j in d["positions"]])
     records, s = [], 0
     for dr in draws:

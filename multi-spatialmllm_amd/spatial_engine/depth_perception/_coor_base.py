@@ -39,18 +39,26 @@ class DepthCoorEngineBase:
     # -- helpers ------------------------------------------------------------------------------
     def _warn(self, message):
         print(message.strip())
+        sink = getattr(self, "_warn_sink", None)
+        if sink is not None:                       # a sharded build: the owner rank collects, rank 0 writes in scene order
+            sink.append(message.strip())
+            return
         if self.warning_file:
             with open(self.warning_file, "a") as wf:
                 wf.write(message.strip())
 
-    def _scene_inputs(self, scene_id):
+    def _visible_points_of(self, scene_id):
         cache = {}
 
         def visible_points(image_id):
             if image_id not in cache:
                 cache[image_id] = self.visibility_info.get_image_to_points_info(scene_id, image_id)
             return cache[image_id]
-        scene = self.scene_info.scene_on_device(scene_id)
+        return visible_points
+
+    def _scene_inputs(self, scene_id, scene=None):
+        visible_points = self._visible_points_of(scene_id)
+        scene = scene if scene is not None else self.scene_info.scene_on_device(scene_id)
         return (self.scene_info.get_all_extrinsic_valid_image_ids(scene_id), _LazyCounts(visible_points),
                 heads.list_point_numerics(scene, visible_points), self.scene_info.get_image_shape(scene_id))
 
@@ -66,8 +74,54 @@ class DepthCoorEngineBase:
     def generate_qa_training_single_scene(self, scene_id):
         raise NotImplementedError
 
+    # -- sharded build of the engines whose draws do not depend on the kernels (the two estimation engines) ------------------
+    DRAWS_AHEAD = False                   # subclasses that implement _scene_draws / _scene_records_on set this
+
+    def _scene_draws(self, scene_id):
+        raise NotImplementedError
+
+    def _scene_records_on(self, scene, scene_id, draws):
+        raise NotImplementedError
+
+    def _sharded_scene_records(self, scene_ids, ctx, num_workers=8):
+        """All scenes' records on rank 0, in scene order, for a job with one process per GPU (upstream: one process, one scene
+        after the other, DE_C:256-262).  Every rank makes the draws of EVERY scene in order -- they read the visibility index
+        only, so the ``random`` stream ends where a single process leaves it, on every rank; the scenes are then dealt over
+        the ranks (``mspa.sweep.sharded_sweep``: longest-first by draws, prefetched, depth frames decoded on the device) and
+        each rank projects, checks, words -- and for the dot engine draws the annotated JPEGs of -- its own scenes' records;
+        JSON lines and warning lines travel to rank 0 per window."""
+        import json
+        from mspa import sweep
+        all_draws = [self._scene_draws(s) for s in scene_ids]
+        costs = [float(sum(len(d["positions"]) for d in dr) + 1) for dr in all_draws]
+        records = []
+
+        def work_items(indices):
+            return self.scene_info.prefetched_scenes([scene_ids[i] for i in indices], num_workers, ctx.device)
+
+        def produce(index, scene):
+            self._warn_sink = []
+            try:
+                recs = self._scene_records_on(scene, scene_ids[index], all_draws[index])
+                warned = list(self._warn_sink)
+            finally:
+                self._warn_sink = None
+            return None, ["".join(json.dumps(r) + "\n" for r in recs).encode(), "\0".join(warned).encode()]
+
+        def consume(index, _rows, blobs):
+            records.extend(heads.JsonLine(line) for line in bytes(blobs[0]).split(b"\n")[:-1])
+            if blobs[1].size and self.warning_file:
+                with open(self.warning_file, "a") as wf:
+                    for w in bytes(blobs[1]).decode().split("\0"):
+                        wf.write(w)
+
+        sweep.sharded_sweep(costs, ctx, work_items, produce, consume)
+        return records
+
     # -- dataset level (reference: generate_qa_training_data / generate_qa_eval_data) --------------
     def generate_qa_training_data(self, output_dir, save_file=True):
+        from mspa import shard
+        ctx = shard.context_from_env() if self.DRAWS_AHEAD else None
         scene_ids = self.scene_info.get_sorted_keys()
         if self.all_max_samples > 0:
             self.max_samples = max(self.all_max_samples // len(scene_ids) + 1, 1)
@@ -76,14 +130,29 @@ class DepthCoorEngineBase:
         else:
             self.max_samples = -1
         self.num_used_scenes = len(scene_ids)
-        train_data = []
-        for scene_id in scene_ids:
-            train_data.extend(self.generate_qa_training_single_scene(scene_id))
-        if len(train_data) > self.all_max_samples:
-            train_data = random.sample(train_data, self.all_max_samples)
-        random.shuffle(train_data)
-        if not save_file:
-            return train_data
+        if ctx is not None:
+            train_data = self._sharded_scene_records(scene_ids, ctx)
+            n = int(shard.broadcast_object(len(train_data), ctx, src=0))
+            order = list(range(n))                 # the sample and the shuffle as index lists: every rank's generator stays in step
+            if n > self.all_max_samples:
+                order = random.sample(order, self.all_max_samples)
+            random.shuffle(order)
+            ctx.barrier()
+            if ctx.rank != 0:
+                return [] if not save_file else None
+            train_data = [train_data[i] for i in order]
+            if not save_file:
+                import json
+                return [json.loads(line) for line in train_data]
+        else:
+            train_data = []
+            for scene_id in scene_ids:
+                train_data.extend(self.generate_qa_training_single_scene(scene_id))
+            if len(train_data) > self.all_max_samples:
+                train_data = random.sample(train_data, self.all_max_samples)
+            random.shuffle(train_data)
+            if not save_file:
+                return train_data
         os.makedirs(output_dir, exist_ok=True)
         path = f"{output_dir}/{self.task_name}.jsonl"
         heads.write_jsonl(path, train_data)
@@ -95,7 +164,11 @@ class DepthCoorEngineBase:
 
     def generate_qa_eval_data(self, output_dir):
         assert self.max_n_points_per_image == 1, "max_n_points_per_image should be 1 for evaluation"
+        from mspa import shard
         data = [self.convert_train_sample_to_eval_sample(s) for s in self.generate_qa_training_data(output_dir, save_file=False)]
+        ctx = shard.context_from_env() if self.DRAWS_AHEAD else None
+        if ctx is not None and ctx.rank != 0:
+            return
         os.makedirs(output_dir, exist_ok=True)
         path = f"{output_dir}/{self.task_name}.jsonl"
         heads.write_jsonl(path, data)

@@ -123,6 +123,19 @@ def _run_everything(out_dir):
     os.makedirs(os.path.join(out_dir, "vcd"), exist_ok=True)
     VCD.build_train_dataset(os.path.join(out_dir, "pairs.parquet"), os.path.join(out_dir, "vcd"), handler0, 30, 1, 60, 1,
                             os.path.join(out_dir, "vis.pkl"), os.path.join(out_dir, "vcd_warn.txt"))
+    # the two depth-estimation engines: draws for every scene on every rank (they read the index only), scenes dealt over the
+    # ranks for the projections, the wording and -- dot engine -- the annotated JPEGs; two calls in a row without reseeding
+    import spatial_engine.depth_perception.depth_estimation_coor_engine as DEC
+    import spatial_engine.depth_perception.depth_estimation_dot_engine as DED
+    random.seed(8)
+    for mod, cls, sub in ((DEC, "DepthEstimationCoorQAEngine", "de_coor"), (DED, "DepthEstimationDotQAEngine", "de_dot")):
+        d = os.path.join(out_dir, sub)
+        os.makedirs(d, exist_ok=True)
+        e = getattr(mod, cls)(INFO, "v1_0", 40, os.path.join(d, "images"), os.path.join(out_dir, "vis.pkl"),
+                              warning_file=os.path.join(d, "warn.txt"))
+        e.generate_qa_training_data(os.path.join(d, "train"))
+        e.all_max_samples = 9
+        e.generate_qa_eval_data(os.path.join(d, "val"))
     eng = OM.TwoFrameVideoQAEngine("tapvid3d_total_distance", "adt")
     random.seed(11)
     eng.generate_qa_training_data([t.scene_id for t in _tracks()], "tapvid", out_dir, os.path.join(out_dir, "om_train.jsonl"),
@@ -248,6 +261,11 @@ def test_drop_in_entry_points_one_rank_vs_two_ranks_from_disk(tmp_path, monkeypa
             assert e["intersection_count"] == int(masks0[e["image_id"]][idx0[o]].sum()) >= max(1, int(0.05 * len(idx0[o])))
     assert all(7 not in covis[s]["object_to_images"] for s in covis)                        # the "wall" is not asked about
     assert len(covis[sc0.scene_id]["object_to_images"]) >= 1 and sum(len(v["object_to_images"]) for v in covis.values()) >= 6
+    for sub, name in (("de_coor", "depth_estimation_coor"), ("de_dot", "depth_estimation_dot")):
+        tr = [json.loads(line) for line in open(os.path.join(root, "one", sub, "train", f"{name}.jsonl"))]
+        ev = [json.loads(line) for line in open(os.path.join(root, "one", sub, "val", f"{name}.jsonl"))]
+        assert 20 <= len(tr) <= 40 and 1 <= len(ev) <= 9 and "text" in ev[0] and {"id", "image", "conversations", "gt_value"} <= set(tr[0])
+    assert len(os.listdir(os.path.join(root, "one", "de_dot", "images"))) >= 3                # annotated frames, per scene
     vcd = [json.loads(line) for line in open(os.path.join(root, "one", "vcd", "train_visual_correspondence_dot_2_multichoice.jsonl"))]
     assert len(vcd) > 8 and all(os.path.exists(os.path.join(root, "one", "vcd", "images", p)) for r in vcd for p in r["image"])
     om = [json.loads(line) for line in open(os.path.join(root, "one", "om_train.jsonl"))]
