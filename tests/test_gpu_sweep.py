@@ -23,6 +23,7 @@ for p in (PKG, ROOT):
 
 N_SCENES = 7
 INFO = "data/scannet/scannet_instance_data/scenes_info.pkl"
+INFO_DEPTH = "data/scannet/scannet_instance_data/scenes_info_depth.pkl"
 
 
 def _scenes():
@@ -70,6 +71,10 @@ def _write_inputs(root):
                 infos[sc.scene_id][o]["aligned_bbox"] = np.append(np.asarray(bbox[o], dtype=np.float64), 0.0)   # + class id
     with open(paths["info_path"], "wb") as f:
         pickle.dump(infos, f)
+    # the depth engines draw visible points per sampled image and, like the reference's random.choices / random.sample, raise
+    # on an image that sees nothing: they get the split without the scene that has such frames
+    with open(INFO_DEPTH if os.path.isabs(INFO_DEPTH) else os.path.join(root, INFO_DEPTH), "wb") as f:
+        pickle.dump({k: v for k, v in infos.items() if k != "scene9305_00"}, f)
     os.makedirs(os.path.join(root, "tapvid"), exist_ok=True)
     for tr in _tracks():
         H, W = tr.image_hw
@@ -131,7 +136,7 @@ def _run_everything(out_dir):
     for mod, cls, sub in ((DEC, "DepthEstimationCoorQAEngine", "de_coor"), (DED, "DepthEstimationDotQAEngine", "de_dot")):
         d = os.path.join(out_dir, sub)
         os.makedirs(d, exist_ok=True)
-        e = getattr(mod, cls)(INFO, "v1_0", 40, os.path.join(d, "images"), os.path.join(out_dir, "vis.pkl"),
+        e = getattr(mod, cls)(INFO_DEPTH, "v1_0", 40, os.path.join(d, "images"), os.path.join(out_dir, "vis.pkl"),
                               warning_file=os.path.join(d, "warn.txt"))
         e.generate_qa_training_data(os.path.join(d, "train"))
         e.all_max_samples = 9
