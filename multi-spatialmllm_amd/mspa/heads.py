@@ -894,7 +894,8 @@ def _depth_comparison_images(image_ids: Sequence[str], max_samples: int, rng) ->
 
 def depth_comparison_records(scene_id: str, image_ids: Sequence[str], n_visible: Dict[str, int], numeric_fn, image_hw,
                              max_samples: int = -1, templates: T.TemplateSet = None, rng=_random,
-                             max_n_points_per_image: int = 1, on_skip=None, dot: bool = False, on_mark=None) -> List[dict]:
+                             max_n_points_per_image: int = 1, on_skip=None, dot: bool = False, on_mark=None,
+                             dry_run: bool = False) -> List[dict]:
     """Records of DC_C.generate_qa_training_single_scene (``dot``: of DC_D's, depth_comparison_dot_engine.py:240-375 --
     lettered discs instead of coordinates; ``on_mark(scene_id, image_id, vertices, points_info, colours)`` gets them).
 
@@ -905,6 +906,8 @@ def depth_comparison_records(scene_id: str, image_ids: Sequence[str], n_visible:
     speculates: it draws for all remaining pairs as if none were skipped, evaluates them in one batch,
     accepts everything up to the first skipped pair, rewinds the generator to just after that pair's vertex
     draw and goes on from there.  Skips are rare (equal millimetre depths), so this is one batch in practice.
+    ``dry_run``: only the draws of a scene WITHOUT a skipped pair are made (no numerics, no records): where the generator
+    stands after such a scene -- what a sharded builder needs to start the next scene before this one has been evaluated.
     """
     templates = templates or T.DEPTH_COMPARISON
     H, W = image_hw
@@ -930,6 +933,8 @@ def depth_comparison_records(scene_id: str, image_ids: Sequence[str], n_visible:
             colors = [(rng.randint(0, 255), rng.randint(0, 255), rng.randint(0, 255)) for _ in range(2)] if dot else []  # DC_D:335-336
             plan.append({"image_id": img, "pos": pos, "after_pick": after_pick, "letters": letters, "order": order,
                          "closer_q": closer_q, "kind": kind, "picks": (qi, ai, ti), "state": state, "colors": colors})
+        if dry_run:
+            return []
         numerics = numeric_fn([(p["image_id"], j) for p in plan for j in p["pos"]])
         skipped_at = None
         for n, p in enumerate(plan):

@@ -118,10 +118,98 @@ class DepthCoorEngineBase:
         sweep.sharded_sweep(costs, ctx, work_items, produce, consume)
         return records
 
+    # -- sharded build of the engines whose draws DO depend on the kernels (the two comparison engines) -------------------------
+    CHAINED = False                       # subclasses that implement _scene_records_on(scene, scene_id, None, dry_run=...) set this
+
+    def _chained_scene_records(self, scene_ids, ctx, num_workers=8):
+        """All scenes' records on rank 0, in scene order, when a scene's draws depend on its numerics: upstream skips a pair of
+        equal millimetre depths BEFORE drawing its templates (DC_C:279-284), so where scene k + 1 starts in the ``random``
+        stream is only known once scene k has been evaluated -- about once in ten scenes differently from the no-skip guess.
+
+        Scenes are taken in windows of one per rank (rank r owns every ``world``-th scene and streams them through the
+        prefetcher).  Per window every rank computes, on the host, where each scene would START if no pair in front of it were
+        skipped (``dry_run`` draws: they read the visibility index only); each rank evaluates its own scene exactly from that
+        guess; one all_gather says whose guess was wrong.  Scenes up to the first wrong one are final; its owner's true end
+        state is broadcast and only the scenes behind it -- still resident on their ranks -- are redone.  Without a skip a
+        window costs one small all_gather and one gather of the finished lines."""
+        import json
+        import torch
+        import torch.distributed as dist
+        from mspa import shard
+        rank, world = ctx.rank, ctx.world
+        my_ids = scene_ids[rank::world]
+        my_scenes = iter(self.scene_info.prefetched_scenes(my_ids, num_workers, ctx.device)) if my_ids else iter(())
+        records = []
+        state = random.getstate()                                  # exact, the same on every rank
+        for w0 in range(0, len(scene_ids), world):
+            window = scene_ids[w0:w0 + world]
+            mine = rank if rank < len(window) else None
+            failure, scene = None, None
+            try:
+                scene = next(my_scenes) if mine is not None else None
+            except Exception as e:                                  # a scene that cannot be read: every rank leaves together
+                failure = e
+            final_upto, result = 0, ([], [])
+            while final_upto < len(window):
+                random.setstate(state)
+                starts = []
+                for j in range(final_upto, len(window)):            # the no-skip guess of every open scene's start
+                    starts.append(random.getstate())
+                    if failure is None:
+                        try:
+                            self._scene_records_on(None, window[j], None, dry_run=True)
+                        except Exception as e:
+                            failure = e
+                starts.append(random.getstate())
+                flag, end_state = 0, None
+                if failure is None and mine is not None and mine >= final_upto:
+                    random.setstate(starts[mine - final_upto])
+                    self._warn_sink = []
+                    try:
+                        recs = self._scene_records_on(scene, window[mine], None)
+                        result = (recs, list(self._warn_sink))
+                        end_state = random.getstate()
+                        flag = int(end_state != starts[mine - final_upto + 1])
+                    except Exception as e:
+                        failure = e
+                    finally:
+                        self._warn_sink = None
+                flags = torch.tensor([2 if failure is not None else flag], dtype=torch.int32, device=ctx.collective_device)
+                gathered = [torch.zeros_like(flags) for _ in range(world)]
+                dist.all_gather(gathered, flags, group=ctx.group)
+                gathered = [int(g.item()) for g in gathered]
+                if 2 in gathered:
+                    if failure is not None:
+                        raise failure
+                    raise RuntimeError("depth comparison (sharded): another rank failed in this window (its own traceback says why)")
+                wrong = [j for j in range(final_upto, len(window)) if gathered[j]]
+                if not wrong:
+                    state = starts[-1]
+                    final_upto = len(window)
+                else:                                               # its owner evaluated it from a correct start: its end is exact
+                    state = shard.broadcast_object(end_state, ctx, src=wrong[0])
+                    final_upto = wrong[0] + 1
+                    if mine is not None and mine > wrong[0]:
+                        result = ([], [])                           # started from a wrong guess: redone in the next round
+            payload = json.dumps({"lines": [json.dumps(r) for r in result[0]], "warned": result[1]}).encode()
+            parts = shard.gather_bytes(payload, ctx, dst=0)
+            if rank == 0:
+                for part in parts[:len(window)]:
+                    got = json.loads(bytes(part).decode()) if len(part) else {"lines": [], "warned": []}
+                    records.extend(heads.JsonLine(line.encode()) for line in got["lines"])
+                    if got["warned"] and self.warning_file:
+                        with open(self.warning_file, "a") as wf:
+                            for msg in got["warned"]:
+                                wf.write(msg)
+        for _ in my_scenes:
+            pass
+        random.setstate(state)
+        return records
+
     # -- dataset level (reference: generate_qa_training_data / generate_qa_eval_data) --------------
     def generate_qa_training_data(self, output_dir, save_file=True):
         from mspa import shard
-        ctx = shard.context_from_env() if self.DRAWS_AHEAD else None
+        ctx = shard.context_from_env() if (self.DRAWS_AHEAD or self.CHAINED) else None
         scene_ids = self.scene_info.get_sorted_keys()
         if self.all_max_samples > 0:
             self.max_samples = max(self.all_max_samples // len(scene_ids) + 1, 1)
@@ -131,7 +219,7 @@ class DepthCoorEngineBase:
             self.max_samples = -1
         self.num_used_scenes = len(scene_ids)
         if ctx is not None:
-            train_data = self._sharded_scene_records(scene_ids, ctx)
+            train_data = self._chained_scene_records(scene_ids, ctx) if self.CHAINED else self._sharded_scene_records(scene_ids, ctx)
             n = int(shard.broadcast_object(len(train_data), ctx, src=0))
             order = list(range(n))                 # the sample and the shuffle as index lists: every rank's generator stays in step
             if n > self.all_max_samples:
@@ -166,7 +254,7 @@ class DepthCoorEngineBase:
         assert self.max_n_points_per_image == 1, "max_n_points_per_image should be 1 for evaluation"
         from mspa import shard
         data = [self.convert_train_sample_to_eval_sample(s) for s in self.generate_qa_training_data(output_dir, save_file=False)]
-        ctx = shard.context_from_env() if self.DRAWS_AHEAD else None
+        ctx = shard.context_from_env() if (self.DRAWS_AHEAD or self.CHAINED) else None
         if ctx is not None and ctx.rank != 0:
             return
         os.makedirs(output_dir, exist_ok=True)

@@ -132,8 +132,13 @@ def _run_everything(out_dir):
     # ranks for the projections, the wording and -- dot engine -- the annotated JPEGs; two calls in a row without reseeding
     import spatial_engine.depth_perception.depth_estimation_coor_engine as DEC
     import spatial_engine.depth_perception.depth_estimation_dot_engine as DED
+    # ... and the two comparison engines, whose draws depend on the numerics (a pair of equal millimetre depths is skipped before
+    # its templates are drawn): windows of one scene per rank, every start guessed without a skip, wrong guesses redone
+    import spatial_engine.depth_perception.depth_comparison_coor_engine as DCC
+    import spatial_engine.depth_perception.depth_comparison_dot_engine as DCD
     random.seed(8)
-    for mod, cls, sub in ((DEC, "DepthEstimationCoorQAEngine", "de_coor"), (DED, "DepthEstimationDotQAEngine", "de_dot")):
+    for mod, cls, sub in ((DEC, "DepthEstimationCoorQAEngine", "de_coor"), (DED, "DepthEstimationDotQAEngine", "de_dot"),
+                          (DCC, "DepthComparisonCoorQAEngine", "dc_coor"), (DCD, "DepthComparisonDotQAEngine", "dc_dot")):
         d = os.path.join(out_dir, sub)
         os.makedirs(d, exist_ok=True)
         e = getattr(mod, cls)(INFO_DEPTH, "v1_0", 40, os.path.join(d, "images"), os.path.join(out_dir, "vis.pkl"),
@@ -266,7 +271,8 @@ def test_drop_in_entry_points_one_rank_vs_two_ranks_from_disk(tmp_path, monkeypa
             assert e["intersection_count"] == int(masks0[e["image_id"]][idx0[o]].sum()) >= max(1, int(0.05 * len(idx0[o])))
     assert all(7 not in covis[s]["object_to_images"] for s in covis)                        # the "wall" is not asked about
     assert len(covis[sc0.scene_id]["object_to_images"]) >= 1 and sum(len(v["object_to_images"]) for v in covis.values()) >= 6
-    for sub, name in (("de_coor", "depth_estimation_coor"), ("de_dot", "depth_estimation_dot")):
+    for sub, name in (("de_coor", "depth_estimation_coor"), ("de_dot", "depth_estimation_dot"), ("dc_coor", "depth_comparison_coor"),
+                      ("dc_dot", "depth_comparison_dot")):
         tr = [json.loads(line) for line in open(os.path.join(root, "one", sub, "train", f"{name}.jsonl"))]
         ev = [json.loads(line) for line in open(os.path.join(root, "one", sub, "val", f"{name}.jsonl"))]
         assert 20 <= len(tr) <= 40 and 1 <= len(ev) <= 9 and "text" in ev[0] and {"id", "image", "conversations", "gt_value"} <= set(tr[0])

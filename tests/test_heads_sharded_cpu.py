@@ -129,3 +129,86 @@ def test_dot_dataset_two_ranks_equals_one_process_with_and_without_a_rewind():
         assert sorted(res[0][1] + res[1][1]) == sorted(want_marks) and res[0][1] and res[1][1]      # every image drawn once, by its owner
         assert res[0][2] == want_state == res[1][2]                # the generator ends where one process leaves it, on every rank
         assert not (set(res[0][3]) & set(res[1][3])) and len(set(res[0][3]) | set(res[1][3])) == 5   # scenes are dealt, not shared
+
+
+# ---- the chained build of the depth-comparison engines (draws depend on the numerics) ------------------------------------
+SCENES = [f"scene{k:04d}_00" for k in range(11)]
+TIED = {"scene0001_00", "scene0002_00", "scene0006_00", "scene0010_00"}       # scenes where a pair is skipped: more draws than guessed
+
+
+def _fake_engine():
+    from spatial_engine.depth_perception._coor_base import DepthCoorEngineBase
+
+    class Info:
+        def prefetched_scenes(self, ids, num_workers=8, device="cpu"):
+            return iter([("resident", s) for s in ids])
+
+        def get_sorted_keys(self):
+            return list(SCENES)
+
+    class Engine(DepthCoorEngineBase):
+        CHAINED = True
+        task_name = "fake_comparison"
+
+        def __init__(self, warning_file):
+            self.scene_info, self.warning_file = Info(), warning_file
+            self.all_max_samples, self.max_n_points_per_image = 25, 1
+
+        def _scene_records_on(self, scene, scene_id, _draws, dry_run=False):
+            n = 3 + int(scene_id[5:9]) % 4
+            draws = [random.random() for _ in range(n)]
+            if dry_run:
+                return []
+            assert scene is None or scene == ("resident", scene_id)
+            if scene_id in TIED:                                  # the evaluated scene turns out to need more of the stream
+                self._warn(f"Warning: a pair of {scene_id} was skipped.\n")
+                draws += [random.random(), random.random()]
+            return [{"id": f"{scene_id}_{k}", "v": v, "conversations": [{"from": "human", "value": f"q{k}"}]} for k, v in enumerate(draws)]
+
+        def generate_qa_training_single_scene(self, scene_id):
+            return self._scene_records_on(None, scene_id, None)
+    return Engine
+
+
+def _chained_rank(rank, world, port, q, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      MSPA_DIST_BACKEND="gloo")
+    ctx = shard.context_from_env(torch.device("cpu"))
+    random.seed(21)
+    eng = _fake_engine()(os.path.join(out_dir, f"warn_w{world}.txt"))
+    eng.generate_qa_training_data(os.path.join(out_dir, f"w{world}"))
+    eng.all_max_samples = 7
+    eng.generate_qa_eval_data(os.path.join(out_dir, f"w{world}_val"))      # a second call in a row: the generator is in step
+    q.put((rank, random.getstate()))
+    ctx.barrier()
+    ctx.close()
+
+
+def test_chained_depth_comparison_build_equals_one_process(tmp_path):
+    import torch.multiprocessing as mp
+    out_dir = str(tmp_path)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    random.seed(21)
+    eng = _fake_engine()(os.path.join(out_dir, "warn_w1.txt"))
+    eng.generate_qa_training_data(os.path.join(out_dir, "w1"))
+    eng.all_max_samples = 7
+    eng.generate_qa_eval_data(os.path.join(out_dir, "w1_val"))
+    want_state = random.getstate()
+    for world in (2, 3):
+        mpc = mp.get_context("spawn")
+        q = mpc.Queue()
+        port = _free_port()
+        procs = [mpc.Process(target=_chained_rank, args=(r, world, port, q, out_dir)) for r in range(world)]
+        for p in procs:
+            p.start()
+        states = [q.get(timeout=120) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert all(s == want_state for _, s in states)
+        for sub in ("", "_val"):
+            a = open(os.path.join(out_dir, f"w1{sub}", "fake_comparison.jsonl"), "rb").read()
+            b = open(os.path.join(out_dir, f"w{world}{sub}", "fake_comparison.jsonl"), "rb").read()
+            assert a == b and len(a) > 100
+        assert open(os.path.join(out_dir, "warn_w1.txt")).read() == open(os.path.join(out_dir, f"warn_w{world}.txt")).read() != ""
