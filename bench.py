@@ -712,7 +712,7 @@ def time_dropin_sweep(n_scenes=8, n_frames=64, n_points=131072, num_workers=None
         shutil.rmtree(root, ignore_errors=True)
 
 
-def time_dropin_sweep_ranks(ranks=(1, 2, 4), n_scenes=16, n_frames=320, passes=2, per_rank=2, timeout_s=170, num_workers=None):
+def time_dropin_sweep_ranks(ranks=(1, 2, 4), n_scenes=32, n_frames=320, passes=2, per_rank=2, timeout_s=240, num_workers=None):
     """`variants.dropin_sweep_ranks`: both split-sweeping drop-in entry points (CFR:200-253, MVI:127-177) over ScanNet-sized
     on-disk scenes with 1, 2 and 4 ranks sharing this GPU over gloo, each world size in its own processes
     (tools/dropin_ranks.py): scenes/s including the writing, rank 0's writer busy time, every rank's wait at the window
