@@ -50,6 +50,7 @@ class SensScene:
     depth: np.ndarray                  # [F,DH,DW] uint16
     color_jpeg: Optional[List[bytes]]  # undecoded payloads (None if not requested)
     export_position: Optional[List[int]] = None   # position of each kept frame among the frames upstream exports (names)
+    depth_device: object = None        # [F,DH,DW] int16 device tensor (the uint16 values) when the frames were inflated on the GPU
 
     @staticmethod
     def index_to_str(index: int) -> str:
@@ -57,14 +58,20 @@ class SensScene:
 
 
 def read_sens(path: str, frame_skip: int = 1, want_color: bool = False, keep_every: int = 1, n_threads: int = 0,
-              native: Optional[bool] = None, want_depth: bool = True) -> SensScene:
+              native: Optional[bool] = None, want_depth: bool = True, depth_to_device=None) -> SensScene:
     """Parse a .sens file keeping every ``frame_skip``-th frame (SENS:106-116) -- the frames upstream exports -- and, of
     those, only every ``keep_every``-th (UPD:20-68 keeps every 5th exported frame; the others need not be inflated at
     all).  One pass over the memory-mapped file collects the frame headers; the kept depth payloads are then inflated
     straight from the mapping into one [F, DH, DW] uint16 array by the library's copy threads
     (``mspa_inflate_blocks_host``; ``native=False`` or a missing library falls back to ``zlib`` frame by frame -- same
     bytes, this is file parsing, not the compute path).  ``want_depth=False`` reads headers and poses only (what the
-    scene-info update needs): no payload is touched and ``depth`` comes back with zero frames."""
+    scene-info update needs): no payload is touched and ``depth`` comes back with zero frames.
+
+    ``depth_to_device`` (a torch device): the kept frames' zlib payloads are copied, still compressed, into one pinned buffer,
+    cross PCIe once and are inflated ON THE DEVICE, one wave per frame (``mspa_inflate_blocks_device``: the per-frame
+    ``zlib.decompress`` of extract_posed_images.py:49-57) -- ``depth_device`` holds the [F, DH, DW] frames, ``depth`` stays empty.
+    A frame the device declines (damaged stream, wrong size, checksum) is inflated by zlib on the host and uploaded on its own;
+    if zlib rejects it too the error is zlib's."""
     import mmap
     with open(path, "rb") as f:
         size = os.fstat(f.fileno()).st_size
@@ -120,11 +127,41 @@ def read_sens(path: str, frame_skip: int = 1, want_color: bool = False, keep_eve
         for k, vals in enumerate(heads):
             poses[k] = np.asarray(vals[:16], dtype=np.float32).reshape(4, 4)
             stamps[k] = (vals[16], vals[17])
-        depth = np.empty((F if want_depth else 0, dh, dw), dtype=np.uint16)
+        on_device = depth_to_device is not None and want_depth and depth_compression == "zlib_ushort" and F > 0
+        depth = np.empty((F if (want_depth and not on_device) else 0, dh, dw), dtype=np.uint16)
+        depth_device = None
         frame_bytes = dh * dw * 2
         jpeg: Optional[List[bytes]] = [bytes(view[o:o + n]) for o, n in zip(c_off, c_len)] if want_color else None
         if not want_depth:
             pass
+        elif on_device:
+            import torch
+            from . import engine, ingest
+            offs = np.zeros(F, dtype=np.int64)
+            total = 0
+            for k in range(F):
+                offs[k] = total
+                total += (d_len[k] + 15) // 16 * 16 + 16
+            stage = ingest.PINNED_POOL.take(total)
+            host = stage.numpy()
+            whole = np.frombuffer(view, dtype=np.uint8)
+            for k in range(F):
+                host[offs[k]:offs[k] + d_len[k]] = whole[d_off[k]:d_off[k] + d_len[k]]
+            del whole
+            dev = torch.device(depth_to_device)
+            src = stage[:total].to(dev, non_blocking=True)
+            raw, status = engine.inflate_blocks_device(src, torch.from_numpy(offs).to(dev), torch.tensor(d_len, dtype=torch.int64, device=dev),
+                                                       frame_bytes)
+            frames = raw[:, :frame_bytes].contiguous().view(torch.int16).view(F, dh, dw) if raw.shape[1] != frame_bytes else \
+                raw.view(torch.int16).view(F, dh, dw)
+            bad = np.nonzero(status.cpu().numpy())[0]            # (synchronises: the staging buffer can go back afterwards)
+            ingest.PINNED_POOL.give(stage)
+            for k in bad:
+                got = zlib.decompress(view[d_off[k]:d_off[k] + d_len[k]])
+                if len(got) != frame_bytes:
+                    raise ValueError(f"{path}: frame {keep[k]} inflates to {len(got)} bytes, expected {frame_bytes}")
+                frames[int(k)] = torch.from_numpy(np.frombuffer(got, dtype="<u2").reshape(dh, dw).view(np.int16).copy()).to(dev)
+            depth_device = frames
         elif depth_compression == "raw_ushort":
             for k in range(F):
                 if d_len[k] != frame_bytes:
@@ -163,7 +200,7 @@ def read_sens(path: str, frame_skip: int = 1, want_color: bool = False, keep_eve
         except BufferError:                   # a view escaped (error path): the mapping goes with the garbage collector
             pass
     return SensScene(name, mats[0], mats[1], mats[2], mats[3], color_compression, depth_compression, (ch, cw), (dh, dw),
-                     float(shift), int(n_frames), keep, poses, stamps, depth, jpeg, positions)
+                     float(shift), int(n_frames), keep, poses, stamps, depth, jpeg, positions, depth_device)
 
 
 def text_roundtrip(matrix: np.ndarray) -> np.ndarray:

@@ -235,3 +235,27 @@ def test_full_size_depth_frames_as_the_dataset_stores_them(tmp_path):
     assert status.cpu().numpy().tolist() == [0] * len(paths)
     assert np.array_equal(out.cpu().numpy().view(np.uint16), host)
     assert np.array_equal(host, np.stack([sc.depth[i] for i in sc.valid_image_ids]))
+
+
+def test_sens_depth_frames_inflated_on_the_device(tmp_path):
+    """A .sens stream's zlib depth payloads (extract_posed_images.py:49-57 inflates them one by one): compressed bytes over PCIe,
+    one wave per frame on the device -- the same frames as the host reader's, a damaged payload handed to zlib (whose error it is)."""
+    import torch
+    from mspa import sens, synth
+    sc = synth.make_scene(31, n_points=512, n_frames=9, color_hw=(240, 320), depth_hw=(240, 320), invalid_pose_frac=0.0, with_color=False)
+    ids = sc.image_ids
+    path = str(tmp_path / "scene.sens")
+    sens.write_sens(path, sc.K.astype(np.float32), [sc.E[i].astype(np.float32) for i in ids], [sc.depth[i] for i in ids])
+    host = sens.read_sens(path, frame_skip=2)
+    dev = sens.read_sens(path, frame_skip=2, depth_to_device="cuda")
+    torch.cuda.synchronize()
+    assert dev.depth.shape[0] == 0 and tuple(dev.depth_device.shape) == (5, 240, 320) and dev.frame_index == host.frame_index
+    assert np.array_equal(dev.depth_device.cpu().numpy().view(np.uint16), host.depth)
+    assert np.array_equal(host.depth, np.stack([sc.depth[i] for i in ids[::2]]))
+    # a payload whose last byte (Adler-32) is damaged: the device declines it, zlib raises
+    raw = bytearray(open(path, "rb").read())
+    raw[-1] ^= 0x10
+    bad = str(tmp_path / "bad.sens")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(zlib.error):
+        sens.read_sens(bad, depth_to_device="cuda")
