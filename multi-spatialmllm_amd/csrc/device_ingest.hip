@@ -5,21 +5,27 @@
 // the per-frame `zlib.decompress` of the .sens reader (extract_posed_images.py:49-57), i.e. the stage that bounds every from-disk
 // sweep: 16 CPUs' worth of container quota inflate ~10 k frames/s (profiles/r06_ingest_scaling.txt) while the kernels downstream
 // take 3 M images/s.  DEFLATE is serial inside a stream, so the parallelism is ACROSS streams: a scene has 320 of them, the
-// loader keeps several scenes in flight, the chip has room for 3 840 such waves.
+// loader keeps several scenes in flight, the chip has room for 3 584 such waves (14 per CU: 11 KB of LDS each).
 //
 // mspa::dinf::inflate_kernel -- one 64-lane workgroup (one wave) per stream:
-//   * everything that steers the decode is WAVE-UNIFORM and lives in SGPRs: the 64-bit bit buffer, the bit count, the input
-//     word index, the output position.  Branches are scalar branches; the vector unit only moves bytes.
+//   * everything that steers the decode is WAVE-UNIFORM and lives in SGPRs: a 128-bit bit buffer, the bit count, the input word
+//     index, the output position.  Branches are scalar branches.
 //   * input: the wave holds 512 B of the compressed stream in two VGPRs (8 B per lane, one coalesced load) with the next 512 B
 //     in flight; a refill is `v_readlane_b32` with a scalar lane index -- no memory latency on the decode's critical path.
-//   * tables: a 10-bit literal/length table and an 8-bit distance table in LDS, read at a uniform address (LDS broadcast) and
-//     brought to an SGPR with `v_readfirstlane_b32`.  Codes longer than the table index (p < 2^-10 each) take the canonical
-//     first-code walk over the length-sorted symbol list -- no sub-tables to build.  The tables of a dynamic block are built by
-//     all 64 lanes (ballot ranks -> canonical codes -> replicated entries).
+//   * symbols in batches: EVERY LANE DECODES THE WHOLE SYMBOL that would start at the bit offset equal to its lane number --
+//     `v_alignbit_b32` cuts its window of the bit buffer, an LDS gather reads the 10-bit literal/length table, a length's extra
+//     bits come from the window, a second gather reads the 8-bit distance table behind them -- and packs total bits, match
+//     length and distance into one word.  The serial part DEFLATE forces is following the chain from offset 0: one
+//     `v_readlane_b32`, a compare, a bit set and an add per literal.  A run's literals are stored by their own lanes in one
+//     instruction (rank = `v_mbcnt` of the run's lane mask).  A lone wave issues one instruction per ~9 cycles and the CU's one
+//     scalar unit is shared by its 14 decode waves: the frame's time is its instruction count (profiles/r06_inflate_v4_pmc.md).
+//   * tables: built per dynamic block by all 64 lanes (ballot ranks -> canonical codes -> replicated entries).  Codes longer than
+//     the table index (p < 2^-10 each), end of block and invalid patterns take a scalar one-symbol path with the canonical
+//     first-code walk over the length-sorted symbol list -- no sub-tables to build.
 //   * output: a 4 KB ring in LDS takes every byte; whole 256-byte lines leave for HBM as one coalesced dword store per lane.
 //     A match whose distance fits the ring (<= 3 838: every filter-row distance of a 640-pixel image, 1 281) is copied LDS to
-//     LDS by the lanes, 64 bytes per step; a farther one reads the flushed bytes back from global memory behind a
-//     workgroup-scope fence.
+//     LDS by the lanes, 64 bytes per step; a farther one loads the flushed bytes from HBM behind `s_waitcnt vmcnt(8)` (the lines
+//     it needs left >= 12 stores ago) and its ring write is deferred until the next match or flush needs it.
 //   * a stream is ACCEPTED only if it ends exactly at the expected size, stays inside its input, and (second kernel,
 //     adler32_kernel) the Adler-32 of the output equals the stream's trailer -- the contract of csrc/inflate_fast.h.  Anything
 //     else is reported per block and the caller decodes that frame on the host.
