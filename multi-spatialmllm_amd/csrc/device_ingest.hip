@@ -467,13 +467,33 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
             bool slow = false;
             for (;;) {
                 // ---- the literal chain: the hot loop ----
-                uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)P, off);
-                while (p - 1u < 15u) {                           // a literal: p is its code length
-                    run |= 1ull << off;
-                    off += (int)p;
-                    if (off > 63) { p = ~0u; break; }
-                    p = (uint32_t)__builtin_amdgcn_readlane((int)P, off);
-                }
+                // while P[off] is a literal (its code length, 1 .. 15): run |= 1 << off; off += P[off]; past lane 63: p = ~0.
+                // Hand-written: as C the compiler wraps this loop in 13 scalar instructions per literal (select / mask juggling of
+                // its structurizer); these are 8, and the frame's time is its scalar instruction count.  All operands are SGPRs
+                // except P; an SGPR written by the scalar unit needs no wait state as `v_readlane_b32`'s lane select, and the SGPR
+                // it writes none before the scalar unit reads it.
+                uint32_t p, t;
+                asm volatile("s_nop 0\n\t"
+                             "v_readlane_b32 %[p], %[P], %[off]\n\t"
+                             "s_sub_u32 %[t], %[p], 1\n\t"
+                             "s_cmp_lt_u32 %[t], 15\n\t"
+                             "s_cbranch_scc0 2f\n"
+                             "1:\n\t"
+                             "s_bitset1_b64 %[run], %[off]\n\t"
+                             "s_add_u32 %[off], %[off], %[p]\n\t"
+                             "s_cmp_gt_u32 %[off], 63\n\t"
+                             "s_cbranch_scc1 3f\n\t"
+                             "v_readlane_b32 %[p], %[P], %[off]\n\t"
+                             "s_sub_u32 %[t], %[p], 1\n\t"
+                             "s_cmp_lt_u32 %[t], 15\n\t"
+                             "s_cbranch_scc1 1b\n\t"
+                             "s_branch 2f\n"
+                             "3:\n\t"
+                             "s_mov_b32 %[p], -1\n"
+                             "2:\n\t"
+                             : [run] "+s"(run), [off] "+s"(off), [p] "=&s"(p), [t] "=&s"(t)
+                             : [P] "v"(P)
+                             : "scc");
                 if (run) {                                       // every literal of the run by its own lane, ranks from the mask
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(run >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)run, 0u));
                     if ((run >> lane) & 1ull) L.ring[(pos + rank) & kRingMask] = (uint8_t)(E >> 16);
