@@ -518,7 +518,7 @@ def test_depth_dot_engines(world, tmp_path):
             assert im.shape[:2] == sc.color_hw and (np.abs(im.astype(int) - 90).max() > 20)
 
 
-def test_correspondence_dot_facade(tmp_path):
+def test_correspondence_dot_facade(tmp_path, monkeypatch):
     import importlib
     import json
     import os
@@ -548,7 +548,7 @@ def test_correspondence_dot_facade(tmp_path):
     warn = str(tmp_path / "w.txt")
     open(warn, "w").close()
     rec = RecordingAnnotator()
-    VD.ANNOTATOR = rec
+    monkeypatch.setattr(VD, "ANNOTATOR", rec)         # restored afterwards: the module outlives this test
     random.seed(61); np.random.seed(61)
     VD.build_train_dataset(table_path, out, h, 24, 1, 60, 1, vis_path, warn)
     got = [json.loads(line) for line in open(os.path.join(out, "train_visual_correspondence_dot_2_multichoice.jsonl"))]

@@ -123,6 +123,7 @@ def _run_everything(out_dir):
                          os.path.join(out_dir, "vc_warn_val.txt"))
     # ... and the multiple-choice builder: the same sharding, plus the two annotated JPEGs per record drawn by the owner rank
     import spatial_engine.visual_correspondence.visual_correspondence_qa_engine_dot_2_multichoice as VCD
+    VCD.ANNOTATOR = None                                     # the default (Pillow) whatever an earlier test installed
     random.seed(6)
     np.random.seed(6)
     os.makedirs(os.path.join(out_dir, "vcd"), exist_ok=True)
