@@ -137,6 +137,11 @@ TIED = {"scene0001_00", "scene0002_00", "scene0006_00", "scene0010_00"}       # 
 
 
 def _fake_engine():
+    for name in [m for m in sys.modules if m == "spatial_engine" or m.startswith("spatial_engine.")]:
+        if not (getattr(sys.modules[name], "__file__", None) or "").startswith(PKG):     # the reference's package, imported by
+            del sys.modules[name]                                                        # an earlier oracle-vs-reference test
+    if sys.path[0] != PKG:
+        sys.path.insert(0, PKG)
     from spatial_engine.depth_perception._coor_base import DepthCoorEngineBase
 
     class Info:
