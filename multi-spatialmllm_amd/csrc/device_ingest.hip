@@ -72,74 +72,66 @@ struct __align__(16) WaveLds {
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-// The wave-uniform decode state.  Members are only ever assigned wave-uniform values (readlane / readfirstlane results, kernel
-// arguments, arithmetic on those), so the compiler keeps them in SGPRs.
+// The decode state.  The POSITION in the stream is wave-uniform and lives in SGPRs (`base`, `rb`); the stream's bytes sit in two
+// VGPRs as a sliding window of 128 words: lane l holds word base + l (W) and word base + 64 + l (Wn, on its way from HBM since
+// the previous re-alignment).  Consuming bits is `rb += k` -- there is no bit buffer to shift or refill.  The vector side cuts
+// every lane's 32-bit window out of W with three `ds_bpermute_b32` (no LDS memory involved); the scalar side (block headers,
+// code-length codes, the rare one-symbol path) reads two words with `v_readlane_b32`.  Once `rb` has moved 56 words into the
+// window (every ~28 batches) the window is re-aligned: W = the words from position `rb >> 5` on (two bpermutes over W / Wn and a
+// select), the next Wn is requested -- its latency hides behind the batches that follow.
 struct Reader {
-    const uint2 *src;            // 8-byte aligned start of the stream
+    const uint32_t *src;         // 8-byte aligned start of the stream
     uint32_t n_words;            // 32-bit words the stream's bytes span (rounded up)
-    uint32_t n_chunks_ok;        // 8-byte units that may be loaded
-    uint2 cur, nxt;              // per lane: 8 bytes of the current / next 512-byte chunk
-    uint32_t widx;               // next 32-bit word of the stream to enter the bit buffer
-    uint64_t lo, hi;             // 128-bit bit buffer: the next bit of the stream is bit 0 of `lo`
-    int cnt;                     // valid bits in (hi : lo)
+    uint32_t n_words_ok;         // words that may be loaded (inside the caller's buffer)
+    uint32_t W, Wn;              // per lane: word base + lane, word base + 64 + lane of the stream (zeros beyond its end)
+    uint32_t base;               // word index of W's lane 0 (wave-uniform)
+    uint32_t rb;                 // the next bit of the stream, relative to word `base` (wave-uniform; < 64 words)
     int lane_;
 
-    __device__ __forceinline__ uint2 load_chunk(uint32_t chunk, int lane) const {
-        const uint32_t unit = chunk * 64u + (uint32_t)lane;
-        uint2 v = make_uint2(0u, 0u);
-        if (unit < n_chunks_ok) v = src[unit];
+    static constexpr uint32_t kRealignAt = 56u * 32u;     // leaves 8 words: more than a batch (111 bits) + the windows behind it
+
+    __device__ __forceinline__ uint32_t load_word(uint32_t i) const {
+        uint32_t v = 0u;
+        if (i < n_words_ok) v = src[i];
         return v;
     }
     __device__ __forceinline__ void seek(uint32_t byte_off, int lane) {
-        widx = byte_off >> 2;
-        const uint32_t chunk = widx >> 7;
-        cur = load_chunk(chunk, lane);
-        nxt = load_chunk(chunk + 1, lane);
-        lo = hi = 0;
-        cnt = 0;
-        refill();
-        drop((int)(byte_off & 3u) * 8);
+        base = byte_off >> 2;
+        rb = (byte_off & 3u) * 8u;
+        W = load_word(base + (uint32_t)lane);
+        Wn = load_word(base + 64u + (uint32_t)lane);
     }
-    __device__ __forceinline__ uint32_t next_word(int lane) {
-        const int l = (int)((widx >> 1) & 63u);
-        const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)cur.x, l);
-        const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)cur.y, l);
-        const uint32_t w = (widx & 1u) ? whi : wlo;
-        ++widx;
-        if ((widx & 127u) == 0u) {                          // the chunk is used up: the prefetched one takes its place
-            cur = nxt;
-            nxt = load_chunk((widx >> 7) + 1u, lane);
-        }
-        return w;
+    __device__ __forceinline__ void realign() {
+        const uint32_t s = rb >> 5;                              // words used up (wave-uniform, < 64)
+        const uint32_t i = (uint32_t)lane_ + s;
+        const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((i & 63u) << 2), (int)W);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((i & 63u) << 2), (int)Wn);
+        W = i < 64u ? a : b;
+        base += s;
+        rb &= 31u;
+        Wn = load_word(base + 64u + (uint32_t)lane_);
     }
-    // > 96 valid bits afterwards (zeros beyond the stream's end): what one batch of the symbol walk may consume
+    // afterwards the next 8 words (256 bits) are in W: a batch of the symbol walk, or any header field sequence between two calls
     __device__ __forceinline__ void refill() {
-        while (cnt <= 96) {
-            const uint64_t w = next_word(lane_);
-            if (cnt < 64) {
-                lo |= w << cnt;
-                if (cnt > 32) hi |= w >> (64 - cnt);
-            } else {
-                hi |= w << (cnt - 64);
-            }
-            cnt += 32;
-        }
+        if (rb >= kRealignAt) realign();
     }
-    __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)lo & ((1u << k) - 1u); }
-    __device__ __forceinline__ void drop(int k) {           // 0 <= k < 64
-        if (k) {
-            lo = (lo >> k) | (hi << (64 - k));
-            hi >>= k;
-            cnt -= k;
-        }
+    __device__ __forceinline__ uint32_t peek(int k) const {  // 0 <= k <= 16 (any k < 32 works)
+        const int j = (int)(rb >> 5);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)W, j);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)W, j + 1);
+        const uint64_t v = ((uint64_t)hi << 32) | lo;
+        return (uint32_t)(v >> (rb & 31u)) & ((1u << k) - 1u);
     }
+    __device__ __forceinline__ void drop(int k) { rb += (uint32_t)k; }
     __device__ __forceinline__ uint32_t take(int k) {
         const uint32_t v = peek(k);
         drop(k);
         return v;
     }
-    // bytes of the stream consumed so far, whole bytes still in the bit buffer given back
-    __device__ __forceinline__ int64_t consumed_bytes() const { return (int64_t)widx * 4 - (int64_t)(cnt >> 3); }
+    __device__ __forceinline__ void to_byte_boundary() { rb = (rb + 7u) & ~7u; }
+    __device__ __forceinline__ uint32_t word_index() const { return base + (rb >> 5); }
+    // bytes of the stream consumed so far (a partly consumed byte counts)
+    __device__ __forceinline__ int64_t consumed_bytes() const { return ((int64_t)base * 32 + (int64_t)rb + 7) >> 3; }
 };
 
 __device__ __forceinline__ uint32_t brev(uint32_t v, int len) { return __builtin_bitreverse32(v) >> (32 - len); }
@@ -315,27 +307,27 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
     }
     Reader r;
     r.lane_ = lane;
-    r.src = (const uint2 *)(src_base + s0);
+    r.src = (const uint32_t *)(src_base + s0);
     r.n_words = (n_src + 3u) >> 2;
-    {   // 8-byte units that lie inside the buffer (the stream's last unit may reach up to 7 bytes past its end)
-        const int64_t room = src_capacity - s0;
-        const int64_t units = (((int64_t)n_src + 7) >> 3);
-        r.n_chunks_ok = (uint32_t)(units * 8 <= room ? units : room >> 3);
+    {   // words that lie inside the buffer (the stream's last word may reach up to 3 bytes past its end)
+        const int64_t room = good ? src_capacity - s0 : 0;
+        r.n_words_ok = (uint32_t)((int64_t)r.n_words * 4 <= room ? (int64_t)r.n_words : room >> 2);
     }
+    r.base = r.rb = r.W = r.Wn = 0u;
     uint32_t pos = 0, flushed = 0;
     uint32_t far_v = 0, far_pos = 0, far_len = 0;       // a far match whose bytes are still on their way from HBM (per lane: byte `lane`)
     const uint32_t out_n = (uint32_t)block_bytes;
     if (good) r.seek(2, lane);
     bool last = false;
     while (good && !last) {
-        if (r.widx > r.n_words + 6u) { good = false; break; }   // ran past the stream's end (zeros decode to nothing useful)
+        if (r.word_index() > r.n_words + 6u) { good = false; break; }   // ran past the stream's end (zeros decode to nothing useful)
         r.refill();
         last = r.take(1) != 0;
         const uint32_t type = r.take(2);
         if (type == 3) { good = false; break; }
         if (type == 0) {
             // ---- stored block: LEN, NLEN at the next byte boundary, then LEN raw bytes ------------------------------------------
-            r.drop(r.cnt & 7);
+            r.to_byte_boundary();
             r.refill();
             const uint32_t len = r.take(16);
             r.refill();
@@ -440,68 +432,71 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
         // one-symbol path; the scalar bit buffer is brought up to date once per batch.
         bool block_done = false;
         while (good && !block_done) {
-            r.refill();                                          // > 96 valid bits
+            r.refill();                                          // the next 256 bits are in W
             uint32_t E, P;
             {
-                const uint32_t w0 = (uint32_t)r.lo, w1 = (uint32_t)(r.lo >> 32), w2 = (uint32_t)r.hi, w3 = (uint32_t)(r.hi >> 32);
-                const uint32_t win = __builtin_amdgcn_alignbit(lane < 32 ? w1 : w2, lane < 32 ? w0 : w1, (uint32_t)lane & 31u);
-                E = L.lit[win & ((1u << kLitBits) - 1u)];        // stream bits [lane, lane + 32) -> the symbol starting there
+                const uint32_t b = r.rb + (uint32_t)lane;            // this lane's bit offset inside the window
+                const int i0 = (int)((b >> 5) << 2);
+                const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(i0, (int)r.W);
+                const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(i0 + 4, (int)r.W);
+                const uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(i0 + 8, (int)r.W);
+                const uint32_t sh = b & 31u;
+                const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, sh);
+                E = L.lit[win & ((1u << kLitBits) - 1u)];        // stream bits [b, b + 32) -> the symbol starting there
                 const uint32_t kE = (E >> 8) & 7u, clen = E & 0xFFu, lx = (E >> 11) & 31u;
                 const uint32_t len = (E >> 16) + ((win >> clen) & ((1u << lx) - 1u));
-                const uint32_t off2 = (uint32_t)lane + clen + lx;      // where the distance code would start (<= 63 + 20)
-                const uint32_t d2 = off2 >> 5;
-                const uint32_t a2 = d2 == 0u ? w0 : d2 == 1u ? w1 : w2, b2 = d2 == 0u ? w1 : d2 == 1u ? w2 : w3;
-                const uint32_t win2 = __builtin_amdgcn_alignbit(b2, a2, off2 & 31u);
+                const uint32_t o2 = sh + clen + lx;                  // where the distance code would start (<= 31 + 20)
+                const uint32_t win2 = __builtin_amdgcn_alignbit(o2 < 32u ? w1 : w2, o2 < 32u ? w0 : w1, o2 & 31u);
                 const uint32_t D = L.dist[win2 & ((1u << kDistBits) - 1u)];
                 const uint32_t kD = (D >> 8) & 7u, dlen = D & 0xFFu, dx = (D >> 11) & 31u;
                 const uint32_t dist = (D >> 16) + ((win2 >> dlen) & ((1u << dx) - 1u));
-                const uint32_t total = kE == 0u ? clen : clen + lx + dlen + dx;
-                // a literal: its code length (1 .. 15); a match: total bits (7) | length (9) << 7 | distance (16) << 16;
-                // 0: not decodable here (long code, end of block, invalid); ~0: the symbol reaches beyond the bits in the buffer
-                // (a code is decided by its own bits -- prefix property -- so "fits the valid bits" is the whole condition)
-                P = kE == 0u ? clen : (kE == 1u && kD == 1u) ? (total | (len << 7) | (dist << 16)) : 0u;
-                if (P != 0u && (uint32_t)lane + total > (uint32_t)r.cnt) P = ~0u;
+                const uint32_t total = clen + lx + dlen + dx;
+                // a literal: its code length (1 .. 15), + 32 if the next symbol starts beyond lane 63 (the batch's last one);
+                // a match: total bits (7) | length (9) << 7 | distance (16) << 16 (>= 384); 16: not decodable here (a code longer
+                // than the table index, end of block, an invalid pattern).  Zeros follow the stream's end: what decodes from
+                // them runs into the output bound or an invalid block header.
+                P = kE == 0u ? (clen + ((uint32_t)lane + clen > 63u ? 32u : 0u))
+                             : (kE == 1u && kD == 1u) ? (total | (len << 7) | (dist << 16)) : 16u;
             }
-            int off = 0;                                         // bits consumed since the gathers (wave-uniform)
+            uint32_t off = 0;                                    // bits consumed since the gathers (wave-uniform)
             uint64_t run = 0;                                    // lanes (= bit offsets) of the pending literal run
             bool slow = false;
             for (;;) {
                 // ---- the literal chain: the hot loop ----
-                // while P[off] is a literal (its code length, 1 .. 15): run |= 1 << off; off += P[off]; past lane 63: p = ~0.
-                // Hand-written: as C the compiler wraps this loop in 13 scalar instructions per literal (select / mask juggling of
-                // its structurizer); these are 8, and the frame's time is its scalar instruction count.  All operands are SGPRs
-                // except P; an SGPR written by the scalar unit needs no wait state as `v_readlane_b32`'s lane select, and the SGPR
-                // it writes none before the scalar unit reads it.
-                uint32_t p, t;
-                asm volatile("s_nop 0\n\t"
-                             "v_readlane_b32 %[p], %[P], %[off]\n\t"
-                             "s_sub_u32 %[t], %[p], 1\n\t"
-                             "s_cmp_lt_u32 %[t], 15\n\t"
-                             "s_cbranch_scc0 2f\n"
-                             "1:\n\t"
-                             "s_bitset1_b64 %[run], %[off]\n\t"
-                             "s_add_u32 %[off], %[off], %[p]\n\t"
-                             "s_cmp_gt_u32 %[off], 63\n\t"
-                             "s_cbranch_scc1 3f\n\t"
-                             "v_readlane_b32 %[p], %[P], %[off]\n\t"
-                             "s_sub_u32 %[t], %[p], 1\n\t"
-                             "s_cmp_lt_u32 %[t], 15\n\t"
-                             "s_cbranch_scc1 1b\n\t"
-                             "s_branch 2f\n"
-                             "3:\n\t"
-                             "s_mov_b32 %[p], -1\n"
+                // while P[off] < 16 (a literal whose successor starts inside the batch): run |= 1 << off; off += P[off].
+                // Hand-written and unrolled: 5 scalar instructions per literal, no taken branch on the way (as C the compiler
+                // wraps the loop in 13 instructions of select / mask juggling per literal; the frame's time is its instruction
+                // count).  All operands are SGPRs except P; an SGPR written by the scalar unit needs no wait state as
+                // `v_readlane_b32`'s lane select, and the SGPR it writes none before the scalar unit reads it.  off <= 63 throughout.
+                uint32_t p;
+#define MSPA_LIT_STEP                                   \
+    "v_readlane_b32 %[p], %[P], %[off]\n\t"             \
+    "s_cmp_lt_u32 %[p], 16\n\t"                         \
+    "s_cbranch_scc0 2f\n\t"                             \
+    "s_bitset1_b64 %[run], %[off]\n\t"                  \
+    "s_add_u32 %[off], %[off], %[p]\n\t"
+                asm volatile("s_nop 0\n"
+                             "1:\n\t" MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP
+                                 MSPA_LIT_STEP "s_branch 1b\n"
                              "2:\n\t"
-                             : [run] "+s"(run), [off] "+s"(off), [p] "=&s"(p), [t] "=&s"(t)
+                             : [run] "+s"(run), [off] "+s"(off), [p] "=&s"(p)
                              : [P] "v"(P)
                              : "scc");
+#undef MSPA_LIT_STEP
+                bool batch_end = false;
+                if ((p & ~15u) == 32u) {                         // the batch's last literal
+                    run |= 1ull << off;
+                    off += p & 15u;
+                    batch_end = true;
+                }
                 if (run) {                                       // every literal of the run by its own lane, ranks from the mask
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(run >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)run, 0u));
                     if ((run >> lane) & 1ull) L.ring[(pos + rank) & kRingMask] = (uint8_t)(E >> 16);
                     pos += (uint32_t)__builtin_popcountll(run);
                     run = 0;
                 }
-                if (p == ~0u) break;                             // out of lanes or out of bits: next batch
-                if (p == 0u) { slow = true; break; }
+                if (batch_end) break;
+                if (p == 16u) { slow = true; break; }
                 // ---- a match ----
                 const uint32_t length = (p >> 7) & 0x1FFu, dist = p >> 16;
                 if (dist > pos || (uint64_t)pos + length > out_n) { good = false; break; }
@@ -522,7 +517,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
                     far_len = length;
                 }
                 pos += length;
-                off += (int)(p & 0x7Fu);
+                off += p & 0x7Fu;
                 if (pos - flushed >= 256u) {
                     if (far_len) {
                         if ((uint32_t)lane < far_len) L.ring[(far_pos + (uint32_t)lane) & kRingMask] = (uint8_t)far_v;
@@ -531,16 +526,11 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
                     wave_lds_fence();
                     flushed = flush_lines(L, dst, pos, flushed, lane);
                 }
-                if (off > 63) break;
+                if (off > 63u) break;
             }
+            r.drop((int)off);                                    // off <= 63 + 48
             if (!good) break;
             if (pos > out_n) { good = false; break; }            // before anything of it leaves the ring
-            if (off >= 64) {                                     // bring the scalar bit buffer up to the walk (off <= 63 + 48)
-                r.drop(32);
-                r.drop(32);
-                off -= 64;
-            }
-            r.drop(off);
             if (pos - flushed >= 256u) {
                 if (far_len) {
                     if ((uint32_t)lane < far_len) L.ring[(far_pos + (uint32_t)lane) & kRingMask] = (uint8_t)far_v;
@@ -560,7 +550,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
             uint32_t e = uni(L.lit[r.peek(kLitBits)]);
             uint32_t kind = (e >> 8) & 7u;
             if (kind == 3u) {
-                const uint32_t lc = uni(long_code(L, 0, kLitBits, L.sorted, (uint32_t)r.lo & 0xFFFFu));
+                const uint32_t lc = uni(long_code(L, 0, kLitBits, L.sorted, r.peek(16)));
                 const uint32_t sym = lc & 0xFFFFu;
                 const uint32_t len = lc >> 16;
                 if (len == 0u) { good = false; break; }
@@ -581,7 +571,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
                 const uint32_t length = (e >> 16) + r.take((int)((e >> 11) & 31u));
                 uint32_t d = uni(L.dist[r.peek(kDistBits)]);
                 if (((d >> 8) & 7u) == 3u) {
-                    const uint32_t lc = uni(long_code(L, 1, kDistBits, L.sorted + kLitSyms, (uint32_t)r.lo & 0xFFFFu));
+                    const uint32_t lc = uni(long_code(L, 1, kDistBits, L.sorted + kLitSyms, r.peek(16)));
                     const uint32_t sym = lc & 0xFFFFu;
                     if ((lc >> 16) == 0u || sym > 29u) { good = false; break; }
                     d = pack(lc >> 16, 1, kDistExtra[sym], kDistBase[sym]);
