@@ -514,7 +514,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
                     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     far_v = (uint32_t)lane < length ? (uint32_t)dst[pos - dist + (uint32_t)lane] : 0u;
                     far_pos = pos;
-                    far_len = length;
+                    far_len = uni(length);
                 }
                 pos += length;
                 off += p & 0x7Fu;
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
                         far_len = 0;
                     }
                     wave_lds_fence();
-                    flushed = flush_lines(L, dst, pos, flushed, lane);
+                    flushed = uni(flush_lines(L, dst, pos, flushed, lane));
                 }
                 if (off > 63u) break;
             }
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
                     far_len = 0;
                 }
                 wave_lds_fence();
-                flushed = flush_lines(L, dst, pos, flushed, lane);
+                flushed = uni(flush_lines(L, dst, pos, flushed, lane));
             }
             if (!slow) continue;
             // ---- one symbol on the scalar path: a long code, end of block, or an invalid pattern ---------------------------------
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
                 break;
             }
             wave_lds_fence();
-            if (pos - flushed >= 256u) flushed = flush_lines(L, dst, pos, flushed, lane);
+            if (pos - flushed >= 256u) flushed = uni(flush_lines(L, dst, pos, flushed, lane));
         }
     }
     if (far_len) {
