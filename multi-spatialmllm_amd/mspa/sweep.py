@@ -279,18 +279,60 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
         elif failure is not None:
             raise failure
 
+    def finish(w, local_rows, local_blobs) -> None:
+        """Window ``w``'s deferred blobs, its vote and its one exchange; rank 0 hands the result to its writer."""
+        failure: Optional[BaseException] = None
+        with timings.span("encode_wait"):
+            for n, (index, blobs) in enumerate(local_blobs):
+                try:
+                    local_blobs[n] = (index, [b.result() if hasattr(b, "result") else b for b in blobs])
+                except Exception as e:                     # a failure on an encoder thread counts like one in produce
+                    failure = e
+                    break
+        vote(failure)
+        with timings.span("exchange"):
+            rows_by_index: Dict[int, np.ndarray] = {}
+            if record_width is not None:
+                dev = ctx.collective_device if ctx is not None else "cpu"
+                local = torch.cat([r.to(dev) for r in local_rows], 0) if local_rows else \
+                    torch.zeros((0, record_width + 1), dtype=torch.float64, device=dev)
+                table = shard.collate_records(local, ctx, dst=0) if ctx is not None else local
+                if rank == 0:
+                    table = table.cpu().numpy()
+                    tags = table[:, 0].astype(np.int64)
+                    # each item's rows are contiguous (cat per item, ranks concatenated): cut at the tag changes
+                    cuts = np.flatnonzero(np.diff(tags)) + 1 if len(tags) else np.zeros(0, np.int64)
+                    for lo, hi in zip(np.concatenate([[0], cuts]).astype(np.int64), np.concatenate([cuts, [len(tags)]]).astype(np.int64)):
+                        if hi > lo:
+                            rows_by_index[int(tags[lo])] = table[lo:hi, 1:]
+            packed = _pack_blobs(local_blobs)
+            if ctx is not None:
+                parts = shard.gather_bytes(packed, ctx, dst=0)
+            else:
+                parts = [np.frombuffer(packed, dtype=np.uint8)]
+        if writer is not None:
+            writer.put(sorted(i for b in w for i in b), rows_by_index, parts)
+
     try:
+        # One window of lag: window w is voted on and exchanged AFTER window w + 1 has been produced, so that the encoder
+        # threads work on w's deferred blobs (63 ms per visibility index) under w + 1's kernels instead of the sweep thread
+        # waiting for the last-produced scene's encode at every window's end.  Every rank runs the same sequence of
+        # collectives -- finish(0), finish(1), ... -- so a rank whose produce fails in window w still finishes w - 1 and then
+        # brings the failure to w's vote: everyone leaves together, the windows before the failing one are complete.
+        pending = None
         for w in wins:
             local_rows, local_blobs = [], []
-            failure: Optional[BaseException] = None
             for index in w[rank]:
                 try:
                     item = next(items)
                     with timings.span("produce"):
                         records, blobs = produce(index, item)
                 except Exception as e:                     # a missing file, a bad pose: the other ranks must not be left
-                    failure = e                            # waiting in the window's exchange (they would, until the timeout)
-                    break
+                    if pending is not None:                # waiting in a window's exchange (they would, until the timeout).
+                        fin, pending = pending, None       # The window before this one is complete: it is exchanged and
+                        finish(*fin)                       # written; THIS window's vote then carries the failure (the other
+                    vote(e)                                # ranks reach it after producing one more window)
+                    raise                                  # (a world of one: vote raises it)
                 if record_width is not None:
                     if records is None:
                         records = torch.zeros((0, record_width), dtype=torch.float64)
@@ -299,38 +341,11 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
                     tagged[:, 1:] = records
                     local_rows.append(tagged)
                 local_blobs.append((index, [encoders.submit(timed_encode, b) if callable(b) else b for b in blobs]))
-            if failure is None:                            # the deferred blobs of this window: wait, a failure there counts too
-                with timings.span("encode_wait"):
-                    for n, (index, blobs) in enumerate(local_blobs):
-                        try:
-                            local_blobs[n] = (index, [b.result() if hasattr(b, "result") else b for b in blobs])
-                        except Exception as e:
-                            failure = e
-                            break
-            vote(failure)
-            # ---- the window's one exchange -----------------------------------------------------------------------
-            with timings.span("exchange"):
-                rows_by_index: Dict[int, np.ndarray] = {}
-                if record_width is not None:
-                    dev = ctx.collective_device if ctx is not None else "cpu"
-                    local = torch.cat([r.to(dev) for r in local_rows], 0) if local_rows else \
-                        torch.zeros((0, record_width + 1), dtype=torch.float64, device=dev)
-                    table = shard.collate_records(local, ctx, dst=0) if ctx is not None else local
-                    if rank == 0:
-                        table = table.cpu().numpy()
-                        tags = table[:, 0].astype(np.int64)
-                        # each item's rows are contiguous (cat per item, ranks concatenated): cut at the tag changes
-                        cuts = np.flatnonzero(np.diff(tags)) + 1 if len(tags) else np.zeros(0, np.int64)
-                        for lo, hi in zip(np.concatenate([[0], cuts]).astype(np.int64), np.concatenate([cuts, [len(tags)]]).astype(np.int64)):
-                            if hi > lo:
-                                rows_by_index[int(tags[lo])] = table[lo:hi, 1:]
-                packed = _pack_blobs(local_blobs)
-                if ctx is not None:
-                    parts = shard.gather_bytes(packed, ctx, dst=0)
-                else:
-                    parts = [np.frombuffer(packed, dtype=np.uint8)]
-            if writer is not None:
-                writer.put(sorted(i for b in w for i in b), rows_by_index, parts)
+            if pending is not None:
+                finish(*pending)
+            pending = (w, local_rows, local_blobs)
+        if pending is not None:
+            finish(*pending)
         for _ in items:                                        # drain: lets the prefetcher's generator finish cleanly
             pass
     except BaseException:
