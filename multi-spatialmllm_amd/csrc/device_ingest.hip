@@ -287,6 +287,197 @@ __device__ __forceinline__ void copy_match(WaveLds &L, const uint8_t *dst, uint3
     wave_lds_fence();
 }
 
+// The bytes of a far match that are still on their way from HBM go to the ring (before anything reads or flushes them).
+__device__ __forceinline__ void settle_far(WaveLds &L, uint32_t far_v, uint32_t far_pos, uint32_t &far_len, int lane) {
+    if (far_len) {
+        if ((uint32_t)lane < far_len) L.ring[(far_pos + (uint32_t)lane) & kRingMask] = (uint8_t)far_v;
+        far_len = 0;
+        wave_lds_fence();
+    }
+}
+
+// The literals of a run, every one by its own lane (rank in the run's lane mask = its place in the output).
+__device__ __forceinline__ void store_run(WaveLds &L, uint64_t run, uint32_t E, uint32_t &pos, int lane) {
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(run >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)run, 0u));
+    if ((run >> lane) & 1ull) L.ring[(pos + rank) & kRingMask] = (uint8_t)(E >> 16);
+    pos += (uint32_t)__builtin_popcountll(run);
+}
+
+// The symbols of one block, tables in LDS.  true: the block's end-of-block symbol was reached; false: the stream is bad.
+//
+// In batches.  Every lane DECODES THE WHOLE SYMBOL that would start at the bit offset equal to its lane number -- the
+// literal/length entry (an LDS gather), for a length its extra bits, the distance entry at the offset behind them (a second
+// gather) and its extra bits -- and packs what the scalar side needs into one word P, INCLUDING the decisions that depend on the
+// symbol alone (which copy routine a match takes).  All of that is vector work on 64 hypotheses at once.  The serial part, the
+// thing DEFLATE forces, is following the chain from offset 0: for a literal one `v_readlane_b32`, a compare, a bit set and an
+// add.  The literals of a run are then stored by their own lanes in ONE instruction.  Symbols the vector path cannot finish -- a
+// code longer than the table index, end of block, an invalid pattern -- take the scalar one-symbol path.
+// Control flow is spelled with labels: every decision is one scalar compare and one branch (written as nested loops with flags
+// the compiler materialises the flags as 64-bit masks and spends five instructions per decision).
+//   P: a literal: its code length (1 .. 15), + 32 if the next symbol starts beyond lane 63 (the batch's last one);
+//      16: not decodable here;
+//      a match (>= 65 536): total bits (6) | routine (2: 0 one-step ring copy, 1 from HBM, 2 the general copy) << 6 |
+//      (length - 3) << 8 | distance << 16.
+// Zeros follow the stream's end: what decodes from them runs into the output bound or an invalid block header.
+__device__ __forceinline__ bool block_symbols(WaveLds &L, Reader &r, uint8_t *__restrict__ dst, uint32_t out_n, int lane, uint32_t &pos,
+                                              uint32_t &flushed, uint32_t &far_v, uint32_t &far_pos, uint32_t &far_len) {
+    uint32_t E, P, off, p;
+    uint64_t run;
+batch:
+    r.refill();                                                  // the next 256 bits are in W
+    {
+        const uint32_t b = r.rb + (uint32_t)lane;                // this lane's bit offset inside the window
+        const int i0 = (int)((b >> 5) << 2);
+        const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(i0, (int)r.W);
+        const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(i0 + 4, (int)r.W);
+        const uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(i0 + 8, (int)r.W);
+        const uint32_t sh = b & 31u;
+        const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, sh);
+        E = L.lit[win & ((1u << kLitBits) - 1u)];                // stream bits [b, b + 32) -> the symbol starting there
+        const uint32_t kE = (E >> 8) & 7u, clen = E & 0xFFu, lx = (E >> 11) & 31u;
+        const uint32_t len = (E >> 16) + ((win >> clen) & ((1u << lx) - 1u));
+        const uint32_t o2 = sh + clen + lx;                      // where the distance code would start (<= 31 + 20)
+        const uint32_t win2 = __builtin_amdgcn_alignbit(o2 < 32u ? w1 : w2, o2 < 32u ? w0 : w1, o2 & 31u);
+        const uint32_t D = L.dist[win2 & ((1u << kDistBits) - 1u)];
+        const uint32_t kD = (D >> 8) & 7u, dlen = D & 0xFFu, dx = (D >> 11) & 31u;
+        const uint32_t dist = (D >> 16) + ((win2 >> dlen) & ((1u << dx) - 1u));
+        const uint32_t total = clen + lx + dlen + dx;
+        const uint32_t routine = len > 64u ? 2u : dist > (uint32_t)kRingNear ? 1u : dist >= len ? 0u : 2u;
+        P = kE == 0u ? (clen + ((uint32_t)lane + clen > 63u ? 32u : 0u))
+                     : (kE == 1u && kD == 1u) ? (total | (routine << 6) | ((len - 3u) << 8) | (dist << 16)) : 16u;
+    }
+    off = 0;                                                     // bits consumed since the gathers (wave-uniform)
+    run = 0;                                                     // lanes (= bit offsets) of the pending literal run
+chain:
+    // ---- the literal chain: the hot loop ----
+    // while P[off] < 16 (a literal whose successor starts inside the batch): run |= 1 << off; off += P[off].
+    // Hand-written and unrolled: 5 scalar instructions per literal, no taken branch on the way.  All operands are SGPRs except P;
+    // an SGPR written by the scalar unit needs no wait state as `v_readlane_b32`'s lane select, and the SGPR it writes none
+    // before the scalar unit reads it.  off <= 63 throughout.
+#define MSPA_LIT_STEP                                   \
+    "v_readlane_b32 %[p], %[P], %[off]\n\t"             \
+    "s_cmp_lt_u32 %[p], 16\n\t"                         \
+    "s_cbranch_scc0 2f\n\t"                             \
+    "s_bitset1_b64 %[run], %[off]\n\t"                  \
+    "s_add_u32 %[off], %[off], %[p]\n\t"
+    asm volatile("s_nop 0\n"
+                 "1:\n\t" MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP
+                     MSPA_LIT_STEP "s_branch 1b\n"
+                 "2:\n\t"
+                 : [run] "+s"(run), [off] "+s"(off), [p] "=&s"(p)
+                 : [P] "v"(P)
+                 : "scc");
+#undef MSPA_LIT_STEP
+    if (p < 48u) {                                               // the batch ends here: its last literal, or a symbol for the scalar path
+        if (p != 16u) {
+            run |= 1ull << off;
+            off += p & 15u;
+        }
+        if (run) store_run(L, run, E, pos, lane);
+        r.drop((int)off);
+        if (pos > out_n) return false;                           // before anything of it leaves the ring
+        if (pos - flushed >= 256u) {
+            settle_far(L, far_v, far_pos, far_len, lane);
+            wave_lds_fence();
+            flushed = uni(flush_lines(L, dst, pos, flushed, lane));
+        }
+        if (p != 16u) goto batch;
+        goto one_symbol;
+    }
+    if (run) {
+        store_run(L, run, E, pos, lane);
+        run = 0;
+    }
+    {   // ---- a match ----
+        const uint32_t length = ((p >> 8) & 0xFFu) + 3u, dist = p >> 16, routine = p & 0xC0u;
+        if (dist > pos) return false;
+        if (pos + length > out_n) return false;
+        settle_far(L, far_v, far_pos, far_len, lane);            // the bytes of the previous far match must be in the ring first
+        switch (routine) {
+        case 0x40u:
+            // beyond the ring: the bytes left for HBM at least 12 lines ago.  vmcnt counts a wave's vector memory operations in
+            // issue order, so "at most 8 outstanding" means those stores have completed; the load's result goes to the ring only
+            // when the next match (or the next line leaving the ring) needs it.
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            far_v = (uint32_t)lane < length ? (uint32_t)dst[pos - dist + (uint32_t)lane] : 0u;
+            far_pos = pos;
+            far_len = uni(length);
+            break;
+        case 0u: {                                               // one step, source and destination apart, both in the ring
+            uint8_t bt = 0;
+            if ((uint32_t)lane < length) bt = L.ring[(pos - dist + (uint32_t)lane) & kRingMask];
+            wave_lds_fence();
+            if ((uint32_t)lane < length) L.ring[(pos + (uint32_t)lane) & kRingMask] = bt;
+            wave_lds_fence();
+            break;
+        }
+        default:
+            copy_match(L, dst, pos, length, dist, lane);
+            break;
+        }
+        pos += length;
+        off += p & 63u;
+        if (pos - flushed >= 256u) {
+            if (pos > out_n) return false;
+            settle_far(L, far_v, far_pos, far_len, lane);
+            wave_lds_fence();
+            flushed = uni(flush_lines(L, dst, pos, flushed, lane));
+        }
+        if (off <= 63u) goto chain;
+        r.drop((int)off);                                        // off <= 63 + 48
+        goto batch;
+    }
+one_symbol:
+    // ---- one symbol on the scalar path: a long code, end of block, or an invalid pattern ---------------------------------------
+    settle_far(L, far_v, far_pos, far_len, lane);
+    r.refill();
+    {
+        uint32_t e = uni(L.lit[r.peek(kLitBits)]);
+        uint32_t kind = (e >> 8) & 7u;
+        if (kind == 3u) {
+            const uint32_t lc = uni(long_code(L, 0, kLitBits, L.sorted, r.peek(16)));
+            const uint32_t sym = lc & 0xFFFFu;
+            const uint32_t len = lc >> 16;
+            if (len == 0u) return false;
+            if (sym < 256u) e = pack(len, 0, 0, sym);
+            else if (sym == 256u) e = pack(len, 2, 0, 0);
+            else if (sym > 285u) e = pack(len, 4, 0, 0);
+            else e = pack(len, 1, kLenExtra[sym - 257u], kLenBase[sym - 257u]);
+            kind = (e >> 8) & 7u;
+        }
+        r.drop((int)(e & 0xFFu));
+        if (kind == 0u) {
+            if (pos >= out_n) return false;
+            if (lane == 0) L.ring[pos & kRingMask] = (uint8_t)(e >> 16);
+            ++pos;
+        } else if (kind == 2u) {
+            wave_lds_fence();
+            if (pos - flushed >= 256u) flushed = uni(flush_lines(L, dst, pos, flushed, lane));
+            return true;
+        } else if (kind == 1u) {
+            const uint32_t length = (e >> 16) + r.take((int)((e >> 11) & 31u));
+            uint32_t d = uni(L.dist[r.peek(kDistBits)]);
+            if (((d >> 8) & 7u) == 3u) {
+                const uint32_t lc = uni(long_code(L, 1, kDistBits, L.sorted + kLitSyms, r.peek(16)));
+                const uint32_t sym = lc & 0xFFFFu;
+                if ((lc >> 16) == 0u || sym > 29u) return false;
+                d = pack(lc >> 16, 1, kDistExtra[sym], kDistBase[sym]);
+            }
+            if (((d >> 8) & 7u) != 1u) return false;
+            r.drop((int)(d & 0xFFu));
+            const uint32_t dist = (d >> 16) + r.take((int)((d >> 11) & 31u));
+            if (dist > pos || pos + length > out_n) return false;
+            copy_match(L, dst, pos, length, dist, lane);
+            pos += length;
+        } else {
+            return false;
+        }
+        wave_lds_fence();
+        if (pos - flushed >= 256u) flushed = uni(flush_lines(L, dst, pos, flushed, lane));
+    }
+    goto batch;
+}
+
 // status codes of a block (int32): 0 accepted; 1 not a valid / supported stream or wrong size; (2 set by the Adler pass: checksum)
 __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__ src_base, const int64_t *__restrict__ src_offsets,
                                                      const int64_t *__restrict__ src_bytes, int64_t src_capacity, uint8_t *__restrict__ dst_base, int64_t dst_pitch,
@@ -422,173 +613,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
         if (!uni(build_table(L, 1, L.lens + kLitSyms, kDistSyms, L.dist, kDistBits, L.sorted + kLitSyms, lane))) { good = false; break; }
 
         // ---- the block's symbols ---------------------------------------------------------------------------------------------
-        // In batches.  Every lane DECODES THE WHOLE SYMBOL that would start at the bit offset equal to its lane number -- the
-        // literal/length entry (an LDS gather), for a length its extra bits, the distance entry at the offset behind them (a
-        // second gather) and its extra bits -- and packs the symbol's total bit count, match length and distance into one word.
-        // All of that is vector work on 64 hypotheses at once.  The serial part, the thing DEFLATE forces, is reduced to
-        // following the chain from offset 0: for a literal one `v_readlane_b32`, a compare, a bit set and an add.  The literals
-        // of a run are then stored by their own lanes in ONE instruction (rank = `v_mbcnt` of the run's lane mask).  Symbols the
-        // vector path cannot finish -- a code longer than the table index, end of block, an invalid pattern -- take the scalar
-        // one-symbol path; the scalar bit buffer is brought up to date once per batch.
-        bool block_done = false;
-        while (good && !block_done) {
-            r.refill();                                          // the next 256 bits are in W
-            uint32_t E, P;
-            {
-                const uint32_t b = r.rb + (uint32_t)lane;            // this lane's bit offset inside the window
-                const int i0 = (int)((b >> 5) << 2);
-                const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(i0, (int)r.W);
-                const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(i0 + 4, (int)r.W);
-                const uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(i0 + 8, (int)r.W);
-                const uint32_t sh = b & 31u;
-                const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, sh);
-                E = L.lit[win & ((1u << kLitBits) - 1u)];        // stream bits [b, b + 32) -> the symbol starting there
-                const uint32_t kE = (E >> 8) & 7u, clen = E & 0xFFu, lx = (E >> 11) & 31u;
-                const uint32_t len = (E >> 16) + ((win >> clen) & ((1u << lx) - 1u));
-                const uint32_t o2 = sh + clen + lx;                  // where the distance code would start (<= 31 + 20)
-                const uint32_t win2 = __builtin_amdgcn_alignbit(o2 < 32u ? w1 : w2, o2 < 32u ? w0 : w1, o2 & 31u);
-                const uint32_t D = L.dist[win2 & ((1u << kDistBits) - 1u)];
-                const uint32_t kD = (D >> 8) & 7u, dlen = D & 0xFFu, dx = (D >> 11) & 31u;
-                const uint32_t dist = (D >> 16) + ((win2 >> dlen) & ((1u << dx) - 1u));
-                const uint32_t total = clen + lx + dlen + dx;
-                // a literal: its code length (1 .. 15), + 32 if the next symbol starts beyond lane 63 (the batch's last one);
-                // a match: total bits (7) | length (9) << 7 | distance (16) << 16 (>= 384); 16: not decodable here (a code longer
-                // than the table index, end of block, an invalid pattern).  Zeros follow the stream's end: what decodes from
-                // them runs into the output bound or an invalid block header.
-                P = kE == 0u ? (clen + ((uint32_t)lane + clen > 63u ? 32u : 0u))
-                             : (kE == 1u && kD == 1u) ? (total | (len << 7) | (dist << 16)) : 16u;
-            }
-            uint32_t off = 0;                                    // bits consumed since the gathers (wave-uniform)
-            uint64_t run = 0;                                    // lanes (= bit offsets) of the pending literal run
-            bool slow = false;
-            for (;;) {
-                // ---- the literal chain: the hot loop ----
-                // while P[off] < 16 (a literal whose successor starts inside the batch): run |= 1 << off; off += P[off].
-                // Hand-written and unrolled: 5 scalar instructions per literal, no taken branch on the way (as C the compiler
-                // wraps the loop in 13 instructions of select / mask juggling per literal; the frame's time is its instruction
-                // count).  All operands are SGPRs except P; an SGPR written by the scalar unit needs no wait state as
-                // `v_readlane_b32`'s lane select, and the SGPR it writes none before the scalar unit reads it.  off <= 63 throughout.
-                uint32_t p;
-#define MSPA_LIT_STEP                                   \
-    "v_readlane_b32 %[p], %[P], %[off]\n\t"             \
-    "s_cmp_lt_u32 %[p], 16\n\t"                         \
-    "s_cbranch_scc0 2f\n\t"                             \
-    "s_bitset1_b64 %[run], %[off]\n\t"                  \
-    "s_add_u32 %[off], %[off], %[p]\n\t"
-                asm volatile("s_nop 0\n"
-                             "1:\n\t" MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP
-                                 MSPA_LIT_STEP "s_branch 1b\n"
-                             "2:\n\t"
-                             : [run] "+s"(run), [off] "+s"(off), [p] "=&s"(p)
-                             : [P] "v"(P)
-                             : "scc");
-#undef MSPA_LIT_STEP
-                bool batch_end = false;
-                if ((p & ~15u) == 32u) {                         // the batch's last literal
-                    run |= 1ull << off;
-                    off += p & 15u;
-                    batch_end = true;
-                }
-                if (run) {                                       // every literal of the run by its own lane, ranks from the mask
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(run >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)run, 0u));
-                    if ((run >> lane) & 1ull) L.ring[(pos + rank) & kRingMask] = (uint8_t)(E >> 16);
-                    pos += (uint32_t)__builtin_popcountll(run);
-                    run = 0;
-                }
-                if (batch_end) break;
-                if (p == 16u) { slow = true; break; }
-                // ---- a match ----
-                const uint32_t length = (p >> 7) & 0x1FFu, dist = p >> 16;
-                if (dist > pos || (uint64_t)pos + length > out_n) { good = false; break; }
-                if (far_len) {                                   // the bytes of the previous far match must be in the ring first
-                    if ((uint32_t)lane < far_len) L.ring[(far_pos + (uint32_t)lane) & kRingMask] = (uint8_t)far_v;
-                    far_len = 0;
-                    wave_lds_fence();
-                }
-                if (dist <= (uint32_t)kRingNear || length > 64u) {
-                    copy_match(L, dst, pos, length, dist, lane);
-                } else {
-                    // beyond the ring: the bytes left for HBM at least 12 lines ago.  vmcnt counts a wave's vector memory
-                    // operations in issue order, so "at most 8 outstanding" means those stores have completed; the load's
-                    // result goes to the ring only when the next match (or the next line leaving the ring) needs it.
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    far_v = (uint32_t)lane < length ? (uint32_t)dst[pos - dist + (uint32_t)lane] : 0u;
-                    far_pos = pos;
-                    far_len = uni(length);
-                }
-                pos += length;
-                off += p & 0x7Fu;
-                if (pos - flushed >= 256u) {
-                    if (far_len) {
-                        if ((uint32_t)lane < far_len) L.ring[(far_pos + (uint32_t)lane) & kRingMask] = (uint8_t)far_v;
-                        far_len = 0;
-                    }
-                    wave_lds_fence();
-                    flushed = uni(flush_lines(L, dst, pos, flushed, lane));
-                }
-                if (off > 63u) break;
-            }
-            r.drop((int)off);                                    // off <= 63 + 48
-            if (!good) break;
-            if (pos > out_n) { good = false; break; }            // before anything of it leaves the ring
-            if (pos - flushed >= 256u) {
-                if (far_len) {
-                    if ((uint32_t)lane < far_len) L.ring[(far_pos + (uint32_t)lane) & kRingMask] = (uint8_t)far_v;
-                    far_len = 0;
-                }
-                wave_lds_fence();
-                flushed = uni(flush_lines(L, dst, pos, flushed, lane));
-            }
-            if (!slow) continue;
-            // ---- one symbol on the scalar path: a long code, end of block, or an invalid pattern ---------------------------------
-            if (far_len) {
-                if ((uint32_t)lane < far_len) L.ring[(far_pos + (uint32_t)lane) & kRingMask] = (uint8_t)far_v;
-                far_len = 0;
-                wave_lds_fence();
-            }
-            r.refill();
-            uint32_t e = uni(L.lit[r.peek(kLitBits)]);
-            uint32_t kind = (e >> 8) & 7u;
-            if (kind == 3u) {
-                const uint32_t lc = uni(long_code(L, 0, kLitBits, L.sorted, r.peek(16)));
-                const uint32_t sym = lc & 0xFFFFu;
-                const uint32_t len = lc >> 16;
-                if (len == 0u) { good = false; break; }
-                if (sym < 256u) e = pack(len, 0, 0, sym);
-                else if (sym == 256u) e = pack(len, 2, 0, 0);
-                else if (sym > 285u) e = pack(len, 4, 0, 0);
-                else e = pack(len, 1, kLenExtra[sym - 257u], kLenBase[sym - 257u]);
-                kind = (e >> 8) & 7u;
-            }
-            r.drop((int)(e & 0xFFu));
-            if (kind == 0u) {
-                if (pos >= out_n) { good = false; break; }
-                if (lane == 0) L.ring[pos & kRingMask] = (uint8_t)(e >> 16);
-                ++pos;
-            } else if (kind == 2u) {
-                block_done = true;
-            } else if (kind == 1u) {
-                const uint32_t length = (e >> 16) + r.take((int)((e >> 11) & 31u));
-                uint32_t d = uni(L.dist[r.peek(kDistBits)]);
-                if (((d >> 8) & 7u) == 3u) {
-                    const uint32_t lc = uni(long_code(L, 1, kDistBits, L.sorted + kLitSyms, r.peek(16)));
-                    const uint32_t sym = lc & 0xFFFFu;
-                    if ((lc >> 16) == 0u || sym > 29u) { good = false; break; }
-                    d = pack(lc >> 16, 1, kDistExtra[sym], kDistBase[sym]);
-                }
-                if (((d >> 8) & 7u) != 1u) { good = false; break; }
-                r.drop((int)(d & 0xFFu));
-                const uint32_t dist = (d >> 16) + r.take((int)((d >> 11) & 31u));
-                if (dist > pos || (uint64_t)pos + length > out_n) { good = false; break; }
-                copy_match(L, dst, pos, length, dist, lane);
-                pos += length;
-            } else {
-                good = false;
-                break;
-            }
-            wave_lds_fence();
-            if (pos - flushed >= 256u) flushed = uni(flush_lines(L, dst, pos, flushed, lane));
-        }
+        if (!block_symbols(L, r, dst, out_n, lane, pos, flushed, far_v, far_pos, far_len)) { good = false; break; }
     }
     if (far_len) {
         if ((uint32_t)lane < far_len) L.ring[(far_pos + (uint32_t)lane) & kRingMask] = (uint8_t)far_v;

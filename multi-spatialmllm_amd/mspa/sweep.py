@@ -232,7 +232,7 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
     without one (``ctx`` None) nothing is exchanged and the same ``consume`` calls happen in the same order.
 
     A window is ``world x per_rank`` items (default: ``MSPA_WINDOW_PER_RANK`` from the environment, else 8).
-    A blob may be a CALLABLE returning the bytes: it runs on a small encoder pool (``MSPA_ENCODE_THREADS``, default: half of the CPUs this rank may use, 2 .. 8) while the
+    A blob -- or the whole list of an item's blobs -- may be a CALLABLE returning the bytes (the list): it runs on a small encoder pool (``MSPA_ENCODE_THREADS``, default: half of the CPUs this rank may use, 2 .. 8) while the
     sweep thread goes on to the next item, and is waited for at the window's exchange -- formatting and compressing a scene's text
     (63 ms for a visibility index) then overlaps the next scenes' kernels instead of standing between them.
     ``consume`` runs on a writer thread of rank 0 (``_WindowWriter``: window w is written while window w + 1 is produced),
@@ -285,6 +285,8 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
         with timings.span("encode_wait"):
             for n, (index, blobs) in enumerate(local_blobs):
                 try:
+                    if hasattr(blobs, "result"):
+                        blobs = blobs.result()
                     local_blobs[n] = (index, [b.result() if hasattr(b, "result") else b for b in blobs])
                 except Exception as e:                     # a failure on an encoder thread counts like one in produce
                     failure = e
@@ -340,7 +342,10 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
                     tagged[:, 0] = index
                     tagged[:, 1:] = records
                     local_rows.append(tagged)
-                local_blobs.append((index, [encoders.submit(timed_encode, b) if callable(b) else b for b in blobs]))
+                if callable(blobs):                        # the whole list deferred (its members may share expensive work)
+                    local_blobs.append((index, encoders.submit(timed_encode, blobs)))
+                else:
+                    local_blobs.append((index, [encoders.submit(timed_encode, b) if callable(b) else b for b in blobs]))
             if pending is not None:
                 finish(*pending)
             pending = (w, local_rows, local_blobs)

@@ -120,10 +120,19 @@ def from_bits(bits, image_ids: List[str], n_points: int) -> VisibilityCSR:
     if F == 0 or n_points == 0:
         return VisibilityCSR(list(image_ids), n_points, np.zeros(F + 1, np.int64), np.zeros(0, np.int32),
                              np.zeros(n_points + 1, np.int64), np.zeros(0, np.int32))
+    import torch
     o1, i1 = engine.bitset_csr(bits)
     t = engine.bits_transpose(bits)                      # [n_words * 64, ceil(F / 64)]; rows >= N are padding (all zero)
     o2, i2 = engine.bitset_csr(t[:n_points].contiguous() if t.shape[0] != n_points else t)
-    return VisibilityCSR(list(image_ids), n_points, o1.cpu().numpy(), i1.cpu().numpy(), o2.cpu().numpy(), i2.cpu().numpy())
+    # ~100 MB per 320-frame scene: into pinned blocks (torch's caching host allocator), all four copies behind ONE wait on the
+    # CURRENT stream -- the sweeps call this on an encoder thread with a stream of its own, next to the sweep thread's kernels
+    host = []
+    for a in (o1, i1, o2, i2):
+        h = torch.empty(a.shape, dtype=a.dtype, pin_memory=True)
+        h.copy_(a, non_blocking=True)
+        host.append(h)
+    torch.cuda.current_stream(bits.device).synchronize()
+    return VisibilityCSR(list(image_ids), n_points, *[h.numpy() for h in host])
 
 
 class SceneRowGroups:

@@ -61,10 +61,44 @@ def process_scene_columns(scene_id, scene_infos, warning_file):
 
 
 def _visibility_csr(scene):
-    return scene.visibility_csr()
+    """K1 launched NOW on the caller's stream, nothing waited for; the returned callable compacts the bit matrix into the two
+    CSR tables (K9) and brings them to the host -- on the calling thread's own stream (``_side_stream``), behind an event
+    recorded after K1.  (May also return the finished ``VisibilityCSR``: what the GPU-less tests stand in.)"""
+    import torch
+    from mspa import visindex
+    if scene.xyz is None:
+        raise ValueError("scene uploaded without vertices")
+    ids, n_points = list(scene.ids), int(scene.xyz.shape[0])
+    if not ids or n_points == 0:                                       # MVI:103-123 with nothing to loop over
+        return visindex.from_bits(None, ids, n_points)
+    bits = scene._visibility()["bits"]
+    launched = torch.cuda.Event()
+    launched.record(torch.cuda.current_stream(bits.device))
+
+    def finish():
+        with torch.cuda.device(bits.device):
+            side = _side_stream(bits.device)
+            side.wait_event(launched)
+            with torch.cuda.stream(side):
+                return visindex.from_bits(bits, ids, n_points)         # returns with the tables on the host
+    return finish
 
 
 _CSR_FIELDS = ("i2p_offsets", "i2p_indices", "p2i_offsets", "p2i_indices")
+_SIDE = __import__("threading").local()
+
+
+def _side_stream(device):
+    """This thread's own stream on ``device`` (the encoder threads of a sweep: their K9 launches and copies run beside the
+    sweep thread's kernels instead of in front of them)."""
+    import torch
+    streams = getattr(_SIDE, "streams", None)
+    if streams is None:
+        streams = _SIDE.streams = {}
+    key = (device.type, device.index)
+    if key not in streams:
+        streams[key] = torch.cuda.Stream(device=device)
+    return streams[key]
 
 
 def run_split(scene_info_path, output_file, warning_file, num_workers=8, keep=True, ctx=None, timings=None):
@@ -105,21 +139,29 @@ def run_split(scene_info_path, output_file, warning_file, num_workers=8, keep=Tr
         return scene_infos.prefetched_scenes([all_scene_ids[i] for i in indices], max(1, int(num_workers)), device, timings)
 
     def produce(index, scene):
+        """K1 is launched here, on the sweep's thread and stream, and nothing is waited for: compacting the bit matrix into the
+        two CSR tables (K9), bringing ~100 MB of indices to the host, formatting and compressing the scene's text all happen on
+        an encoder thread with a stream of its own -- the sweep thread goes straight on to the next scene."""
         scene_id = all_scene_ids[index]
         print(f"[process_scene] Start: {scene_id}")
-        csr = _visibility_csr(scene)
-        lines = [f"[Warning] {scene_id}: {image_id} has no in-bound points.\n" for image_id in csr.empty_images()]
-        blobs = ["".join(lines).encode()]
-        if not as_pkl:
-            # columns all the way: bitsets -> CSR on the device -> JSON text by libmspa's host formatters, straight into
-            # arrow's buffers -> this scene's row group, encoded and compressed HERE; what leaves this rank is finished parquet
-            # bytes.  No dictionary pages: every key and every JSON list is unique, one would be built, overflow and be dropped.
-            # ... on the sweep's encoder threads (a callable blob): 63 ms of formatting + compression per 320-frame scene
-            blobs.append(lambda csr=csr, scene_id=scene_id: parquet_splice.encode_row_group(csr.to_arrow(scene_id), use_dictionary=False))
-        if want_csr:
-            blobs += [np.ascontiguousarray(getattr(csr, f)) for f in _CSR_FIELDS]
+        later = _visibility_csr(scene)
+
+        def finish_scene():
+            csr = later() if callable(later) else later
+            lines = [f"[Warning] {scene_id}: {image_id} has no in-bound points.\n" for image_id in csr.empty_images()]
+            blobs = ["".join(lines).encode()]
+            if not as_pkl:
+                # columns all the way: bitsets -> CSR on the device -> JSON text by libmspa's host formatters, straight into
+                # arrow's buffers -> this scene's row group, encoded and compressed HERE; what leaves this rank is finished
+                # parquet bytes.  No dictionary pages: every key and every JSON list is unique, one would be built, overflow and
+                # be dropped.  63 ms of formatting + compression per 320-frame scene.
+                blobs.append(parquet_splice.encode_row_group(csr.to_arrow(scene_id), use_dictionary=False))
+            if want_csr:
+                blobs += [np.ascontiguousarray(getattr(csr, f)) for f in _CSR_FIELDS]
+            return blobs
+
         print(f"[process_scene] Done: {scene_id}")
-        return None, blobs
+        return None, finish_scene
 
     def consume(index, _rows, blobs):
         scene_id = all_scene_ids[index]
