@@ -718,12 +718,45 @@ def time_dropin_sweep_ranks(ranks=(1, 2, 4), n_scenes=32, n_frames=320, passes=2
     (tools/dropin_ranks.py): scenes/s including the writing, rank 0's writer busy time, every rank's wait at the window
     exchange, and whether the files equal the one-rank run's byte for byte.  The kernels are < 1 % of a scene, so this is the
     host-side scaling of an N-GPU job; the GPU and its PCIe link are the one thing the ranks share here."""
+    import shutil
+    import tempfile
+    mod = _tool("dropin_ranks")
+    root = tempfile.mkdtemp(prefix="mspa_dropin_ranks_")
+    try:
+        res = mod.drive(ranks=tuple(ranks), n_scenes=n_scenes, n_frames=n_frames, workers=num_workers, passes=passes,
+                        per_rank=per_rank, timeout_s=timeout_s, keep_root=root)
+        # the same inputs once more, ONE rank with the sweeps' own defaults at this size: depth frames inflated on the MI355X
+        # (csrc/device_ingest.hip), windows of 8 scenes, 8 loader threads -- what one GPU of a node does with its share of a split
+        try:
+            dev = mod.drive(ranks=(1,), n_scenes=n_scenes, n_frames=n_frames, workers=8, passes=3, per_rank=8, timeout_s=120,
+                            keep_root=root, decode="device")
+            res["one_rank_device_decode"] = dict(dev["worlds"].get("1", {}), num_workers=8, window_scenes_per_rank=8,
+                                                 depth_decode="device", passes=3)
+        except Exception as e:                               # informational
+            res["one_rank_device_decode"] = {"skipped": f"{type(e).__name__}: {e}"}
+        return res
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def _tool(name):
     import importlib.util
-    spec = importlib.util.spec_from_file_location("mspa_dropin_ranks", os.path.join(ROOT, "tools", "dropin_ranks.py"))
+    spec = importlib.util.spec_from_file_location("mspa_tool_" + name, os.path.join(ROOT, "tools", name + ".py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.drive(ranks=tuple(ranks), n_scenes=n_scenes, n_frames=n_frames, workers=num_workers, passes=passes,
-                     per_rank=per_rank, timeout_s=timeout_s)
+    return mod
+
+
+def time_device_decode(streams=3584):
+    """`variants.device_decode`: the depth decode on the MI355X by itself (tools/device_ingest_bench.py) -- `streams` 640 x 480
+    16-bit depth PNGs (level 6, Pillow's adaptive row filters) resident in HBM as compressed bytes, inflated by one wave each
+    (mspa_inflate_blocks_device incl. the Adler-32 pass) and un-filtered (mspa_png_unfilter_device), HIP events around the two
+    calls; beside it the host reader on the CPUs this container may use.  Instruction-bound, not HBM-bound: the roofline of
+    this kernel is its instruction count (profiles/r06_inflate_v5_pmc.md), so what is reported is frames/s and the ratio."""
+    r = _tool("device_ingest_bench").run(streams=streams, reps=3, with_composed=False)
+    r["what"] = ("replaces the per-frame cv2.imread / zlib.decompress of info_handler.py:149-155 and extract_posed_images.py:49-57 for "
+                 "streaming sweeps of >= 1 536 frames")
+    return r
 
 
 def run_scene_workload(args, rank, world, device, dist_ctx, share):
@@ -1183,6 +1216,10 @@ def main():
                     extra["dropin_sweep"] = time_dropin_sweep()
                 except Exception as e:                       # e.g. no Pillow / no pyarrow on the box: the leg is informational
                     extra["dropin_sweep"] = {"skipped": f"{type(e).__name__}: {e}"}
+            try:
+                extra["device_decode"] = time_device_decode()
+            except Exception as e:                           # informational: never costs the line
+                extra["device_decode"] = {"skipped": f"{type(e).__name__}: {e}"}
             if not args.no_dropin_ranks:
                 try:
                     extra["dropin_sweep_ranks"] = time_dropin_sweep_ranks()

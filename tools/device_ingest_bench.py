@@ -24,13 +24,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "multi-spatialmllm_amd"), ROOT]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--streams", type=int, default=2560)
-    ap.add_argument("--base-frames", type=int, default=16)
-    ap.add_argument("--level", type=int, default=6)
-    ap.add_argument("--reps", type=int, default=5)
-    a = ap.parse_args()
+def run(streams=2560, base_frames=16, level=6, reps=5, with_host=True, with_composed=True):
+    """One measurement -> dict (bench.py's `variants.device_decode` leg calls this in-process)."""
+    a = argparse.Namespace(streams=streams, base_frames=base_frames, level=level, reps=reps)
     import torch
     from PIL import Image
     from mspa import engine, hostinfo, ingest, synth
@@ -86,6 +82,8 @@ def main():
                           "frames_per_s": round(n / ((ms_inf + ms_unf) * 1e-3)), "GBps_out": round(out_bytes / ((ms_inf + ms_unf) * 1e-3) / 1e9, 2),
                           "inflate_only_frames_per_s": round(n / (ms_inf * 1e-3)),
                           "compressed_GBps_in": round(float(nb.sum()) / ((ms_inf) * 1e-3) / 1e9, 2)}}
+        if not with_host:
+            return res
         # the host decode on the same files, with the threads the quota allows
         threads = hostinfo.effective_cpus()
         many = (paths * (-(-320 // nb_files)))[:320]
@@ -100,6 +98,8 @@ def main():
         res["host"] = {"threads": threads, "host_cpus": hostinfo.describe(), "frames": len(many), "ms": round(th * 1e3, 2),
                        "frames_per_s": round(len(many) / th), "GBps_out": round(len(many) * H * W * 2 / th / 1e9, 2)}
         res["device_over_host"] = round(res["device"]["frames_per_s"] / res["host"]["frames_per_s"], 2)
+        if not with_composed:
+            return res
         # the composed reader on a 320-frame scene: file reads + pack + H2D + kernels + status read-back
         ingest.read_depth_frames_device(many, dev, threads)
         t = []
@@ -112,9 +112,19 @@ def main():
         tc = float(np.median(t))
         res["composed_320_frame_scene"] = {"ms": round(tc * 1e3, 2), "frames_per_s": round(len(many) / tc),
                                           "equals_host": bool(np.array_equal(d.cpu().numpy().view(np.uint16), dst))}
-        print(json.dumps(res))
+        return res
     finally:
         shutil.rmtree(root, ignore_errors=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=2560)
+    ap.add_argument("--base-frames", type=int, default=16)
+    ap.add_argument("--level", type=int, default=6)
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    print(json.dumps(run(a.streams, a.base_frames, a.level, a.reps)))
 
 
 if __name__ == "__main__":

@@ -125,10 +125,11 @@ def drive(ranks=(1, 2, 4), n_scenes=32, n_frames=320, n_points=131072, workers=N
     root = keep_root or tempfile.mkdtemp(prefix="mspa_dropin_ranks_")
     try:
         t0 = time.perf_counter()
-        paths = write_inputs(root, n_scenes, n_frames, n_points)
-        json.dump(paths, open(os.path.join(root, "paths.json"), "w"))
+        if not os.path.exists(os.path.join(root, "paths.json")):      # (a kept root: the inputs of an earlier call serve again)
+            paths = write_inputs(root, n_scenes, n_frames, n_points)
+            json.dump(paths, open(os.path.join(root, "paths.json"), "w"))
         t_inputs = time.perf_counter() - t0
-        out_dir = os.path.join(root, "out")
+        out_dir = os.path.join(root, "out_" + (decode or "default"))
         os.makedirs(out_dir, exist_ok=True)
         res = {"scenes": n_scenes, "frames_per_scene": n_frames, "vertices": n_points, "num_workers_per_rank": workers,
                "depth_decode": decode or os.environ.get("MSPA_DEPTH_DECODE", "device"), "cpus_per_rank": max(1, eff // max(ranks)), "scenes_in_flight_per_rank": 2, "window_scenes_per_rank": per_rank, "passes": passes, "host_cpus": hostinfo.describe(),
