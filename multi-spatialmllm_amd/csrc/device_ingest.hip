@@ -287,10 +287,14 @@ __device__ __forceinline__ void copy_match(WaveLds &L, const uint8_t *dst, uint3
     wave_lds_fence();
 }
 
-// The bytes of a far match that are still on their way from HBM go to the ring (before anything reads or flushes them).
-__device__ __forceinline__ void settle_far(WaveLds &L, uint32_t far_v, uint32_t far_pos, uint32_t &far_len, int lane) {
+// The bytes of a far match that are still on their way from HBM go to the ring (before anything reads or flushes them).  They
+// live in a0, an accumulation register only the hand-written statements here and in block_symbols touch: the load that fills it
+// is issued by hand and is still in flight while C code runs, so it must not sit in a register the compiler may copy or reuse.
+__device__ __forceinline__ void settle_far(WaveLds &L, uint32_t far_pos, uint32_t &far_len, int lane) {
     if (far_len) {
-        if ((uint32_t)lane < far_len) L.ring[(far_pos + (uint32_t)lane) & kRingMask] = (uint8_t)far_v;
+        uint32_t v;
+        asm volatile("s_waitcnt vmcnt(0)\n\tv_accvgpr_read_b32 %0, a0" : "=v"(v) : : "memory", "a0");
+        if ((uint32_t)lane < far_len) L.ring[(far_pos + (uint32_t)lane) & kRingMask] = (uint8_t)v;
         far_len = 0;
         wave_lds_fence();
     }
@@ -320,7 +324,7 @@ __device__ __forceinline__ void store_run(WaveLds &L, uint64_t run, uint32_t E, 
 //      (length - 3) << 8 | distance << 16.
 // Zeros follow the stream's end: what decodes from them runs into the output bound or an invalid block header.
 __device__ __forceinline__ bool block_symbols(WaveLds &L, Reader &r, uint8_t *__restrict__ dst, uint32_t out_n, int lane, uint32_t &pos,
-                                              uint32_t &flushed, uint32_t &far_v, uint32_t &far_pos, uint32_t &far_len) {
+                                              uint32_t &flushed, uint32_t &far_pos, uint32_t &far_len) {
     uint32_t E, P, off, p;
     uint64_t run;
 batch:
@@ -349,87 +353,145 @@ batch:
     off = 0;                                                     // bits consumed since the gathers (wave-uniform)
     run = 0;                                                     // lanes (= bit offsets) of the pending literal run
 chain:
-    // ---- the literal chain: the hot loop ----
-    // while P[off] < 16 (a literal whose successor starts inside the batch): run |= 1 << off; off += P[off].
-    // Hand-written and unrolled: 5 scalar instructions per literal, no taken branch on the way.  All operands are SGPRs except P;
-    // an SGPR written by the scalar unit needs no wait state as `v_readlane_b32`'s lane select, and the SGPR it writes none
-    // before the scalar unit reads it.  off <= 63 throughout.
+    // ---- the symbol chain of a batch: hand-written -----------------------------------------------------------------------------
+    // As C this loop cost ~90 scalar-side instructions per match (the compiler carries the decode state through register copies at
+    // every merge and materialises each decision as a 64-bit mask); written out it is ~35, and the frame's time is its
+    // instruction count (profiles/r06_inflate_v5_pmc.md).  What it does, per symbol at bit offset `off`:
+    //   literal (P[off] < 16)      run |= 1 << off; off += P[off]                      (5 instructions, unrolled 8 x)
+    //   anything else              the run's literals go to the ring, every one by its own lane (exec = run, rank = mbcnt(exec));
+    //     last literal / 16        leave (why 0): the batch ends, or the scalar one-symbol path takes over
+    //     match                    bounds checked (why 1 = bad stream); the bytes of a far match still on their way from HBM are
+    //                              put into the ring; then by routine: one ds_read_u8 / ds_write_b8 pair (ring to ring), or
+    //                              `s_waitcnt vmcnt(8)` + global_load_ubyte into a0 (consumed by the NEXT match or flush), or
+    //                              leave for the general copy (why 2); pos / off advance; leave when 256 bytes are ready to be
+    //                              flushed (why 3) or the batch is used up (why 4), else back into the literal loop.
+    // exec is all ones on entry (one wave, uniform control flow) and on exit.  Hazards (gfx9 rules): no VALU-written SGPR is used
+    // as a lane select or by VMEM; a0 is waited for with vmcnt(0) before it is stored (nothing but the window prefetch can
+    // have been issued behind its load: a flush settles it first).
+    {
+        uint32_t why, len_s, dist_s, t0, va, vb;
 #define MSPA_LIT_STEP                                   \
     "v_readlane_b32 %[p], %[P], %[off]\n\t"             \
     "s_cmp_lt_u32 %[p], 16\n\t"                         \
     "s_cbranch_scc0 2f\n\t"                             \
     "s_bitset1_b64 %[run], %[off]\n\t"                  \
     "s_add_u32 %[off], %[off], %[p]\n\t"
-    asm volatile("s_nop 0\n"
-                 "1:\n\t" MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP
-                     MSPA_LIT_STEP "s_branch 1b\n"
-                 "2:\n\t"
-                 : [run] "+s"(run), [off] "+s"(off), [p] "=&s"(p)
-                 : [P] "v"(P)
-                 : "scc");
+        asm volatile(
+            "s_nop 0\n"
+            "1:\n\t" MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP
+            "s_branch 1b\n"
+            "2:\n\t"                                              // p >= 16
+            "s_cmp_gt_u32 %[p], 47\n\t"
+            "s_cbranch_scc1 3f\n\t"                               // a match
+            "s_cmp_eq_u32 %[p], 16\n\t"
+            "s_cbranch_scc1 3f\n\t"
+            "s_bitset1_b64 %[run], %[off]\n\t"                    // the batch's last literal
+            "s_and_b32 %[t0], %[p], 15\n\t"
+            "s_add_u32 %[off], %[off], %[t0]\n"
+            "3:\n\t"
+            "s_cmp_eq_u64 %[run], 0\n\t"
+            "s_cbranch_scc1 4f\n\t"
+            "s_mov_b64 exec, %[run]\n\t"                          // the run's literals, each by its own lane
+            "v_mbcnt_lo_u32_b32 %[va], exec_lo, 0\n\t"
+            "v_mbcnt_hi_u32_b32 %[va], exec_hi, %[va]\n\t"
+            "v_add_u32 %[va], %[pos], %[va]\n\t"
+            "v_and_b32 %[va], 0xfff, %[va]\n\t"
+            "ds_write_b8_d16_hi %[va], %[E] offset:%[ring]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "s_bcnt1_i32_b64 %[t0], %[run]\n\t"
+            "s_add_u32 %[pos], %[pos], %[t0]\n\t"
+            "s_mov_b64 %[run], 0\n"
+            "4:\n\t"
+            "s_mov_b32 %[why], 0\n\t"
+            "s_cmp_lt_u32 %[p], 0x10000\n\t"
+            "s_cbranch_scc1 9f\n\t"                               // not a match: why 0
+            "s_bfe_u32 %[len], %[p], 0x80008\n\t"
+            "s_add_u32 %[len], %[len], 3\n\t"
+            "s_lshr_b32 %[dist], %[p], 16\n\t"
+            "s_mov_b32 %[why], 1\n\t"
+            "s_cmp_gt_u32 %[dist], %[pos]\n\t"
+            "s_cbranch_scc1 9f\n\t"                               // reaches in front of the output: bad
+            "s_add_u32 %[t0], %[pos], %[len]\n\t"
+            "s_cmp_gt_u32 %[t0], %[out_n]\n\t"
+            "s_cbranch_scc1 9f\n\t"                               // runs past the expected size: bad
+            "s_cmp_eq_u32 %[far_len], 0\n\t"
+            "s_cbranch_scc1 5f\n\t"
+            "v_cmp_gt_u32 vcc, %[far_len], %[lane]\n\t"           // the previous far match's bytes into the ring
+            "s_mov_b64 exec, vcc\n\t"
+            "v_add_u32 %[va], %[far_pos], %[lane]\n\t"
+            "v_and_b32 %[va], 0xfff, %[va]\n\t"
+            "s_waitcnt vmcnt(0)\n\t"
+            "ds_write_b8 %[va], a0 offset:%[ring]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "s_mov_b32 %[far_len], 0\n"
+            "5:\n\t"
+            "s_mov_b32 %[why], 2\n\t"
+            "s_bitcmp1_b32 %[p], 7\n\t"
+            "s_cbranch_scc1 9f\n\t"                               // the general copy: why 2
+            "v_cmp_gt_u32 vcc, %[len], %[lane]\n\t"
+            "s_mov_b64 exec, vcc\n\t"                             // lanes < length
+            "v_add_u32 %[va], %[pos], %[lane]\n\t"
+            "s_bitcmp1_b32 %[p], 6\n\t"
+            "s_cbranch_scc1 6f\n\t"
+            "v_subrev_u32 %[vb], %[dist], %[va]\n\t"              // ring to ring, source and destination apart
+            "v_and_b32 %[vb], 0xfff, %[vb]\n\t"
+            "ds_read_u8 %[vb], %[vb] offset:%[ring]\n\t"
+            "v_and_b32 %[va], 0xfff, %[va]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "ds_write_b8 %[va], %[vb] offset:%[ring]\n\t"
+            "s_branch 7f\n"
+            "6:\n\t"
+            "s_waitcnt vmcnt(8)\n\t"                              // from HBM: the lines it reads left >= 12 stores ago
+            "v_subrev_u32 %[va], %[dist], %[va]\n\t"
+            "global_load_ubyte a0, %[va], %[dst]\n\t"
+            "s_mov_b32 %[far_pos], %[pos]\n\t"
+            "s_mov_b32 %[far_len], %[len]\n"
+            "7:\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "s_add_u32 %[pos], %[pos], %[len]\n\t"
+            "s_and_b32 %[t0], %[p], 63\n\t"
+            "s_add_u32 %[off], %[off], %[t0]\n\t"
+            "s_mov_b32 %[why], 3\n\t"
+            "s_sub_u32 %[t0], %[pos], %[flushed]\n\t"
+            "s_cmp_ge_u32 %[t0], 0x100\n\t"
+            "s_cbranch_scc1 9f\n\t"                               // lines are ready to leave the ring: why 3
+            "s_cmp_gt_u32 %[off], 63\n\t"
+            "s_cbranch_scc0 1b\n\t"                               // on with the chain
+            "s_mov_b32 %[why], 4\n"
+            "9:\n\t"
+            : [run] "+s"(run), [off] "+s"(off), [pos] "+s"(pos), [far_pos] "+s"(far_pos), [far_len] "+s"(far_len),
+              [p] "=&s"(p), [why] "=&s"(why), [len] "=&s"(len_s), [dist] "=&s"(dist_s), [t0] "=&s"(t0), [va] "=&v"(va), [vb] "=&v"(vb)
+            : [P] "v"(P), [E] "v"(E), [lane] "v"(lane), [flushed] "s"(flushed), [out_n] "s"(out_n), [dst] "s"(dst),
+              [ring] "n"(offsetof(WaveLds, ring))
+            : "scc", "vcc", "memory", "a0");
 #undef MSPA_LIT_STEP
-    if (p < 48u) {                                               // the batch ends here: its last literal, or a symbol for the scalar path
-        if (p != 16u) {
-            run |= 1ull << off;
-            off += p & 15u;
+        if (why == 1u) return false;
+        if (why == 2u) {                                         // the general copy (overlapping or longer than a step): in C
+            copy_match(L, dst, pos, len_s, dist_s, lane);
+            pos += len_s;
+            off += p & 63u;
+            why = pos - flushed >= 256u ? 3u : off > 63u ? 4u : 5u;
+            if (why == 5u) goto chain;
         }
-        if (run) store_run(L, run, E, pos, lane);
-        r.drop((int)off);
-        if (pos > out_n) return false;                           // before anything of it leaves the ring
-        if (pos - flushed >= 256u) {
-            settle_far(L, far_v, far_pos, far_len, lane);
+        if (why == 3u) {
+            settle_far(L, far_pos, far_len, lane);
             wave_lds_fence();
             flushed = uni(flush_lines(L, dst, pos, flushed, lane));
+            if (off <= 63u) goto chain;
         }
-        if (p != 16u) goto batch;
-        goto one_symbol;
     }
-    if (run) {
-        store_run(L, run, E, pos, lane);
-        run = 0;
+    // ---- the batch is used up (or the scalar path takes the next symbol) ----
+    r.drop((int)off);                                            // off <= 63 + 48
+    if (pos > out_n) return false;                               // before anything of it leaves the ring
+    if (pos - flushed >= 256u) {
+        settle_far(L, far_pos, far_len, lane);
+        wave_lds_fence();
+        flushed = uni(flush_lines(L, dst, pos, flushed, lane));
     }
-    {   // ---- a match ----
-        const uint32_t length = ((p >> 8) & 0xFFu) + 3u, dist = p >> 16, routine = p & 0xC0u;
-        if (dist > pos) return false;
-        if (pos + length > out_n) return false;
-        settle_far(L, far_v, far_pos, far_len, lane);            // the bytes of the previous far match must be in the ring first
-        switch (routine) {
-        case 0x40u:
-            // beyond the ring: the bytes left for HBM at least 12 lines ago.  vmcnt counts a wave's vector memory operations in
-            // issue order, so "at most 8 outstanding" means those stores have completed; the load's result goes to the ring only
-            // when the next match (or the next line leaving the ring) needs it.
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            far_v = (uint32_t)lane < length ? (uint32_t)dst[pos - dist + (uint32_t)lane] : 0u;
-            far_pos = pos;
-            far_len = uni(length);
-            break;
-        case 0u: {                                               // one step, source and destination apart, both in the ring
-            uint8_t bt = 0;
-            if ((uint32_t)lane < length) bt = L.ring[(pos - dist + (uint32_t)lane) & kRingMask];
-            wave_lds_fence();
-            if ((uint32_t)lane < length) L.ring[(pos + (uint32_t)lane) & kRingMask] = bt;
-            wave_lds_fence();
-            break;
-        }
-        default:
-            copy_match(L, dst, pos, length, dist, lane);
-            break;
-        }
-        pos += length;
-        off += p & 63u;
-        if (pos - flushed >= 256u) {
-            if (pos > out_n) return false;
-            settle_far(L, far_v, far_pos, far_len, lane);
-            wave_lds_fence();
-            flushed = uni(flush_lines(L, dst, pos, flushed, lane));
-        }
-        if (off <= 63u) goto chain;
-        r.drop((int)off);                                        // off <= 63 + 48
-        goto batch;
-    }
-one_symbol:
+    if (p != 16u) goto batch;
+    // one_symbol:
     // ---- one symbol on the scalar path: a long code, end of block, or an invalid pattern ---------------------------------------
-    settle_far(L, far_v, far_pos, far_len, lane);
+    settle_far(L, far_pos, far_len, lane);
     r.refill();
     {
         uint32_t e = uni(L.lit[r.peek(kLitBits)]);
@@ -506,7 +568,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
     }
     r.base = r.rb = r.W = r.Wn = 0u;
     uint32_t pos = 0, flushed = 0;
-    uint32_t far_v = 0, far_pos = 0, far_len = 0;       // a far match whose bytes are still on their way from HBM (per lane: byte `lane`)
+    uint32_t far_pos = 0, far_len = 0;                  // a far match whose bytes are still on their way from HBM (in a0, per lane: byte `lane`)
     const uint32_t out_n = (uint32_t)block_bytes;
     if (good) r.seek(2, lane);
     bool last = false;
@@ -613,12 +675,9 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
         if (!uni(build_table(L, 1, L.lens + kLitSyms, kDistSyms, L.dist, kDistBits, L.sorted + kLitSyms, lane))) { good = false; break; }
 
         // ---- the block's symbols ---------------------------------------------------------------------------------------------
-        if (!block_symbols(L, r, dst, out_n, lane, pos, flushed, far_v, far_pos, far_len)) { good = false; break; }
+        if (!block_symbols(L, r, dst, out_n, lane, pos, flushed, far_pos, far_len)) { good = false; break; }
     }
-    if (far_len) {
-        if ((uint32_t)lane < far_len) L.ring[(far_pos + (uint32_t)lane) & kRingMask] = (uint8_t)far_v;
-        far_len = 0;
-    }
+    settle_far(L, far_pos, far_len, lane);
     // the tail of the ring, byte by byte
     wave_lds_fence();
     if (good) {
