@@ -39,7 +39,7 @@
 namespace mspa {
 namespace dinf {
 
-constexpr int kLitBits = 10, kDistBits = 8;
+constexpr int kLitBits = 11, kDistBits = 8;
 constexpr int kRing = 4096, kRingMask = kRing - 1;
 constexpr int kRingNear = kRing - 258;          // a match at most this far back never reads a ring slot it is overwriting
 constexpr int kLitSyms = 288, kDistSyms = 32;
@@ -51,6 +51,22 @@ __device__ __forceinline__ uint32_t pack(uint32_t len, uint32_t kind, uint32_t e
     return len | (kind << 8) | (extra << 11) | (payload << 16);
 }
 constexpr uint32_t kInvalid = 1u | (4u << 8);
+// The literal/length table holds 2 048 entries (11-bit index: the noisy depth frames' Huffman trees give ~5 % of the symbols
+// an 11-bit code and < 1 % a longer one; every code beyond the index costs a trip through the scalar one-symbol path and a
+// batch of its own) in 16 bits each, so that it still fits 4 KB: bits 0..3 code length, 4..7 kind (0 literal, 1..6 a length with
+// kind - 1 extra bits, 7 end of block, 8 longer than the index, 9 invalid), 8..15 the literal's byte / the length's base - 3.
+__device__ __forceinline__ uint32_t narrow(uint32_t e) {
+    const uint32_t kind = (e >> 8) & 7u, extra = (e >> 11) & 31u, payload = e >> 16;
+    const uint32_t k4 = kind == 0u ? 0u : kind == 1u ? 1u + extra : kind + 5u;          // 2, 3, 4 -> 7, 8, 9
+    const uint32_t pay = kind == 1u ? payload - 3u : payload & 0xFFu;
+    return (e & 15u) | (k4 << 4) | (pay << 8);
+}
+__device__ __forceinline__ uint32_t widen(uint32_t n) {
+    const uint32_t len = n & 15u, k4 = (n >> 4) & 15u, pay = (n >> 8) & 0xFFu;
+    if (k4 == 0u) return pack(len, 0, 0, pay);
+    if (k4 < 7u) return pack(len, 1, k4 - 1u, pay + 3u);
+    return pack(len, k4 - 5u, 0, 0);
+}
 
 __constant__ uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __constant__ uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -59,7 +75,7 @@ __constant__ uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5,
 __constant__ uint8_t kPreOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 struct __align__(16) WaveLds {
-    uint32_t lit[1 << kLitBits];        // 4 096 B
+    uint16_t lit[1 << kLitBits];        // 4 096 B (narrow entries)
     uint32_t dist[1 << kDistBits];      // 1 024 B
     uint8_t ring[kRing];                // 4 096 B
     uint32_t pre[128];                  //   512 B  code-length code, 7-bit index
@@ -139,7 +155,7 @@ __device__ __forceinline__ uint32_t brev(uint32_t v, int len) { return __builtin
 // Canonical Huffman tables of one alphabet from its code lengths, by all 64 lanes.  lens[0 .. n_syms) in LDS; `table` has
 // 1 << bits entries; `sorted` receives the symbols ordered by (length, symbol).  `kind`: 0 literal/length alphabet, 1 distance,
 // 2 code-length code.  Returns false (wave-uniform) for an over-subscribed set.
-__device__ __attribute__((noinline)) bool build_table(WaveLds &L, int alpha, const uint8_t *lens, int n_syms, uint32_t *table, int bits, uint16_t *sorted,
+__device__ __attribute__((noinline)) bool build_table(WaveLds &L, int alpha, const uint8_t *lens, int n_syms, void *table_, int bits, uint16_t *sorted,
                             int lane) {
     // 1. symbols per code length (ballots over chunks of 64 symbols)
     uint32_t cnt[16];
@@ -176,7 +192,13 @@ __device__ __attribute__((noinline)) bool build_table(WaveLds &L, int alpha, con
         L.count[alpha][lane] = c;
         L.offs[alpha][lane] = o;
     }
-    for (int i = lane; i < (1 << bits); i += 64) table[i] = kInvalid;
+    uint32_t *const table = (uint32_t *)table_;                  // wide entries (distance and code-length alphabets)
+    uint16_t *const table16 = (uint16_t *)table_;                // narrow entries (the literal/length alphabet)
+    const bool is_narrow = alpha == 0;
+    for (int i = lane; i < (1 << bits); i += 64) {
+        if (is_narrow) table16[i] = (uint16_t)narrow(kInvalid);
+        else table[i] = kInvalid;
+    }
     wave_lds_fence();
     // 3. every symbol: its rank among the symbols of its length (in symbol order) -> canonical code -> entries
     uint32_t seen[16];
@@ -211,9 +233,16 @@ __device__ __attribute__((noinline)) bool build_table(WaveLds &L, int alpha, con
                 } else {
                     e = pack((uint32_t)len, 0, 0, (uint32_t)s);
                 }
-                for (uint32_t i = rev; i < (1u << bits); i += 1u << len) table[i] = e;
+                if (is_narrow) {
+                    const uint16_t n = (uint16_t)narrow(e);
+                    for (uint32_t i = rev; i < (1u << bits); i += 1u << len) table16[i] = n;
+                } else {
+                    for (uint32_t i = rev; i < (1u << bits); i += 1u << len) table[i] = e;
+                }
             } else {
-                table[rev & ((1u << bits) - 1u)] = pack((uint32_t)bits, 3, 0, 0);      // a longer code starts with these bits
+                const uint32_t e = pack((uint32_t)bits, 3, 0, 0);      // a longer code starts with these bits
+                if (is_narrow) table16[rev & ((1u << bits) - 1u)] = (uint16_t)narrow(e);
+                else table[rev & ((1u << bits) - 1u)] = e;
             }
         }
     }
@@ -300,13 +329,6 @@ __device__ __forceinline__ void settle_far(WaveLds &L, uint32_t far_pos, uint32_
     }
 }
 
-// The literals of a run, every one by its own lane (rank in the run's lane mask = its place in the output).
-__device__ __forceinline__ void store_run(WaveLds &L, uint64_t run, uint32_t E, uint32_t &pos, int lane) {
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(run >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)run, 0u));
-    if ((run >> lane) & 1ull) L.ring[(pos + rank) & kRingMask] = (uint8_t)(E >> 16);
-    pos += (uint32_t)__builtin_popcountll(run);
-}
-
 // The symbols of one block, tables in LDS.  true: the block's end-of-block symbol was reached; false: the stream is bad.
 //
 // In batches.  Every lane DECODES THE WHOLE SYMBOL that would start at the bit offset equal to its lane number -- the
@@ -337,9 +359,12 @@ batch:
         const uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(i0 + 8, (int)r.W);
         const uint32_t sh = b & 31u;
         const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, sh);
-        E = L.lit[win & ((1u << kLitBits) - 1u)];                // stream bits [b, b + 32) -> the symbol starting there
-        const uint32_t kE = (E >> 8) & 7u, clen = E & 0xFFu, lx = (E >> 11) & 31u;
-        const uint32_t len = (E >> 16) + ((win >> clen) & ((1u << lx) - 1u));
+        const uint32_t N = L.lit[win & ((1u << kLitBits) - 1u)];     // stream bits [b, b + 32) -> the symbol starting there
+        const uint32_t k4 = (N >> 4) & 15u, clen = N & 15u;
+        const bool is_len = k4 - 1u < 6u;
+        const uint32_t lx = is_len ? k4 - 1u : 0u;
+        E = N >> 8;                                              // a literal's byte
+        const uint32_t len = E + 3u + ((win >> clen) & ((1u << lx) - 1u));
         const uint32_t o2 = sh + clen + lx;                      // where the distance code would start (<= 31 + 20)
         const uint32_t win2 = __builtin_amdgcn_alignbit(o2 < 32u ? w1 : w2, o2 < 32u ? w0 : w1, o2 & 31u);
         const uint32_t D = L.dist[win2 & ((1u << kDistBits) - 1u)];
@@ -347,8 +372,8 @@ batch:
         const uint32_t dist = (D >> 16) + ((win2 >> dlen) & ((1u << dx) - 1u));
         const uint32_t total = clen + lx + dlen + dx;
         const uint32_t routine = len > 64u ? 2u : dist > (uint32_t)kRingNear ? 1u : dist >= len ? 0u : 2u;
-        P = kE == 0u ? (clen + ((uint32_t)lane + clen > 63u ? 32u : 0u))
-                     : (kE == 1u && kD == 1u) ? (total | (routine << 6) | ((len - 3u) << 8) | (dist << 16)) : 16u;
+        P = k4 == 0u ? (clen + ((uint32_t)lane + clen > 63u ? 32u : 0u))
+                     : (is_len && kD == 1u) ? (total | (routine << 6) | ((len - 3u) << 8) | (dist << 16)) : 16u;
     }
     off = 0;                                                     // bits consumed since the gathers (wave-uniform)
     run = 0;                                                     // lanes (= bit offsets) of the pending literal run
@@ -396,7 +421,7 @@ chain:
             "v_mbcnt_hi_u32_b32 %[va], exec_hi, %[va]\n\t"
             "v_add_u32 %[va], %[pos], %[va]\n\t"
             "v_and_b32 %[va], 0xfff, %[va]\n\t"
-            "ds_write_b8_d16_hi %[va], %[E] offset:%[ring]\n\t"
+            "ds_write_b8 %[va], %[E] offset:%[ring]\n\t"
             "s_mov_b64 exec, -1\n\t"
             "s_bcnt1_i32_b64 %[t0], %[run]\n\t"
             "s_add_u32 %[pos], %[pos], %[t0]\n\t"
@@ -494,7 +519,7 @@ chain:
     settle_far(L, far_pos, far_len, lane);
     r.refill();
     {
-        uint32_t e = uni(L.lit[r.peek(kLitBits)]);
+        uint32_t e = widen(uni((uint32_t)L.lit[r.peek(kLitBits)]));
         uint32_t kind = (e >> 8) & 7u;
         if (kind == 3u) {
             const uint32_t lc = uni(long_code(L, 0, kLitBits, L.sorted, r.peek(16)));
