@@ -250,16 +250,20 @@ __device__ __attribute__((noinline)) bool build_table(WaveLds &L, int alpha, con
     return true;
 }
 
-// A code longer than the table index: walk the lengths above it (first-code test on the bit-reversed prefix).  Returns
-// symbol | length << 16, length 0 when no code matches (an incomplete set's unused pattern).  All wave-uniform.
-__device__ __forceinline__ uint32_t long_code(const WaveLds &L, int alpha, int bits, const uint16_t *sorted, uint32_t peek16) {
-    for (int l = bits + 1; l <= 15; ++l) {
-        const uint32_t code = brev(peek16 & ((1u << l) - 1u), l);
-        const uint32_t f = uni(L.first[alpha][l]), c = uni(L.count[alpha][l]);
-        if (code - f < c)                                       // unsigned: code >= f and code < f + c
-            return uni((uint32_t)sorted[uni(L.offs[alpha][l]) + (code - f)]) | ((uint32_t)l << 16);
-    }
-    return 0;
+// A code longer than the table index, by the lanes: lane l tests length l (first-code test on the bit-reversed prefix: one read
+// of first / count / offs per lane instead of a scalar walk with three dependent LDS round trips per length), the shortest
+// length that matches wins.  Returns symbol | length << 16, length 0 when no code matches (an incomplete set's unused pattern).
+// Wave-uniform result; every lane must call it.
+__device__ __forceinline__ uint32_t long_code(const WaveLds &L, int alpha, int bits, const uint16_t *sorted, uint32_t peek16, int lane) {
+    const int l = lane & 15;
+    const uint32_t code = brev(peek16 & ((1u << l) - 1u), l ? l : 1);
+    const uint32_t f = L.first[alpha][l], c = L.count[alpha][l], o = L.offs[alpha][l];
+    const bool hit = lane < 16 && l > bits && code - f < c;      // unsigned: code >= f and code < f + c
+    const uint64_t m = __ballot(hit);
+    if (m == 0) return 0;
+    const int len = __builtin_ctzll(m);
+    const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)(o + (code - f)), len);
+    return uni((uint32_t)sorted[at]) | ((uint32_t)len << 16);
 }
 
 // Whole 256-byte lines leave the ring: one coalesced dword store per lane and line.  Returns the new `flushed`.
@@ -505,24 +509,17 @@ chain:
             if (off <= 63u) goto chain;
         }
     }
-    // ---- the batch is used up (or the scalar path takes the next symbol) ----
-    r.drop((int)off);                                            // off <= 63 + 48
-    if (pos > out_n) return false;                               // before anything of it leaves the ring
-    if (pos - flushed >= 256u) {
-        settle_far(L, far_pos, far_len, lane);
-        wave_lds_fence();
-        flushed = uni(flush_lines(L, dst, pos, flushed, lane));
-    }
-    if (p != 16u) goto batch;
-    // one_symbol:
-    // ---- one symbol on the scalar path: a long code, end of block, or an invalid pattern ---------------------------------------
-    settle_far(L, far_pos, far_len, lane);
-    r.refill();
-    {
+    if (p == 16u) {
+        // ---- one symbol on the scalar path: a code longer than the table index, end of block, or an invalid pattern ----------------
+        // It starts `off` bits into the batch.  The bits in front of it stay undropped: P is a function of the bit offset alone, so
+        // behind this symbol the chain goes on in the SAME batch (a batch costs three LDS round trips and ~120 instructions).
+        if (pos > out_n) return false;
+        const uint32_t rb0 = r.rb;
+        r.rb += off;                                             // (inside the window: refill() left 8 words, a batch uses < 4)
         uint32_t e = widen(uni((uint32_t)L.lit[r.peek(kLitBits)]));
         uint32_t kind = (e >> 8) & 7u;
         if (kind == 3u) {
-            const uint32_t lc = uni(long_code(L, 0, kLitBits, L.sorted, r.peek(16)));
+            const uint32_t lc = long_code(L, 0, kLitBits, L.sorted, r.peek(16), lane);
             const uint32_t sym = lc & 0xFFFFu;
             const uint32_t len = lc >> 16;
             if (len == 0u) return false;
@@ -533,11 +530,12 @@ chain:
             kind = (e >> 8) & 7u;
         }
         r.drop((int)(e & 0xFFu));
-        if (kind == 0u) {
+        if (kind == 0u) {                                        // (a far match's bytes may stay on their way: they lie in front of pos)
             if (pos >= out_n) return false;
             if (lane == 0) L.ring[pos & kRingMask] = (uint8_t)(e >> 16);
             ++pos;
         } else if (kind == 2u) {
+            settle_far(L, far_pos, far_len, lane);
             wave_lds_fence();
             if (pos - flushed >= 256u) flushed = uni(flush_lines(L, dst, pos, flushed, lane));
             return true;
@@ -545,7 +543,7 @@ chain:
             const uint32_t length = (e >> 16) + r.take((int)((e >> 11) & 31u));
             uint32_t d = uni(L.dist[r.peek(kDistBits)]);
             if (((d >> 8) & 7u) == 3u) {
-                const uint32_t lc = uni(long_code(L, 1, kDistBits, L.sorted + kLitSyms, r.peek(16)));
+                const uint32_t lc = long_code(L, 1, kDistBits, L.sorted + kLitSyms, r.peek(16), lane);
                 const uint32_t sym = lc & 0xFFFFu;
                 if ((lc >> 16) == 0u || sym > 29u) return false;
                 d = pack(lc >> 16, 1, kDistExtra[sym], kDistBase[sym]);
@@ -554,13 +552,29 @@ chain:
             r.drop((int)(d & 0xFFu));
             const uint32_t dist = (d >> 16) + r.take((int)((d >> 11) & 31u));
             if (dist > pos || pos + length > out_n) return false;
+            settle_far(L, far_pos, far_len, lane);
             copy_match(L, dst, pos, length, dist, lane);
             pos += length;
         } else {
             return false;
         }
         wave_lds_fence();
-        if (pos - flushed >= 256u) flushed = uni(flush_lines(L, dst, pos, flushed, lane));
+        off = r.rb - rb0;
+        r.rb = rb0;
+        if (pos - flushed >= 256u) {
+            settle_far(L, far_pos, far_len, lane);
+            wave_lds_fence();
+            flushed = uni(flush_lines(L, dst, pos, flushed, lane));
+        }
+        if (off <= 63u) goto chain;
+    }
+    // ---- the batch is used up ----
+    r.drop((int)off);                                            // off <= 63 + 48
+    if (pos > out_n) return false;                               // before anything of it leaves the ring
+    if (pos - flushed >= 256u) {
+        settle_far(L, far_pos, far_len, lane);
+        wave_lds_fence();
+        flushed = uni(flush_lines(L, dst, pos, flushed, lane));
     }
     goto batch;
 }
