@@ -335,70 +335,37 @@ __device__ __forceinline__ void settle_far(WaveLds &L, uint32_t far_pos, uint32_
 
 // The symbols of one block, tables in LDS.  true: the block's end-of-block symbol was reached; false: the stream is bad.
 //
-// In batches.  Every lane DECODES THE WHOLE SYMBOL that would start at the bit offset equal to its lane number -- the
-// literal/length entry (an LDS gather), for a length its extra bits, the distance entry at the offset behind them (a second
-// gather) and its extra bits -- and packs what the scalar side needs into one word P, INCLUDING the decisions that depend on the
-// symbol alone (which copy routine a match takes).  All of that is vector work on 64 hypotheses at once.  The serial part, the
-// thing DEFLATE forces, is following the chain from offset 0: for a literal one `v_readlane_b32`, a compare, a bit set and an
-// add.  The literals of a run are then stored by their own lanes in ONE instruction.  Symbols the vector path cannot finish -- a
-// code longer than the table index, end of block, an invalid pattern -- take the scalar one-symbol path.
-// Control flow is spelled with labels: every decision is one scalar compare and one branch (written as nested loops with flags
-// the compiler materialises the flags as 64-bit masks and spends five instructions per decision).
+// In batches of 64 bit offsets.  Every lane DECODES THE WHOLE SYMBOL that would start at the bit offset equal to its lane
+// number -- its 32-bit window of the stream (three `ds_bpermute_b32` over the window register W), the literal/length entry (an LDS
+// gather), for a length its extra bits, the distance entry at the offset behind them (a second gather) and its extra bits -- and
+// packs what the scalar side needs into one word P, INCLUDING the decisions that depend on the symbol alone (which copy routine
+// a match takes).  All of that is vector work on 64 hypotheses at once.  The serial part, the thing DEFLATE forces, is following
+// the chain from offset 0: for a literal one `v_readlane_b32`, a compare, a bit set and an add.  The literals of a run are then
+// stored by their own lanes in ONE instruction.
 //   P: a literal: its code length (1 .. 15), + 32 if the next symbol starts beyond lane 63 (the batch's last one);
-//      16: not decodable here;
+//      16: not decodable here (a code longer than the table index, end of block, an invalid pattern): the scalar one-symbol path;
 //      a match (>= 65 536): total bits (6) | routine (2: 0 one-step ring copy, 1 from HBM, 2 the general copy) << 6 |
 //      (length - 3) << 8 | distance << 16.
 // Zeros follow the stream's end: what decodes from them runs into the output bound or an invalid block header.
+//
+// THE WHOLE BATCH LOOP IS ONE HAND-WRITTEN STATEMENT.  The frame's time is its instruction count (profiles/r06_inflate_v6_pmc.md):
+// as C the compiler carried the decode state through register copies at every merge and materialised each decision as a 64-bit
+// lane mask -- ~90 scalar-side instructions per match, ~80 per batch; written out they are ~30 and ~12.  The statement leaves for
+// what is rare, says why, and is re-entered where it left:
+//   why 0  the symbol at `off` is for the scalar path (then enter 2)       why 1  bad stream
+//   why 2  a match for the general copy routine, in p (then enter 2)       why 3  >= 256 bytes ready to leave the ring, mid-batch (enter 3)
+//   why 5  the window register must be re-aligned (enter 0)                why 6  >= 256 bytes ready, at a batch's end (enter 0)
+//   enter 0 a new batch, 1 on with the chain, 2 behind a symbol handled outside (lines ready? batch used up?), 3 behind a flush
+// exec is all ones on entry (one wave, uniform control flow) and on every exit.  v90 .. v101 are its scratch registers.  Hazards (gfx9
+// rules): no VALU-written SGPR is used as a lane select or by VMEM; a0 (the far match's bytes, see settle_far) is waited for with
+// vmcnt(0) before it is stored.
 __device__ __forceinline__ bool block_symbols(WaveLds &L, Reader &r, uint8_t *__restrict__ dst, uint32_t out_n, int lane, uint32_t &pos,
                                               uint32_t &flushed, uint32_t &far_pos, uint32_t &far_len) {
-    uint32_t E, P, off, p;
-    uint64_t run;
-batch:
-    r.refill();                                                  // the next 256 bits are in W
-    {
-        const uint32_t b = r.rb + (uint32_t)lane;                // this lane's bit offset inside the window
-        const int i0 = (int)((b >> 5) << 2);
-        const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(i0, (int)r.W);
-        const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(i0 + 4, (int)r.W);
-        const uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(i0 + 8, (int)r.W);
-        const uint32_t sh = b & 31u;
-        const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, sh);
-        const uint32_t N = L.lit[win & ((1u << kLitBits) - 1u)];     // stream bits [b, b + 32) -> the symbol starting there
-        const uint32_t k4 = (N >> 4) & 15u, clen = N & 15u;
-        const bool is_len = k4 - 1u < 6u;
-        const uint32_t lx = is_len ? k4 - 1u : 0u;
-        E = N >> 8;                                              // a literal's byte
-        const uint32_t len = E + 3u + ((win >> clen) & ((1u << lx) - 1u));
-        const uint32_t o2 = sh + clen + lx;                      // where the distance code would start (<= 31 + 20)
-        const uint32_t win2 = __builtin_amdgcn_alignbit(o2 < 32u ? w1 : w2, o2 < 32u ? w0 : w1, o2 & 31u);
-        const uint32_t D = L.dist[win2 & ((1u << kDistBits) - 1u)];
-        const uint32_t kD = (D >> 8) & 7u, dlen = D & 0xFFu, dx = (D >> 11) & 31u;
-        const uint32_t dist = (D >> 16) + ((win2 >> dlen) & ((1u << dx) - 1u));
-        const uint32_t total = clen + lx + dlen + dx;
-        const uint32_t routine = len > 64u ? 2u : dist > (uint32_t)kRingNear ? 1u : dist >= len ? 0u : 2u;
-        P = k4 == 0u ? (clen + ((uint32_t)lane + clen > 63u ? 32u : 0u))
-                     : (is_len && kD == 1u) ? (total | (routine << 6) | ((len - 3u) << 8) | (dist << 16)) : 16u;
-    }
-    off = 0;                                                     // bits consumed since the gathers (wave-uniform)
-    run = 0;                                                     // lanes (= bit offsets) of the pending literal run
-chain:
-    // ---- the symbol chain of a batch: hand-written -----------------------------------------------------------------------------
-    // As C this loop cost ~90 scalar-side instructions per match (the compiler carries the decode state through register copies at
-    // every merge and materialises each decision as a 64-bit mask); written out it is ~35, and the frame's time is its
-    // instruction count (profiles/r06_inflate_v5_pmc.md).  What it does, per symbol at bit offset `off`:
-    //   literal (P[off] < 16)      run |= 1 << off; off += P[off]                      (5 instructions, unrolled 8 x)
-    //   anything else              the run's literals go to the ring, every one by its own lane (exec = run, rank = mbcnt(exec));
-    //     last literal / 16        leave (why 0): the batch ends, or the scalar one-symbol path takes over
-    //     match                    bounds checked (why 1 = bad stream); the bytes of a far match still on their way from HBM are
-    //                              put into the ring; then by routine: one ds_read_u8 / ds_write_b8 pair (ring to ring), or
-    //                              `s_waitcnt vmcnt(8)` + global_load_ubyte into a0 (consumed by the NEXT match or flush), or
-    //                              leave for the general copy (why 2); pos / off advance; leave when 256 bytes are ready to be
-    //                              flushed (why 3) or the batch is used up (why 4), else back into the literal loop.
-    // exec is all ones on entry (one wave, uniform control flow) and on exit.  Hazards (gfx9 rules): no VALU-written SGPR is used
-    // as a lane select or by VMEM; a0 is waited for with vmcnt(0) before it is stored (nothing but the window prefetch can
-    // have been issued behind its load: a flush settles it first).
-    {
-        uint32_t why, len_s, dist_s, t0, va, vb;
+    uint32_t E = 0, P = 0, off = 0, enter = 0;
+    for (;;) {
+        uint32_t p, why, len_s, dist_s, t0;
+        uint64_t run, m0;
+        if (enter == 0u) r.refill();                              // (the statement asks for it with why 5 as well)
 #define MSPA_LIT_STEP                                   \
     "v_readlane_b32 %[p], %[P], %[off]\n\t"             \
     "s_cmp_lt_u32 %[p], 16\n\t"                         \
@@ -406,7 +373,83 @@ chain:
     "s_bitset1_b64 %[run], %[off]\n\t"                  \
     "s_add_u32 %[off], %[off], %[p]\n\t"
         asm volatile(
-            "s_nop 0\n"
+            "s_mov_b64 %[run], 0\n\t"
+            "s_cmp_eq_u32 %[enter], 0\n\t"
+            "s_cbranch_scc1 20f\n\t"
+            "s_cmp_eq_u32 %[enter], 1\n\t"
+            "s_cbranch_scc1 1f\n\t"
+            "s_cmp_eq_u32 %[enter], 2\n\t"
+            "s_cbranch_scc1 7f\n\t"
+            "s_branch 8f\n"
+            // ---- a new batch: every lane decodes the symbol at its bit offset --------------------------------------------------
+            "20:\n\t"
+            "s_mov_b32 %[why], 5\n\t"
+            "s_cmp_ge_u32 %[rb], 0x700\n\t"                       // Reader::kRealignAt
+            "s_cbranch_scc1 9f\n\t"
+            "v_add_u32 v90, %[rb], %[lane]\n\t"                   // b: this lane's bit offset inside the window
+            "v_lshrrev_b32 v91, 3, v90\n\t"
+            "v_and_b32 v91, 0x1fc, v91\n\t"
+            "ds_bpermute_b32 v92, v91, %[W]\n\t"                  // the three words its windows can touch
+            "ds_bpermute_b32 v93, v91, %[W] offset:4\n\t"
+            "ds_bpermute_b32 v94, v91, %[W] offset:8\n\t"
+            "v_and_b32 v97, 31, v90\n\t"                          // sh
+            "s_waitcnt lgkmcnt(1)\n\t"
+            "v_alignbit_b32 v95, v93, v92, v90\n\t"               // win: stream bits [b, b + 32)
+            "v_and_b32 v91, 0x7ff, v95\n\t"
+            "v_lshlrev_b32 v91, 1, v91\n\t"
+            "ds_read_u16 v96, v91 offset:%[lit]\n\t"              // the narrow literal/length entry
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_and_b32 v98, 15, v96\n\t"                          // clen
+            "v_bfe_u32 v99, v96, 4, 4\n\t"                        // kind
+            "v_lshrrev_b32 %[E], 8, v96\n\t"                      // a literal's byte / a length's base - 3
+            "v_add_u32 v100, -1, v99\n\t"
+            "v_cmp_gt_u32 vcc, 6, v100\n\t"                       // a length (kind 1 .. 6)
+            "v_cndmask_b32 v100, 0, v100, vcc\n\t"                // lx: its extra bits
+            "s_mov_b64 %[m0], vcc\n\t"
+            "v_lshrrev_b32 v101, v98, v95\n\t"
+            "v_bfe_u32 v101, v101, 0, v100\n\t"
+            "v_add_u32 v101, %[E], v101\n\t"                      // length - 3
+            "v_add3_u32 v97, v97, v98, v100\n\t"                  // o2: where the distance code starts (<= 31 + 20)
+            "v_cmp_gt_u32 vcc, 32, v97\n\t"
+            "v_cndmask_b32 v92, v93, v92, vcc\n\t"
+            "v_cndmask_b32 v93, v94, v93, vcc\n\t"
+            "v_alignbit_b32 v92, v93, v92, v97\n\t"               // win2
+            "v_and_b32 v93, 0xff, v92\n\t"
+            "v_lshlrev_b32 v93, 2, v93\n\t"
+            "ds_read_b32 v93, v93 offset:%[dtab]\n\t"             // the distance entry
+            "v_add_u32 v94, %[lane], v98\n\t"                     // a literal's word meanwhile
+            "v_cmp_lt_u32 vcc, 63, v94\n\t"
+            "v_cndmask_b32_e64 v94, 0, 32, vcc\n\t"
+            "v_or_b32 v94, v94, v98\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_bfe_u32 v95, v93, 11, 5\n\t"                       // dx
+            "v_and_b32 v96, 0xff, v93\n\t"                        // dlen
+            "v_lshrrev_b32 v92, v96, v92\n\t"
+            "v_bfe_u32 v92, v92, 0, v95\n\t"
+            "v_lshrrev_b32 v97, 16, v93\n\t"
+            "v_add_u32 v92, v97, v92\n\t"                         // distance
+            "v_add3_u32 v96, v96, v95, v98\n\t"
+            "v_add_u32 v96, v96, v100\n\t"                        // total bits
+            "v_bfe_u32 v95, v93, 8, 3\n\t"
+            "v_cmp_eq_u32 vcc, 1, v95\n\t"                        // a distance entry
+            "s_and_b64 %[m0], %[m0], vcc\n\t"                     // a whole match
+            "v_add_u32 v95, 3, v101\n\t"                          // length
+            "v_cmp_lt_u32 vcc, v92, v95\n\t"                      // overlapping: the general copy
+            "v_cndmask_b32_e64 v97, 0, 1, vcc\n\t"
+            "v_lshlrev_b32 v97, 7, v97\n\t"
+            "v_cmp_lt_u32 vcc, %[near], v92\n\t"                  // beyond the ring: from HBM
+            "v_cndmask_b32_e64 v97, v97, 64, vcc\n\t"
+            "v_mov_b32 v95, 0x80\n\t"
+            "v_cmp_lt_u32 vcc, 61, v101\n\t"                      // longer than one step: the general copy
+            "v_cndmask_b32 v97, v97, v95, vcc\n\t"
+            "v_lshl_or_b32 v96, v101, 8, v96\n\t"
+            "v_lshl_or_b32 v96, v92, 16, v96\n\t"
+            "v_or_b32 v96, v96, v97\n\t"
+            "v_cndmask_b32_e64 %[P], 16, v96, %[m0]\n\t"
+            "v_cmp_eq_u32 vcc, 0, v99\n\t"
+            "v_cndmask_b32 %[P], %[P], v94, vcc\n\t"
+            "s_mov_b32 %[off], 0\n"
+            // ---- the chain ---------------------------------------------------------------------------------------------------
             "1:\n\t" MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP MSPA_LIT_STEP
             "s_branch 1b\n"
             "2:\n\t"                                              // p >= 16
@@ -421,19 +464,23 @@ chain:
             "s_cmp_eq_u64 %[run], 0\n\t"
             "s_cbranch_scc1 4f\n\t"
             "s_mov_b64 exec, %[run]\n\t"                          // the run's literals, each by its own lane
-            "v_mbcnt_lo_u32_b32 %[va], exec_lo, 0\n\t"
-            "v_mbcnt_hi_u32_b32 %[va], exec_hi, %[va]\n\t"
-            "v_add_u32 %[va], %[pos], %[va]\n\t"
-            "v_and_b32 %[va], 0xfff, %[va]\n\t"
-            "ds_write_b8 %[va], %[E] offset:%[ring]\n\t"
+            "v_mbcnt_lo_u32_b32 v90, exec_lo, 0\n\t"
+            "v_mbcnt_hi_u32_b32 v90, exec_hi, v90\n\t"
+            "v_add_u32 v90, %[pos], v90\n\t"
+            "v_and_b32 v90, 0xfff, v90\n\t"
+            "ds_write_b8 v90, %[E] offset:%[ring]\n\t"
             "s_mov_b64 exec, -1\n\t"
             "s_bcnt1_i32_b64 %[t0], %[run]\n\t"
             "s_add_u32 %[pos], %[pos], %[t0]\n\t"
             "s_mov_b64 %[run], 0\n"
             "4:\n\t"
+            "s_cmp_gt_u32 %[p], 0xffff\n\t"
+            "s_cbranch_scc1 10f\n\t"                              // a match
             "s_mov_b32 %[why], 0\n\t"
-            "s_cmp_lt_u32 %[p], 0x10000\n\t"
-            "s_cbranch_scc1 9f\n\t"                               // not a match: why 0
+            "s_cmp_eq_u32 %[p], 16\n\t"
+            "s_cbranch_scc1 9f\n\t"                               // the scalar path's symbol: why 0
+            "s_branch 11f\n"                                      // the last literal: the batch is used up
+            "10:\n\t"
             "s_bfe_u32 %[len], %[p], 0x80008\n\t"
             "s_add_u32 %[len], %[len], 3\n\t"
             "s_lshr_b32 %[dist], %[p], 16\n\t"
@@ -447,10 +494,10 @@ chain:
             "s_cbranch_scc1 5f\n\t"
             "v_cmp_gt_u32 vcc, %[far_len], %[lane]\n\t"           // the previous far match's bytes into the ring
             "s_mov_b64 exec, vcc\n\t"
-            "v_add_u32 %[va], %[far_pos], %[lane]\n\t"
-            "v_and_b32 %[va], 0xfff, %[va]\n\t"
+            "v_add_u32 v90, %[far_pos], %[lane]\n\t"
+            "v_and_b32 v90, 0xfff, v90\n\t"
             "s_waitcnt vmcnt(0)\n\t"
-            "ds_write_b8 %[va], a0 offset:%[ring]\n\t"
+            "ds_write_b8 v90, a0 offset:%[ring]\n\t"
             "s_mov_b64 exec, -1\n\t"
             "s_mov_b32 %[far_len], 0\n"
             "5:\n\t"
@@ -459,60 +506,76 @@ chain:
             "s_cbranch_scc1 9f\n\t"                               // the general copy: why 2
             "v_cmp_gt_u32 vcc, %[len], %[lane]\n\t"
             "s_mov_b64 exec, vcc\n\t"                             // lanes < length
-            "v_add_u32 %[va], %[pos], %[lane]\n\t"
+            "v_add_u32 v90, %[pos], %[lane]\n\t"
             "s_bitcmp1_b32 %[p], 6\n\t"
             "s_cbranch_scc1 6f\n\t"
-            "v_subrev_u32 %[vb], %[dist], %[va]\n\t"              // ring to ring, source and destination apart
-            "v_and_b32 %[vb], 0xfff, %[vb]\n\t"
-            "ds_read_u8 %[vb], %[vb] offset:%[ring]\n\t"
-            "v_and_b32 %[va], 0xfff, %[va]\n\t"
+            "v_subrev_u32 v91, %[dist], v90\n\t"                  // ring to ring, source and destination apart
+            "v_and_b32 v91, 0xfff, v91\n\t"
+            "ds_read_u8 v91, v91 offset:%[ring]\n\t"
+            "v_and_b32 v90, 0xfff, v90\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
-            "ds_write_b8 %[va], %[vb] offset:%[ring]\n\t"
-            "s_branch 7f\n"
+            "ds_write_b8 v90, v91 offset:%[ring]\n\t"
+            "s_branch 12f\n"
             "6:\n\t"
             "s_waitcnt vmcnt(8)\n\t"                              // from HBM: the lines it reads left >= 12 stores ago
-            "v_subrev_u32 %[va], %[dist], %[va]\n\t"
-            "global_load_ubyte a0, %[va], %[dst]\n\t"
+            "v_subrev_u32 v90, %[dist], v90\n\t"
+            "global_load_ubyte a0, v90, %[dst]\n\t"
             "s_mov_b32 %[far_pos], %[pos]\n\t"
             "s_mov_b32 %[far_len], %[len]\n"
-            "7:\n\t"
+            "12:\n\t"
             "s_mov_b64 exec, -1\n\t"
             "s_add_u32 %[pos], %[pos], %[len]\n\t"
             "s_and_b32 %[t0], %[p], 63\n\t"
-            "s_add_u32 %[off], %[off], %[t0]\n\t"
+            "s_add_u32 %[off], %[off], %[t0]\n"
+            "7:\n\t"                                              // behind a match (or a symbol handled outside)
             "s_mov_b32 %[why], 3\n\t"
             "s_sub_u32 %[t0], %[pos], %[flushed]\n\t"
             "s_cmp_ge_u32 %[t0], 0x100\n\t"
-            "s_cbranch_scc1 9f\n\t"                               // lines are ready to leave the ring: why 3
+            "s_cbranch_scc1 9f\n"                                 // lines are ready to leave the ring: why 3
+            "8:\n\t"
             "s_cmp_gt_u32 %[off], 63\n\t"
-            "s_cbranch_scc0 1b\n\t"                               // on with the chain
-            "s_mov_b32 %[why], 4\n"
+            "s_cbranch_scc0 1b\n"                                 // on with the chain
+            "11:\n\t"                                             // ---- the batch is used up ----
+            "s_add_u32 %[rb], %[rb], %[off]\n\t"
+            "s_mov_b32 %[why], 1\n\t"
+            "s_cmp_gt_u32 %[pos], %[out_n]\n\t"
+            "s_cbranch_scc1 9f\n\t"                               // more output than expected: bad (before any of it leaves the ring)
+            "s_mov_b32 %[why], 6\n\t"
+            "s_sub_u32 %[t0], %[pos], %[flushed]\n\t"
+            "s_cmp_ge_u32 %[t0], 0x100\n\t"
+            "s_cbranch_scc0 20b\n"                                // the next batch
             "9:\n\t"
-            : [run] "+s"(run), [off] "+s"(off), [pos] "+s"(pos), [far_pos] "+s"(far_pos), [far_len] "+s"(far_len),
-              [p] "=&s"(p), [why] "=&s"(why), [len] "=&s"(len_s), [dist] "=&s"(dist_s), [t0] "=&s"(t0), [va] "=&v"(va), [vb] "=&v"(vb)
-            : [P] "v"(P), [E] "v"(E), [lane] "v"(lane), [flushed] "s"(flushed), [out_n] "s"(out_n), [dst] "s"(dst),
-              [ring] "n"(offsetof(WaveLds, ring))
-            : "scc", "vcc", "memory", "a0");
+            : [rb] "+s"(r.rb), [off] "+s"(off), [pos] "+s"(pos), [far_pos] "+s"(far_pos), [far_len] "+s"(far_len),
+              [p] "=&s"(p), [why] "=&s"(why), [len] "=&s"(len_s), [dist] "=&s"(dist_s), [t0] "=&s"(t0), [run] "=&s"(run), [m0] "=&s"(m0),
+              [P] "+v"(P), [E] "+v"(E)          // (the vector operands last: behind one, the compiler takes scalar results for divergent)
+            : [enter] "s"(enter), [W] "v"(r.W), [lane] "v"(lane), [flushed] "s"(flushed), [out_n] "s"(out_n), [dst] "s"(dst),
+              [near] "s"((uint32_t)kRingNear), [ring] "n"(offsetof(WaveLds, ring)), [lit] "n"(offsetof(WaveLds, lit)),
+              [dtab] "n"(offsetof(WaveLds, dist))
+            : "scc", "vcc", "memory", "a0", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101");
 #undef MSPA_LIT_STEP
-        if (why == 1u) return false;
-        if (why == 2u) {                                         // the general copy (overlapping or longer than a step): in C
-            copy_match(L, dst, pos, len_s, dist_s, lane);
-            pos += len_s;
-            off += p & 63u;
-            why = pos - flushed >= 256u ? 3u : off > 63u ? 4u : 5u;
-            if (why == 5u) goto chain;
+        // ---- what is rare: in C ----
+        if (why == 5u) {                                         // (refill() at the top re-aligns)
+            enter = 0;
+            continue;
         }
-        if (why == 3u) {
+        if (why == 3u || why == 6u) {
             settle_far(L, far_pos, far_len, lane);
             wave_lds_fence();
             flushed = uni(flush_lines(L, dst, pos, flushed, lane));
-            if (off <= 63u) goto chain;
+            enter = why == 3u ? 3u : 0u;
+            continue;
         }
-    }
-    if (p == 16u) {
-        // ---- one symbol on the scalar path: a code longer than the table index, end of block, or an invalid pattern ----------------
+        if (why == 2u) {                                         // the general copy (overlapping or longer than a step)
+            copy_match(L, dst, pos, len_s, dist_s, lane);
+            pos += len_s;
+            off += uni(p) & 63u;                                 // (uni: the compiler takes this one scalar result for divergent)
+            enter = 2;
+            continue;
+        }
+        if (why != 0u) return false;
+        // ---- one symbol on the scalar path: a code longer than the table index, end of block, or an invalid pattern -------------------
         // It starts `off` bits into the batch.  The bits in front of it stay undropped: P is a function of the bit offset alone, so
-        // behind this symbol the chain goes on in the SAME batch (a batch costs three LDS round trips and ~120 instructions).
+        // behind this symbol the chain goes on in the SAME batch.
         if (pos > out_n) return false;
         const uint32_t rb0 = r.rb;
         r.rb += off;                                             // (inside the window: refill() left 8 words, a batch uses < 4)
@@ -559,24 +622,10 @@ chain:
             return false;
         }
         wave_lds_fence();
-        off = r.rb - rb0;
+        off = uni(r.rb - rb0);
         r.rb = rb0;
-        if (pos - flushed >= 256u) {
-            settle_far(L, far_pos, far_len, lane);
-            wave_lds_fence();
-            flushed = uni(flush_lines(L, dst, pos, flushed, lane));
-        }
-        if (off <= 63u) goto chain;
+        enter = 2;
     }
-    // ---- the batch is used up ----
-    r.drop((int)off);                                            // off <= 63 + 48
-    if (pos > out_n) return false;                               // before anything of it leaves the ring
-    if (pos - flushed >= 256u) {
-        settle_far(L, far_pos, far_len, lane);
-        wave_lds_fence();
-        flushed = uni(flush_lines(L, dst, pos, flushed, lane));
-    }
-    goto batch;
 }
 
 // status codes of a block (int32): 0 accepted; 1 not a valid / supported stream or wrong size; (2 set by the Adler pass: checksum)
