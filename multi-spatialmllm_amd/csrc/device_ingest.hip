@@ -5,27 +5,33 @@
 // the per-frame `zlib.decompress` of the .sens reader (extract_posed_images.py:49-57), i.e. the stage that bounds every from-disk
 // sweep: 16 CPUs' worth of container quota inflate ~10 k frames/s (profiles/r06_ingest_scaling.txt) while the kernels downstream
 // take 3 M images/s.  DEFLATE is serial inside a stream, so the parallelism is ACROSS streams: a scene has 320 of them, the
-// loader keeps several scenes in flight, the chip has room for 3 584 such waves (14 per CU: 11 KB of LDS each).
+// loader keeps several scenes in flight, the chip has room for 3 584 such waves (14 per CU: 11 KB of LDS each): 75 k frames/s.
 //
-// mspa::dinf::inflate_kernel -- one 64-lane workgroup (one wave) per stream:
-//   * everything that steers the decode is WAVE-UNIFORM and lives in SGPRs: a 128-bit bit buffer, the bit count, the input word
-//     index, the output position.  Branches are scalar branches.
-//   * input: the wave holds 512 B of the compressed stream in two VGPRs (8 B per lane, one coalesced load) with the next 512 B
-//     in flight; a refill is `v_readlane_b32` with a scalar lane index -- no memory latency on the decode's critical path.
-//   * symbols in batches: EVERY LANE DECODES THE WHOLE SYMBOL that would start at the bit offset equal to its lane number --
-//     `v_alignbit_b32` cuts its window of the bit buffer, an LDS gather reads the 10-bit literal/length table, a length's extra
-//     bits come from the window, a second gather reads the 8-bit distance table behind them -- and packs total bits, match
-//     length and distance into one word.  The serial part DEFLATE forces is following the chain from offset 0: one
-//     `v_readlane_b32`, a compare, a bit set and an add per literal.  A run's literals are stored by their own lanes in one
-//     instruction (rank = `v_mbcnt` of the run's lane mask).  A lone wave issues one instruction per ~9 cycles and the CU's one
-//     scalar unit is shared by its 14 decode waves: the frame's time is its instruction count (profiles/r06_inflate_v4_pmc.md).
+// mspa::dinf::inflate_kernel -- one 64-lane workgroup (one wave) per stream (v6):
+//   * the POSITION in the stream is wave-uniform and lives in two SGPRs; the stream's bytes sit in two VGPRs as a sliding window of
+//     128 words (lane l: word base + l, and word base + 64 + l on its way from HBM), re-aligned every ~28 batches with two
+//     `ds_bpermute_b32`.  Consuming bits is an addition: there is no bit buffer to shift or refill.
+//   * symbols in batches of 64 bit offsets: EVERY LANE DECODES THE WHOLE SYMBOL that would start at the bit offset equal to its
+//     lane number -- three `ds_bpermute_b32` cut its windows out of the window register, an LDS gather reads the 11-bit
+//     literal/length table (16-bit entries), a length's extra bits come from the window, a second gather reads the 8-bit distance
+//     table behind them -- and packs total bits, copy routine, match length and distance into one word.  The serial part DEFLATE
+//     forces is following the chain from offset 0: one `v_readlane_b32`, a compare, a bit set and an add per literal.  A run's
+//     literals are stored by their own lanes in one instruction (exec = the run's lane mask, rank = `v_mbcnt` of exec).
+//   * the whole batch loop -- that decode, the chain, the bounds checks, the two hot copy routines (one `ds_read_u8` /
+//     `ds_write_b8` pair ring to ring; `global_load_ubyte` from the flushed bytes for what lies beyond the ring), the batch's
+//     bookkeeping -- is ONE hand-written statement (block_symbols): the frame's time is its instruction count (8.6 M per 640 x 480
+//     frame; the CU issues ~1.1 per cycle with 14 such waves, profiles/r06_inflate_v6_pmc.md), and compiled from C the same loop took
+//     three times the scalar instructions.  C handles what is rare: the general copy (overlapping or longer than 64 bytes), a
+//     flush, a window re-alignment, a code longer than the table index, the block headers.
 //   * tables: built per dynamic block by all 64 lanes (ballot ranks -> canonical codes -> replicated entries).  Codes longer than
-//     the table index (p < 2^-10 each), end of block and invalid patterns take a scalar one-symbol path with the canonical
-//     first-code walk over the length-sorted symbol list -- no sub-tables to build.
+//     the table index (< 1 % of the symbols of a noisy depth frame with 11 bits; 5 % with 10), end of block and invalid patterns
+//     take a scalar one-symbol path: the lanes test one code length each against the canonical first codes, the chain then goes
+//     on in the same batch.
 //   * output: a 4 KB ring in LDS takes every byte; whole 256-byte lines leave for HBM as one coalesced dword store per lane.
 //     A match whose distance fits the ring (<= 3 838: every filter-row distance of a 640-pixel image, 1 281) is copied LDS to
-//     LDS by the lanes, 64 bytes per step; a farther one loads the flushed bytes from HBM behind `s_waitcnt vmcnt(8)` (the lines
-//     it needs left >= 12 stores ago) and its ring write is deferred until the next match or flush needs it.
+//     LDS by the lanes; a farther one loads the flushed bytes from HBM behind `s_waitcnt vmcnt(8)` (the lines it needs left >= 12
+//     stores ago) into a0 -- an accumulation register only the hand-written statements touch, because the load is still in
+//     flight while compiled code runs -- and its ring write is deferred until the next match or flush needs it.
 //   * a stream is ACCEPTED only if it ends exactly at the expected size, stays inside its input, and (second kernel,
 //     adler32_kernel) the Adler-32 of the output equals the stream's trailer -- the contract of csrc/inflate_fast.h.  Anything
 //     else is reported per block and the caller decodes that frame on the host.
@@ -640,6 +646,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
     uint8_t *const dst = dst_base + k * dst_pitch;
     // a stream must lie inside the buffer, start on an 8-byte unit and be shorter than 2 GiB
     bool good = nb >= 6 && nb < (1ll << 31) && s0 >= 0 && (s0 & 7) == 0 && s0 + nb <= src_capacity;
+    // block_symbols addresses the tables and the ring by their offsets inside WaveLds: the kernel's only LDS object, at address 0
+    good = good && (uint32_t)(uintptr_t)&L == 0u;
     const uint32_t n_src = good ? (uint32_t)nb : 0u;
     // zlib header: CM = 8, window <= 32 K, FCHECK, no preset dictionary
     if (good) {
