@@ -363,6 +363,24 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
     vote(writer.close() if writer is not None else None)
 
 
+_SIDE = threading.local()
+
+
+def side_stream(device):
+    """This THREAD's own stream on ``device``.  A sweep's ``produce`` only launches a scene's kernels; what has to wait for them --
+    K9 compaction, downloads, encoding -- runs as a deferred blob on an encoder thread, behind an event, on that thread's stream:
+    beside the sweep thread's kernels instead of in front of the next scene's."""
+    import torch
+    streams = getattr(_SIDE, "streams", None)
+    if streams is None:
+        streams = _SIDE.streams = {}
+    device = torch.device(device)
+    key = (device.type, device.index)
+    if key not in streams:
+        streams[key] = torch.cuda.Stream(device=device)
+    return streams[key]
+
+
 def prefetched_scenes(host_scenes: Iterable[HostScene], device="cuda", timings: Optional[Timings] = None,
                       decode_on_device: bool = False):
     """HostScenes -> resident ``SceneOnDevice`` objects through pinned staging on a copy stream (upload.ScenePrefetcher);

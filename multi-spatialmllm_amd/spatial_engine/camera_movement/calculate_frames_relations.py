@@ -144,7 +144,10 @@ def process_scene_columns(scene_id, scene_infos, warning_file) -> PairTable:
 
 
 def _empty_frames(scene):
-    return scene.empty_frames()
+    """Frames that see no vertex (CFR:159-161).  K1 is launched NOW; the returned callable reads its per-frame counts back -- later,
+    on the calling thread's stream.  (May also return the list itself: what the GPU-less tests stand in.)"""
+    cnt, ids = scene._visibility()["count"], list(scene.ids)
+    return lambda: [k for k, c in zip(ids, cnt.cpu().numpy()) if c == 0]
 
 
 def _device_rows(scene):
@@ -202,23 +205,44 @@ def run_split(scene_info_path, output_parquet, warning_file, num_workers=15, sav
         return scene_infos.prefetched_scenes([all_scene_ids[i] for i in indices], max(1, int(num_workers)), device, timings)
 
     def produce(index, scene):
+        """K1 / K2 / K4 are launched here, on the sweep's thread and stream, and nothing is waited for: the pair table's download,
+        its warning lines and the two row groups' encoding happen on an encoder thread with a stream of its own, behind an event --
+        the sweep thread goes straight on to the next scene (it used to stand 8 ms per scene in two `.cpu()` calls, behind the decode
+        waves of the scenes in flight)."""
         scene_id = all_scene_ids[index]
         print(f"Start processing {scene_id}.")
-        lines = [f"{scene_id}: {image_id} has no in bound points\n" for image_id in _empty_frames(scene)]
+        empty = _empty_frames(scene)
         rows_dev = _device_rows(scene)
-        rows = rows_dev.cpu().numpy()
-        ids = list(scene_infos.get_all_extrinsic_valid_image_ids(scene_id))
-        arrays = _row_arrays(rows)
-        lines += _bad_value_lines(scene_id, ids, arrays)
-        t = PairTable(scene_id, ids, arrays)
-        # The two row groups are encoded on the sweep's encoder threads (callable blobs).  Dictionary pages for the three id
-        # columns only: on the float64 columns the encoder hashes every value, overflows its dictionary page and falls back to
-        # plain anyway -- 4 x the encoding time of a row group and a LARGER file (measured: 22.6 -> 5.9 ms, 1.92 -> 1.56 MB per
-        # 51 040-row scene); readers see the same table
-        blobs = ["".join(lines).encode()] + [
-            (lambda nz=nz: parquet_splice.encode_row_group(t.to_arrow(nz), use_dictionary=_COLUMNS[:3])) for nz in (False, True)]
+        launched = None
+        if rows_dev.is_cuda:
+            launched = torch.cuda.Event()
+            launched.record(torch.cuda.current_stream(rows_dev.device))
+
+        def download():
+            return (empty() if callable(empty) else empty), rows_dev.cpu().numpy()
+
+        def finish_scene():
+            if launched is None:
+                empty_ids, rows = download()
+            else:
+                with torch.cuda.device(rows_dev.device):
+                    side = sweep.side_stream(rows_dev.device)
+                    side.wait_event(launched)
+                    with torch.cuda.stream(side):
+                        empty_ids, rows = download()
+            lines = [f"{scene_id}: {image_id} has no in bound points\n" for image_id in empty_ids]
+            ids = list(scene_infos.get_all_extrinsic_valid_image_ids(scene_id))
+            arrays = _row_arrays(rows)
+            lines += _bad_value_lines(scene_id, ids, arrays)
+            t = PairTable(scene_id, ids, arrays)
+            # Dictionary pages for the three id columns only: on the float64 columns the encoder hashes every value, overflows its
+            # dictionary page and falls back to plain anyway -- 4 x the encoding time of a row group and a LARGER file (measured:
+            # 22.6 -> 5.9 ms, 1.92 -> 1.56 MB per 51 040-row scene); readers see the same table
+            return ["".join(lines).encode()] + [parquet_splice.encode_row_group(t.to_arrow(nz), use_dictionary=_COLUMNS[:3])
+                                                for nz in (False, True)]
+
         print(f"Finished scene {scene_id}.")
-        return (rows_dev if keep else None), blobs
+        return (rows_dev if keep else None), finish_scene
 
     def consume(index, rows, blobs):
         scene_id = all_scene_ids[index]

@@ -62,10 +62,10 @@ def process_scene_columns(scene_id, scene_infos, warning_file):
 
 def _visibility_csr(scene):
     """K1 launched NOW on the caller's stream, nothing waited for; the returned callable compacts the bit matrix into the two
-    CSR tables (K9) and brings them to the host -- on the calling thread's own stream (``_side_stream``), behind an event
+    CSR tables (K9) and brings them to the host -- on the calling thread's own stream (``sweep.side_stream``), behind an event
     recorded after K1.  (May also return the finished ``VisibilityCSR``: what the GPU-less tests stand in.)"""
     import torch
-    from mspa import visindex
+    from mspa import sweep, visindex
     if scene.xyz is None:
         raise ValueError("scene uploaded without vertices")
     ids, n_points = list(scene.ids), int(scene.xyz.shape[0])
@@ -77,7 +77,7 @@ def _visibility_csr(scene):
 
     def finish():
         with torch.cuda.device(bits.device):
-            side = _side_stream(bits.device)
+            side = sweep.side_stream(bits.device)
             side.wait_event(launched)
             with torch.cuda.stream(side):
                 return visindex.from_bits(bits, ids, n_points)         # returns with the tables on the host
@@ -85,21 +85,6 @@ def _visibility_csr(scene):
 
 
 _CSR_FIELDS = ("i2p_offsets", "i2p_indices", "p2i_offsets", "p2i_indices")
-_SIDE = __import__("threading").local()
-
-
-def _side_stream(device):
-    """This thread's own stream on ``device`` (the encoder threads of a sweep: their K9 launches and copies run beside the
-    sweep thread's kernels instead of in front of them)."""
-    import torch
-    streams = getattr(_SIDE, "streams", None)
-    if streams is None:
-        streams = _SIDE.streams = {}
-    key = (device.type, device.index)
-    if key not in streams:
-        streams[key] = torch.cuda.Stream(device=device)
-    return streams[key]
-
 
 def run_split(scene_info_path, output_file, warning_file, num_workers=8, keep=True, ctx=None, timings=None):
     """Visibility index of every scene of a split -> ``output_file`` (.parquet in the readers' format, or .pkl as the nested

@@ -23,6 +23,6 @@ for tag, title in (("k3_stats", "bench.py --steps 20 --warmup 5 (headline K3 lau
     print()
 PY
 rm -rf $OUT/k3_stats $OUT/decode_stats
-bash tools/pmc_inflate.sh r06_inflate_v4 3584 > $OUT/pmc_inflate.log 2>&1
-cp gpurun_out/pmc_r06_inflate_v4/summary.md $OUT/pmc_inflate_v4.md
+bash tools/pmc_inflate.sh r06_inflate_v6 3584 > $OUT/pmc_inflate.log 2>&1
+cp gpurun_out/pmc_r06_inflate_v6/summary.md $OUT/pmc_inflate_v6.md
 tail -3 $OUT/bench_n1.time
