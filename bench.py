@@ -754,8 +754,26 @@ def time_device_decode(streams=3584):
     calls; beside it the host reader on the CPUs this container may use.  Instruction-bound, not HBM-bound: the roofline of
     this kernel is its instruction count (profiles/r06_inflate_v5_pmc.md), so what is reported is frames/s and the ratio."""
     r = _tool("device_ingest_bench").run(streams=streams, reps=3, with_composed=False)
+    # the roofline that bounds it: instruction issue.  Instruction counts per frame from the committed PMC passes of the same
+    # build (not measured in this run); cycles from this run's inflate time at the device's clock.
+    pmc = {"salu": 3.83e6, "branch": 1.35e6, "valu": 3.07e6, "lds": 0.34e6, "source": "profiles/r06_inflate_v6_pmc.md (committed PMC pass, NOT measured in this run)"}
+    try:
+        import torch
+        from mspa import _lib
+        info = _lib.device_info(torch.cuda.current_device())
+        n_cu, clock = int(info["n_cu"]), float(info["clock_khz"]) * 1e3
+        cyc = r["device"]["inflate_adler_ms"] * 1e-3 * clock                      # (the Adler pass is < 1 % of it)
+        per_cu = streams / n_cu
+        tot = pmc["salu"] + pmc["branch"] + pmc["valu"] + pmc["lds"]
+        r["roofline_issue"] = {"bound": "instruction issue (one scalar + one vector instruction per cycle and CU at most; DEFLATE's chain is scalar)",
+                               "instructions_per_frame": round(tot), "waves_per_cu": round(per_cu, 1),
+                               "achieved_instr_per_cycle_per_cu": round(per_cu * tot / cyc, 3),
+                               "salu_issue_frac": round(per_cu * pmc["salu"] / cyc, 3), "valu_issue_frac": round(per_cu * pmc["valu"] / cyc, 3),
+                               "counts": pmc}
+    except Exception as e:                                   # informational
+        r["roofline_issue"] = {"skipped": f"{type(e).__name__}: {e}"}
     r["what"] = ("replaces the per-frame cv2.imread / zlib.decompress of info_handler.py:149-155 and extract_posed_images.py:49-57 for "
-                 "streaming sweeps of >= 1 536 frames")
+                 "streaming sweeps of >= 512 frames")
     return r
 
 

@@ -335,14 +335,15 @@ class SceneInfoHandler:
         if lookahead is None:
             lookahead = min(4, max(2, hostinfo.effective_cpus() // (2 * max(1, int(num_workers)))))
         # The streaming sweeps decode the depth frames on the MI355X (MSPA_DEPTH_DECODE=host / device overrides) -- when there
-        # are enough of them: one wave inflates one frame and takes ~70 ms for it however idle the chip is, so the device only
-        # wins with a thousand or more frames in flight (8 scenes x 64 frames: 70 scenes/s on the device, 135 on 16 host CPUs;
-        # 48 x 320: 58 against 31, profiles/r06_dropin_decode.md).
+        # are enough of them: one wave inflates one frame and takes ~33 ms for it however idle the chip is (inflate v6; 70 ms with
+        # v4, when the threshold was 1 536 frames).  Measured on one box, device against 16 host CPUs, pair-table sweep: 8 scenes x
+        # 64 frames 125 against 112 scenes/s, 16 x 64 137 against 123, 4 x 320 51 against 25, 48 x 320 110 against 31
+        # (profiles/r06_dropin_decode.md).  Below ~500 frames the host's 2 ms per small scene wins.
         scene_ids = list(scene_ids)
         decode = decode or os.environ.get("MSPA_DEPTH_DECODE")
         if decode is None:
             frames = sum(len(self.get_all_extrinsic_valid_image_ids(sid)) for sid in scene_ids)
-            decode = "device" if frames >= 1536 else "host"
+            decode = "device" if frames >= 512 else "host"
         loader = sweep.SceneLoader(lambda sid: self.host_scene(sid, num_workers, with_points, decode), list(scene_ids), lookahead,
                                    timings)
         return sweep.prefetched_scenes(loader, device, timings, decode_on_device=(decode == "device"))
