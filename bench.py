@@ -773,7 +773,7 @@ def time_device_decode(streams=3584):
     except Exception as e:                                   # informational
         r["roofline_issue"] = {"skipped": f"{type(e).__name__}: {e}"}
     r["what"] = ("replaces the per-frame cv2.imread / zlib.decompress of info_handler.py:149-155 and extract_posed_images.py:49-57 for "
-                 "streaming sweeps of >= 512 frames")
+                 "streaming sweeps of >= 1 024 frames")
     return r
 
 

@@ -338,12 +338,13 @@ class SceneInfoHandler:
         # are enough of them: one wave inflates one frame and takes ~33 ms for it however idle the chip is (inflate v6; 70 ms with
         # v4, when the threshold was 1 536 frames).  Measured on one box, device against 16 host CPUs, pair-table sweep: 8 scenes x
         # 64 frames 125 against 112 scenes/s, 16 x 64 137 against 123, 4 x 320 51 against 25, 48 x 320 110 against 31
-        # (profiles/r06_dropin_decode.md).  Below ~500 frames the host's 2 ms per small scene wins.
+        # (profiles/r06_dropin_decode.md).  At 512 frames the two are level (and with 16 loader threads the host is ahead: 126
+        # against 112 scenes/s in bench.py's small leg), so the device takes over from 1 024 frames on.
         scene_ids = list(scene_ids)
         decode = decode or os.environ.get("MSPA_DEPTH_DECODE")
         if decode is None:
             frames = sum(len(self.get_all_extrinsic_valid_image_ids(sid)) for sid in scene_ids)
-            decode = "device" if frames >= 512 else "host"
+            decode = "device" if frames >= 1024 else "host"
         loader = sweep.SceneLoader(lambda sid: self.host_scene(sid, num_workers, with_points, decode), list(scene_ids), lookahead,
                                    timings)
         return sweep.prefetched_scenes(loader, device, timings, decode_on_device=(decode == "device"))
