@@ -330,6 +330,27 @@ int64_t mspa_format_int_keys_host(const char *prefix_host, int64_t first, int64_
                                   int64_t capacity, int32_t *out_text_offsets_host);
 
 /*
+ * The same text written ON the device (round 6, K10: csrc/format_lists.hip) -- every list item formatted by its own lane at its
+ * final byte position -- for the visibility-index sweep, whose encoder threads spent half of their time per scene in the host
+ * loops above (make_visibility_info.py:38-73: json.dumps per key).  DEVICE pointers; two launches around two prefix sums
+ * that are the caller's plumbing (as for mspa_bits_popcount -> prefix sum -> mspa_bits_expand):
+ *   mspa_format_list_costs_device  out_cost[e] = bytes of item e's text + 2.  token_offsets_dev NULL: items are integers
+ *                                  (decimal, '-' for negatives); else item e is token values[e] of n_tokens tokens
+ *                                  (token t = tokens[token_offsets[t] .. token_offsets[t+1])); an id outside sets *bad_flag_dev
+ *   mspa_format_lists_device       cost_prefix_dev: exclusive prefix sum of out_cost as int64, nnz + 1 entries;
+ *                                  nonempty_prefix_dev[r]: lists q < r with offsets[q+1] > offsets[q], n_lists + 1 int64 entries;
+ *                                  text_bytes = 2 n_lists + cost_prefix[nnz] - 2 nonempty_prefix[n_lists] (< 2 GiB);
+ *                                  writes the text and arrow's int32 string offsets (n_lists + 1 entries).
+ * Bit-exact with the host formatters (and json.dumps).
+ */
+int mspa_format_list_costs_device(const int32_t *values_dev, int64_t nnz, const int32_t *token_offsets_dev, int32_t n_tokens,
+                                  int32_t *out_cost_dev, int32_t *bad_flag_dev, mspa_stream_t stream);
+int mspa_format_lists_device(const int64_t *offsets_dev, const int32_t *values_dev, int64_t n_lists, int64_t nnz,
+                             const int64_t *cost_prefix_dev, const int64_t *nonempty_prefix_dev, const char *tokens_dev,
+                             const int32_t *token_offsets_dev, char *out_text_dev, int64_t text_bytes,
+                             int32_t *out_text_offsets_dev, mspa_stream_t stream);
+
+/*
  * Host-side staging of a scene's depth frames (the loop that fills the frame stack in the reference: CFR / MVI read one
  * image per frame into its own array): n_blocks equally sized host blocks are gathered into one contiguous destination
  * -- the pinned buffer the H2D copy reads -- by up to n_threads copy threads.  Host pointers only; no device work.

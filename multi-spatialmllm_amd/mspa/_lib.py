@@ -68,6 +68,9 @@ _SIGNATURES = {
     "mspa_format_token_lists_host": (c_int64, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_int64,
                                                c_void_p]),
     "mspa_format_int_keys_host": (c_int64, [c_char_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "mspa_format_list_costs_device": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "mspa_format_lists_device": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                         c_void_p, c_void_p]),
     "mspa_gather_blocks_host": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int32]),
     "mspa_inflate_blocks_host": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32]),
     "mspa_read_depth_png_host": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p]),

@@ -484,6 +484,45 @@ def bitset_csr(bits: torch.Tensor):
     return offsets, indices
 
 
+def format_lists_device(offsets: torch.Tensor, values: torch.Tensor, tokens: Optional[Sequence[bytes]] = None):
+    """K10: the JSON text of every list of a CSR table, written on the device (``json.dumps`` form: "[1, 2, 3]", "[]";
+    make_visibility_info.py:38-73).  ``offsets`` [n + 1] int64, ``values`` [nnz] int32 (device).  ``tokens`` None: the items are
+    integers; else item e is the text ``tokens[values[e]]`` (bytes, e.g. an already quoted image id).  Returns (text [bytes] uint8,
+    text_offsets [n + 1] int32) on the device: arrow's string layout."""
+    _require_gpu()
+    lib = _lib.load()
+    _require(offsets.dtype == torch.int64 and offsets.dim() == 1 and offsets.is_cuda and offsets.is_contiguous() and offsets.numel() >= 1,
+             "offsets: contiguous device int64 [n_lists + 1]")
+    _require(values.dtype == torch.int32 and values.dim() == 1 and values.is_cuda and values.is_contiguous(), "values: contiguous device int32 [nnz]")
+    dev = offsets.device
+    n, nnz = offsets.numel() - 1, values.numel()
+    tok = tok_off = None
+    n_tokens = 0
+    if tokens is not None:
+        n_tokens = len(tokens)
+        lens = np.array([len(t) for t in tokens], dtype=np.int64)
+        tok_off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev)
+        tok = torch.from_numpy(np.frombuffer(b"".join(tokens) or b"\0", dtype=np.uint8).copy()).to(dev)
+    cost = torch.empty((max(nnz, 1),), dtype=torch.int32, device=dev)
+    bad = torch.zeros((1,), dtype=torch.int32, device=dev)
+    _lib.check(lib.mspa_format_list_costs_device(_ptr(values) if nnz else None, nnz, _ptr(tok_off), n_tokens, _ptr(cost), _ptr(bad), _stream_ptr()))
+    T = torch.zeros((nnz + 1,), dtype=torch.int64, device=dev)                   # torch as plumbing: two prefix sums
+    if nnz:
+        torch.cumsum(cost[:nnz], dim=0, dtype=torch.int64, out=T[1:])
+    NE = torch.zeros((n + 1,), dtype=torch.int64, device=dev)
+    if n:
+        torch.cumsum((offsets[1:] > offsets[:-1]).to(torch.int64), dim=0, out=NE[1:])
+    head = torch.stack([2 * n + T[-1] - 2 * NE[-1], bad[0].to(torch.int64)]).cpu()     # one small read-back: the size to allocate
+    total = int(head[0])
+    _require(int(head[1]) == 0, "format_lists_device: token id out of range")
+    _require(total <= 0x7fffffff, "format_lists_device: more than 2 GiB of text")
+    text = torch.empty((max(total, 1),), dtype=torch.uint8, device=dev)
+    text_offsets = torch.empty((n + 1,), dtype=torch.int32, device=dev)
+    _lib.check(lib.mspa_format_lists_device(_ptr(offsets), _ptr(values) if nnz else None, n, nnz, _ptr(T), _ptr(NE), _ptr(tok), _ptr(tok_off),
+                                            _ptr(text), total, _ptr(text_offsets), _stream_ptr()))
+    return text[:total], text_offsets
+
+
 def bits_transpose(bits: torch.Tensor) -> torch.Tensor:
     """K9: [R, n_words] int64 bit matrix -> its transpose [n_words * 64, ceil(R / 64)] (padding bits zero)."""
     _require_gpu()

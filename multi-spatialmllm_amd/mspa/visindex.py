@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import dataclasses
 import json
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import numpy as np
 
@@ -27,6 +27,10 @@ class VisibilityCSR:
     i2p_indices: np.ndarray      # [nnz] int32 vertex indices, ascending within an image
     p2i_offsets: np.ndarray      # [N + 1] int64
     p2i_indices: np.ndarray      # [nnz] int32 image indices (positions in image_ids), ascending within a vertex
+    # the lists' JSON text already written on the device (K10, engine.format_lists_device), as arrow string buffers
+    # (int32 offsets [rows + 1], uint8 data): what ``to_arrow`` uses instead of the host formatters when present
+    i2p_text: Optional[tuple] = None
+    p2i_text: Optional[tuple] = None
 
     def empty_images(self) -> List[str]:
         n = np.diff(self.i2p_offsets)
@@ -84,6 +88,30 @@ class VisibilityCSR:
             return a.ctypes.data if a.size else None
 
         F, N = len(self.image_ids), self.n_points
+
+        def preformatted(n, pair):
+            offs, data = pair
+            return pa.StringArray.from_buffers(n, pa.py_buffer(offs), pa.py_buffer(data)) if n else pa.array([], type=pa.string())
+
+        if self.i2p_text is not None and self.p2i_text is not None:
+            i2p_vals, p2i_vals = preformatted(F, self.i2p_text), preformatted(N, self.p2i_text)
+        else:
+            i2p_vals, p2i_vals = self._format_on_host(lib, string_array, ptr, pa)
+        # keys
+        i2p_keys = pa.array([f"{scene_id}:image_to_points:{i}" for i in self.image_ids], type=pa.string())
+        prefix = f"{scene_id}:point_to_images:".encode()
+        cap = (len(prefix) + 21) * N + 16
+        text, offs = np.empty(cap, dtype=np.uint8), np.empty(N + 1, dtype=np.int32)
+        nb = lib.mspa_format_int_keys_host(prefix, 0, N, text.ctypes.data, cap, offs.ctypes.data) if N else 0
+        p2i_keys = string_array(N, text, offs, nb) if N else pa.array([], type=pa.string())
+        return pa.table({"key": pa.concat_arrays([i2p_keys, p2i_keys]), "values": pa.concat_arrays([i2p_vals, p2i_vals])})
+
+    def quoted_image_ids(self) -> List[bytes]:
+        return [json.dumps(i).encode() for i in self.image_ids]
+
+    def _format_on_host(self, lib, string_array, ptr, pa):
+        """Both value columns by libmspa's host formatters (sequential loops: ~40 ms of one core per 320-frame scene)."""
+        F, N = len(self.image_ids), self.n_points
         i2p_off = np.ascontiguousarray(self.i2p_offsets, dtype=np.int64)
         i2p_idx = np.ascontiguousarray(self.i2p_indices, dtype=np.int32)
         p2i_off = np.ascontiguousarray(self.p2i_offsets, dtype=np.int64)
@@ -94,7 +122,7 @@ class VisibilityCSR:
         nb = lib.mspa_format_int_lists_host(ptr(i2p_off), ptr(i2p_idx), F, text.ctypes.data, cap, offs.ctypes.data) if F else 0
         i2p_vals = string_array(F, text, offs, nb) if F else pa.array([], type=pa.string())
         # values of point_to_images: lists of quoted image ids
-        quoted = [json.dumps(i).encode() for i in self.image_ids]
+        quoted = self.quoted_image_ids()
         tok_off = np.concatenate([[0], np.cumsum([len(q) for q in quoted])]).astype(np.int32)
         tokens = np.frombuffer(b"".join(quoted) or b"\0", dtype=np.uint8)
         longest = max([len(q) for q in quoted], default=0)
@@ -103,18 +131,15 @@ class VisibilityCSR:
         nb = lib.mspa_format_token_lists_host(ptr(p2i_off), ptr(p2i_idx), N, tokens.ctypes.data, tok_off.ctypes.data, F,
                                               text.ctypes.data, cap, offs.ctypes.data) if N else 0
         p2i_vals = string_array(N, text, offs, nb) if N else pa.array([], type=pa.string())
-        # keys
-        i2p_keys = pa.array([f"{scene_id}:image_to_points:{i}" for i in self.image_ids], type=pa.string())
-        prefix = f"{scene_id}:point_to_images:".encode()
-        cap = (len(prefix) + 21) * N + 16
-        text, offs = np.empty(cap, dtype=np.uint8), np.empty(N + 1, dtype=np.int32)
-        nb = lib.mspa_format_int_keys_host(prefix, 0, N, text.ctypes.data, cap, offs.ctypes.data) if N else 0
-        p2i_keys = string_array(N, text, offs, nb) if N else pa.array([], type=pa.string())
-        return pa.table({"key": pa.concat_arrays([i2p_keys, p2i_keys]), "values": pa.concat_arrays([i2p_vals, p2i_vals])})
+        return i2p_vals, p2i_vals
 
 
-def from_bits(bits, image_ids: List[str], n_points: int) -> VisibilityCSR:
-    """K1's bitsets [F, ceil(N/64)] (device int64 tensor) -> both CSR tables, compacted on the device."""
+def from_bits(bits, image_ids: List[str], n_points: int, text: bool = False, indices: bool = True) -> VisibilityCSR:
+    """K1's bitsets [F, ceil(N/64)] (device int64 tensor) -> both CSR tables, compacted on the device.
+    ``text``: also write both lists' JSON text on the device (K10) and bring it along as arrow string buffers -- what
+    ``to_arrow`` then uses (only when the image ids are in sorted() order, MVI:117: always, for ScanNet's zero-padded frame
+    numbers).  ``indices=False``: the index arrays themselves stay on the device (a parquet sweep that keeps nothing needs only
+    the text: 83 MB instead of 83 + 39)."""
     from . import engine
     F = len(image_ids)
     if F == 0 or n_points == 0:
@@ -124,15 +149,28 @@ def from_bits(bits, image_ids: List[str], n_points: int) -> VisibilityCSR:
     o1, i1 = engine.bitset_csr(bits)
     t = engine.bits_transpose(bits)                      # [n_words * 64, ceil(F / 64)]; rows >= N are padding (all zero)
     o2, i2 = engine.bitset_csr(t[:n_points].contiguous() if t.shape[0] != n_points else t)
-    # ~100 MB per 320-frame scene: into pinned blocks (torch's caching host allocator), all four copies behind ONE wait on the
+    ids = list(image_ids)
+    text = text and ids == sorted(ids)
+    want = [o1, i1 if indices or not text else None, o2, i2 if indices or not text else None]
+    if text:
+        csr0 = VisibilityCSR(ids, n_points, None, None, None, None)
+        want += list(engine.format_lists_device(o1, i1)[::-1]) + list(engine.format_lists_device(o2, i2, csr0.quoted_image_ids())[::-1])
+    # ~100 MB per 320-frame scene: into pinned blocks (torch's caching host allocator), all copies behind ONE wait on the
     # CURRENT stream -- the sweeps call this on an encoder thread with a stream of its own, next to the sweep thread's kernels
     host = []
-    for a in (o1, i1, o2, i2):
+    for a in want:
+        if a is None:
+            host.append(None)
+            continue
         h = torch.empty(a.shape, dtype=a.dtype, pin_memory=True)
         h.copy_(a, non_blocking=True)
         host.append(h)
     torch.cuda.current_stream(bits.device).synchronize()
-    return VisibilityCSR(list(image_ids), n_points, *[h.numpy() for h in host])
+    host = [None if h is None else h.numpy() for h in host]
+    csr = VisibilityCSR(ids, n_points, *host[:4])
+    if text:
+        csr.i2p_text, csr.p2i_text = (host[4], host[5]), (host[6], host[7])
+    return csr
 
 
 class SceneRowGroups:

@@ -75,12 +75,12 @@ def _visibility_csr(scene):
     launched = torch.cuda.Event()
     launched.record(torch.cuda.current_stream(bits.device))
 
-    def finish():
+    def finish(text=False, indices=True):
         with torch.cuda.device(bits.device):
             side = sweep.side_stream(bits.device)
             side.wait_event(launched)
             with torch.cuda.stream(side):
-                return visindex.from_bits(bits, ids, n_points)         # returns with the tables on the host
+                return visindex.from_bits(bits, ids, n_points, text=text, indices=indices)     # returns with the tables on the host
     return finish
 
 
@@ -132,7 +132,9 @@ def run_split(scene_info_path, output_file, warning_file, num_workers=8, keep=Tr
         later = _visibility_csr(scene)
 
         def finish_scene():
-            csr = later() if callable(later) else later
+            # the lists' JSON text is written on the device (K10) when a parquet file is what is asked for; the index arrays
+            # themselves come to the host only if somebody wants them (the .pkl output, keep=True)
+            csr = later(text=not as_pkl, indices=want_csr) if callable(later) else later
             lines = [f"[Warning] {scene_id}: {image_id} has no in-bound points.\n" for image_id in csr.empty_images()]
             blobs = ["".join(lines).encode()]
             if not as_pkl:

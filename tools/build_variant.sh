@@ -7,7 +7,7 @@ NAME=$1; shift
 B=/tmp/mspa_variant_$NAME
 mkdir -p $B $ROOT/tools/ab
 cd $ROOT/multi-spatialmllm_amd/csrc
-for f in api pair_reproject vertex_visibility pair_overlap pose_tracks samples object_extents bitset_index host_ingest device_ingest; do
+for f in api pair_reproject vertex_visibility pair_overlap pose_tracks samples object_extents bitset_index host_ingest device_ingest format_lists; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-result "$@" -c $f.hip -o $B/$f.o &
 done
 wait
