@@ -315,13 +315,25 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
         if writer is not None:
             writer.put(sorted(i for b in w for i in b), rows_by_index, parts)
 
+    # Every collective of the sweep -- a window's vote and its exchange -- runs on ONE thread of its own, in submission order, and
+    # up to two windows behind the sweep thread: the encoder threads work on window w's deferred blobs (85 ms per visibility
+    # index) while windows w + 1 and w + 2 are being produced, and the sweep thread never stands in `encode_wait` or in the
+    # exchange (it used to, 0.34 s of a 0.80 s pass of the index sweep).  Every rank runs the same sequence of collectives --
+    # finish(0), finish(1), ... -- so a rank whose produce fails in window w still finishes w - 1 and then brings the failure to
+    # w's vote: everyone leaves together, the windows before the failing one are complete.
+    exchanger = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mspa-exchange")
+    behind: collections.deque = collections.deque()
+
+    def on_exchange_thread(fn, *a):
+        if ctx is not None and getattr(ctx.device, "type", "cpu") == "cuda":
+            torch.cuda.set_device(ctx.device)
+        return fn(*a)
+
+    def settle(limit: int) -> None:
+        while len(behind) > limit:
+            behind.popleft().result()                      # raises what finish raised: its own failure, or the vote's
+
     try:
-        # One window of lag: window w is voted on and exchanged AFTER window w + 1 has been produced, so that the encoder
-        # threads work on w's deferred blobs (63 ms per visibility index) under w + 1's kernels instead of the sweep thread
-        # waiting for the last-produced scene's encode at every window's end.  Every rank runs the same sequence of
-        # collectives -- finish(0), finish(1), ... -- so a rank whose produce fails in window w still finishes w - 1 and then
-        # brings the failure to w's vote: everyone leaves together, the windows before the failing one are complete.
-        pending = None
         for w in wins:
             local_rows, local_blobs = [], []
             for index in w[rank]:
@@ -330,11 +342,9 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
                     with timings.span("produce"):
                         records, blobs = produce(index, item)
                 except Exception as e:                     # a missing file, a bad pose: the other ranks must not be left
-                    if pending is not None:                # waiting in a window's exchange (they would, until the timeout).
-                        fin, pending = pending, None       # The window before this one is complete: it is exchanged and
-                        finish(*fin)                       # written; THIS window's vote then carries the failure (the other
-                    vote(e)                                # ranks reach it after producing one more window)
-                    raise                                  # (a world of one: vote raises it)
+                    settle(0)                              # waiting in a window's exchange (they would, until the timeout).
+                    exchanger.submit(on_exchange_thread, vote, e).result()     # The windows before this one are complete; THIS
+                    raise                                  # window's vote carries the failure (a world of one: vote raises it)
                 if record_width is not None:
                     if records is None:
                         records = torch.zeros((0, record_width), dtype=torch.float64)
@@ -346,18 +356,18 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
                     local_blobs.append((index, encoders.submit(timed_encode, blobs)))
                 else:
                     local_blobs.append((index, [encoders.submit(timed_encode, b) if callable(b) else b for b in blobs]))
-            if pending is not None:
-                finish(*pending)
-            pending = (w, local_rows, local_blobs)
-        if pending is not None:
-            finish(*pending)
+            settle(1)
+            behind.append(exchanger.submit(on_exchange_thread, finish, w, local_rows, local_blobs))
+        settle(0)
         for _ in items:                                        # drain: lets the prefetcher's generator finish cleanly
             pass
     except BaseException:
+        exchanger.shutdown(wait=True)                      # (windows already submitted are exchanged or fail at their vote)
         encoders.shutdown(wait=True)
         if writer is not None:
             writer.close()          # windows exchanged before the failure are complete: they are written, then the error leaves
         raise
+    exchanger.shutdown(wait=True)
     encoders.shutdown(wait=True)
     # the tail: rank 0 waits for its writer, and the ranks agree once more that nothing failed after the last window's vote
     vote(writer.close() if writer is not None else None)
