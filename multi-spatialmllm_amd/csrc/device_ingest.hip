@@ -37,9 +37,10 @@
 //     else is reported per block and the caller decodes that frame on the host.
 // mspa::dinf::png_unfilter_kernel -- one wave per image.  Images whose rows use only None / Sub / Up (what adaptive writers choose
 //   for depth maps) go row by row with the lanes along the row: coalesced dword loads, bytewise SWAR adds, Sub as a wave-wide
-//   prefix sum.  An image with an Average or Paeth row takes the skewed pipeline: 64 rows at a time, lane y works on column t - y
-//   at step t, so the left, upper and upper-left neighbours are a register, the lane above's previous output via DPP, and the one
-//   before that.  Both write host-order uint16 pixels.
+//   prefix sum.  An image with an Average or Paeth row (smooth depth: practically every row is Paeth) takes the skewed pipeline:
+//   64 rows at a time, lane y works on pixel pair i - y at step i, so the left, upper and upper-left neighbours are a register,
+//   the lane above's previous output via DPP, and the one before that; the row's raw bytes arrive through prefetched aligned
+//   dwords.  Both write host-order uint16 pixels.
 #include "mspa_common.h"
 
 namespace mspa {
@@ -49,6 +50,7 @@ constexpr int kLitBits = 11, kDistBits = 8;
 constexpr int kRing = 4096, kRingMask = kRing - 1;
 constexpr int kRingNear = kRing - 258;          // a match at most this far back never reads a ring slot it is overwriting
 constexpr int kLitSyms = 288, kDistSyms = 32;
+constexpr int32_t kPendingHard = 0x40000000;   // status of an image between png_unfilter_kernel and png_unfilter_hard_kernel
 
 // entry: bits 0..7 code length, 8..10 kind, 11..15 extra-bit count, 16..31 payload
 //   kind 0 literal (payload = byte) / code-length symbol; 1 length or distance (payload = base); 2 end of block;
@@ -922,6 +924,86 @@ __device__ void unfilter_rows(const uint8_t *__restrict__ raw, int64_t raw_pitch
     }
 }
 
+// One byte channel of one pixel: raw + predictor(left a, up b, upper-left c) by filter type (PNG 9.2).  Every variant is computed
+// and selected (the lanes of a band hold rows of different types); `all_paeth` (wave-uniform) skips the selection.
+__device__ __forceinline__ uint32_t unfilter_byte(uint32_t raw, uint32_t a, uint32_t b, uint32_t c, int ft, bool all_paeth) {
+    const int p = (int)a + (int)b - (int)c;
+    const int pa = abs(p - (int)a), pb = abs(p - (int)b), pc = abs(p - (int)c);
+    const uint32_t pae = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+    uint32_t pred = pae;
+    if (!all_paeth) pred = ft == 4 ? pae : ft == 3 ? ((a + b) >> 1) : ft == 2 ? b : ft == 1 ? a : 0u;
+    return (raw + pred) & 0xFFu;
+}
+
+// Images with Average / Paeth rows (what an adaptive PNG writer picks for smooth depth: practically every row), even width:
+// the skewed pipeline on pixel PAIRS.  64 rows at a time, lane y works on pixels 2 (i - y), 2 (i - y) + 1 at step i, so that the
+// upper pair is the lane above's previous output (one DPP shift per step), the upper-left pixel the pair it handed down one step
+// earlier, the left pixel this lane's own last output.  The raw bytes of a lane's row come through three registers of aligned
+// dwords -- the load for pair j + 3 is issued while pair j is worked on -- and are re-aligned with v_alignbyte; every step stores
+// one dword (two host-order samples).  The first version read two bytes and wrote one uint16 per step and lane with nothing in
+// flight: 35 ms per 3 584 smooth frames, the latency of 2 x 5 600 dependent byte loads per image; this one is bound by its ~100
+// vector instructions per step.
+constexpr int kUpRowPairs = 2048;                                // widest image of the pair pipeline: 4 096 pixels
+// up_row: the row above the band (lane 0's upper neighbour), staged in LDS once per band: read from memory step by step it cost
+// the whole wave one L2 round trip per step
+__device__ void unfilter_skewed_pairs(const uint8_t *__restrict__ raw, int64_t raw_pitch, int64_t stride, int32_t h, int32_t w,
+                                      uint16_t *__restrict__ out, int lane, uint32_t *up_row) {
+    const int wp = w >> 1;                                       // pixel pairs per row
+    const int64_t last = (raw_pitch - 4) & ~(int64_t)3;          // no load past the image's own block
+    uint32_t *const out32 = (uint32_t *)out;
+    for (int y0 = 0; y0 < h; y0 += 64) {
+        const int y = y0 + lane;
+        const bool row = y < h;
+        const int64_t a0 = (int64_t)(row ? y : 0) * stride + 1;  // the row's first sample byte
+        const int ft = row ? (int)raw[a0 - 1] : 0;
+        const bool all_paeth = __all(!row || ft == 4);
+        const int64_t base = a0 & ~(int64_t)3;
+        const uint32_t sh = (uint32_t)(a0 & 3);
+        auto ld = [&](int k) {
+            int64_t o = base + 4 * (int64_t)k;
+            o = o < last ? o : last;
+            return *(const uint32_t *)(raw + o);
+        };
+        if (y0 > 0) {                                            // the row above the band was written by this wave
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        const bool has_up = y0 > 0;
+        if (has_up) {
+            const uint32_t *uprow = out32 + (int64_t)(y0 - 1) * wp;
+            for (int k = lane; k < wp; k += 64) up_row[k] = uprow[k];
+            wave_lds_fence();
+        }
+        uint32_t wc = ld(0), wn = ld(1), wf = ld(2);             // dwords j, j + 1, j + 2 of this lane's row
+        uint32_t upn = has_up ? up_row[0] : 0u;
+        uint32_t X = 0;                                          // this lane's last output pair, bytes in stream order: x0 hi, x0 lo, x1 hi, x1 lo
+        uint32_t Uprev = 0;                                      // the pair above, one step earlier (its second pixel: upper-left)
+        const int steps = wp + 63;
+        for (int i = 0; i < steps; ++i) {
+            const int j = i - lane;
+            const bool on = row && j >= 0 && j < wp;
+            // the lane above finished pair j one step ago: its output through a DPP wave shift (one vector instruction; a
+            // ds_bpermute would put an LDS round trip on every step's critical path)
+            uint32_t U = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+            if (lane == 0) U = ((upn & 0x00FF00FFu) << 8) | ((upn >> 8) & 0x00FF00FFu);      // host-order samples -> stream order
+            if (has_up) upn = up_row[i + 1 < wp ? i + 1 : 0];   // (wave-uniform address: one LDS broadcast read, a step ahead)
+            if (on) {
+                const uint32_t d = __builtin_amdgcn_alignbyte(wn, wc, sh);
+                wc = wn;
+                wn = wf;
+                wf = ld(j + 3);
+                const uint32_t x0h = unfilter_byte(d & 0xFFu, (X >> 16) & 0xFFu, U & 0xFFu, (Uprev >> 16) & 0xFFu, ft, all_paeth);
+                const uint32_t x0l = unfilter_byte((d >> 8) & 0xFFu, X >> 24, (U >> 8) & 0xFFu, Uprev >> 24, ft, all_paeth);
+                const uint32_t x1h = unfilter_byte((d >> 16) & 0xFFu, x0h, (U >> 16) & 0xFFu, U & 0xFFu, ft, all_paeth);
+                const uint32_t x1l = unfilter_byte(d >> 24, x0l, U >> 24, (U >> 8) & 0xFFu, ft, all_paeth);
+                X = x0h | (x0l << 8) | (x1h << 16) | (x1l << 24);
+                out32[(int64_t)y * wp + j] = (x0h << 8) | x0l | (x1h << 24) | (x1l << 16);
+            }
+            Uprev = U;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t *__restrict__ raw_base, int64_t raw_pitch, int32_t h, int32_t w,
                                                           uint16_t *__restrict__ out_base, int32_t *__restrict__ status) {
     const int64_t k = blockIdx.x;
@@ -944,6 +1026,28 @@ __global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t *__restr
     const int nd = (w + 127) / 128;
     if (!__any(hard) && (w & 1) == 0 && nd <= 8 && (((uintptr_t)out) & 3u) == 0) {
         unfilter_rows(raw, raw_pitch, stride, h, w, out, lane, nd);
+        return;
+    }
+    // Average / Paeth rows: the second launch (png_unfilter_hard_kernel) takes the image
+    if (lane == 0) status[k] = kPendingHard;
+}
+
+// Images with Average / Paeth rows.  A launch of its own because it wants FEW waves per CU: every lane streams its own row, so a
+// wave keeps 128 cache lines open (64 rows read, 64 written) for 32 steps each -- 3 584 such waves (14 per CU) are 59 MB of open
+// lines against 32 MB of L2, and partly written lines travel to the memory side and back (16.3 ms per 3 584 smooth frames; with
+// the waves per CU held to 4 by this kernel's 40 KB of LDS: 10.2 ms, profiles/r06_device_ingest.md).
+__global__ __launch_bounds__(64) void png_unfilter_hard_kernel(const uint8_t *__restrict__ raw_base, int64_t raw_pitch, int32_t h, int32_t w,
+                                                               uint16_t *__restrict__ out_base, int32_t *__restrict__ status) {
+    __shared__ uint32_t lds[10240];                              // 40 KB: 2 048 dwords of it hold the row above the band
+    const int64_t k = blockIdx.x;
+    if (status[k] != kPendingHard) return;
+    const int lane = (int)threadIdx.x;
+    const uint8_t *raw = raw_base + k * raw_pitch;
+    uint16_t *out = out_base + k * (int64_t)h * w;
+    const int64_t stride = (int64_t)w * 2 + 1;
+    if ((w & 1) == 0 && w >= 4 && w <= 2 * kUpRowPairs && (((uintptr_t)out) & 3u) == 0 && (((uintptr_t)raw) & 3u) == 0) {
+        unfilter_skewed_pairs(raw, raw_pitch, stride, h, w, out, lane, lds);
+        if (lane == 0) status[k] = 0;
         return;
     }
     for (int y0 = 0; y0 < h; y0 += 64) {
@@ -994,6 +1098,7 @@ __global__ __launch_bounds__(64) void png_unfilter_kernel(const uint8_t *__restr
             b_lo = nb_lo;
         }
     }
+    if (lane == 0) status[k] = 0;
 }
 
 }  // namespace dinf
@@ -1030,6 +1135,8 @@ extern "C" int mspa_png_unfilter_device(const void *raw_dev, int64_t raw_pitch, 
     if (!raw_dev || !out_dev || !status_dev) return fail(MSPA_EINVAL, "mspa_png_unfilter_device: null pointer");
     if (n_images > 0x7fffffffll) return fail(MSPA_EINVAL, "mspa_png_unfilter_device: too many images");
     hipLaunchKernelGGL(dinf::png_unfilter_kernel, dim3((unsigned)n_images), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)raw_dev,
+                       raw_pitch, h, w, out_dev, status_dev);
+    hipLaunchKernelGGL(dinf::png_unfilter_hard_kernel, dim3((unsigned)n_images), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)raw_dev,
                        raw_pitch, h, w, out_dev, status_dev);
     return check_hip(hipGetLastError(), "mspa_png_unfilter_device");
 }
