@@ -772,6 +772,15 @@ def time_device_decode(streams=3584):
                                "counts": pmc}
     except Exception as e:                                   # informational
         r["roofline_issue"] = {"skipped": f"{type(e).__name__}: {e}"}
+    # the same frames without their sensor noise: an adaptive PNG writer then gives practically every row the Paeth filter (as it
+    # does for real sensor depth of smooth surfaces) -- fewer literals for the inflate, the skewed pipeline for the un-filter
+    try:
+        sm = _tool("device_ingest_bench").run(streams=streams, reps=3, with_composed=False, smooth=True)
+        r["smooth_frames"] = {"frames": sm["frames"], "png_bytes_per_frame": sm["png_bytes_per_frame"], "device": sm["device"], "host": {k: sm["host"][k] for k in ("threads", "frames_per_s")},
+                              "device_over_host": sm["device_over_host"], "status_nonzero": sm["status_nonzero"],
+                              "bit_identical_to_the_rendered_frames": sm["bit_identical_to_the_rendered_frames"]}
+    except Exception as e:                                   # informational
+        r["smooth_frames"] = {"skipped": f"{type(e).__name__}: {e}"}
     r["what"] = ("replaces the per-frame cv2.imread / zlib.decompress of info_handler.py:149-155 and extract_posed_images.py:49-57 for "
                  "streaming sweeps of >= 1 024 frames")
     return r
