@@ -237,6 +237,36 @@ def test_full_size_depth_frames_as_the_dataset_stores_them(tmp_path):
     assert np.array_equal(host, np.stack([sc.depth[i] for i in sc.valid_image_ids]))
 
 
+def test_smooth_full_size_frames_take_the_paeth_pipeline(tmp_path):
+    """The same room without its sensor noise: Pillow's adaptive writer gives nearly every row the Paeth filter (what smooth real
+    depth gets), so the un-filter's skewed pixel-pair pipeline -- the second launch, png_unfilter_hard_kernel -- is what decodes
+    these frames.  Every pixel against the host reader and the rendered frames; heights that leave the last band ragged."""
+    import torch
+    from PIL import Image
+    from scipy.ndimage import uniform_filter
+    from mspa import engine, ingest, synth
+    sc = synth.make_scene(78, n_points=2048, n_frames=4, color_hw=(480, 640), depth_hw=(480, 640), invalid_pose_frac=0.0, with_color=False)
+    for h in (480, 417):
+        frames, paths = [], []
+        for k, image_id in enumerate(sc.valid_image_ids):
+            a = uniform_filter(sc.depth[image_id].astype(np.float64), 9).astype(np.uint16)[:h]
+            p = str(tmp_path / f"s{h}_{image_id}.png")
+            Image.fromarray(a).save(p, compress_level=[1, 6, 9, 6][k % 4])
+            frames.append(a)
+            paths.append(p)
+        buf, offsets, nbytes, st, cap = ingest.pack_depth_pngs(paths, h, 640, 4)
+        assert (st == 0).all()
+        scan = zlib.decompress(buf[offsets[0]:offsets[0] + nbytes[0]].tobytes())
+        assert sum(scan[y * 1281] == 4 for y in range(h)) > 0.9 * h                 # Paeth rows
+        src = torch.from_numpy(buf[:cap]).cuda()
+        raw, status = engine.inflate_blocks_device(src, torch.from_numpy(offsets).cuda(), torch.from_numpy(nbytes).cuda(), h * 1281)
+        out = engine.png_unfilter_device(raw, h, 640, status)
+        torch.cuda.synchronize()
+        assert status.cpu().numpy().tolist() == [0] * len(paths)
+        assert np.array_equal(out.cpu().numpy().view(np.uint16), np.stack(frames))
+        assert np.array_equal(ingest.read_depth_frames(paths, 4), np.stack(frames))
+
+
 def test_sens_depth_frames_inflated_on_the_device(tmp_path):
     """A .sens stream's zlib depth payloads (extract_posed_images.py:49-57 inflates them one by one): compressed bytes over PCIe,
     one wave per frame on the device -- the same frames as the host reader's, a damaged payload handed to zlib (whose error it is)."""
