@@ -324,10 +324,20 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
     exchanger = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mspa-exchange")
     behind: collections.deque = collections.deque()
 
+    left = {"early": False}
+
     def on_exchange_thread(fn, *a):
+        # Once a vote has failed every rank has left the sequence of collectives AT THAT VOTE: what was queued behind it must
+        # not start another one (the other ranks would never join it).
+        if left["early"]:
+            return None
         if ctx is not None and getattr(ctx.device, "type", "cpu") == "cuda":
             torch.cuda.set_device(ctx.device)
-        return fn(*a)
+        try:
+            return fn(*a)
+        except BaseException:
+            left["early"] = True
+            raise
 
     def settle(limit: int) -> None:
         while len(behind) > limit:

@@ -273,6 +273,48 @@ def test_a_failing_rank_stops_every_rank_at_the_window(tmp_path):
     assert results[0][1] == [0, 1, 2, 3]                     # window 0 (items 0..3) was consumed on rank 0 before item 5 failed
 
 
+def _failing_encoder_main(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), MSPA_DIST_BACKEND="gloo")
+    for p in (PKG, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    ctx = shard.context_from_env(torch.device("cpu"))
+
+    def produce(index, item):
+        def deferred():
+            if index == 1:                                      # an encoder thread's failure, in the FIRST of six windows
+                raise ValueError("row group of item 1 could not be encoded")
+            return [b"y" * 10]
+        return None, deferred
+    seen = []
+    try:
+        sweep.sharded_sweep([1.0] * 24, ctx, lambda idx: iter(idx), produce, lambda i, r, b: seen.append(i), per_rank=2)
+        q.put((rank, "finished", seen))
+    except Exception as e:
+        q.put((rank, type(e).__name__, seen))
+
+
+def test_a_failing_encoder_stops_every_rank_and_nothing_queued_behind_it_starts_a_collective(tmp_path):
+    """A deferred blob raises on one rank's encoder thread while the sweep thread is already windows ahead: the failure reaches
+    that window's vote, every rank raises there, and the exchanges queued behind it are dropped (they would wait for ranks that
+    have left) -- the job ends in seconds, not at the communicator's timeout."""
+    import time
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    t0 = time.time()
+    procs = [mpc.Process(target=_failing_encoder_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict((r, (kind, seen)) for r, kind, seen in (q.get(timeout=90) for _ in procs))
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(k for k, _ in results.values()) == ["RuntimeError", "ValueError"], results
+    assert results[0][1] == [] and time.time() - t0 < 80
+
+
 def _failing_writer_main(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), MSPA_DIST_BACKEND="gloo")
