@@ -924,25 +924,31 @@ __device__ void unfilter_rows(const uint8_t *__restrict__ raw, int64_t raw_pitch
     }
 }
 
-// One byte channel of one pixel: raw + predictor(left a, up b, upper-left c) by filter type (PNG 9.2).  Every variant is computed
-// and selected (the lanes of a band hold rows of different types); `all_paeth` (wave-uniform) skips the selection.
-__device__ __forceinline__ uint32_t unfilter_byte(uint32_t raw, uint32_t a, uint32_t b, uint32_t c, int ft, bool all_paeth) {
-    const int p = (int)a + (int)b - (int)c;
-    const int pa = abs(p - (int)a), pb = abs(p - (int)b), pc = abs(p - (int)c);
-    const uint32_t pae = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+// One 16-bit pixel = two byte channels, worked on TOGETHER as two 16-bit halves of a register (v_pk_* instructions): raw +
+// predictor(left a, up b, upper-left c) by filter type (PNG 9.2), each half 0 .. 255.  Paeth's three distances are
+// |b - c|, |a - c|, |(b - c) + (a - c)|; "x <= y" per half is the sign of y - x spread over the half by an arithmetic shift, the
+// choice a bit-field insert.  Every filter's predictor is computed and selected (the lanes of a band hold rows of different
+// types); `all_paeth` (wave-uniform) skips the selection.
+typedef short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t as_u32(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ pk16 as_pk(uint32_t v) { return __builtin_bit_cast(pk16, v); }
+__device__ __forceinline__ pk16 pk_abs(pk16 v) { return __builtin_elementwise_max(v, -v); }
+__device__ __forceinline__ uint32_t unfilter_pixel(uint32_t raw, uint32_t a, uint32_t b, uint32_t c, int ft, bool all_paeth) {
+    const pk16 A = as_pk(a), B = as_pk(b), C = as_pk(c);
+    const pk16 t = B - C, u = A - C;
+    const pk16 pa = pk_abs(t), pb = pk_abs(u), pc = pk_abs(t + u);
+    const uint32_t a_gt_b = as_u32((pb - pa) >> 15), a_gt_c = as_u32((pc - pa) >> 15), b_gt_c = as_u32((pc - pb) >> 15);   // all ones where pa > pb, ...
+    const uint32_t bc = (c & b_gt_c) | (b & ~b_gt_c);            // pb <= pc ? b : c
+    const uint32_t not_a = a_gt_b | a_gt_c;
+    const uint32_t pae = (bc & not_a) | (a & ~not_a);            // pa <= pb && pa <= pc ? a : bc
     uint32_t pred = pae;
-    if (!all_paeth) pred = ft == 4 ? pae : ft == 3 ? ((a + b) >> 1) : ft == 2 ? b : ft == 1 ? a : 0u;
-    return (raw + pred) & 0xFFu;
+    if (!all_paeth) {
+        const uint32_t avg = as_u32(as_pk(as_u32(A + B)) >> 1);  // halves are 0 .. 510: the arithmetic shift is the logical one
+        pred = ft == 4 ? pae : ft == 3 ? avg : ft == 2 ? b : ft == 1 ? a : 0u;
+    }
+    return as_u32(as_pk(raw) + as_pk(pred)) & 0x00FF00FFu;
 }
 
-// Images with Average / Paeth rows (what an adaptive PNG writer picks for smooth depth: practically every row), even width:
-// the skewed pipeline on pixel PAIRS.  64 rows at a time, lane y works on pixels 2 (i - y), 2 (i - y) + 1 at step i, so that the
-// upper pair is the lane above's previous output (one DPP shift per step), the upper-left pixel the pair it handed down one step
-// earlier, the left pixel this lane's own last output.  The raw bytes of a lane's row come through three registers of aligned
-// dwords -- the load for pair j + 3 is issued while pair j is worked on -- and are re-aligned with v_alignbyte; every step stores
-// one dword (two host-order samples).  The first version read two bytes and wrote one uint16 per step and lane with nothing in
-// flight: 35 ms per 3 584 smooth frames, the latency of 2 x 5 600 dependent byte loads per image; this one is bound by its ~100
-// vector instructions per step.
 constexpr int kUpRowPairs = 2048;                                // widest image of the pair pipeline: 4 096 pixels
 // up_row: the row above the band (lane 0's upper neighbour), staged in LDS once per band: read from memory step by step it cost
 // the whole wave one L2 round trip per step
@@ -959,11 +965,6 @@ __device__ void unfilter_skewed_pairs(const uint8_t *__restrict__ raw, int64_t r
         const bool all_paeth = __all(!row || ft == 4);
         const int64_t base = a0 & ~(int64_t)3;
         const uint32_t sh = (uint32_t)(a0 & 3);
-        auto ld = [&](int k) {
-            int64_t o = base + 4 * (int64_t)k;
-            o = o < last ? o : last;
-            return *(const uint32_t *)(raw + o);
-        };
         if (y0 > 0) {                                            // the row above the band was written by this wave
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -974,14 +975,24 @@ __device__ void unfilter_skewed_pairs(const uint8_t *__restrict__ raw, int64_t r
             for (int k = lane; k < wp; k += 64) up_row[k] = uprow[k];
             wave_lds_fence();
         }
-        uint32_t wc = ld(0), wn = ld(1), wf = ld(2);             // dwords j, j + 1, j + 2 of this lane's row
+        // The row's dwords go through FOUR registers that change roles from step to step (the loop is unrolled by four): a
+        // register is loaded three steps before it is used and never copied -- copying the freshly loaded register into the
+        // next role, as a rolled loop must, waits for the load it has just issued, one memory round trip per step (what the
+        // first pair version did: 1.7 ms per image for a lone wave).  To let every lane rotate in the same step, all of them
+        // load "dword i - lane" at step i, whether their pair is inside the row yet or not (addresses clamped into the block).
+        auto ld = [&](int k) {                                   // dword k of this lane's row (k < 0: bytes in front of it, unused)
+            int64_t o = base + 4 * (int64_t)k;
+            o = o < 0 ? 0 : (o < last ? o : last);
+            return *(const uint32_t *)(raw + o);
+        };
         uint32_t upn = has_up ? up_row[0] : 0u;
         uint32_t X = 0;                                          // this lane's last output pair, bytes in stream order: x0 hi, x0 lo, x1 hi, x1 lo
         uint32_t Uprev = 0;                                      // the pair above, one step earlier (its second pixel: upper-left)
         const int steps = wp + 63;
-        for (int i = 0; i < steps; ++i) {
+        auto step = [&](int i, uint32_t wc, uint32_t wn, uint32_t &reload) {
             const int j = i - lane;
             const bool on = row && j >= 0 && j < wp;
+            reload = ld(j + 4);                                  // dwords j, j + 1 are wc, wn; j + 2, j + 3 on their way
             // the lane above finished pair j one step ago: its output through a DPP wave shift (one vector instruction; a
             // ds_bpermute would put an LDS round trip on every step's critical path)
             uint32_t U = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
@@ -989,17 +1000,30 @@ __device__ void unfilter_skewed_pairs(const uint8_t *__restrict__ raw, int64_t r
             if (has_up) upn = up_row[i + 1 < wp ? i + 1 : 0];   // (wave-uniform address: one LDS broadcast read, a step ahead)
             if (on) {
                 const uint32_t d = __builtin_amdgcn_alignbyte(wn, wc, sh);
-                wc = wn;
-                wn = wf;
-                wf = ld(j + 3);
-                const uint32_t x0h = unfilter_byte(d & 0xFFu, (X >> 16) & 0xFFu, U & 0xFFu, (Uprev >> 16) & 0xFFu, ft, all_paeth);
-                const uint32_t x0l = unfilter_byte((d >> 8) & 0xFFu, X >> 24, (U >> 8) & 0xFFu, Uprev >> 24, ft, all_paeth);
-                const uint32_t x1h = unfilter_byte((d >> 16) & 0xFFu, x0h, (U >> 16) & 0xFFu, U & 0xFFu, ft, all_paeth);
-                const uint32_t x1l = unfilter_byte(d >> 24, x0l, U >> 24, (U >> 8) & 0xFFu, ft, all_paeth);
-                X = x0h | (x0l << 8) | (x1h << 16) | (x1l << 24);
-                out32[(int64_t)y * wp + j] = (x0h << 8) | x0l | (x1h << 24) | (x1l << 16);
+                // pixels as (hi | lo << 16): stream bytes 0, 1 -> pixel 0, bytes 2, 3 -> pixel 1
+                const uint32_t r0 = __builtin_amdgcn_perm(0u, d, 0x0C010C00u), r1 = __builtin_amdgcn_perm(0u, d, 0x0C030C02u);
+                const uint32_t u0 = __builtin_amdgcn_perm(0u, U, 0x0C010C00u), u1 = __builtin_amdgcn_perm(0u, U, 0x0C030C02u);
+                const uint32_t ul = __builtin_amdgcn_perm(0u, Uprev, 0x0C030C02u);       // the pair above, one step earlier: its pixel 1
+                const uint32_t xl = __builtin_amdgcn_perm(0u, X, 0x0C030C02u);           // this lane's last output: its pixel 1
+                const uint32_t x0 = unfilter_pixel(r0, xl, u0, ul, ft, all_paeth);
+                const uint32_t x1 = unfilter_pixel(r1, x0, u1, u0, ft, all_paeth);
+                X = __builtin_amdgcn_perm(x1, x0, 0x06040200u);                          // bytes x0 hi, x0 lo, x1 hi, x1 lo
+                out32[(int64_t)y * wp + j] = __builtin_amdgcn_perm(x1, x0, 0x04060002u); // two host-order samples: x0 lo, x0 hi, x1 lo, x1 hi
             }
             Uprev = U;
+        };
+        uint32_t w0 = ld(0 - lane), w1 = ld(1 - lane), w2 = ld(2 - lane), w3 = ld(3 - lane);     // step 0's dwords j .. j + 3
+        int i = 0;
+        for (; i + 3 < steps; i += 4) {
+            step(i, w0, w1, w0);
+            step(i + 1, w1, w2, w1);
+            step(i + 2, w2, w3, w2);
+            step(i + 3, w3, w0, w3);
+        }
+        for (int r = 0; i < steps; ++i, ++r) {                   // the last one to three steps
+            if (r == 0) step(i, w0, w1, w0);
+            else if (r == 1) step(i, w1, w2, w1);
+            else step(i, w2, w3, w2);
         }
     }
 }
