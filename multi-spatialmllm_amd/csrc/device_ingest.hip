@@ -975,8 +975,9 @@ __device__ void unfilter_skewed_pairs(const uint8_t *__restrict__ raw, int64_t r
             for (int k = lane; k < wp; k += 64) up_row[k] = uprow[k];
             wave_lds_fence();
         }
-        // The row's dwords go through FOUR registers that change roles from step to step (the loop is unrolled by four): a
-        // register is loaded three steps before it is used and never copied -- copying the freshly loaded register into the
+        // The row's dwords go through EIGHT registers that change roles from step to step (the loop is unrolled by eight): a
+        // register is loaded seven steps (~3 000 cycles: an HBM miss, which some lane of the wave has at nearly every step)
+        // before it is used and never copied -- copying the freshly loaded register into the
         // next role, as a rolled loop must, waits for the load it has just issued, one memory round trip per step (what the
         // first pair version did: 1.7 ms per image for a lone wave).  To let every lane rotate in the same step, all of them
         // load "dword i - lane" at step i, whether their pair is inside the row yet or not (addresses clamped into the block).
@@ -992,7 +993,7 @@ __device__ void unfilter_skewed_pairs(const uint8_t *__restrict__ raw, int64_t r
         auto step = [&](int i, uint32_t wc, uint32_t wn, uint32_t &reload) {
             const int j = i - lane;
             const bool on = row && j >= 0 && j < wp;
-            reload = ld(j + 4);                                  // dwords j, j + 1 are wc, wn; j + 2, j + 3 on their way
+            reload = ld(j + 8);                                  // dwords j, j + 1 are wc, wn; j + 2 .. j + 7 on their way
             // the lane above finished pair j one step ago: its output through a DPP wave shift (one vector instruction; a
             // ds_bpermute would put an LDS round trip on every step's critical path)
             uint32_t U = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)X, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
@@ -1012,18 +1013,29 @@ __device__ void unfilter_skewed_pairs(const uint8_t *__restrict__ raw, int64_t r
             }
             Uprev = U;
         };
-        uint32_t w0 = ld(0 - lane), w1 = ld(1 - lane), w2 = ld(2 - lane), w3 = ld(3 - lane);     // step 0's dwords j .. j + 3
+        uint32_t w0 = ld(0 - lane), w1 = ld(1 - lane), w2 = ld(2 - lane), w3 = ld(3 - lane);     // step 0's dwords j .. j + 7
+        uint32_t w4 = ld(4 - lane), w5 = ld(5 - lane), w6 = ld(6 - lane), w7 = ld(7 - lane);
         int i = 0;
-        for (; i + 3 < steps; i += 4) {
+        for (; i + 7 < steps; i += 8) {
             step(i, w0, w1, w0);
             step(i + 1, w1, w2, w1);
             step(i + 2, w2, w3, w2);
-            step(i + 3, w3, w0, w3);
+            step(i + 3, w3, w4, w3);
+            step(i + 4, w4, w5, w4);
+            step(i + 5, w5, w6, w5);
+            step(i + 6, w6, w7, w6);
+            step(i + 7, w7, w0, w7);
         }
-        for (int r = 0; i < steps; ++i, ++r) {                   // the last one to three steps
-            if (r == 0) step(i, w0, w1, w0);
-            else if (r == 1) step(i, w1, w2, w1);
-            else step(i, w2, w3, w2);
+        for (int r = 0; i < steps; ++i, ++r) {                   // the last one to seven steps
+            switch (r) {
+            case 0: step(i, w0, w1, w0); break;
+            case 1: step(i, w1, w2, w1); break;
+            case 2: step(i, w2, w3, w2); break;
+            case 3: step(i, w3, w4, w3); break;
+            case 4: step(i, w4, w5, w4); break;
+            case 5: step(i, w5, w6, w5); break;
+            default: step(i, w6, w7, w6); break;
+            }
         }
     }
 }
