@@ -39,14 +39,21 @@ sys.path[:0] = [os.path.join(ROOT, "multi-spatialmllm_amd"), ROOT]
 ENTRY_POINTS = ("calculate_frames_relations.run_split", "make_visibility_info.run_split")
 
 
-def write_inputs(root, n_scenes, n_frames, n_points, base_scenes=4):
+def write_inputs(root, n_scenes, n_frames, n_points, base_scenes=4, smooth=False):
     """`n_scenes` scene ids over `base_scenes` rendered scenes of 8 frames each; a scene's `n_frames` image ids cycle through
-    its 8 frames (hard links).  Returns write_scannet_layout's paths."""
+    its 8 frames (hard links).  ``smooth``: the frames without their sensor noise (a 9 x 9 box filter, as
+    tools/device_ingest_bench.py --smooth): the PNG writer then picks the Paeth filter for practically every row, which is what
+    real sensor depth of smooth surfaces gets.  Returns write_scannet_layout's paths."""
     import numpy as np
     from mspa import synth
     H, W = 480, 640
     bases = [synth.make_scene(5000 + k, n_points=n_points, n_frames=8, color_hw=(H, W), depth_hw=(H, W), invalid_pose_frac=0.0,
                               with_color=False) for k in range(min(base_scenes, n_scenes))]
+    if smooth:
+        from scipy.ndimage import uniform_filter
+        for b in bases:
+            for i in list(b.depth):
+                b.depth[i] = uniform_filter(b.depth[i].astype(np.float64), 9).astype(np.uint16)
     scenes = []
     for s in range(n_scenes):
         b = bases[s % len(bases)]
@@ -108,7 +115,7 @@ def worker(a):
 
 
 def drive(ranks=(1, 2, 4), n_scenes=32, n_frames=320, n_points=131072, workers=None, passes=3, per_rank=2, timeout_s=900,
-          keep_root=None, decode="host"):
+          keep_root=None, decode="host", smooth=False):
     """Returns the leg's dict (see the module docstring).  ``workers`` = decode threads per scene in flight PER RANK, the same
     for every world size (an N-GPU node gives every rank its own cores: what is measured is whether the job scales when the
     per-rank resources are fixed).  Default: the CPUs this container may use (cgroup quota, mspa/hostinfo.py) divided by the
@@ -126,13 +133,13 @@ def drive(ranks=(1, 2, 4), n_scenes=32, n_frames=320, n_points=131072, workers=N
     try:
         t0 = time.perf_counter()
         if not os.path.exists(os.path.join(root, "paths.json")):      # (a kept root: the inputs of an earlier call serve again)
-            paths = write_inputs(root, n_scenes, n_frames, n_points)
+            paths = write_inputs(root, n_scenes, n_frames, n_points, smooth=smooth)
             json.dump(paths, open(os.path.join(root, "paths.json"), "w"))
         t_inputs = time.perf_counter() - t0
         out_dir = os.path.join(root, "out_" + (decode or "default"))
         os.makedirs(out_dir, exist_ok=True)
         res = {"scenes": n_scenes, "frames_per_scene": n_frames, "vertices": n_points, "num_workers_per_rank": workers,
-               "depth_decode": decode or os.environ.get("MSPA_DEPTH_DECODE", "device"), "cpus_per_rank": max(1, eff // max(ranks)), "scenes_in_flight_per_rank": 2, "window_scenes_per_rank": per_rank, "passes": passes, "host_cpus": hostinfo.describe(),
+               "frames": "smooth (Paeth rows)" if smooth else "noisy (Sub / Up rows)", "depth_decode": decode or os.environ.get("MSPA_DEPTH_DECODE", "device"), "cpus_per_rank": max(1, eff // max(ranks)), "scenes_in_flight_per_rank": 2, "window_scenes_per_rank": per_rank, "passes": passes, "host_cpus": hostinfo.describe(),
                "inputs_written_in_s": round(t_inputs, 1),
                "what": "ranks share ONE GPU and its PCIe link (gloo); decode threads, exchange and rank 0's writer are the real "
                        "ones -- the host-side scaling an N-GPU node sees",
@@ -226,11 +233,12 @@ def main():
     ap.add_argument("--per-rank", type=int, default=2)
     ap.add_argument("--timeout", type=int, default=900)
     ap.add_argument("--decode", default="host", help="host (default: the ranks share one GPU) | device")
+    ap.add_argument("--smooth", action="store_true", help="frames without sensor noise (Paeth rows, what real sensor depth gets)")
     a = ap.parse_args()
     if a.worker:
         worker(a)
         return
-    res = drive(tuple(int(x) for x in a.ranks.split(",")), a.scenes, a.frames, a.points, a.workers, a.passes, a.per_rank, a.timeout, decode=a.decode)
+    res = drive(tuple(int(x) for x in a.ranks.split(",")), a.scenes, a.frames, a.points, a.workers, a.passes, a.per_rank, a.timeout, decode=a.decode, smooth=a.smooth)
     print(json.dumps(res))
 
 

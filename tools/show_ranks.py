@@ -4,7 +4,7 @@ import json, sys
 for f in sys.argv[1:]:
     d = json.load(open(f))
     print(f"# {f}: {d['scenes']} scenes x {d['frames_per_scene']} frames, {d['num_workers_per_rank']} decode threads x {d.get('scenes_in_flight_per_rank')} scenes in flight, "
-          f"{d.get('cpus_per_rank')} CPUs per rank; depth decode: {d.get('depth_decode')}; host {d.get('host_cpus')}")
+          f"{d.get('cpus_per_rank')} CPUs per rank; depth decode: {d.get('depth_decode')}; frames: {d.get('frames', 'noisy')}; host {d.get('host_cpus')}")
     for w, v in d["worlds"].items():
         for n, l in v.items():
             if isinstance(l, dict) and "scenes_per_s" in l:
