@@ -747,12 +747,14 @@ def _tool(name):
     return mod
 
 
-def time_device_decode(streams=3584):
+def time_device_decode(streams=4096):
     """`variants.device_decode`: the depth decode on the MI355X by itself (tools/device_ingest_bench.py) -- `streams` 640 x 480
     16-bit depth PNGs (level 6, Pillow's adaptive row filters) resident in HBM as compressed bytes, inflated by one wave each
     (mspa_inflate_blocks_device incl. the Adler-32 pass) and un-filtered (mspa_png_unfilter_device), HIP events around the two
     calls; beside it the host reader on the CPUs this container may use.  Instruction-bound, not HBM-bound: the roofline of
-    this kernel is its instruction count (profiles/r06_inflate_v5_pmc.md), so what is reported is frames/s and the ratio."""
+    this kernel is its instruction count (profiles/r06_inflate_v5_pmc.md), so what is reported is frames/s and the ratio.
+    4 096 streams = 16 waves per compute unit, what a wave's 104 registers and 9 KB of LDS (2 KB output ring) allow; the leg ran 3 584
+    (14 per unit, 11 KB of LDS each) until the ring shrank."""
     r = _tool("device_ingest_bench").run(streams=streams, reps=3, with_composed=False)
     # the roofline that bounds it: instruction issue.  Instruction counts per frame from the committed PMC passes of the same
     # build (not measured in this run); cycles from this run's inflate time at the device's clock.

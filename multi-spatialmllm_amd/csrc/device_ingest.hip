@@ -5,7 +5,8 @@
 // the per-frame `zlib.decompress` of the .sens reader (extract_posed_images.py:49-57), i.e. the stage that bounds every from-disk
 // sweep: 16 CPUs' worth of container quota inflate ~10 k frames/s (profiles/r06_ingest_scaling.txt) while the kernels downstream
 // take 3 M images/s.  DEFLATE is serial inside a stream, so the parallelism is ACROSS streams: a scene has 320 of them, the
-// loader keeps several scenes in flight, the chip has room for 3 584 such waves (14 per CU: 11 KB of LDS each): 75 k frames/s.
+// loader keeps several scenes in flight, the chip has room for 4 096 such waves (16 per CU: 104 registers and 9 KB of LDS each):
+// 86 k frames/s (75 k with 3 584).
 //
 // mspa::dinf::inflate_kernel -- one 64-lane workgroup (one wave) per stream (v6):
 //   * the POSITION in the stream is wave-uniform and lives in two SGPRs; the stream's bytes sit in two VGPRs as a sliding window of
@@ -27,8 +28,8 @@
 //     the table index (< 1 % of the symbols of a noisy depth frame with 11 bits; 5 % with 10), end of block and invalid patterns
 //     take a scalar one-symbol path: the lanes test one code length each against the canonical first codes, the chain then goes
 //     on in the same batch.
-//   * output: a 4 KB ring in LDS takes every byte; whole 256-byte lines leave for HBM as one coalesced dword store per lane.
-//     A match whose distance fits the ring (<= 3 838: every filter-row distance of a 640-pixel image, 1 281) is copied LDS to
+//   * output: a 2 KB ring in LDS takes every byte; whole 256-byte lines leave for HBM as one coalesced dword store per lane.
+//     A match whose distance fits the ring (<= 1 790: every filter-row distance of a 640-pixel image, 1 281) is copied LDS to
 //     LDS by the lanes; a farther one loads the flushed bytes from HBM behind `s_waitcnt vmcnt(8)` (the lines it needs left >= 12
 //     stores ago) into a0 -- an accumulation register only the hand-written statements touch, because the load is still in
 //     flight while compiled code runs -- and its ring write is deferred until the next match or flush needs it.
@@ -47,8 +48,22 @@ namespace mspa {
 namespace dinf {
 
 constexpr int kLitBits = 11, kDistBits = 8;
-constexpr int kRing = 4096, kRingMask = kRing - 1;
+#ifndef MSPA_INFLATE_RING
+// 2 KB, not 4: a wave's LDS is 9 KB instead of 11, so that the compute unit holds the 16 waves its registers allow instead of 14
+// (4 096 streams: 85.8 k frames/s against 75.6 k at 3 584; per wave the two sizes decode at the same speed: tools/ab_ring.sh,
+// profiles/r06_sweep_timeline.md).  Distances of 1 791 .. 3 838 take the HBM path with it; the row above (1 281) stays in the ring.
+#define MSPA_INFLATE_RING 2048
+#endif
+constexpr int kRing = MSPA_INFLATE_RING, kRingMask = kRing - 1;
+static_assert(kRing >= 2048 && (kRing & kRingMask) == 0, "the ring is a power of two that holds a row-to-row distance of a 640-pixel image");
 constexpr int kRingNear = kRing - 258;          // a match at most this far back never reads a ring slot it is overwriting
+// A far match (beyond kRingNear, at most 64 bytes) reads bytes that left the ring as whole 256-byte lines.  When it is looked at,
+// fewer than 256 + 64 bytes are unflushed (the check behind every match and every batch, then one batch's literals), so the last
+// line it reads was stored at least kFarLinesAgo line stores ago; stores and loads of one wave complete in order, so with at most
+// kFarLinesAgo - 1 memory operations outstanding that store has landed.
+constexpr int kFarLinesAgo = (kRingNear - 64 - 320) / 256 - 1;
+constexpr int kFarVmcnt = kFarLinesAgo - 1 < 8 ? kFarLinesAgo - 1 : 8;
+static_assert(kFarVmcnt >= 1, "ring too small for the deferred far-match load");
 constexpr int kLitSyms = 288, kDistSyms = 32;
 constexpr int32_t kPendingHard = 0x40000000;   // status of an image between png_unfilter_kernel and png_unfilter_hard_kernel
 
@@ -85,7 +100,7 @@ __constant__ uint8_t kPreOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 1
 struct __align__(16) WaveLds {
     uint16_t lit[1 << kLitBits];        // 4 096 B (narrow entries)
     uint32_t dist[1 << kDistBits];      // 1 024 B
-    uint8_t ring[kRing];                // 4 096 B
+    uint8_t ring[kRing];                // 2 048 B (MSPA_INFLATE_RING)
     uint32_t pre[128];                  //   512 B  code-length code, 7-bit index
     uint16_t sorted[kLitSyms + kDistSyms];   // 640 B  symbols by (code length, symbol), literal/length then distance alphabet
     uint8_t lens[kLitSyms + kDistSyms];      // 320 B
@@ -364,7 +379,7 @@ __device__ __forceinline__ void settle_far(WaveLds &L, uint32_t far_pos, uint32_
 //   why 2  a match for the general copy routine, in p (then enter 2)       why 3  >= 256 bytes ready to leave the ring, mid-batch (enter 3)
 //   why 5  the window register must be re-aligned (enter 0)                why 6  >= 256 bytes ready, at a batch's end (enter 0)
 //   enter 0 a new batch, 1 on with the chain, 2 behind a symbol handled outside (lines ready? batch used up?), 3 behind a flush
-// exec is all ones on entry (one wave, uniform control flow) and on every exit.  v90 .. v101 are its scratch registers.  Hazards (gfx9
+// exec is all ones on entry (one wave, uniform control flow) and on every exit.  v90 .. v101 are its scratch registers -- on purpose ABOVE what the compiler needs: the kernel then counts 102 registers, four waves per SIMD, and a compute unit's 16 waves sit 4 + 4 + 4 + 4.  With v64 .. v75 it counts 87, five waves fit a SIMD, the dispatcher packs 5 + 5 + 5 + 1 and 4 096 streams take 52.0 ms instead of 45.8 (a SIMD issues for four of these waves without slowing them, not for five).  Hazards (gfx9
 // rules): no VALU-written SGPR is used as a lane select or by VMEM; a0 (the far match's bytes, see settle_far) is waited for with
 // vmcnt(0) before it is stored.
 __device__ __forceinline__ bool block_symbols(WaveLds &L, Reader &r, uint8_t *__restrict__ dst, uint32_t out_n, int lane, uint32_t &pos,
@@ -475,7 +490,7 @@ __device__ __forceinline__ bool block_symbols(WaveLds &L, Reader &r, uint8_t *__
             "v_mbcnt_lo_u32_b32 v90, exec_lo, 0\n\t"
             "v_mbcnt_hi_u32_b32 v90, exec_hi, v90\n\t"
             "v_add_u32 v90, %[pos], v90\n\t"
-            "v_and_b32 v90, 0xfff, v90\n\t"
+            "v_and_b32 v90, %[rmask], v90\n\t"
             "ds_write_b8 v90, %[E] offset:%[ring]\n\t"
             "s_mov_b64 exec, -1\n\t"
             "s_bcnt1_i32_b64 %[t0], %[run]\n\t"
@@ -503,7 +518,7 @@ __device__ __forceinline__ bool block_symbols(WaveLds &L, Reader &r, uint8_t *__
             "v_cmp_gt_u32 vcc, %[far_len], %[lane]\n\t"           // the previous far match's bytes into the ring
             "s_mov_b64 exec, vcc\n\t"
             "v_add_u32 v90, %[far_pos], %[lane]\n\t"
-            "v_and_b32 v90, 0xfff, v90\n\t"
+            "v_and_b32 v90, %[rmask], v90\n\t"
             "s_waitcnt vmcnt(0)\n\t"
             "ds_write_b8 v90, a0 offset:%[ring]\n\t"
             "s_mov_b64 exec, -1\n\t"
@@ -518,14 +533,14 @@ __device__ __forceinline__ bool block_symbols(WaveLds &L, Reader &r, uint8_t *__
             "s_bitcmp1_b32 %[p], 6\n\t"
             "s_cbranch_scc1 6f\n\t"
             "v_subrev_u32 v91, %[dist], v90\n\t"                  // ring to ring, source and destination apart
-            "v_and_b32 v91, 0xfff, v91\n\t"
+            "v_and_b32 v91, %[rmask], v91\n\t"
             "ds_read_u8 v91, v91 offset:%[ring]\n\t"
-            "v_and_b32 v90, 0xfff, v90\n\t"
+            "v_and_b32 v90, %[rmask], v90\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             "ds_write_b8 v90, v91 offset:%[ring]\n\t"
             "s_branch 12f\n"
             "6:\n\t"
-            "s_waitcnt vmcnt(8)\n\t"                              // from HBM: the lines it reads left >= 12 stores ago
+            "s_waitcnt vmcnt(%[farcnt])\n\t"                      // from HBM: the lines it reads left > kFarVmcnt stores ago
             "v_subrev_u32 v90, %[dist], v90\n\t"
             "global_load_ubyte a0, v90, %[dst]\n\t"
             "s_mov_b32 %[far_pos], %[pos]\n\t"
@@ -558,7 +573,7 @@ __device__ __forceinline__ bool block_symbols(WaveLds &L, Reader &r, uint8_t *__
               [P] "+v"(P), [E] "+v"(E)          // (the vector operands last: behind one, the compiler takes scalar results for divergent)
             : [enter] "s"(enter), [W] "v"(r.W), [lane] "v"(lane), [flushed] "s"(flushed), [out_n] "s"(out_n), [dst] "s"(dst),
               [near] "s"((uint32_t)kRingNear), [ring] "n"(offsetof(WaveLds, ring)), [lit] "n"(offsetof(WaveLds, lit)),
-              [dtab] "n"(offsetof(WaveLds, dist))
+              [dtab] "n"(offsetof(WaveLds, dist)), [rmask] "n"(kRingMask), [farcnt] "n"(kFarVmcnt)
             : "scc", "vcc", "memory", "a0", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101");
 #undef MSPA_LIT_STEP
         // ---- what is rare: in C ----

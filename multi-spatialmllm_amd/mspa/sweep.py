@@ -46,6 +46,8 @@ class HostScene:
     packed: object = None                  # ingest.PackedDepth: the frames still compressed (decoded on the device); then
     #                                        ``depth`` is empty and ``depth_ids`` names the frames ``packed`` holds, in order
     depth_ids: Optional[List[str]] = None
+    prepared: Optional[dict] = None        # upload.prepare_tables(K, A, E, points): computed on the loader's thread, so that the one
+    #                                        staging thread only copies it (absent: the staging thread computes it itself)
 
 
 class Timings:

@@ -29,7 +29,7 @@ UPLOAD_SLOTS = int(os.environ.get("MSPA_UPLOAD_SLOTS", "3"))
 # takes ~70 ms for a 640 x 480 frame, so a 320-frame scene alone keeps 320 of the chip's ~3 600 such waves busy; eight scenes side
 # by side (each on its own stream) run at 27 k frames/s (profiles/r06_device_ingest.md).  Slots cost HBM, not host time: depth +
 # scanline scratch + compressed bytes = 0.5 GB per 320-frame scene.  The FRAMES in flight are capped as well: a decode wave owns
-# 11 KB of its compute unit's LDS for its whole life, 14 of them leave nothing for the geometry kernels of the scene being
+# 9 KB (11 KB until the ring shrank to 2 KB) of its compute unit's LDS for its whole life, 14 of them left nothing for the geometry kernels of the scene being
 # consumed (K1: 13.4 KB per workgroup), which then wait milliseconds for a wave to retire (measured: 16 ms per scene with 3 200
 # frames in flight); at 2 560 (10 per unit) a third of every unit's LDS stays free.
 DECODE_SLOTS = int(os.environ.get("MSPA_DECODE_SLOTS", "8"))
@@ -54,6 +54,36 @@ def _decode_stream(device) -> "torch.cuda.Stream":
     return torch.cuda.ExternalStream(ptr.value, device=device)
 STAGE_THREADS = int(os.environ.get("MSPA_STAGE_THREADS", "4"))           # native copy threads per staged chunk
 STAGE_CHUNK_FRAMES = int(os.environ.get("MSPA_STAGE_CHUNK_FRAMES", "160"))  # frames per chunk (98 MB at 640 x 480)
+
+
+def prepare_tables(K, A, E, points=None, ids=None) -> dict:
+    """Everything ``UploadSlot.stage_and_upload`` derives from a scene's poses and vertices, as plain arrays: the frames with a
+    finite pose, ``A @ E`` per frame, the frame / camera records of the kernels, K4's pose tables, the vertices' xyz columns as
+    one contiguous block.  A loader thread MAY compute this ahead (``sweep.HostScene.prepared``, ``MSPA_PREPARE_ON_LOADER=1``) so
+    that the one staging thread only copies the arrays into its page-locked buffers; without it the staging thread calls this
+    function itself, so the bytes are the same either way.  Measured (tools/ab_prepare.sh, profiles/r06_sweep_timeline.md): the
+    staging thread's 6-7 ms per scene drop to 3 ms -- and the from-disk sweep gets SLOWER (88-117 against 122-135 scenes/s, five
+    A/B rounds in two boxes): with scenes arriving faster the device-side H2D and inflate of each scene take 1.3-1.5 x as long
+    and the slots are held longer than the staging saved.  Off by default."""
+    if ids is None:
+        ids = valid_image_ids(E)
+    F = len(ids)
+    K, A = np.asarray(K, np.float64), np.asarray(A, np.float64)
+    # one batched matmul; bit-identical to A @ E per frame (tests/test_host_cpu.py)
+    E_al = list(np.matmul(A, np.stack([np.asarray(E[i], np.float64) for i in ids]))) if F else []
+    out = {"ids": ids, "K": K, "A": A, "E_al": E_al, "fmats": None, "cmats": None, "pose": None, "xyz": None}
+    if F:
+        out["fmats"] = engine.frame_matrices(K, A, [E[i] for i in ids])
+        out["cmats"] = engine.camera_matrices(K, E_al)
+        # K4's per-frame tables travel with the scene: uploaded by the consumer they would be pageable copies queued
+        # behind the next scene's 197 MB on the same copy engine
+        pose = np.empty((18 * F,), dtype=np.float64)
+        pose[:16 * F].reshape(F, 16)[:] = np.stack(E_al).reshape(F, 16)
+        pose[16 * F:17 * F], pose[17 * F:18 * F] = engine.extract_yaw_pitch_host(E_al)
+        out["pose"] = pose
+    if points is not None and int(points.shape[0]):
+        out["xyz"] = np.ascontiguousarray(np.asarray(points, np.float64)[:, :3])
+    return out
 
 
 class UploadSlot:
@@ -156,7 +186,8 @@ class UploadSlot:
         """Fill the pinned buffers from ``sc`` (K, A, E, depth, color_hw, points) and enqueue the copies on ``copy_stream``.
         A scene that carries ``packed`` compressed frames (``sweep.HostScene.packed``) is decoded on the device instead, on
         the slot's own stream, so that several scenes' decodes run side by side."""
-        ids = valid_image_ids(sc.E)
+        prep = getattr(sc, "prepared", None)
+        ids = prep["ids"] if prep is not None else valid_image_ids(sc.E)
         F = len(ids)
         packed = getattr(sc, "packed", None)
         if packed is not None:
@@ -197,19 +228,15 @@ class UploadSlot:
 
         depth_done = _stage_pool().submit(depth_job)
         try:
-            K, A = np.asarray(sc.K, np.float64), np.asarray(sc.A, np.float64)
-            # one batched matmul; bit-identical to A @ E per frame (tests/test_host_cpu.py)
-            E_al = list(np.matmul(A, np.stack([np.asarray(sc.E[i], np.float64) for i in ids]))) if F else []
+            if prep is None:                      # (a scene that arrives with its tables -- the sweeps' loader threads -- skips this)
+                prep = prepare_tables(sc.K, sc.A, sc.E, points, ids)
+            K, A, E_al = prep["K"], prep["A"], prep["E_al"]
             if F:
-                self.h_fmats.numpy()[:F] = engine.frame_matrices(K, A, [sc.E[i] for i in ids])
-                self.h_cmats.numpy()[:F] = engine.camera_matrices(K, E_al)
-                # K4's per-frame tables travel with the scene: uploaded by the consumer they would be pageable copies queued
-                # behind the next scene's 197 MB on the same copy engine
-                hp = self.h_pose.numpy()
-                hp[:16 * F].reshape(F, 16)[:] = np.stack(E_al).reshape(F, 16)
-                hp[16 * F:17 * F], hp[17 * F:18 * F] = engine.extract_yaw_pitch_host(E_al)
+                self.h_fmats.numpy()[:F] = prep["fmats"]
+                self.h_cmats.numpy()[:F] = prep["cmats"]
+                self.h_pose.numpy()[:18 * F] = prep["pose"]
             if N:
-                np.copyto(self.h_xyz.numpy()[:N], np.asarray(points, np.float64)[:, :3])
+                np.copyto(self.h_xyz.numpy()[:N], prep["xyz"])
         except BaseException:
             depth_done.exception()               # a bad pose must not leave the helper writing into a slot that is handed back
             raise

@@ -197,7 +197,7 @@ def run_split(scene_info_path, output_parquet, warning_file, num_workers=15, sav
     if out_dir and rank == 0:
         os.makedirs(out_dir, exist_ok=True)
     timings = timings if timings is not None else sweep.Timings()
-    costs = [scene_infos.scene_cost(s) for s in all_scene_ids]
+    costs = scene_infos.scene_costs(all_scene_ids, ctx.world if ctx is not None else 1)
     device = ctx.device if ctx is not None else "cuda"
     tables, writers, paths = {}, [None, None], (output_parquet, nonzero_parquet)
 

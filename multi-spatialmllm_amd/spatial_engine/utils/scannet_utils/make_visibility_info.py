@@ -116,7 +116,7 @@ def run_split(scene_info_path, output_file, warning_file, num_workers=8, keep=Tr
     as_pkl = output_file.endswith(".pkl")
     want_csr = as_pkl or keep                      # rank 0 rebuilds the nested dict from the CSR tables
     timings = timings if timings is not None else sweep.Timings()
-    costs = [scene_infos.scene_cost(s) for s in all_scene_ids]
+    costs = scene_infos.scene_costs(all_scene_ids, ctx.world if ctx is not None else 1)
     device = ctx.device if ctx is not None else "cuda"
     scene_visibility_dict, state = {}, {"writer": None, "n": 0}
 

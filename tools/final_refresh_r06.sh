@@ -9,11 +9,11 @@ export TMPDIR=/tmp
 ( time timeout 600 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err ) 2> $OUT/bench_n1.time
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k3_stats -o p -- python $ROOT/bench.py --steps 20 --warmup 5 --no-scene-legs --no-sweep --also none --no-cpu-baseline --no-live-traffic > $OUT/k3_stats.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/decode_stats -o p -- python $ROOT/tools/device_ingest_bench.py --streams 3584 --reps 3 > $OUT/decode_stats.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/decode_stats -o p -- python $ROOT/tools/device_ingest_bench.py --streams 4096 --reps 3 > $OUT/decode_stats.log 2>&1
 cd $ROOT
 python - <<PY > $OUT/kernel_stats.md
 import csv, glob
-for tag, title in (("k3_stats", "bench.py --steps 20 --warmup 5 (headline K3 launch: 1 000 pairs of 640x480)"), ("decode_stats", "tools/device_ingest_bench.py --streams 3584 (depth decode on the device)")):
+for tag, title in (("k3_stats", "bench.py --steps 20 --warmup 5 (headline K3 launch: 1 000 pairs of 640x480)"), ("decode_stats", "tools/device_ingest_bench.py --streams 4096 (depth decode on the device)")):
     print(f"## rocprofv3 --kernel-trace --stats -- {title}\n")
     print("| kernel | calls | avg us | min us | max us | % of GPU time |\n|---|---|---|---|---|---|")
     for f in glob.glob("$OUT/" + tag + "/**/*kernel_stats.csv", recursive=True):
@@ -23,6 +23,6 @@ for tag, title in (("k3_stats", "bench.py --steps 20 --warmup 5 (headline K3 lau
     print()
 PY
 rm -rf $OUT/k3_stats $OUT/decode_stats
-bash tools/pmc_inflate.sh r06_inflate_v6 3584 > $OUT/pmc_inflate.log 2>&1
+bash tools/pmc_inflate.sh r06_inflate_v6 4096 > $OUT/pmc_inflate.log 2>&1
 cp gpurun_out/pmc_r06_inflate_v6/summary.md $OUT/pmc_inflate_v6.md
 tail -3 $OUT/bench_n1.time
