@@ -144,3 +144,29 @@ def device_info(device: int = 0) -> dict:
                                   ctypes.byref(clock), name, 64))
     return {"name": name.value.decode(), "n_cu": n_cu.value, "wave_size": wave.value,
             "hbm_bytes": hbm.value, "clock_khz": clock.value}
+
+
+_OWN_STREAMS: dict = {}
+_OWN_STREAMS_LOCK = __import__("threading").Lock()
+
+
+def own_stream(role: str, device):
+    """A HIP stream of this process's OWN for a long-lived role (a decode slot, the sweeps' copy stream, an encoder thread's side
+    stream), created once per (role, device) through mspa_stream_create_reserving(0) and kept: ``torch.cuda.ExternalStream``.
+
+    ``torch.cuda.Stream()`` is not that: it hands out the next of a pool of 32 streams per device, round robin.  A process that
+    sweeps more than once asks for 1 + 8 streams per pass (copy stream, encoder threads) on top of its 8 decode slots -- from the
+    third pass on an encoder thread's "own" stream IS a decode slot's stream, its downloads queue behind a 40 ms inflate and the
+    slot's next scene behind them (the fourth pass of every multi-pass measurement was the slow one: profiles/r06_sweep_timeline.md)."""
+    import torch
+    device = torch.device(device)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (role, index)
+    with _OWN_STREAMS_LOCK:
+        st = _OWN_STREAMS.get(key)
+        if st is None:
+            ptr = ctypes.c_void_p(0)
+            with torch.cuda.device(index):
+                check(load().mspa_stream_create_reserving(0, ctypes.byref(ptr)))
+            st = _OWN_STREAMS[key] = torch.cuda.ExternalStream(ptr.value, device=torch.device("cuda", index))
+        return st

@@ -385,22 +385,14 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
     vote(writer.close() if writer is not None else None)
 
 
-_SIDE = threading.local()
-
-
 def side_stream(device):
     """This THREAD's own stream on ``device``.  A sweep's ``produce`` only launches a scene's kernels; what has to wait for them --
     K9 compaction, downloads, encoding -- runs as a deferred blob on an encoder thread, behind an event, on that thread's stream:
-    beside the sweep thread's kernels instead of in front of the next scene's."""
-    import torch
-    streams = getattr(_SIDE, "streams", None)
-    if streams is None:
-        streams = _SIDE.streams = {}
-    device = torch.device(device)
-    key = (device.type, device.index)
-    if key not in streams:
-        streams[key] = torch.cuda.Stream(device=device)
-    return streams[key]
+    beside the sweep thread's kernels instead of in front of the next scene's.  Keyed by the thread's NAME: every sweep starts a new
+    encoder pool whose threads carry the same names ("mspa-encode_0" ...), so a process that sweeps many times keeps using the same
+    few streams instead of walking through torch's pool of 32 and landing on a decode slot's stream (``_lib.own_stream``)."""
+    from . import _lib
+    return _lib.own_stream("side:" + threading.current_thread().name, device)
 
 
 def prefetched_scenes(host_scenes: Iterable[HostScene], device="cuda", timings: Optional[Timings] = None,

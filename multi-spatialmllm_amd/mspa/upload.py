@@ -40,12 +40,17 @@ DECODE_MAX_FRAMES = int(os.environ.get("MSPA_DECODE_MAX_FRAMES", "2560"))
 DECODE_RESERVED_CUS = int(os.environ.get("MSPA_DECODE_RESERVED_CUS", "0"))
 
 
+_DECODE_STREAMS_MADE = [0]
+
+
 def _decode_stream(device) -> "torch.cuda.Stream":
-    """A stream for the on-device decode: CU-masked so that DECODE_RESERVED_CUS compute units stay free for other kernels."""
+    """A stream of its own for one slot's on-device decode (never one of torch's 32 pooled streams: ``_lib.own_stream``); with
+    DECODE_RESERVED_CUS, CU-masked so that that many compute units stay free for other kernels."""
     import ctypes
     from . import _lib
     if DECODE_RESERVED_CUS <= 0:
-        return torch.cuda.Stream(device=device)
+        _DECODE_STREAMS_MADE[0] += 1
+        return _lib.own_stream(f"decode-slot-{_DECODE_STREAMS_MADE[0]}", device)
     ptr = ctypes.c_void_p(0)
     with torch.cuda.device(device):
         info = _lib.device_info(torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device())
@@ -308,7 +313,8 @@ class ScenePrefetcher:
 
     def __iter__(self) -> Iterator[SceneOnDevice]:
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        copy_stream = torch.cuda.Stream(device=dev_index)
+        from . import _lib
+        copy_stream = _lib.own_stream("sweep-copy", dev_index)       # (not torch.cuda.Stream(): see _lib.own_stream)
         free_slots: "queue.Queue[UploadSlot]" = queue.Queue()
         my_slots = [_take_slot(self.device) for _ in range(self.n_slots)]
         for sl in my_slots:
