@@ -385,14 +385,23 @@ def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work
     vote(writer.close() if writer is not None else None)
 
 
+SIDE_STREAMS = 4
+
+
 def side_stream(device):
-    """This THREAD's own stream on ``device``.  A sweep's ``produce`` only launches a scene's kernels; what has to wait for them --
-    K9 compaction, downloads, encoding -- runs as a deferred blob on an encoder thread, behind an event, on that thread's stream:
-    beside the sweep thread's kernels instead of in front of the next scene's.  Keyed by the thread's NAME: every sweep starts a new
-    encoder pool whose threads carry the same names ("mspa-encode_0" ...), so a process that sweeps many times keeps using the same
-    few streams instead of walking through torch's pool of 32 and landing on a decode slot's stream (``_lib.own_stream``)."""
+    """The calling THREAD's side stream on ``device``.  A sweep's ``produce`` only launches a scene's kernels; what has to wait for
+    them -- K9 compaction, downloads, encoding -- runs as a deferred blob on an encoder thread, behind an event, on a side stream:
+    beside the sweep thread's kernels instead of in front of the next scene's.  Keyed by the thread's NAME, folded onto
+    ``SIDE_STREAMS`` streams: every sweep starts a new encoder pool whose threads carry the same names ("mspa-encode_0" ...), so a
+    process that sweeps many times keeps using the same few streams instead of walking through torch's pool of 32 and landing on a
+    decode slot's stream (``_lib.own_stream``); and eight decode slots + the copy stream + four side streams + the default stream
+    stay inside the 16 hardware queues the runtime is given (mspa/__init__.py) -- what an encoder thread puts on its stream is an
+    event wait and a few small downloads it then blocks on, two threads taking turns on one stream lose nothing."""
     from . import _lib
-    return _lib.own_stream("side:" + threading.current_thread().name, device)
+    name = threading.current_thread().name
+    tail = name.rsplit("_", 1)[-1]
+    k = int(tail) if tail.isdigit() else sum(name.encode())
+    return _lib.own_stream(f"side-{k % SIDE_STREAMS}", device)
 
 
 def prefetched_scenes(host_scenes: Iterable[HostScene], device="cuda", timings: Optional[Timings] = None,
