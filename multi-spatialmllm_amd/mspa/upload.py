@@ -34,6 +34,10 @@ UPLOAD_SLOTS = int(os.environ.get("MSPA_UPLOAD_SLOTS", "3"))
 # frames in flight); at 2 560 (10 per unit) a third of every unit's LDS stays free.
 DECODE_SLOTS = int(os.environ.get("MSPA_DECODE_SLOTS", "8"))
 DECODE_MAX_FRAMES = int(os.environ.get("MSPA_DECODE_MAX_FRAMES", "2560"))
+# What takes a scene's frames off the in-flight count: "taken" -- the consumer has taken the scene (with 8 slots the slots bind
+# first: a new scene is admitted when the consumer RELEASES one); "complete" -- its decode kernels have retired on the device
+# (an event query), so that with more slots than DECODE_MAX_FRAMES / frames-per-scene the cap's worth of frames is decoding at all times.
+DECODE_GATE = os.environ.get("MSPA_DECODE_GATE", "taken")
 # Tried and dropped as the default: decode streams that leave 32 compute units alone (mspa_stream_create_reserving, a CU mask).
 # Every masked stream is a hardware queue of its own; ten of them next to the process's other queues oversubscribe the queue
 # slots and the firmware time-slices them: 47 -> 12.5 scenes/s (profiles/r06_dropin_decode.md).  0 = plain streams.
@@ -107,6 +111,7 @@ class UploadSlot:
         self.d_comp = self.d_raw = self.d_status = self.d_off = self.d_nb = None
         self.h_status = self.h_off = self.h_nb = None
         self.pending_decode = None               # (PackedDepth, F): status still to be looked at (ScenePrefetcher._consume)
+        self.decoded = None                      # event behind the slot's decode kernels
 
     def _ensure(self, n_frames, depth_hw, n_points, copy_stream, host_depth=True):
         grown = False
@@ -168,6 +173,9 @@ class UploadSlot:
             engine.inflate_blocks_device(self.d_comp, self.d_off[:F], self.d_nb[:F], h * (2 * w + 1), self.d_raw, self.d_status)
             engine.png_unfilter_device(self.d_raw[:F], h, w, self.d_status, self.d_depth[:F])
             self.h_status[:F].copy_(self.d_status[:F], non_blocking=True)
+            if self.decoded is None:
+                self.decoded = torch.cuda.Event()
+            self.decoded.record(stream)          # the scene's decode waves have retired (DECODE_GATE = "complete" polls it)
         self.pending_decode = (packed, F)
 
     def finish_decode(self):
@@ -341,6 +349,12 @@ class ScenePrefetcher:
                     n_packed = len(sc.packed) if getattr(sc, "packed", None) is not None else 0
                     while n_packed and not stop.is_set():       # frames being decoded on the device: capped (see DECODE_MAX_FRAMES)
                         with in_flight_lock:
+                            if DECODE_GATE == "complete":
+                                for sl in my_slots:
+                                    if getattr(sl, "in_flight_frames", 0) and sl.decoded is not None and getattr(sl, "decode_launched", False) \
+                                            and sl.decoded.query():
+                                        in_flight["frames"] -= sl.in_flight_frames
+                                        sl.in_flight_frames = 0
                             if in_flight["frames"] == 0 or in_flight["frames"] + n_packed <= DECODE_MAX_FRAMES:
                                 in_flight["frames"] += n_packed
                                 break
@@ -352,8 +366,13 @@ class ScenePrefetcher:
                         except queue.Empty:
                             pass
                     if slot is not None:
+                        slot.decode_launched = False
                         slot.in_flight_frames = n_packed
-                    if slot is None or not put((self._stage(slot, sc, copy_stream), slot, None)):
+                    if slot is None:
+                        return
+                    staged = self._stage(slot, sc, copy_stream)
+                    slot.decode_launched = True              # (its `decoded` event is this scene's from here on)
+                    if not put((staged, slot, None)):
                         return
             except BaseException as e:                 # surfaces in the consumer
                 put((None, None, e))
