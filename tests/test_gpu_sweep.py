@@ -369,6 +369,59 @@ def test_device_decode_of_the_sweeps_equals_the_host_decode(tmp_path, monkeypatc
     assert digests["device"] == digests["host"] and len(digests["device"]) == 3
 
 
+def test_long_lived_streams_are_the_process_own_and_prepared_scenes_are_the_same_scenes(tmp_path, monkeypatch):
+    """(1) Decode slots, the sweeps' copy stream and the encoder threads' side streams are streams of the process's own
+    (``_lib.own_stream``), one per role however often they are asked for -- ``torch.cuda.Stream()`` walks a pool of 32 and, from a
+    process's third sweep on, handed an encoder thread a decode slot's stream.  (2) A scene staged from tables a loader thread
+    prepared (``host_scene(prepare=True)``) is bit for bit the scene staged without them."""
+    import threading
+    import torch
+    from test_gpu_facade import facade
+    from mspa import _lib, sweep, upload
+    SceneInfoHandler = facade().IH.SceneInfoHandler
+    a, b = _lib.own_stream("test-role", "cuda"), _lib.own_stream("test-role", "cuda:0")
+    assert a is b and a.cuda_stream != _lib.own_stream("test-role-2", "cuda").cuda_stream
+    pooled = {torch.cuda.Stream().cuda_stream for _ in range(40)}            # the whole pool, more than once around
+    seen = {}
+
+    def ask(name):
+        seen[name] = sweep.side_stream("cuda").cuda_stream
+    for rep in range(3):                                                      # three "sweeps": same names, same streams
+        ts = [threading.Thread(target=ask, args=(f"mspa-encode_{k}",), name=f"mspa-encode_{k}") for k in range(8)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        if rep == 0:
+            first = dict(seen)
+        assert seen == first
+    assert len(set(first.values())) == sweep.SIDE_STREAMS and first["mspa-encode_1"] == first[f"mspa-encode_{1 + sweep.SIDE_STREAMS}"]
+    own = set(first.values()) | {a.cuda_stream, _lib.own_stream("sweep-copy", "cuda").cuda_stream}
+    assert not (own & pooled)
+    root = str(tmp_path)
+    _write_inputs(root)
+    monkeypatch.chdir(root)
+    for stub in ("mmengine", "cv2"):
+        if getattr(sys.modules.get(stub), "__file__", None) is None:
+            monkeypatch.delitem(sys.modules, stub, raising=False)
+    h = SceneInfoHandler(INFO)
+    sids = h.get_all_scene_ids()
+    got = {}
+    for prepare in (False, True):
+        hosts = [h.host_scene(sid, 3, True, "device", prepare=prepare) for sid in sids]
+        assert all((hs.prepared is not None) == prepare for hs in hosts)
+        out = []
+        for sc in upload.ScenePrefetcher(hosts, "cuda", decode_on_device=True):
+            out.append([t.clone() for t in (sc.depth, sc.cam_mats, sc.frame_mats, sc.xyz, sc.pose_tables()[0], sc.pose_tables()[2])]
+                       + [sc.frames_relations_arrays()["overlap"].copy()])
+        torch.cuda.synchronize()
+        got[prepare] = out
+        slot_streams = {sl.stream.cuda_stream for sl in upload._SLOT_POOL.get("cuda", []) + upload._SLOT_POOL.get("cuda:0", [])
+                        if sl.stream is not None}
+        assert slot_streams and not (slot_streams & pooled)
+    assert len(got[True]) == len(sids)
+    for x, y in zip(got[False], got[True]):
+        assert all(torch.equal(p, q) for p, q in zip(x[:-1], y[:-1])) and np.array_equal(x[-1], y[-1], equal_nan=True)
+
+
 def test_reference_cli_unchanged_under_the_launcher(tmp_path):
     """`python -m spatial_engine.camera_movement.calculate_frames_relations` and `python -m mspa.pipeline --scene-info ...`,
     started the way a user starts a multi-GPU job (`torch.distributed.run`, one process per GPU; here two processes on the one

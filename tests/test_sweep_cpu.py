@@ -586,3 +586,61 @@ def test_ingest_pool_survives_fork_and_concurrent_callers(tmp_path):
     assert q.get(timeout=60) is True
     child.join(timeout=30)
     assert child.exitcode == 0
+
+
+def test_pose_validity_and_scene_costs_of_the_handler(tmp_path):
+    """``get_all_extrinsic_valid_image_ids`` answers with one ``isfinite`` over the scene's stacked poses: the same ids, in the same
+    order, as the reference's image-by-image form (IH:409-418) -- also for a scene with -inf poses, and image by image as before
+    for keys that are not their own "%05d" key.  ``scene_cost`` reads the vertex file's header (same N as loading it);
+    ``scene_costs`` prices nothing for one rank."""
+    _install_oracle_standins()
+    from mspa import shard
+    from spatial_engine.utils.scannet_utils.handler.info_handler import SceneInfoHandler
+    root = str(tmp_path)
+    paths = _write_layout(root)
+    h = SceneInfoHandler(paths["info_path"], posed_images_root=paths["posed_images_root"], instance_data_root=paths["instance_data_root"])
+    sids = h.get_all_scene_ids()
+    some_invalid = False
+    for sid in sids:
+        by_image = [i for i in h.get_all_image_ids(sid) if h.is_posed_image_valid(sid, i)]
+        assert h.get_all_extrinsic_valid_image_ids(sid) == by_image
+        some_invalid |= len(by_image) < len(h.get_all_image_ids(sid))
+        n = np.load(os.path.join(paths["instance_data_root"], sid, "aligned_points.npy")).shape[0]
+        assert h.scene_cost(sid) == shard.scene_cost(len(by_image), n)
+    assert some_invalid                                        # the layout holds a scene with -inf poses
+    assert h.scene_costs(sids, 1) == [1.0] * len(sids) and h.scene_costs(sids, 2) == [h.scene_cost(s) for s in sids]
+    # keys that are not canonical: "7" names image 00007 upstream (a KeyError there if it is missing), "x" is no image id at all
+    sid = sids[0]
+    images = h.infos[sid]["images_info"]
+    first = next(iter(images))
+    images["x"] = images[first]
+    assert h.get_all_extrinsic_valid_image_ids(sid) == [i for i in h.get_all_image_ids(sid) if h.is_posed_image_valid(sid, i)]
+    assert "x" not in h.get_all_extrinsic_valid_image_ids(sid)
+    del images["x"]
+    # a missing vertex file prices like one vertex instead of raising
+    os.rename(os.path.join(paths["instance_data_root"], sid, "aligned_points.npy"), os.path.join(paths["instance_data_root"], sid, "gone.npy"))
+    assert h.scene_cost(sid) == shard.scene_cost(len(h.get_all_extrinsic_valid_image_ids(sid)), 1)
+
+
+def test_prepared_tables_are_what_the_staging_thread_computes(tmp_path):
+    """``upload.prepare_tables`` (what a loader thread may compute ahead, ``HostScene.prepared``) against the per-frame NumPy forms
+    the staging code used to evaluate in place: the same bits, so a scene staged from its prepared tables is the scene staged
+    without them."""
+    _install_oracle_standins()
+    from mspa import engine, upload
+    sc = _make_scenes()[2]                                     # the scene with -inf poses
+    prep = upload.prepare_tables(sc.K, sc.A, sc.E, sc.points)
+    ids = prep["ids"]
+    assert ids == sc.valid_image_ids and len(ids) < len(sc.E)
+    A = np.asarray(sc.A, np.float64)
+    E_al = [A @ np.asarray(sc.E[i], np.float64) for i in ids]
+    assert all(np.array_equal(a, b) for a, b in zip(prep["E_al"], E_al))
+    assert np.array_equal(prep["fmats"], engine.frame_matrices(np.asarray(sc.K, np.float64), A, [sc.E[i] for i in ids]))
+    assert np.array_equal(prep["cmats"], engine.camera_matrices(np.asarray(sc.K, np.float64), E_al))
+    F = len(ids)
+    yaw, pitch = engine.extract_yaw_pitch_host(E_al)
+    assert np.array_equal(prep["pose"][:16 * F].reshape(F, 4, 4), np.stack(E_al))
+    assert np.array_equal(prep["pose"][16 * F:17 * F], yaw) and np.array_equal(prep["pose"][17 * F:], pitch)
+    assert prep["xyz"].flags.c_contiguous and np.array_equal(prep["xyz"], np.asarray(sc.points, np.float64)[:, :3])
+    empty = upload.prepare_tables(sc.K, sc.A, {}, None)
+    assert empty["ids"] == [] and empty["fmats"] is None and empty["xyz"] is None
