@@ -289,3 +289,37 @@ def test_sens_depth_frames_inflated_on_the_device(tmp_path):
     open(bad, "wb").write(bytes(raw))
     with pytest.raises(zlib.error):
         sens.read_sens(bad, depth_to_device="cuda")
+
+
+@pytest.mark.parametrize("h,w", [(120, 1296), (60, 2000), (200, 896)])
+def test_wide_frames_whose_row_distance_lies_beyond_the_ring(h, w, tmp_path):
+    """The inflate's output ring is 2 KB: a match up to 1 790 bytes back is copied LDS to LDS, a farther one loads the flushed bytes
+    from HBM (deferred, behind ``vmcnt``).  A 640-pixel row is 1 281 bytes, so ScanNet's depth never leaves the ring for the row
+    above; THESE frames do with every such match -- 896 pixels: 1 793 bytes, the first distance past the ring; 1 296: 2 593 (inside
+    the 4 KB ring this kernel had before); 2 000: 4 001 -- smooth content (long matches, Up / Paeth rows from an adaptive writer),
+    repeated rows (matches at exactly one and two rows' distance) and noise; every pixel against the host reader and the source."""
+    import torch
+    from PIL import Image
+    from mspa import ingest
+    rng = np.random.default_rng(h + w)
+    y, x = np.mgrid[0:h, 0:w]
+    smooth = (1500 + 40 * np.sin(x / 37.0) + 25 * np.cos(y / 11.0) + x // 7).astype(np.uint16)
+    rows = np.tile(rng.integers(0, 65536, (2, w), dtype=np.uint16), (h // 2, 1))             # row n == row n - 2: distance 2 (2 w + 1)
+    noisy = (smooth + rng.integers(0, 6, (h, w))).astype(np.uint16)
+    holes = smooth.copy()
+    holes[rng.random((h, w)) < 0.07] = 0
+    frames, paths = [], []
+    for k, (a, level) in enumerate([(smooth, 6), (rows, 6), (noisy, 1), (holes, 9), (smooth, 1)]):
+        p = str(tmp_path / f"w{k}.png")
+        if k == 4:
+            from test_sweep_cpu import _png_gray16
+            open(p, "wb").write(_png_gray16(a, [2], level))                                  # Up rows only: the residue repeats row to row
+        else:
+            Image.fromarray(a).save(p, compress_level=level)
+        frames.append(a)
+        paths.append(p)
+    dev = ingest.read_depth_frames_device(paths, "cuda", 2)
+    torch.cuda.synchronize()
+    host = ingest.read_depth_frames(paths, 2)
+    assert np.array_equal(host, np.stack(frames))
+    assert np.array_equal(dev.cpu().numpy().view(np.uint16), host)
