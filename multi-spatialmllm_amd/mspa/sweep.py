@@ -19,6 +19,7 @@ torch is plumbing here (streams, collectives); nothing is computed in this modul
 from __future__ import annotations
 
 import collections
+import contextlib
 import dataclasses
 import struct
 import threading
@@ -222,9 +223,45 @@ class _WindowWriter:
         return self.error
 
 
+@contextlib.contextmanager
+def quiet_collector():
+    """For the duration of a sweep: what the process holds when it begins is taken out of the cyclic collector's sight
+    (``gc.freeze()``) and a young-generation pass needs 50 000 net allocations instead of 700.
+
+    A sweep runs a dozen Python threads (the sweep thread, the staging thread, loaders, encoders, the writer, the exchange thread) that
+    all stop for every pass of the collector.  With the split's scene infos in memory -- a dict of dicts of arrays per image: about a
+    million container objects for 192 scenes of 320 images, several millions for ScanNet -- one full collection in the middle of a
+    pass took 70-150 ms and the ~250 young-generation passes another 15-20: 7-13 % of a 192-scene pass (tools/sweep_timeline.py
+    --series, profiles/r06_sweep_timeline.md: 123-138 -> 142-146 scenes/s).  Nothing the sweep allocates is cyclic garbage worth
+    looking for; at the end the thresholds are restored and the frozen objects handed back (unless the application had frozen
+    objects of its own before: then they stay frozen).  ``MSPA_GC_FREEZE=0`` leaves the collector alone."""
+    import gc
+    import os
+    if os.environ.get("MSPA_GC_FREEZE", "1") == "0" or not gc.isenabled():
+        yield
+        return
+    was, frozen_before = gc.get_threshold(), gc.get_freeze_count()
+    gc.freeze()
+    gc.set_threshold(max(was[0], 50000), was[1], was[2])
+    try:
+        yield
+    finally:
+        gc.set_threshold(*was)
+        if frozen_before == 0:
+            gc.unfreeze()
+
+
 def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work_items: Callable[[List[int]], Iterator],
                   produce: Callable, consume: Callable, record_width: Optional[int] = None, per_rank: Optional[int] = None,
                   timings: Optional[Timings] = None, writer_depth: int = 2, rank0_share: Optional[float] = None) -> None:
+    """``_sharded_sweep`` (below: the arguments are its) inside ``quiet_collector``."""
+    with quiet_collector():
+        _sharded_sweep(costs, ctx, work_items, produce, consume, record_width, per_rank, timings, writer_depth, rank0_share)
+
+
+def _sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work_items: Callable[[List[int]], Iterator],
+                   produce: Callable, consume: Callable, record_width: Optional[int] = None, per_rank: Optional[int] = None,
+                   timings: Optional[Timings] = None, writer_depth: int = 2, rank0_share: Optional[float] = None) -> None:
     """Run ``produce(index, item) -> (records | None, [blob, ...])`` for this rank's items and ``consume(index, records,
     blobs)`` on rank 0 for EVERY item, in index order.
 

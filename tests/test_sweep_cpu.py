@@ -644,3 +644,32 @@ def test_prepared_tables_are_what_the_staging_thread_computes(tmp_path):
     assert prep["xyz"].flags.c_contiguous and np.array_equal(prep["xyz"], np.asarray(sc.points, np.float64)[:, :3])
     empty = upload.prepare_tables(sc.K, sc.A, {}, None)
     assert empty["ids"] == [] and empty["fmats"] is None and empty["xyz"] is None
+
+
+def test_quiet_collector_restores_the_collector(monkeypatch):
+    """``sweep.quiet_collector``: inside, what the process held is frozen and the young generation's threshold raised; afterwards
+    thresholds and freeze count are what they were -- also after an exception, not at all with MSPA_GC_FREEZE=0, and an
+    application's own frozen objects stay frozen."""
+    import gc
+    from mspa import sweep
+    was = gc.get_threshold()
+    assert gc.get_freeze_count() == 0
+    with sweep.quiet_collector():
+        assert gc.get_freeze_count() > 0 and gc.get_threshold()[0] >= 50000 and gc.get_threshold()[1:] == was[1:]
+    assert gc.get_threshold() == was and gc.get_freeze_count() == 0
+    with pytest.raises(RuntimeError):
+        with sweep.quiet_collector():
+            raise RuntimeError("a failing sweep")
+    assert gc.get_threshold() == was and gc.get_freeze_count() == 0
+    monkeypatch.setenv("MSPA_GC_FREEZE", "0")
+    with sweep.quiet_collector():
+        assert gc.get_freeze_count() == 0 and gc.get_threshold() == was
+    monkeypatch.delenv("MSPA_GC_FREEZE")
+    gc.freeze()                                                # the application's own
+    try:
+        n = gc.get_freeze_count()
+        with sweep.quiet_collector():
+            pass
+        assert gc.get_freeze_count() >= n > 0 and gc.get_threshold() == was
+    finally:
+        gc.unfreeze()

@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--per-rank", type=int, default=8)
     ap.add_argument("--smooth", action="store_true")
     ap.add_argument("--brief", action="store_true", help="only the summary line")
+    ap.add_argument("--nogc", action="store_true", help="gc.disable() for the passes (is the once-per-pass stall the collector?)")
+    ap.add_argument("--gc", default="", help="freeze: gc.freeze() before the passes; freeze+thr: and gen-0 threshold 50 000")
+    ap.add_argument("--series", action="store_true", help="per-scene series of the device-side durations")
     ap.add_argument("--switch", type=float, default=None, help="sys.setswitchinterval (seconds; the interpreter's default is 0.005)")
     a = ap.parse_args()
     os.environ.setdefault("MSPA_DEPTH_DECODE", "device")
@@ -122,7 +125,19 @@ def main():
         upload.UploadSlot.finish_decode, upload.ScenePrefetcher._consume = fin, staticmethod(cons)
         fn, fname = (CFR.run_split, "pairs.parquet") if a.entry == "cfr" else (MVI.run_split, "vis.parquet")
         res = []
+        import gc
+        if a.nogc:
+            gc.collect()
+            gc.disable()
+        if a.gc.startswith("freeze"):
+            gc.collect()
+            gc.freeze()
+            if a.gc.endswith("thr"):
+                gc.set_threshold(50000, 20, 100)
+        gc_log = []
+        gc.callbacks.append(lambda phase, info: gc_log.append((phase, info.get("generation"), now())))
         for rep in range(a.passes):
+            gc_log.clear()
             log.clear()
             torch.cuda.synchronize()
             base["ev"] = torch.cuda.Event(enable_timing=True)
@@ -177,6 +192,14 @@ def main():
                 "consumer_waits_in_finish_decode_ms": round(mean(lambda w: w["seen"] - w["fin0"]), 2),
                 "consumer_holds_ms": round(mean(lambda w: w["rel"] - w["seen"]), 2),
                 "interval_between_releases_ms": round(float(np.mean(np.diff([w["rel"] for w in mid]))), 2)}
+        if a.series:
+            print("inflate_ms per scene:", [round(w["inf1"] - w["h2d1"], 1) for w in rows])
+            print("h2d_ms per scene:", [round(w["h2d1"] - w["h2d0"], 1) for w in rows])
+            pauses = [(g0[1], round((g1[2] - g0[2]) * 1e3, 1), round((g0[2] - t0) * 1e3)) for g0, g1 in zip(gc_log[::2], gc_log[1::2])]
+            print("collector runs in the pass (generation, ms, at ms):", [p_ for p_ in pauses if p_[1] >= 2.0], "of", len(pauses), "total ms", round(sum(p_[1] for p_ in pauses), 1))
+            big = [(i, round(b["rel"] - a_["rel"], 1), round(a_["rel"])) for i, (a_, b) in enumerate(zip(rows, rows[1:])) if b["rel"] - a_["rel"] > 20]
+            print("release intervals > 20 ms (scene, ms, at ms):", big)
+            print("release interval ms:", [round(b["rel"] - a_["rel"], 1) for a_, b in zip(rows, rows[1:])])
         print(json.dumps(summ))
     finally:
         shutil.rmtree(root, ignore_errors=True)
