@@ -24,6 +24,7 @@ from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import templates as T
+from .hostinfo import quietly
 
 
 # --------------------------------------------------------------------------------------------
@@ -150,6 +151,7 @@ def camera_movement_records(scene, rows: Sequence[dict], question_type: str, ima
             for k, r in enumerate(rows)]
 
 
+@quietly
 def camera_movement_dataset(rows: Sequence, frame_pose, image_hw_of, question_type: str,
                             templates: T.TemplateSet = T.CAMERA_MOVEMENT, rng=_random, device="cuda", ctx=None,
                             transform=None) -> List:
@@ -340,6 +342,7 @@ def visual_correspondence_records(scene, rows: Sequence[dict], image_hw, start_i
     return records
 
 
+@quietly
 def visual_correspondence_dataset(rows: Sequence, get_scene, get_bits=None, templates: T.TemplateSet = T.VISUAL_CORRESPONDENCE,
                                   rng=_random, max_points_per_pair: int = 1, on_warn=None, ctx=None,
                                   transform=None) -> List[Optional[dict]]:
@@ -587,6 +590,7 @@ class GpuCorrespondenceBackend:
         return [(int(vert_h[s]), uv[s], uv[s + m], bool(ok[s]), bool(ok[s + m])) for s in range(m)]
 
 
+@quietly
 def visual_correspondence_dot_dataset(rows: Sequence, backend, templates: T.TemplateSet = None, rng=_random, on_warn=None,
                                       on_mark=None, ctx=None, transform=None) -> List[Optional[dict]]:
     """Record loop of the multiple-choice correspondence head (visual_correspondence_qa_engine_dot_2_multichoice.py

@@ -8,6 +8,7 @@ staging thread, the thread that feeds the GPU -- which is the 2 x pass-to-pass a
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import Dict, Optional
 
@@ -74,3 +75,43 @@ def describe() -> Dict[str, object]:
     return {"os_cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
             "cgroup_cpu_quota": _cgroup_quota(), "effective_cpus": effective_cpus(per_rank=False),
             "effective_cpus_per_rank": effective_cpus()}
+
+
+@contextlib.contextmanager
+def quiet_collector():
+    """For the duration of a sweep: what the process holds when it begins is taken out of the cyclic collector's sight
+    (``gc.freeze()``) and a young-generation pass needs 50 000 net allocations instead of 700.
+
+    A sweep runs a dozen Python threads (the sweep thread, the staging thread, loaders, encoders, the writer, the exchange thread) that
+    all stop for every pass of the collector.  With the split's scene infos in memory -- a dict of dicts of arrays per image: about a
+    million container objects for 192 scenes of 320 images, several millions for ScanNet -- one full collection in the middle of a
+    pass took 70-150 ms and the ~250 young-generation passes another 15-20: 7-13 % of a 192-scene pass (tools/sweep_timeline.py
+    --series, profiles/r06_sweep_timeline.md: 123-138 -> 142-146 scenes/s).  Nothing the sweep allocates is cyclic garbage worth
+    looking for; at the end the thresholds are restored and the frozen objects handed back (unless the application had frozen
+    objects of its own before: then they stay frozen).  ``MSPA_GC_FREEZE=0`` leaves the collector alone."""
+    import gc
+    if os.environ.get("MSPA_GC_FREEZE", "1") == "0" or not gc.isenabled():
+        yield
+        return
+    was, frozen_before = gc.get_threshold(), gc.get_freeze_count()
+    gc.freeze()
+    gc.set_threshold(max(was[0], 50000), was[1], was[2])
+    try:
+        yield
+    finally:
+        gc.set_threshold(*was)
+        if frozen_before == 0:
+            gc.unfreeze()
+
+
+def quietly(fn):
+    """Decorator: ``fn`` runs inside ``quiet_collector`` (the dataset builders' record loops: a list of a few hundred thousand dict
+    records that all stay alive is the collector's worst case -- tools/heads_bench.py: camera movement 63 k -> 116 k records/s,
+    coordinate correspondences 27 k -> 77 k, object movement 17.6 k -> 32.9 k with the young generation's threshold raised)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        with quiet_collector():
+            return fn(*a, **k)
+    return wrapped

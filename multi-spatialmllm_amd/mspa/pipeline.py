@@ -36,6 +36,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from . import heads, sampling, shard
+from .hostinfo import quietly
 from . import templates as T
 
 
@@ -271,6 +272,7 @@ class RecordSpill:
             os.remove(pth)
 
 
+@quietly
 def run(scenes: Sequence, out_dir: str, ctx: Optional[shard.DistContext] = None, device="cuda", seed: int = 0,
         n_camera: int = 64, n_correspondence: int = 64, depth_images_per_scene: int = 4,
         overlap_range=(6, 35), question_types: Sequence[str] = ("total_distance", "displacement_vector"),

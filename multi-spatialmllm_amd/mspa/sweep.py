@@ -223,32 +223,7 @@ class _WindowWriter:
         return self.error
 
 
-@contextlib.contextmanager
-def quiet_collector():
-    """For the duration of a sweep: what the process holds when it begins is taken out of the cyclic collector's sight
-    (``gc.freeze()``) and a young-generation pass needs 50 000 net allocations instead of 700.
-
-    A sweep runs a dozen Python threads (the sweep thread, the staging thread, loaders, encoders, the writer, the exchange thread) that
-    all stop for every pass of the collector.  With the split's scene infos in memory -- a dict of dicts of arrays per image: about a
-    million container objects for 192 scenes of 320 images, several millions for ScanNet -- one full collection in the middle of a
-    pass took 70-150 ms and the ~250 young-generation passes another 15-20: 7-13 % of a 192-scene pass (tools/sweep_timeline.py
-    --series, profiles/r06_sweep_timeline.md: 123-138 -> 142-146 scenes/s).  Nothing the sweep allocates is cyclic garbage worth
-    looking for; at the end the thresholds are restored and the frozen objects handed back (unless the application had frozen
-    objects of its own before: then they stay frozen).  ``MSPA_GC_FREEZE=0`` leaves the collector alone."""
-    import gc
-    import os
-    if os.environ.get("MSPA_GC_FREEZE", "1") == "0" or not gc.isenabled():
-        yield
-        return
-    was, frozen_before = gc.get_threshold(), gc.get_freeze_count()
-    gc.freeze()
-    gc.set_threshold(max(was[0], 50000), was[1], was[2])
-    try:
-        yield
-    finally:
-        gc.set_threshold(*was)
-        if frozen_before == 0:
-            gc.unfreeze()
+from .hostinfo import quiet_collector, quietly  # noqa: E402,F401  (kept importable from here: the sweeps are where it was found)
 
 
 def sharded_sweep(costs: Sequence[float], ctx: Optional[shard.DistContext], work_items: Callable[[List[int]], Iterator],

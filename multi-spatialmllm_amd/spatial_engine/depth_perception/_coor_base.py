@@ -7,6 +7,7 @@ import random
 
 from mspa import heads
 from spatial_engine.utils.scannet_utils.handler.info_handler import SceneInfoHandler, VisibilityInfoHandler
+from mspa.hostinfo import quietly
 
 
 class _LazyCounts:
@@ -207,6 +208,7 @@ class DepthCoorEngineBase:
         return records
 
     # -- dataset level (reference: generate_qa_training_data / generate_qa_eval_data) --------------
+    @quietly
     def generate_qa_training_data(self, output_dir, save_file=True):
         from mspa import shard
         ctx = shard.context_from_env() if (self.DRAWS_AHEAD or self.CHAINED) else None
@@ -250,6 +252,7 @@ class DepthCoorEngineBase:
         train_sample["text"] = train_sample["conversations"][0]["value"]      # upstream keeps `conversations` here
         return train_sample
 
+    @quietly
     def generate_qa_eval_data(self, output_dir):
         assert self.max_n_points_per_image == 1, "max_n_points_per_image should be 1 for evaluation"
         from mspa import shard

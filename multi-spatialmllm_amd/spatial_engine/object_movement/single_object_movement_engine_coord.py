@@ -9,6 +9,7 @@ import torch
 
 from mspa import engine, heads
 from mspa import templates as T
+from mspa.hostinfo import quietly
 
 
 def rigid_body_segmentation(points, threshold=0.1, smoothing_factor=0.01):
@@ -139,6 +140,7 @@ class TwoFrameVideoQAEngine:
                                             points_pos_world=None, points_pos_cam=tracks_xyz, image_height=image_height,
                                             image_width=image_width, extrinsics_w2c=extrinsics_w2c)
 
+    @quietly
     def _all_scenes(self, scene_id_list, source_data_root, img_output_dir, npoints_per_group, npairs_per_bin, augment,
                     augment_ratio, num_workers=20, ctx=None):
         """Upstream maps the scenes over a fork pool (:584-585), so every scene starts from a copy of the parent's ``random``

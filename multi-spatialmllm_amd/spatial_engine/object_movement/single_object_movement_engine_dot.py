@@ -11,6 +11,7 @@ import torch
 from mspa import engine, heads
 from mspa import templates as T
 from mspa.annotate import Mark
+from mspa.hostinfo import quietly
 from spatial_engine.object_movement.single_object_movement_engine_coord import (TwoFrameVideoQAEngine, filter_large_groups,
                                                                                 jpeg_size, rigid_body_segmentation,
                                                                                 sharded_scenes)
@@ -93,6 +94,7 @@ class TwoFrameVideoQAEngineDot(TwoFrameVideoQAEngine):
         return self.format_training_samples(sample_pairs, intrinsics, scene_id, None, tracks_xyz, image_height, image_width,
                                             extrinsics_w2c, base_img_dir, img_output_dir)
 
+    @quietly
     def _all_scenes_dot(self, scene_id_list, source_data_root, base_img_dir, img_output_dir, npoints_per_group, npairs_per_bin,
                         augment, augment_ratio, num_workers=20, ctx=None):
         parent = random.getstate()                  # fork-pool semantics, see TwoFrameVideoQAEngine._all_scenes

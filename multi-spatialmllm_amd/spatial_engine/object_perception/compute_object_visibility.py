@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from mspa.scene import object_visibility_from_bits, pack_index_lists
+from mspa.hostinfo import quietly
 
 NONINFORMATIVE_DESC = {"wall", "object", "floor", "ceiling", "window"}
 
@@ -73,6 +74,7 @@ def load_visibility_dict(parquet_file):
     return dict(zip(df["key"].tolist(), df["values"].tolist()))
 
 
+@quietly
 def process_split(split_name, scene_info_path, visibility_parquet_file, output_dir, ctx=None):
     """``output_dir/object_visibility.pkl`` ({scene: result}, scenes in the split's order) and ``warning.txt`` for a split
     (reference: :153-195, one process, the whole index in memory).

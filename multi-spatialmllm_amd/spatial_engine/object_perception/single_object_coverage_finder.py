@@ -14,6 +14,7 @@ import torch
 
 from mspa import coverage as _cov
 from mspa.scene import pack_index_lists
+from mspa.hostinfo import quietly
 
 random.seed(0)           # as upstream: the module seeds ``random`` when it is imported
 TOLERANCE = _cov.TOLERANCE
@@ -135,6 +136,7 @@ def _run_scenes(scene_ids, handler, vis_dict, obj_vis):
     return tables
 
 
+@quietly
 def process_split_objects(split_name, scene_info_path, visibility_parquet_file, object_visibility_file, output_dir):
     os.makedirs(output_dir, exist_ok=True)
     with open(os.path.join(output_dir, "coverage_finding_warning_objects.txt"), "w") as wf:

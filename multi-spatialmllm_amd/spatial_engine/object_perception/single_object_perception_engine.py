@@ -12,6 +12,7 @@ import numpy as np
 
 from mspa import heads
 from mspa import templates as T
+from mspa.hostinfo import quietly
 
 random.seed(1)
 np.random.seed(1)
@@ -33,6 +34,7 @@ def _image_hw(handler):
     return lambda scene_id: tuple(handler.get_image_shape(scene_id))
 
 
+@quietly
 def build_lwh_qa_samples(scene_info_handler, dimension_info_path, dimension_name, split, output_dir, max_k=6, max_samples=-1):
     """One JSONL per combination size K: object_perception_{dimension}_k{K}_{split}_{max_samples}.jsonl."""
     print(f"Processing dimension: {dimension_name}, split: {split}")

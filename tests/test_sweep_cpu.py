@@ -588,12 +588,15 @@ def test_ingest_pool_survives_fork_and_concurrent_callers(tmp_path):
     assert child.exitcode == 0
 
 
-def test_pose_validity_and_scene_costs_of_the_handler(tmp_path):
+def test_pose_validity_and_scene_costs_of_the_handler(tmp_path, monkeypatch):
     """``get_all_extrinsic_valid_image_ids`` answers with one ``isfinite`` over the scene's stacked poses: the same ids, in the same
     order, as the reference's image-by-image form (IH:409-418) -- also for a scene with -inf poses, and image by image as before
     for keys that are not their own "%05d" key.  ``scene_cost`` reads the vertex file's header (same N as loading it);
     ``scene_costs`` prices nothing for one rank."""
     _install_oracle_standins()
+    for stub in ("mmengine", "cv2"):                           # an earlier module's stand-ins for the reference's imports
+        if getattr(sys.modules.get(stub), "__file__", None) is None:
+            monkeypatch.delitem(sys.modules, stub, raising=False)
     from mspa import shard
     from spatial_engine.utils.scannet_utils.handler.info_handler import SceneInfoHandler
     root = str(tmp_path)
