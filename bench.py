@@ -725,13 +725,13 @@ def time_dropin_sweep_ranks(ranks=(1, 2, 4), n_scenes=32, n_frames=320, passes=2
     try:
         res = mod.drive(ranks=tuple(ranks), n_scenes=n_scenes, n_frames=n_frames, workers=num_workers, passes=passes,
                         per_rank=per_rank, timeout_s=timeout_s, keep_root=root)
-        # the same inputs once more, ONE rank with the sweeps' own defaults at this size: depth frames inflated on the MI355X
+        # once more, ONE rank with the sweeps' own defaults at this size: depth frames inflated on the MI355X
         # (csrc/device_ingest.hip), windows of 8 scenes, 8 loader threads -- what one GPU of a node does with its share of a split
         try:
-            dev = mod.drive(ranks=(1,), n_scenes=n_scenes, n_frames=n_frames, workers=8, passes=3, per_rank=8, timeout_s=120,
-                            keep_root=root, decode="device")
-            res["one_rank_device_decode"] = dict(dev["worlds"].get("1", {}), num_workers=8, window_scenes_per_rank=8,
-                                                 depth_decode="device", passes=3)
+            # (its own inputs, 96 scenes: a pass over the 32 above is a quarter of a second, a third of it the pipeline filling and draining)
+            dev = mod.drive(ranks=(1,), n_scenes=96, n_frames=n_frames, workers=8, passes=4, per_rank=8, timeout_s=150, decode="device")
+            res["one_rank_device_decode"] = dict(dev["worlds"].get("1", {}), scenes=96, num_workers=8, window_scenes_per_rank=8,
+                                                 depth_decode="device", passes=4)
         except Exception as e:                               # informational
             res["one_rank_device_decode"] = {"skipped": f"{type(e).__name__}: {e}"}
         return res
