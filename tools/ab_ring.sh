@@ -1,4 +1,6 @@
 #!/bin/bash
+# (Run when the 4 KB ring was the default and tools/ab/libmspa_ring2k.so the variant; today the default is 2 KB and the variant is
+# tools/build_variant.sh ring4k -DMSPA_INFLATE_RING=4096 -- tools/ring_validate.sh is the current form of this A/B.)
 # A/B inside one box: the inflate kernel with a 2 KB ring (9 KB of LDS per wave) against the 4 KB ring (11 KB): the gate benchmark
 # per streams in flight, the device-ingest tests on the variant, then the from-disk sweep per slots / frames in flight.
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (Run when the 4 KB ring was the default and tools/ab/libmspa_ring2k.so the variant; today the default is 2 KB and the variant is
+# tools/build_variant.sh ring4k -DMSPA_INFLATE_RING=4096 -- tools/ring_validate.sh is the current form of this A/B.)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $ROOT
 V=$ROOT/tools/ab/libmspa_ring2k.so
