@@ -12,4 +12,4 @@ for k, v in d["worlds"]["1"].items():
 print()
 P
 }
-run 8 2560; run 10 3200; run 12 3840; run 8 2560; run 10 3200; run 8 2560 --smooth
+run 8 2560; run 10 3200; run 8 2560; run 10 3200; run 10 3200 --smooth
