@@ -93,15 +93,27 @@ def quiet_collector():
     if os.environ.get("MSPA_GC_FREEZE", "1") == "0" or not gc.isenabled():
         yield
         return
-    was, frozen_before = gc.get_threshold(), gc.get_freeze_count()
-    gc.freeze()
-    gc.set_threshold(max(was[0], 50000), was[1], was[2])
+    # collector settings are the process's: the outermost user (of any thread) changes them, the last one out puts them back
+    with _QUIET_LOCK:
+        _QUIET["depth"] += 1
+        if _QUIET["depth"] == 1:
+            _QUIET["was"], _QUIET["frozen_before"] = gc.get_threshold(), gc.get_freeze_count()
+            gc.freeze()
+            was = _QUIET["was"]
+            gc.set_threshold(max(was[0], 50000), was[1], was[2])
     try:
         yield
     finally:
-        gc.set_threshold(*was)
-        if frozen_before == 0:
-            gc.unfreeze()
+        with _QUIET_LOCK:
+            _QUIET["depth"] -= 1
+            if _QUIET["depth"] == 0:
+                gc.set_threshold(*_QUIET["was"])
+                if _QUIET["frozen_before"] == 0:
+                    gc.unfreeze()
+
+
+_QUIET = {"depth": 0, "was": None, "frozen_before": 0}
+_QUIET_LOCK = __import__("threading").Lock()
 
 
 def quietly(fn):

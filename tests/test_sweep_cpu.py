@@ -664,6 +664,24 @@ def test_quiet_collector_restores_the_collector(monkeypatch):
         with sweep.quiet_collector():
             raise RuntimeError("a failing sweep")
     assert gc.get_threshold() == was and gc.get_freeze_count() == 0
+    # nested, and from two threads that leave in the other order: the outermost user sets, the last one out restores
+    import threading
+    inside, leave = threading.Event(), threading.Event()
+
+    def other():
+        with sweep.quiet_collector():
+            inside.set()
+            leave.wait(10)
+    t = threading.Thread(target=other)
+    with sweep.quiet_collector():
+        t.start()
+        assert inside.wait(10)
+        with sweep.quiet_collector():
+            assert gc.get_threshold()[0] >= 50000
+    assert gc.get_threshold()[0] >= 50000 and gc.get_freeze_count() > 0          # the other thread is still inside
+    leave.set()
+    t.join()
+    assert gc.get_threshold() == was and gc.get_freeze_count() == 0
     monkeypatch.setenv("MSPA_GC_FREEZE", "0")
     with sweep.quiet_collector():
         assert gc.get_freeze_count() == 0 and gc.get_threshold() == was
