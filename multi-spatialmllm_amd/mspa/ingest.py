@@ -150,6 +150,9 @@ class PinnedBytesPool:
         n = max(self.STEP, -(-int(nbytes) // self.STEP) * self.STEP)
         t = torch.empty(n, dtype=torch.uint8)
         try:
+            # (not torch.empty(..., pin_memory=True): page-locked memory nobody has touched yet makes the pack threads' reads fault it in
+            # and the buffer's first H2D crawl -- a cold 96-scene pass took 2.3-2.6 s that way against 1.3 s; pin_memory() copies
+            # from `t` and thereby touches every page.  tools/sweep_timeline.py --passes 1)
             return t.pin_memory()
         except RuntimeError:                                # no GPU in this process (CPU tests): pageable memory works too
             return t
